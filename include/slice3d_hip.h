@@ -1,0 +1,167 @@
+/*
+ * slice3d_hip.h — C ABI of libslice3d_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the Slice3D regression hot path.  The reference has NO plugin / FFI layer for
+ * this path (it is nn.Module code over ATen ops); the boundary a maintainer binds is
+ * therefore "one C entry point per reference function", each citing the reference code it replaces.
+ * The Python mirror of the reference's module API (slice3d_amd/models.py, generator.py) calls these
+ * through ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory
+ *     (outputs, packed weights, workspace).  The library never allocates or frees device memory and
+ *     keeps no global device state.
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns immediately.
+ *   - return value: 0 = ok, <0 = S3D_E_* argument/size error (message via s3d_last_error()),
+ *     >0 = a hipError_t raised by a launch.
+ *   - all tensors are fp32.  Activations the library produces are channels-last (NHWC); the image
+ *     input and the reconstructed slice images cross the boundary in the reference's NCHW layout.
+ *   - batch x slice flattening is batch-major (row b*n_slices+s), as in the reference
+ *     (unet_custom.py:35-38, models.py:66,70,78).
+ */
+#ifndef SLICE3D_HIP_H
+#define SLICE3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3D_VERSION 100          /* 0.1.0 */
+#define S3D_E_ARG (-1)           /* bad argument / unsupported shape */
+#define S3D_E_WORKSPACE (-2)     /* workspace or packed-weight buffer too small */
+
+#define S3D_N_LEVELS 5           /* feature pyramid levels, coarse -> fine (unet_custom.py:58-67) */
+#define S3D_D_MODEL 128
+#define S3D_N_LAYERS 3
+#define S3D_FFN 2048
+#define S3D_N_TOKENS_MAX 13      /* 1 point token + up to 12 slice tokens (models.py:82) */
+
+/* arithmetic mode of the MFMA contractions (argument `prec`) */
+#define S3D_PREC_F32 0           /* v_mfma_f32_16x16x4_f32: exact fp32, the parity mode */
+#define S3D_PREC_BF16X3 1        /* 3x bf16 MFMA on hi/lo splits (~fp32 products), decode FFN only */
+
+int s3d_version(void);
+const char* s3d_last_error(void);           /* thread-local, valid until the next failing call */
+
+/* ---------------------------------------------------------------------------------------------
+ * U-Net slice generator  — replaces UNet.forward (reg_slices/src/unet_custom.py:40-69) and the
+ * DoubleConv/Up/OutConv blocks it calls (reg_slices/src/unet_parts.py:8-84), eval-mode BatchNorm.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Raw parameters in the reference's own state_dict layout (PyTorch conv weight [Cout][Cin][kh][kw],
+ * ConvTranspose2d weight [Cin][Cout][2][2]).  bn_* entries are {weight,bias,running_mean,running_var}. */
+typedef struct {
+    const float* w;      /* conv weight */
+    const float* b;      /* conv bias or NULL */
+    const float* bn[4];  /* BN following this conv (gamma, beta, mean, var) or all NULL */
+} S3dConvParams;
+
+typedef struct {
+    S3dConvParams enc[13];        /* VGG16-BN convs down1.0 ... down5.40 with the BN that follows each
+                                     (enc[12].bn = down5_.41 is unused by the forward and may be NULL) */
+    S3dConvParams trans_c;        /* 1x1 (512+128)->512, bias            unet_custom.py:22 */
+    S3dConvParams trans_up[4];    /* 1x1 skip projections trans_up1..4   unet_custom.py:24-30 */
+    S3dConvParams up_t[4];        /* ConvTranspose2d 2x2 s2 of up1..4    unet_parts.py:53 */
+    S3dConvParams up_c1[4];       /* DoubleConv conv0 + BN1 (no bias)    unet_parts.py:16-17 */
+    S3dConvParams up_c2[4];       /* DoubleConv conv3 + BN4 (no bias)    unet_parts.py:19-20 */
+    S3dConvParams outc;           /* 1x1 32->3 + tanh                    unet_parts.py:78-84 */
+    const float* emds;            /* (n_slices,128) slice embeddings     unet_custom.py:32 */
+    int n_slices;
+} S3dUNetParams;
+
+/* Bytes of the packed (MFMA-fragment-ordered, BN-folded) weight image for n_slices. */
+size_t s3d_unet_packed_bytes(int n_slices);
+/* Repack raw parameters into `packed` (device, >= s3d_unet_packed_bytes).  Re-run after every
+ * parameter update.  `params_host` is a HOST struct of DEVICE pointers. */
+int s3d_unet_pack(const S3dUNetParams* params_host, void* packed, size_t packed_bytes, void* stream);
+
+/* Feature pyramid handle: level l is (B*n_slices, H_l, W_l, C_l) NHWC fp32 with
+ * C = {512,256,128,64,32}, H_l = S/16 * 2^l  (coarse -> fine).  Caller allocates. */
+typedef struct {
+    float* level[S3D_N_LEVELS];
+    int n_img;                    /* B*n_slices */
+    int size;                     /* S (input image side; levels are S/16 ... S) */
+} S3dPyramid;
+
+size_t s3d_unet_workspace_bytes(int batch, int size, int n_slices);
+/* img (B,3,S,S) NCHW in [-1,1]  ->  pyramid (5 NHWC levels) and, if slices_rec != NULL, the
+ * reconstructed slice images (B*n_slices,3,S,S) NCHW (tanh output, models.py:65-66).
+ * S must be a multiple of 16. */
+int s3d_unet_encode_fwd(const void* packed, const float* img, const S3dPyramid* out,
+                        float* slices_rec, int batch, int size, int n_slices,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-query decoder — replaces Slices3DRegModel.forward lines models.py:53-84:
+ * query rotation / flip, project_coord (models.py:28-36), 5x sample_from_planes (models.py:38-46,
+ * 69-78), fc_p / fc_s (models.py:79-80), the 3-layer post-LN TransformerEncoder (models.py:18-19,83)
+ * and fc_out (models.py:22-24,84).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* in_proj_w;  const float* in_proj_b;    /* (384,128), (384) */
+    const float* out_proj_w; const float* out_proj_b;   /* (128,128), (128) */
+    const float* lin1_w;     const float* lin1_b;       /* (2048,128), (2048) */
+    const float* lin2_w;     const float* lin2_b;       /* (128,2048), (128) */
+    const float* norm1_w;    const float* norm1_b;      /* (128) */
+    const float* norm2_w;    const float* norm2_b;      /* (128) */
+} S3dLayerParams;
+
+typedef struct {
+    const float* fc_p_w;  const float* fc_p_b;          /* (128,3), (128)   models.py:20 */
+    const float* fc_s_w;  const float* fc_s_b;          /* (128,992), (128) models.py:21 */
+    S3dLayerParams layer[S3D_N_LAYERS];                 /* att_decoder.layers.{0,1,2} */
+    const float* fc_out_w; const float* fc_out_b;       /* (1,128), (1)     models.py:22-24 */
+} S3dHeadParams;
+
+size_t s3d_head_packed_bytes(void);
+int s3d_head_pack(const S3dHeadParams* params_host, void* packed, size_t packed_bytes, void* stream);
+
+/* "Latent code" c of the ConvONet-style encode()/decode() split: the three coarse pyramid levels with
+ * fc_s folded in (bilinear sampling and fc_s are both linear, so sampling the projected maps equals
+ * projecting the sampled features; SURVEY.md section 7 "Sampler layout"), plus the two fine levels raw.
+ * proj[l] is (n_img, H_l, W_l, 128) NHWC for l = 0,1,2. */
+typedef struct {
+    float* proj[3];
+    const float* fine[2];         /* pyramid levels 3 and 4, (n_img,S/2,S/2,64), (n_img,S,S,32) */
+    int n_img;
+    int size;
+} S3dLatent;
+
+int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, const S3dLatent* out, void* stream);
+
+size_t s3d_decode_workspace_bytes(int batch, long n_qry, int n_slices);
+/* qry (B,Q,3); rot (B,3,3) or NULL; trans (B,4,3) = trans_mat_wo_rot_tp; flip_yz != 0 selects the
+ * mode='test' prologue (y,z negated, no rotation; models.py:53-56).  sdf_out (B,Q). */
+int s3d_decode_points_fwd(const void* head_packed, const S3dLatent* latent, const float* qry,
+                          const float* rot, const float* trans, int flip_yz, float* sdf_out,
+                          int batch, long n_qry, int n_slices, int prec,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Dense-grid evaluation for Generator3D with upsampling_steps == 0 (reconstruct.py:135-146):
+ * query coordinates box*linspace(-.5,.5,nx)^3 (x slowest, z fastest; common.py:145-164) are generated
+ * in-kernel; logits_out[nx^3] = -sdf (reconstruct.py:97).  batch is 1. */
+int s3d_decode_grid_fwd(const void* head_packed, const S3dLatent* latent, const float* trans,
+                        int nx, float box, float* logits_out, int n_slices, int prec,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stand-alone ops of the module's helper API
+ * ------------------------------------------------------------------------------------------- */
+/* project_coord (models.py:28-36): coords (B,Q,3), trans (B,4,3) -> out (B,Q,2) */
+int s3d_project_coord_fwd(const float* coords, const float* trans, float* out, int batch, long n_qry,
+                          void* stream);
+/* sample_from_planes (models.py:38-46) on a channels-last plane: plane (N,H,W,C), grid (N,M,2)
+ * -> out (N,M,C); bilinear, zeros padding, align_corners=True.  C % 4 == 0. */
+int s3d_sample_planes_fwd(const float* plane, const float* grid, float* out, int n, int h, int w,
+                          int c, long m, void* stream);
+/* layout helpers: (N,C,H,W) <-> (N,H,W,C) */
+int s3d_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, void* stream);
+int s3d_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLICE3D_HIP_H */

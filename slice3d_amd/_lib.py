@@ -1,0 +1,113 @@
+"""ctypes binding of libslice3d_hip.so (C ABI declared in include/slice3d_hip.h).
+
+The library is built in-tree by `make -C slice3d_amd/csrc` (see __graft_entry__.build()).  There is NO
+fallback: if the shared object is missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libslice3d_hip.so")
+
+N_LEVELS = 5
+N_LAYERS = 3
+PREC_F32 = 0
+PREC_BF16X3 = 1
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class S3dConvParams(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("bn", C.c_void_p * 4)]
+
+
+class S3dUNetParams(C.Structure):
+    _fields_ = [("enc", S3dConvParams * 13), ("trans_c", S3dConvParams),
+                ("trans_up", S3dConvParams * 4), ("up_t", S3dConvParams * 4),
+                ("up_c1", S3dConvParams * 4), ("up_c2", S3dConvParams * 4),
+                ("outc", S3dConvParams), ("emds", C.c_void_p), ("n_slices", C.c_int)]
+
+
+class S3dPyramid(C.Structure):
+    _fields_ = [("level", C.c_void_p * N_LEVELS), ("n_img", C.c_int), ("size", C.c_int)]
+
+
+class S3dLayerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w",
+                 "lin2_b", "norm1_w", "norm1_b", "norm2_w", "norm2_b")]
+
+
+class S3dHeadParams(C.Structure):
+    _fields_ = [("fc_p_w", C.c_void_p), ("fc_p_b", C.c_void_p), ("fc_s_w", C.c_void_p),
+                ("fc_s_b", C.c_void_p), ("layer", S3dLayerParams * N_LAYERS),
+                ("fc_out_w", C.c_void_p), ("fc_out_b", C.c_void_p)]
+
+
+class S3dLatent(C.Structure):
+    _fields_ = [("proj", C.c_void_p * 3), ("fine", C.c_void_p * 2), ("n_img", C.c_int),
+                ("size", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/slice3d_hip.h declares
+_vp, _i, _l, _sz, _f = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_float
+SYMBOLS = {
+    "s3d_version": (_i, []),
+    "s3d_last_error": (C.c_char_p, []),
+    "s3d_unet_packed_bytes": (_sz, [_i]),
+    "s3d_unet_pack": (_i, [C.POINTER(S3dUNetParams), _vp, _sz, _vp]),
+    "s3d_unet_workspace_bytes": (_sz, [_i, _i, _i]),
+    "s3d_unet_encode_fwd": (_i, [_vp, _vp, C.POINTER(S3dPyramid), _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "s3d_head_packed_bytes": (_sz, []),
+    "s3d_head_pack": (_i, [C.POINTER(S3dHeadParams), _vp, _sz, _vp]),
+    "s3d_latent_build": (_i, [_vp, C.POINTER(S3dPyramid), C.POINTER(S3dLatent), _vp]),
+    "s3d_decode_workspace_bytes": (_sz, [_i, _l, _i]),
+    "s3d_decode_points_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _vp, _vp, _i, _vp, _i, _l, _i, _i,
+                                   _vp, _sz, _vp]),
+    "s3d_decode_grid_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _i, _f, _vp, _i, _i, _vp, _sz, _vp]),
+    "s3d_project_coord_fwd": (_i, [_vp, _vp, _vp, _i, _l, _vp]),
+    "s3d_sample_planes_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _vp]),
+    "s3d_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "s3d_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+class S3dError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise S3dError(
+            "libslice3d_hip.so not found at %s — build it with `make -C slice3d_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.s3d_version() < 100:
+        raise S3dError("libslice3d_hip.so too old: %d" % lib.s3d_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().s3d_last_error()
+        raise S3dError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous() and t.dtype.is_floating_point and t.element_size() == 4, \
+        "expected a contiguous fp32 tensor"
+    return t.data_ptr()

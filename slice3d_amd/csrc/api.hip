@@ -1,0 +1,541 @@
+// api.hip — exported C ABI (include/slice3d_hip.h): weight packing + kernel orchestration.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "conv.h"
+#include "decode.h"
+
+static thread_local char g_err[512] = "";
+
+void s3d_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int s3d_version(void) { return S3D_VERSION; }
+extern "C" const char* s3d_last_error(void) { return g_err; }
+
+#define TRY(x)              \
+    do {                    \
+        int rc__ = (x);     \
+        if (rc__) return rc__; \
+    } while (0)
+
+// =============================================================================================
+// U-Net
+// =============================================================================================
+static const int kEncCin[13] = {3, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512};
+static const int kEncCout[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+static const bool kEncTap[13] = {false, true, false, true, false, false, true,
+                                 false, false, true, false, false, true};
+static const int kUpC[4] = {512, 256, 128, 64};  // input channels of up1..4; Ct = C/2
+
+struct PackedConv {
+    size_t w, scale, shift;  // float offsets
+    int cout_pad, KU;
+};
+struct UNetLayout {
+    PackedConv enc[13];
+    size_t pool_scale[4], pool_shift[4];  // BN that follows tap convs 1,3,6,9 (applied by the pool kernel)
+    PackedConv trans_c, trans_up[4], up_t[4], up_c1[4], up_c2[4], outc;
+    size_t emds;
+    size_t total;
+};
+
+static int pad16(int c) { return (c + 15) / 16 * 16; }
+
+static UNetLayout unet_layout(int n_slices) {
+    UNetLayout L;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += (n + 3) / 4 * 4;
+        return o;
+    };
+    auto conv = [&](PackedConv& pc, int cout_pad, int KU) {
+        pc.cout_pad = cout_pad;
+        pc.KU = KU;
+        pc.w = take((size_t)cout_pad * KU * 16);
+        pc.scale = take(cout_pad);
+        pc.shift = take(cout_pad);
+    };
+    for (int i = 0; i < 13; ++i) conv(L.enc[i], kEncCout[i], 9 * pad16(kEncCin[i]) / 16);
+    const int tapc[4] = {64, 128, 256, 512};
+    for (int i = 0; i < 4; ++i) {
+        L.pool_scale[i] = take(tapc[i]);
+        L.pool_shift[i] = take(tapc[i]);
+    }
+    conv(L.trans_c, 512, 640 / 16);
+    for (int i = 0; i < 4; ++i) {
+        const int C = kUpC[i], Ct = C / 2;
+        conv(L.trans_up[i], Ct, C / 16);
+        conv(L.up_t[i], 4 * Ct, C / 16);
+        conv(L.up_c1[i], Ct, 2 * 9 * Ct / 16);
+        conv(L.up_c2[i], Ct, 9 * Ct / 16);
+    }
+    conv(L.outc, 16, 32 / 16);
+    L.emds = take((size_t)n_slices * 128);
+    L.total = off;
+    return L;
+}
+
+extern "C" size_t s3d_unet_packed_bytes(int n_slices) { return unet_layout(n_slices).total * sizeof(float); }
+
+static int pack_conv3(const float* w, float* dst, int cout, int cout_pad, int cin_tot, int cin_begin, int cseg,
+                      int KU_total, int u_off, int taps, hipStream_t st) {
+    PackArgs a = {};
+    a.src = w; a.dst = dst; a.kind = S3D_PACK_CONV;
+    a.n_valid = cout; a.n_pad = cout_pad;
+    a.KU_total = KU_total; a.u_off = u_off;
+    a.cseg = pad16(cseg); a.cseg_valid = cseg; a.cin_tot = cin_tot; a.cin_begin = cin_begin; a.taps = taps;
+    a.ku_seg = taps * a.cseg / 16;
+    return launch_pack(a, st);
+}
+
+static int pack_linear(const float* w, float* dst, int n, int n_pad, int k, int ld, int chunk_ku, hipStream_t st) {
+    PackArgs a = {};
+    a.src = w; a.dst = dst; a.kind = S3D_PACK_LINEAR;
+    a.n_valid = n; a.n_pad = n_pad;
+    a.KU_total = pad16(k) / 16; a.u_off = 0; a.ku_seg = a.KU_total;
+    a.ld = ld; a.k_valid = k; a.chunk_ku = chunk_ku;
+    return launch_pack(a, st);
+}
+
+extern "C" int s3d_unet_pack(const S3dUNetParams* P, void* packed, size_t packed_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    S3D_CHECK_ARG(P && packed, "unet_pack: null argument");
+    S3D_CHECK_ARG(P->n_slices >= 1 && P->n_slices <= 12, "unet_pack: n_slices %d", P->n_slices);
+    const UNetLayout L = unet_layout(P->n_slices);
+    if (packed_bytes < L.total * sizeof(float)) {
+        s3d_set_error("unet_pack: packed buffer %zu < %zu bytes", packed_bytes, L.total * sizeof(float));
+        return S3D_E_WORKSPACE;
+    }
+    float* base = (float*)packed;
+    for (int i = 0; i < 13; ++i) {
+        const PackedConv& pc = L.enc[i];
+        TRY(pack_conv3(P->enc[i].w, base + pc.w, kEncCout[i], pc.cout_pad, kEncCin[i], 0, kEncCin[i], pc.KU, 0, 9,
+                       st));
+        if (kEncTap[i])  // raw conv output is the skip tensor: bias only
+            TRY(launch_fold_bn(P->enc[i].b, nullptr, base + pc.scale, base + pc.shift, kEncCout[i], pc.cout_pad, 1,
+                               0, st));
+        else
+            TRY(launch_fold_bn(P->enc[i].b, P->enc[i].bn, base + pc.scale, base + pc.shift, kEncCout[i],
+                               pc.cout_pad, 1, 1, st));
+    }
+    const int tapi[4] = {1, 3, 6, 9};
+    for (int i = 0; i < 4; ++i)
+        TRY(launch_fold_bn(nullptr, P->enc[tapi[i]].bn, base + L.pool_scale[i], base + L.pool_shift[i],
+                           kEncCout[tapi[i]], kEncCout[tapi[i]], 1, 0, st));
+    TRY(pack_linear(P->trans_c.w, base + L.trans_c.w, 512, 512, 640, 640, 0, st));
+    TRY(launch_fold_bn(P->trans_c.b, nullptr, base + L.trans_c.scale, base + L.trans_c.shift, 512, 512, 1, 0, st));
+    for (int i = 0; i < 4; ++i) {
+        const int C = kUpC[i], Ct = C / 2;
+        TRY(pack_linear(P->trans_up[i].w, base + L.trans_up[i].w, Ct, Ct, C, C, 0, st));
+        TRY(launch_fold_bn(P->trans_up[i].b, nullptr, base + L.trans_up[i].scale, base + L.trans_up[i].shift, Ct,
+                           Ct, 1, 0, st));
+        {  // ConvTranspose2d weight [Cin][Ct][2][2] -> GEMM rows n = q*Ct + co
+            PackArgs a = {};
+            a.src = P->up_t[i].w; a.dst = base + L.up_t[i].w; a.kind = S3D_PACK_CONVT;
+            a.n_valid = 4 * Ct; a.n_pad = 4 * Ct; a.KU_total = C / 16; a.u_off = 0; a.ku_seg = C / 16;
+            a.k_valid = C; a.ct = Ct;
+            TRY(launch_pack(a, st));
+            TRY(launch_fold_bn(P->up_t[i].b, nullptr, base + L.up_t[i].scale, base + L.up_t[i].shift, Ct, 4 * Ct, 4,
+                               0, st));
+        }
+        // DoubleConv conv0 on cat([skip_proj, up]) (unet_parts.py:73): two K segments
+        TRY(pack_conv3(P->up_c1[i].w, base + L.up_c1[i].w, Ct, Ct, C, 0, Ct, L.up_c1[i].KU, 0, 9, st));
+        TRY(pack_conv3(P->up_c1[i].w, base + L.up_c1[i].w, Ct, Ct, C, Ct, Ct, L.up_c1[i].KU, 9 * Ct / 16, 9, st));
+        TRY(launch_fold_bn(nullptr, P->up_c1[i].bn, base + L.up_c1[i].scale, base + L.up_c1[i].shift, Ct, Ct, 1, 0,
+                           st));
+        TRY(pack_conv3(P->up_c2[i].w, base + L.up_c2[i].w, Ct, Ct, Ct, 0, Ct, L.up_c2[i].KU, 0, 9, st));
+        TRY(launch_fold_bn(nullptr, P->up_c2[i].bn, base + L.up_c2[i].scale, base + L.up_c2[i].shift, Ct, Ct, 1, 0,
+                           st));
+    }
+    TRY(pack_linear(P->outc.w, base + L.outc.w, 3, 16, 32, 32, 0, st));
+    TRY(launch_fold_bn(P->outc.b, nullptr, base + L.outc.scale, base + L.outc.shift, 3, 16, 1, 0, st));
+    hipError_t e = hipMemcpyAsync(base + L.emds, P->emds, (size_t)P->n_slices * 128 * sizeof(float),
+                                  hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        s3d_set_error("unet_pack: memcpy failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+struct UNetWs {
+    size_t in16, a, b, x[5], p[4], proj, up, mid;
+    size_t total;
+};
+static UNetWs unet_ws(int B, int S, int ns) {
+    UNetWs W;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += (n + 63) / 64 * 64;
+        return o;
+    };
+    const size_t px = (size_t)B * S * S;
+    W.in16 = take(px * 16);
+    W.a = take(px * 64);   // ping-pong buffers for the non-tap encoder activations (largest: 64 ch @ S)
+    W.b = take(px * 64 / 2);
+    const int xc[5] = {64, 128, 256, 512, 512};
+    for (int i = 0; i < 5; ++i) W.x[i] = take((px >> (2 * i)) * xc[i]);
+    for (int i = 0; i < 4; ++i) W.p[i] = take((px >> (2 * (i + 1))) * xc[i]);
+    W.proj = take(px * 32);                 // largest skip projection: (B,S,S,32)
+    W.up = take(px * ns * 32);              // largest ConvT output: (B*ns,S,S,32)
+    W.mid = take(px * ns * 32);
+    W.total = off;
+    return W;
+}
+
+extern "C" size_t s3d_unet_workspace_bytes(int batch, int size, int n_slices) {
+    return unet_ws(batch, size, n_slices).total * sizeof(float);
+}
+
+static ConvLaunch conv_desc(const float* base, const PackedConv& pc, int N, int H, int W, int ks, int act) {
+    ConvLaunch c = {};
+    c.N = N; c.H = H; c.W = W; c.ks = ks;
+    c.CoutPad = pc.cout_pad; c.wpk = base + pc.w; c.KU = pc.KU;
+    c.scale = base + pc.scale; c.shift = base + pc.shift;
+    c.act = act; c.out_mode = S3D_OUT_NHWC; c.cout_store = pc.cout_pad; c.out_cstride = pc.cout_pad;
+    return c;
+}
+static ConvSrc plain_src(const float* p, int C) { return ConvSrc{p, C, 1, 0, 0}; }
+
+extern "C" int s3d_unet_encode_fwd(const void* packed, const float* img, const S3dPyramid* out,
+                                   float* slices_rec, int B, int S, int ns, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    S3D_CHECK_ARG(packed && img && out && workspace, "unet_encode: null argument");
+    S3D_CHECK_ARG(B >= 1 && S >= 16 && S % 16 == 0, "unet_encode: B=%d S=%d (S must be a multiple of 16)", B, S);
+    S3D_CHECK_ARG(ns >= 1 && ns <= 12, "unet_encode: n_slices %d", ns);
+    S3D_CHECK_ARG(out->n_img == B * ns && out->size == S, "unet_encode: pyramid handle mismatch");
+    const UNetLayout L = unet_layout(ns);
+    const UNetWs W = unet_ws(B, S, ns);
+    if (workspace_bytes < W.total * sizeof(float)) {
+        s3d_set_error("unet_encode: workspace %zu < %zu bytes", workspace_bytes, W.total * sizeof(float));
+        return S3D_E_WORKSPACE;
+    }
+    const float* base = (const float*)packed;
+    float* ws = (float*)workspace;
+
+    TRY(launch_nchw_to_nhwc(img, ws + W.in16, B, 3, S, S, 16, st));
+    // ---- VGG16-BN encoder (unet_custom.py:43-47) ----
+    const float* cur = ws + W.in16;
+    int curC = 16, res = S, tap_i = 0;
+    float* pp[2] = {ws + W.a, ws + W.b};
+    int flip = 0;
+    for (int i = 0; i < 13; ++i) {
+        ConvLaunch c = conv_desc(base, L.enc[i], B, res, res, 3, kEncTap[i] ? S3D_ACT_NONE : S3D_ACT_RELU);
+        c.nsrc = 1;
+        c.src[0] = plain_src(cur, curC);
+        float* dst = kEncTap[i] ? ws + W.x[tap_i] : pp[flip];
+        c.out = dst;
+        TRY(launch_conv(c, st));
+        cur = dst;
+        curC = kEncCout[i];
+        if (!kEncTap[i]) flip ^= 1;
+        if (kEncTap[i]) {
+            if (tap_i < 4) {  // BN + ReLU + MaxPool open the next block
+                TRY(launch_bn_relu_pool(ws + W.x[tap_i], base + L.pool_scale[tap_i], base + L.pool_shift[tap_i],
+                                        ws + W.p[tap_i], B, res, res, curC, st));
+                cur = ws + W.p[tap_i];
+                res /= 2;
+            }
+            ++tap_i;
+        }
+    }
+    // ---- latent = trans_c(cat[tile(x5), emb])  (unet_custom.py:50-58) ----
+    const int r5 = S / 16;
+    {
+        ConvLaunch c = conv_desc(base, L.trans_c, B * ns, r5, r5, 1, S3D_ACT_NONE);
+        c.nsrc = 2;
+        c.src[0] = ConvSrc{ws + W.x[4], 512, ns, 0, 0};
+        c.src[1] = ConvSrc{base + L.emds, 128, 1, ns, 1};
+        c.out = out->level[0];
+        TRY(launch_conv(c, st));
+    }
+    // ---- up1..up4 (unet_custom.py:60-67, unet_parts.py:55-75) ----
+    const float* prev = out->level[0];
+    int rp = r5;
+    for (int i = 0; i < 4; ++i) {
+        const int C = kUpC[i], Ct = C / 2, ro = rp * 2;
+        {  // skip projection, once per image: trans_up(expand_bs(x)) == expand_bs(trans_up(x))
+            ConvLaunch c = conv_desc(base, L.trans_up[i], B, ro, ro, 1, S3D_ACT_NONE);
+            c.nsrc = 1;
+            c.src[0] = plain_src(ws + W.x[3 - i], C);
+            c.out = ws + W.proj;
+            TRY(launch_conv(c, st));
+        }
+        {  // ConvTranspose2d 2x2 s2 as a 1x1 GEMM with N = 4*Ct and a quadrant-scatter store
+            ConvLaunch c = conv_desc(base, L.up_t[i], B * ns, rp, rp, 1, S3D_ACT_NONE);
+            c.nsrc = 1;
+            c.src[0] = plain_src(prev, C);
+            c.out = ws + W.up;
+            c.out_mode = S3D_OUT_CONVT;
+            c.cout_store = Ct;
+            TRY(launch_conv(c, st));
+        }
+        {
+            ConvLaunch c = conv_desc(base, L.up_c1[i], B * ns, ro, ro, 3, S3D_ACT_RELU);
+            c.nsrc = 2;
+            c.src[0] = ConvSrc{ws + W.proj, Ct, ns, 0, 0};
+            c.src[1] = plain_src(ws + W.up, Ct);
+            c.out = ws + W.mid;
+            TRY(launch_conv(c, st));
+        }
+        {
+            ConvLaunch c = conv_desc(base, L.up_c2[i], B * ns, ro, ro, 3, S3D_ACT_RELU);
+            c.nsrc = 1;
+            c.src[0] = plain_src(ws + W.mid, Ct);
+            c.out = out->level[i + 1];
+            TRY(launch_conv(c, st));
+        }
+        prev = out->level[i + 1];
+        rp = ro;
+    }
+    if (slices_rec) {  // OutConv 1x1 + tanh -> NCHW (unet_parts.py:78-84)
+        ConvLaunch c = conv_desc(base, L.outc, B * ns, S, S, 1, S3D_ACT_TANH);
+        c.nsrc = 1;
+        c.src[0] = plain_src(prev, 32);
+        c.out = slices_rec;
+        c.out_mode = S3D_OUT_NCHW;
+        c.cout_store = 3;
+        TRY(launch_conv(c, st));
+    }
+    return 0;
+}
+
+// =============================================================================================
+// head
+// =============================================================================================
+HeadLayout head_layout() {
+    HeadLayout H;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += (n + 3) / 4 * 4;
+        return o;
+    };
+    H.fcp_w = take(128 * 3);
+    H.fcp_b = take(128);
+    H.fcs_b = take(128);
+    const int lc[3] = {512, 256, 128};
+    for (int l = 0; l < 3; ++l) H.wproj[l] = take((size_t)128 * lc[l]);
+    H.ws34 = take(128 * 96);
+    for (int l = 0; l < S3D_N_LAYERS; ++l) {
+        H.L[l].inw = take(384 * 128);
+        H.L[l].inb = take(384);
+        H.L[l].outw = take(128 * 128);
+        H.L[l].outb = take(128);
+        H.L[l].ln1g = take(128);
+        H.L[l].ln1b = take(128);
+        H.L[l].w1 = take((size_t)S3D_FFN * 128);
+        H.L[l].b1 = take(S3D_FFN);
+        H.L[l].w2 = take((size_t)128 * S3D_FFN);
+        H.L[l].b2 = take(128);
+        H.L[l].ln2g = take(128);
+        H.L[l].ln2b = take(128);
+    }
+    H.fco_w = take(128);
+    H.fco_b = take(4);
+    H.total = off;
+    return H;
+}
+
+extern "C" size_t s3d_head_packed_bytes(void) { return head_layout().total * sizeof(float); }
+
+static int copy_vec(float* dst, const float* src, size_t n, hipStream_t st) {
+    hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        s3d_set_error("head_pack: memcpy failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    S3D_CHECK_ARG(P && packed, "head_pack: null argument");
+    const HeadLayout H = head_layout();
+    if (packed_bytes < H.total * sizeof(float)) {
+        s3d_set_error("head_pack: packed buffer %zu < %zu bytes", packed_bytes, H.total * sizeof(float));
+        return S3D_E_WORKSPACE;
+    }
+    float* b = (float*)packed;
+    TRY(copy_vec(b + H.fcp_w, P->fc_p_w, 128 * 3, st));
+    TRY(copy_vec(b + H.fcp_b, P->fc_p_b, 128, st));
+    TRY(copy_vec(b + H.fcs_b, P->fc_s_b, 128, st));
+    const int lc[3] = {512, 256, 128}, lo[3] = {0, 512, 768};
+    for (int l = 0; l < 3; ++l) TRY(pack_linear(P->fc_s_w + lo[l], b + H.wproj[l], 128, 128, lc[l], 992, 0, st));
+    TRY(pack_linear(P->fc_s_w + 896, b + H.ws34, 128, 128, 96, 992, 0, st));
+    for (int l = 0; l < S3D_N_LAYERS; ++l) {
+        const S3dLayerParams& p = P->layer[l];
+        TRY(pack_linear(p.in_proj_w, b + H.L[l].inw, 384, 384, 128, 128, 0, st));
+        TRY(copy_vec(b + H.L[l].inb, p.in_proj_b, 384, st));
+        TRY(pack_linear(p.out_proj_w, b + H.L[l].outw, 128, 128, 128, 128, 0, st));
+        TRY(copy_vec(b + H.L[l].outb, p.out_proj_b, 128, st));
+        TRY(copy_vec(b + H.L[l].ln1g, p.norm1_w, 128, st));
+        TRY(copy_vec(b + H.L[l].ln1b, p.norm1_b, 128, st));
+        TRY(pack_linear(p.lin1_w, b + H.L[l].w1, S3D_FFN, S3D_FFN, 128, 128, 0, st));
+        TRY(copy_vec(b + H.L[l].b1, p.lin1_b, S3D_FFN, st));
+        TRY(pack_linear(p.lin2_w, b + H.L[l].w2, 128, 128, S3D_FFN, S3D_FFN, S3D_FFN_CHUNK / 16, st));
+        TRY(copy_vec(b + H.L[l].b2, p.lin2_b, 128, st));
+        TRY(copy_vec(b + H.L[l].ln2g, p.norm2_w, 128, st));
+        TRY(copy_vec(b + H.L[l].ln2b, p.norm2_b, 128, st));
+    }
+    TRY(copy_vec(b + H.fco_w, P->fc_out_w, 128, st));
+    TRY(copy_vec(b + H.fco_b, P->fc_out_b, 1, st));
+    return 0;
+}
+
+extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, const S3dLatent* out,
+                                void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    S3D_CHECK_ARG(head_packed && pyr && out, "latent_build: null argument");
+    S3D_CHECK_ARG(out->n_img == pyr->n_img && out->size == pyr->size, "latent_build: handle mismatch");
+    S3D_CHECK_ARG(out->fine[0] == pyr->level[3] && out->fine[1] == pyr->level[4],
+                  "latent_build: latent.fine must alias pyramid levels 3,4");
+    const HeadLayout H = head_layout();
+    const float* b = (const float*)head_packed;
+    const int lc[3] = {512, 256, 128};
+    for (int l = 0; l < 3; ++l) {
+        const int r = (pyr->size / 16) << l;
+        ConvLaunch c = {};
+        c.N = pyr->n_img; c.H = r; c.W = r; c.ks = 1;
+        c.CoutPad = 128; c.wpk = b + H.wproj[l]; c.KU = lc[l] / 16;
+        c.scale = nullptr; c.shift = nullptr;  // identity epilogue: fc_s bias is added by the sampler
+        c.act = S3D_ACT_NONE; c.out_mode = S3D_OUT_NHWC; c.cout_store = 128; c.out_cstride = 128;
+        c.nsrc = 1;
+        c.src[0] = plain_src(pyr->level[l], lc[l]);
+        c.out = out->proj[l];
+        TRY(launch_conv(c, st));
+    }
+    return 0;
+}
+
+// =============================================================================================
+// decode
+// =============================================================================================
+#define S3D_CHUNK_GROUPS 16384  // 262144 queries per pass: X = 16384*13*16*128*4 B = 1.74 GB
+
+struct DecodeWs {
+    size_t X, X0, total;
+};
+static DecodeWs decode_ws(int batch, long n_qry, int ns) {
+    const long gpb = (n_qry + S3D_GROUP - 1) / S3D_GROUP;
+    long g = gpb * batch;
+    if (g > S3D_CHUNK_GROUPS) g = S3D_CHUNK_GROUPS;
+    DecodeWs W;
+    W.X = 0;
+    W.X0 = (size_t)g * (ns + 1) * S3D_GROUP * 128;
+    W.total = W.X0 + (size_t)g * S3D_GROUP * 128;
+    return W;
+}
+
+extern "C" size_t s3d_decode_workspace_bytes(int batch, long n_qry, int n_slices) {
+    return decode_ws(batch, n_qry, n_slices).total * sizeof(float);
+}
+
+static LayerPtrs layer_ptrs(const float* b, const HeadLayout& H, int l) {
+    LayerPtrs p;
+    p.inw = b + H.L[l].inw; p.inb = b + H.L[l].inb; p.outw = b + H.L[l].outw; p.outb = b + H.L[l].outb;
+    p.ln1g = b + H.L[l].ln1g; p.ln1b = b + H.L[l].ln1b; p.w1 = b + H.L[l].w1; p.b1 = b + H.L[l].b1;
+    p.w2 = b + H.L[l].w2; p.b2 = b + H.L[l].b2; p.ln2g = b + H.L[l].ln2g; p.ln2b = b + H.L[l].ln2b;
+    return p;
+}
+
+static int decode_impl(const void* head_packed, const S3dLatent* lat, const float* qry, const float* rot,
+                       const float* trans, int flip_yz, int nx, float box, float sign, float* out, int batch,
+                       long n_qry, int ns, int prec, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    S3D_CHECK_ARG(head_packed && lat && trans && out && workspace, "decode: null argument");
+    S3D_CHECK_ARG(batch >= 1 && n_qry >= 1, "decode: batch=%d n_qry=%ld", batch, n_qry);
+    S3D_CHECK_ARG(ns >= 1 && ns <= 12, "decode: n_slices %d", ns);
+    S3D_CHECK_ARG(lat->n_img == batch * ns, "decode: latent has %d images, expected %d", lat->n_img, batch * ns);
+    S3D_CHECK_ARG(prec == S3D_PREC_F32, "decode: precision mode %d not built", prec);
+    const DecodeWs W = decode_ws(batch, n_qry, ns);
+    if (workspace_bytes < W.total * sizeof(float)) {
+        s3d_set_error("decode: workspace %zu < %zu bytes", workspace_bytes, W.total * sizeof(float));
+        return S3D_E_WORKSPACE;
+    }
+    const HeadLayout H = head_layout();
+    const float* b = (const float*)head_packed;
+    float* X = (float*)workspace + W.X;
+    float* X0 = (float*)workspace + W.X0;
+    const int T = ns + 1;
+    const long gpb = (n_qry + S3D_GROUP - 1) / S3D_GROUP;
+    const long G = gpb * batch;
+    for (long g0 = 0; g0 < G; g0 += S3D_CHUNK_GROUPS) {
+        const long gc = G - g0 < S3D_CHUNK_GROUPS ? G - g0 : S3D_CHUNK_GROUPS;
+        SampleArgs sa = {};
+        for (int l = 0; l < 3; ++l) sa.proj[l] = lat->proj[l];
+        sa.fine[0] = lat->fine[0]; sa.fine[1] = lat->fine[1];
+        sa.size = lat->size; sa.n_slices = ns;
+        sa.fcp_w = b + H.fcp_w; sa.fcp_b = b + H.fcp_b; sa.fcs_b = b + H.fcs_b; sa.ws34 = b + H.ws34;
+        sa.qry = qry; sa.rot = rot; sa.trans = trans; sa.flip_yz = flip_yz;
+        sa.n_qry = n_qry; sa.groups_per_batch = gpb; sa.g_begin = g0; sa.g_count = gc;
+        sa.nx = nx; sa.box = box; sa.X = X;
+        TRY(launch_sample_tokens(sa, st));
+        for (int l = 0; l < S3D_N_LAYERS; ++l) {
+            const LayerPtrs lp = layer_ptrs(b, H, l);
+            const bool last = l == S3D_N_LAYERS - 1;
+            TRY(launch_attn_layer(X, last ? X0 : nullptr, gc, T, lp, st));
+            if (!last)
+                TRY(launch_ffn_layer(X, gc * T * S3D_GROUP, lp, nullptr, nullptr, nullptr, 1.f, gpb, n_qry, g0,
+                                     prec, st));
+            else
+                TRY(launch_ffn_layer(X0, gc * S3D_GROUP, lp, b + H.fco_w, b + H.fco_b, out, sign, gpb, n_qry, g0,
+                                     prec, st));
+        }
+    }
+    return 0;
+}
+
+extern "C" int s3d_decode_points_fwd(const void* head_packed, const S3dLatent* latent, const float* qry,
+                                     const float* rot, const float* trans, int flip_yz, float* sdf_out,
+                                     int batch, long n_qry, int n_slices, int prec, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    S3D_CHECK_ARG(qry, "decode_points: qry is NULL");
+    return decode_impl(head_packed, latent, qry, rot, trans, flip_yz, 0, 1.f, 1.f, sdf_out, batch, n_qry,
+                       n_slices, prec, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int s3d_decode_grid_fwd(const void* head_packed, const S3dLatent* latent, const float* trans, int nx,
+                                   float box, float* logits_out, int n_slices, int prec, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    S3D_CHECK_ARG(nx >= 2 && nx <= 1024, "decode_grid: nx %d", nx);
+    const long n = (long)nx * nx * nx;
+    // mode='test' prologue (reconstruct.py:336 builds the model with mode='test'); logits = -sdf
+    return decode_impl(head_packed, latent, nullptr, nullptr, trans, 1, nx, box, -1.f, logits_out, 1, n, n_slices,
+                       prec, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// =============================================================================================
+// stand-alone ops
+// =============================================================================================
+extern "C" int s3d_project_coord_fwd(const float* coords, const float* trans, float* out, int batch, long n_qry,
+                                     void* stream) {
+    S3D_CHECK_ARG(coords && trans && out, "project_coord: null argument");
+    return launch_project_coord(coords, trans, out, batch, n_qry, (hipStream_t)stream);
+}
+
+extern "C" int s3d_sample_planes_fwd(const float* plane, const float* grid, float* out, int n, int h, int w,
+                                     int c, long m, void* stream) {
+    S3D_CHECK_ARG(plane && grid && out, "sample_planes: null argument");
+    S3D_CHECK_ARG(n >= 1 && h >= 1 && w >= 1 && m >= 0, "sample_planes: bad dims");
+    return launch_sample_planes(plane, grid, out, n, h, w, c, m, (hipStream_t)stream);
+}
+
+extern "C" int s3d_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, void* stream) {
+    S3D_CHECK_ARG(in && out, "nchw_to_nhwc: null argument");
+    return launch_nchw_to_nhwc(in, out, n, c, h, w, c, (hipStream_t)stream);
+}
+
+extern "C" int s3d_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, void* stream) {
+    S3D_CHECK_ARG(in && out, "nhwc_to_nchw: null argument");
+    return launch_nhwc_to_nchw(in, out, n, c, h, w, (hipStream_t)stream);
+}

@@ -1,0 +1,71 @@
+// common.h — shared device helpers for libslice3d_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/slice3d_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// MFMA  v_mfma_f32_16x16x4_f32  (exact fp32: bitwise a k-ordered fmaf chain).
+// Operand maps (cdna_hip_programming.md section 3):  lane l:  A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15],  C/D[row = (l>>4)*4 + reg][col = l&15].
+// Every GEMM in this library is written in the "swapped" form  D^T = W * X^T :
+//   A <- weight rows (output channel r = l&15, k-slot g = l>>4)
+//   B <- activation rows (row / pixel / query m = l&15, k-slot g = l>>4)
+//   D[reg i] = out[m = l&15][n = 4*g + i]
+// so a lane owns 4 CONSECUTIVE output channels of ONE activation row (16-byte stores), and the D
+// registers of one GEMM are directly the B operand of the next one (k-slot g <-> channel 4*g+i).
+// A 16-deep K chunk is consumed by 4 MFMA steps e = 0..3 with k-slot g <-> k = 4*g + e, so each
+// operand fragment of a chunk is one 16-byte (f32x4) load per lane.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// sum over the 4 lanes that share l&15 (the 4 k-slot groups of one activation row)
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// Packed weight fragment image: W[N][K] (N, K multiples of 16) is stored as
+//   P[(j*KU + u)*256 + lane*4 + e] = W[16*j + (lane&15)][16*u + 4*(lane>>4) + e],   KU = K/16
+// so the A fragment of (row tile j, k chunk u) is one contiguous, lane-linear 1 KiB block:
+// coalesced from global, conflict-free from LDS.
+__device__ __forceinline__ const float* frag_ptr(const float* packed, int j, int u, int KU, int lane) {
+    return packed + ((size_t)(j * KU + u) * 64 + lane) * 4;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side error plumbing
+// ---------------------------------------------------------------------------------------------
+void s3d_set_error(const char* fmt, ...);
+#define S3D_CHECK_ARG(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            s3d_set_error(__VA_ARGS__);     \
+            return S3D_E_ARG;               \
+        }                                   \
+    } while (0)
+#define S3D_LAUNCH_CHECK()                                            \
+    do {                                                              \
+        hipError_t e__ = hipGetLastError();                           \
+        if (e__ != hipSuccess) {                                      \
+            s3d_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return (int)e__;                                          \
+        }                                                             \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,63 @@
+// conv.h — internal interface of the implicit-GEMM convolution engine (conv.hip).
+#pragma once
+#include "common.h"
+
+// One activation source of a convolution.  The K loop walks sources in order, which gives the
+// reference's torch.cat([skip, up], 1) (unet_parts.py:73) without materialising the concat, and
+// expand_bs (unet_custom.py:35-38) / the slice-embedding tile (unet_custom.py:52) without tiling:
+//   source image index = (bmod ? n % bmod : n) / bdiv ;  sbcast: one C-vector per image, any pixel.
+struct ConvSrc {
+    const float* p;  // (n_src, H, W, C) NHWC   (or (n_src, C) when sbcast)
+    int C;           // multiple of 16
+    int bdiv, bmod, sbcast;
+};
+
+enum { S3D_ACT_NONE = 0, S3D_ACT_RELU = 1, S3D_ACT_TANH = 2 };
+enum { S3D_OUT_NHWC = 0, S3D_OUT_CONVT = 1, S3D_OUT_NCHW = 2 };
+
+struct ConvLaunch {
+    ConvSrc src[2];
+    int nsrc;
+    int N, H, W;         // images and spatial size of the output grid (= input grid, "same" padding)
+    int ks;              // 1 or 3
+    int CoutPad;         // GEMM N, multiple of 16 (padded rows of the packed weight are zero)
+    const float* wpk;    // packed A fragments [CoutPad/16][KU][64][4]
+    int KU;              // total K chunks = sum over sources of ks*ks*C/16
+    const float* scale;  // [CoutPad]  y = acc*scale + shift   (BN folded / bias)
+    const float* shift;  // [CoutPad]
+    int act;
+    float* out;
+    int out_mode;
+    int cout_store;      // channels actually stored (NHWC/NCHW), or Ct of a ConvT (CoutPad = 4*Ct)
+    int out_cstride;     // channel stride of the NHWC output tensor
+};
+
+int launch_conv(const ConvLaunch& a, hipStream_t stream);
+
+// weight / epilogue packers (device kernels behind them)
+enum { S3D_PACK_LINEAR = 0, S3D_PACK_CONV = 1, S3D_PACK_CONVT = 2 };
+// dst fragment image rows [0, n_pad) x chunks [u_off, u_off + ku_seg) of a KU_total-wide image.
+//  LINEAR: elem(n,k) = src[n*ld + k]                      (k < k_valid)
+//  CONV:   k = tap*cseg + c ; elem = src[(n*cin_tot + cin_begin + c)*taps + tap]  (c < cseg_valid)
+//  CONVT:  n = q*ct + co ; elem(n, k=ci) = src[(ci*ct + co)*4 + q]                (ci < k_valid)
+struct PackArgs {
+    const float* src;
+    float* dst;
+    int kind;
+    int n_valid, n_pad;
+    int KU_total, u_off, ku_seg;
+    int ld, k_valid;
+    int taps, cseg, cseg_valid, cin_tot, cin_begin;
+    int ct;
+    int chunk_ku;  // LINEAR only: if > 0 the image is stored [k-chunk group][row tile][chunk_ku] (FFN W2 staging order)
+};
+int launch_pack(const PackArgs& a, hipStream_t stream);
+// scale/shift for conv epilogues.  bn may be all-NULL (scale = 1, shift = bias or 0).
+// rep > 1 tiles the vector (ConvT: 4 quadrants share the bias).
+int launch_fold_bn(const float* bias, const float* const bn[4], float* scale, float* shift, int c_valid,
+                   int c_pad, int rep, int bias_before_bn, hipStream_t stream);
+
+int launch_bn_relu_pool(const float* in, const float* scale, const float* shift, float* out, int n, int h,
+                        int w, int c, hipStream_t stream);
+int launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int cpad, hipStream_t stream);
+int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, hipStream_t stream);

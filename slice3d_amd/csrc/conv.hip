@@ -1,0 +1,330 @@
+// conv.hip — implicit-GEMM convolution engine for the U-Net slice generator (gfx950, fp32 MFMA).
+//
+// Replaces the stock ATen ops the reference calls in reg_slices/src/unet_custom.py:40-69 and
+// reg_slices/src/unet_parts.py:8-84: conv2d 3x3 (pad 1) / 1x1, conv_transpose2d 2x2 s2, eval-mode
+// batch_norm, relu, max_pool2d 2x2, tanh, torch.cat along channels and the batch tiling of expand_bs.
+//
+// GEMM view (swapped form, see common.h):  out^T[co][pixel] = sum_k Wp[co][k] * patch[pixel][k],
+//   M = pixels of all images (flattened, so any H/W incl. 2x2 maps works), N = Cout,
+//   K = sum over sources of ks*ks*C   (k order: source, tap, channel).
+// A fragments (weights) come from the pre-packed lane-linear image (1 KiB contiguous per fragment,
+// L2-resident); B fragments (activations) are 16-byte per-lane loads from the NHWC tensors, zero for
+// padding taps.  fp32 MFMA runs at 256 FLOP/clk/CU, i.e. one 16-byte operand load feeds 128 cycles of
+// MFMA per (MT|NT)-fold reuse, so the operand streams fit the L1/L2 path at this precision.
+#include "conv.h"
+
+template <int MT, int NT, int WM, int WN, int KS>
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvLaunch a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int m = lane & 15, g = lane >> 4;
+    constexpr int PIX_WG = WM * MT * 16;
+    constexpr int CO_WG = WN * NT * 16;
+    const long P = (long)a.N * a.H * a.W;
+    const int n_co_blk = a.CoutPad / CO_WG;
+    const int blk_co = blockIdx.x % n_co_blk;
+    const long blk_px = blockIdx.x / n_co_blk;
+    const int HW = a.H * a.W;
+
+    int pn[MT], py[MT], px[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long p = blk_px * PIX_WG + (long)(wm * MT + mt) * 16 + m;
+        pv[mt] = p < P;
+        const long pc = pv[mt] ? p : 0;
+        pn[mt] = (int)(pc / HW);
+        const int r = (int)(pc - (long)pn[mt] * HW);
+        py[mt] = r / a.W;
+        px[mt] = r - py[mt] * a.W;
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero4();
+
+    const int jt0 = blk_co * (CO_WG / 16) + wn * NT;
+    int ubase = 0;
+#pragma unroll 1
+    for (int s = 0; s < a.nsrc; ++s) {
+        const ConvSrc S = a.src[s];
+        const int cu = S.C >> 4;
+#pragma unroll 1
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int dy = tap / KS - KS / 2, dx = tap % KS - KS / 2;
+            const float* bp[MT];
+            bool ok[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int y = py[mt] + dy, x = px[mt] + dx;
+                ok[mt] = pv[mt] && y >= 0 && y < a.H && x >= 0 && x < a.W;
+                const int ni = (S.bmod ? pn[mt] % S.bmod : pn[mt]) / S.bdiv;
+                const long off = S.sbcast ? (long)ni * S.C : ((long)(ni * a.H + y) * a.W + x) * S.C;
+                bp[mt] = S.p + (ok[mt] ? off : 0) + 4 * g;
+            }
+            const float* wp = frag_ptr(a.wpk, jt0, ubase + tap * cu, a.KU, lane);
+#pragma unroll 2
+            for (int c = 0; c < cu; ++c) {
+                f32x4 b[MT], w[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) b[mt] = ok[mt] ? ld4(bp[mt] + 16 * c) : zero4();
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w[nt] = ld4(wp + ((size_t)nt * a.KU + c) * 256);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma4(w[nt], b[mt], acc[mt][nt]);
+            }
+        }
+        ubase += KS * KS * cu;
+    }
+
+    // epilogue: lane owns channels co..co+3 of pixel (pn,py,px)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = (jt0 + nt) * 16 + 4 * g;
+        const f32x4 sc = a.scale ? ld4(a.scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh = a.shift ? ld4(a.shift + co) : zero4();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!pv[mt]) continue;
+            f32x4 v = acc[mt][nt] * sc + sh;
+            if (a.act == S3D_ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            } else if (a.act == S3D_ACT_TANH) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = tanhf(v[i]);
+            }
+            if (a.out_mode == S3D_OUT_NHWC) {
+                if (co < a.cout_store) {  // cout_store is a multiple of 4 in this mode
+                    float* o = a.out + ((long)(pn[mt] * a.H + py[mt]) * a.W + px[mt]) * a.out_cstride + co;
+                    st4(o, v);
+                }
+            } else if (a.out_mode == S3D_OUT_CONVT) {
+                const int ct = a.cout_store;  // multiple of 16: a lane's 4 channels share a quadrant
+                const int q = co / ct, c = co - q * ct;
+                if (q < 4) {
+                    const int oy = 2 * py[mt] + (q >> 1), ox = 2 * px[mt] + (q & 1);
+                    float* o = a.out + ((long)(pn[mt] * 2 * a.H + oy) * (2 * a.W) + ox) * ct + c;
+                    st4(o, v);
+                }
+            } else {  // NCHW, arbitrary cout_store
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (co + i < a.cout_store)
+                        a.out[((long)(pn[mt] * a.cout_store + co + i) * a.H + py[mt]) * a.W + px[mt]] = v[i];
+            }
+        }
+    }
+}
+
+template <int MT, int NT, int WM, int WN>
+static int launch_cfg(const ConvLaunch& a, hipStream_t stream) {
+    constexpr int PIX_WG = WM * MT * 16, CO_WG = WN * NT * 16;
+    const long P = (long)a.N * a.H * a.W;
+    const long nblk = ((P + PIX_WG - 1) / PIX_WG) * (a.CoutPad / CO_WG);
+    S3D_CHECK_ARG(nblk > 0 && nblk < (1L << 31), "conv grid out of range (%ld)", nblk);
+    dim3 grid((unsigned)nblk), block(WM * WN * 64);
+    if (a.ks == 3)
+        hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, WM, WN, 3>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, WM, WN, 1>), grid, block, 0, stream, a);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_conv(const ConvLaunch& a, hipStream_t stream) {
+    S3D_CHECK_ARG(a.ks == 1 || a.ks == 3, "conv: ks must be 1 or 3");
+    S3D_CHECK_ARG(a.CoutPad % 16 == 0 && a.CoutPad > 0, "conv: CoutPad %d", a.CoutPad);
+    for (int s = 0; s < a.nsrc; ++s)
+        S3D_CHECK_ARG(a.src[s].C % 16 == 0 && a.src[s].bdiv >= 1, "conv: bad source %d", s);
+    const long P = (long)a.N * a.H * a.W;
+    // Tile menu: (pixels x couts) per workgroup of 4 waves.  Prefer the largest tile that still
+    // yields >= ~2 workgroups per CU; small late-encoder maps fall through to the small tiles.
+    const long want = 512;
+    auto nblk = [&](int pix, int co) { return ((P + pix - 1) / pix) * (a.CoutPad / co); };
+    if (a.CoutPad % 128 == 0) {
+        if (nblk(128, 128) >= want) return launch_cfg<4, 4, 2, 2>(a, stream);
+        if (nblk(64, 128) >= want) return launch_cfg<2, 4, 2, 2>(a, stream);
+        if (a.CoutPad % 128 == 0 && nblk(32, 128) >= want / 2) return launch_cfg<1, 4, 2, 2>(a, stream);
+        return launch_cfg<1, 1, 2, 2>(a, stream);  // 32 px x 32 co
+    }
+    if (a.CoutPad % 64 == 0) {
+        if (nblk(256, 64) >= want) return launch_cfg<4, 4, 4, 1>(a, stream);
+        if (nblk(64, 64) >= want / 2) return launch_cfg<2, 2, 2, 2>(a, stream);
+        return launch_cfg<1, 1, 2, 2>(a, stream);
+    }
+    if (a.CoutPad % 32 == 0) {
+        if (nblk(256, 32) >= want) return launch_cfg<4, 2, 4, 1>(a, stream);
+        return launch_cfg<1, 1, 2, 2>(a, stream);
+    }
+    if (nblk(256, 16) >= want) return launch_cfg<4, 1, 4, 1>(a, stream);
+    return launch_cfg<1, 1, 4, 1>(a, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// packers
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_frag_kernel(const PackArgs a) {
+    const long total = (long)(a.n_pad / 16) * a.ku_seg * 256;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int e = idx & 3, lane = (idx >> 2) & 63;
+        const long fu = idx >> 8;
+        const int ul = (int)(fu % a.ku_seg), j = (int)(fu / a.ku_seg);
+        const int n = 16 * j + (lane & 15);
+        const int k = 16 * ul + 4 * (lane >> 4) + e;
+        float v = 0.f;
+        if (n < a.n_valid) {
+            if (a.kind == S3D_PACK_LINEAR) {
+                if (k < a.k_valid) v = a.src[(long)n * a.ld + k];
+            } else if (a.kind == S3D_PACK_CONV) {
+                const int tap = k / a.cseg, c = k - tap * a.cseg;
+                if (c < a.cseg_valid) v = a.src[((long)n * a.cin_tot + a.cin_begin + c) * a.taps + tap];
+            } else {
+                const int q = n / a.ct, co = n - q * a.ct;
+                if (k < a.k_valid) v = a.src[((long)k * a.ct + co) * 4 + q];
+            }
+        }
+        long fi;
+        if (a.chunk_ku > 0)
+            fi = ((long)(ul / a.chunk_ku) * (a.n_pad / 16) + j) * a.chunk_ku + ul % a.chunk_ku;
+        else
+            fi = (long)j * a.KU_total + a.u_off + ul;
+        a.dst[(fi * 64 + lane) * 4 + e] = v;
+    }
+}
+
+int launch_pack(const PackArgs& a, hipStream_t stream) {
+    S3D_CHECK_ARG(a.n_pad % 16 == 0 && a.ku_seg > 0, "pack: bad dims");
+    const long total = (long)(a.n_pad / 16) * a.ku_seg * 256;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void fold_bn_kernel(const float* bias, const float* g, const float* b, const float* mu,
+                               const float* var, float* scale, float* shift, int c_valid, int c_pad, int rep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c_pad) return;
+    float sc = 1.f, sh = 0.f;
+    if (i < c_valid * rep) {
+        const int c = i % c_valid;
+        const float bv = bias ? bias[c] : 0.f;
+        if (g) {
+            sc = g[c] / sqrtf(var[c] + 1e-5f);
+            sh = (bv - mu[c]) * sc + b[c];
+        } else {
+            sh = bv;
+        }
+    }
+    scale[i] = sc;
+    shift[i] = sh;
+}
+
+int launch_fold_bn(const float* bias, const float* const bn[4], float* scale, float* shift, int c_valid,
+                   int c_pad, int rep, int, hipStream_t stream) {
+    const float* g = bn ? bn[0] : nullptr;
+    hipLaunchKernelGGL(fold_bn_kernel, dim3((c_pad + 127) / 128), dim3(128), 0, stream, bias, g,
+                       g ? bn[1] : nullptr, g ? bn[2] : nullptr, g ? bn[3] : nullptr, scale, shift, c_valid,
+                       c_pad, rep);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BN(eval) + ReLU + MaxPool2d(2)  on NHWC  (the block that opens down2..down5, unet_custom.py:13-19)
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_relu_pool_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, float* __restrict__ out, int n, int h,
+                                    int w, int c) {
+    const int c4 = c >> 2, ho = h >> 1, wo = w >> 1;
+    const long total = (long)n * ho * wo * c4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(idx % c4) * 4;
+        long r = idx / c4;
+        const int x = (int)(r % wo);
+        r /= wo;
+        const int y = (int)(r % ho);
+        const int ni = (int)(r / ho);
+        const f32x4 sc = ld4(scale + cc), sh = ld4(shift + cc);
+        f32x4 best;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float* p = in + ((long)(ni * h + 2 * y + (t >> 1)) * w + 2 * x + (t & 1)) * c + cc;
+            f32x4 v = ld4(p) * sc + sh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = fmaxf(v[i], 0.f);
+                best[i] = t == 0 ? v[i] : fmaxf(best[i], v[i]);
+            }
+        }
+        st4(out + idx * 4, best);
+    }
+}
+
+int launch_bn_relu_pool(const float* in, const float* scale, const float* shift, float* out, int n, int h,
+                        int w, int c, hipStream_t stream) {
+    S3D_CHECK_ARG(c % 4 == 0 && h % 2 == 0 && w % 2 == 0, "pool: bad dims");
+    const long total = (long)n * (h / 2) * (w / 2) * (c / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(blocks), dim3(256), 0, stream, in, scale, shift, out, n, h, w,
+                       c);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int c,
+                                    int h, int w, int cpad) {
+    const long total = (long)n * h * w * cpad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(idx % cpad);
+        long r = idx / cpad;
+        const int x = (int)(r % w);
+        r /= w;
+        const int y = (int)(r % h);
+        const int ni = (int)(r / h);
+        out[idx] = cc < c ? in[((long)(ni * c + cc) * h + y) * w + x] : 0.f;
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int c,
+                                    int h, int w) {
+    const long total = (long)n * c * h * w;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w);
+        long r = idx / w;
+        const int y = (int)(r % h);
+        r /= h;
+        const int cc = (int)(r % c);
+        const int ni = (int)(r / c);
+        out[idx] = in[((long)(ni * h + y) * w + x) * c + cc];
+    }
+}
+
+int launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int cpad, hipStream_t stream) {
+    const long total = (long)n * h * w * cpad;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, in, out, n, c, h, w, cpad);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, hipStream_t stream) {
+    const long total = (long)n * c * h * w;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, stream, in, out, n, c, h, w);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,61 @@
+// decode.h — internal interface of the per-query decoder kernels (decode.hip).
+#pragma once
+#include "common.h"
+
+#define S3D_GROUP 16          // queries per group = one MFMA row tile per token
+#define S3D_FFN_CHUNK 32      // hidden units staged per LDS chunk
+#define S3D_FFN_NCHUNK (S3D_FFN / S3D_FFN_CHUNK)
+
+// offsets (in floats) into the packed head-weight image
+struct HeadLayout {
+    size_t fcp_w, fcp_b, fcs_b;
+    size_t wproj[3];   // fc_s column blocks of pyramid levels 0..2 as [8][C_l/16] fragment images
+    size_t ws34;       // fc_s columns 896..991 (levels 3,4) as an [8][6] fragment image
+    struct {
+        size_t inw, inb, outw, outb, ln1g, ln1b;
+        size_t w1, b1, w2, b2, ln2g, ln2b;   // w1: [128 tiles][8] image; w2: chunked [64][8][2] image
+    } L[S3D_N_LAYERS];
+    size_t fco_w, fco_b;
+    size_t total;
+};
+HeadLayout head_layout();
+
+struct LayerPtrs {
+    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+};
+
+struct SampleArgs {
+    // latent
+    const float* proj[3];
+    const float* fine[2];
+    int size;            // S
+    int n_slices;        // T = n_slices + 1 tokens
+    // head
+    const float *fcp_w, *fcp_b, *fcs_b, *ws34;
+    // queries
+    const float* qry;    // (B,Q,3) or NULL in grid mode
+    const float* rot;    // (B,3,3) or NULL
+    const float* trans;  // (B,4,3)
+    int flip_yz;
+    long n_qry;          // Q per batch item
+    long groups_per_batch;
+    long g_begin, g_count;   // group range handled by this launch (chunking)
+    // grid mode (qry == NULL): coordinates box*linspace(-.5,.5,nx) generated from the query index
+    int nx;
+    float box;
+    float* X;            // out [g_count][T][16][128]
+};
+
+int launch_sample_tokens(const SampleArgs& a, hipStream_t stream);
+// X: [groups][T][16][128] in place;  if x0_out != NULL this is the LAST layer: only token 0 is
+// produced, compactly, into x0_out [groups*16][128].
+int launch_attn_layer(float* X, float* x0_out, long groups, int T, const LayerPtrs& w, hipStream_t stream);
+// rows x 128 in place; if sdf_out != NULL: final layer, writes sign*(fc_out(LN2(..))) per row instead.
+int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w, const float* fco_b,
+                     float* sdf_out, float sign, long groups_per_batch, long n_qry, long g_begin, int prec,
+                     hipStream_t stream);
+
+int launch_project_coord(const float* coords, const float* trans, float* out, int batch, long n_qry,
+                         hipStream_t stream);
+int launch_sample_planes(const float* plane, const float* grid, float* out, int n, int h, int w, int c, long m,
+                         hipStream_t stream);

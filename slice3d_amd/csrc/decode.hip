@@ -1,0 +1,564 @@
+// decode.hip — per-query decoder of Slices3DRegModel (gfx950, fp32 MFMA).
+//
+// Replaces reg_slices/src/models.py:53-84: query rotation/flip, project_coord (models.py:28-36),
+// 5x sample_from_planes (models.py:38-46,69-78), fc_p/fc_s (models.py:79-80), the 3-layer post-LN
+// nn.TransformerEncoder (d=128, 4 heads, FFN 2048, relu; models.py:18-19,83) and fc_out (models.py:84).
+//
+// Token tensor layout in HBM:  X[group][token t][16 queries][128]  (group = 16 consecutive queries of
+// one batch item; token 0 = point token, token 1+s = slice s), so every 16x128 block is one MFMA row
+// tile of ONE token index and the token-0 rows needed by the pruned last layer are whole tiles.
+//
+// All GEMMs use the swapped form of common.h: a lane (m = l&15, g = l>>4) holds, for activation row m,
+// the 4-channel groups {16j + 4g .. +3}.  The same registers serve as B operand of the next GEMM, as
+// residual input and as the layout of the LayerNorm reductions (4 lanes per row -> 2 shuffles).
+#include "decode.h"
+
+#define LN_EPS 1e-5f
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------
+struct Tap4 {          // bilinear footprint of one query in one level (grid_sample, align_corners=True)
+    int off[4];        // element offset of the tap pixel (before * C), clamped in-bounds
+    float w[4];        // tap weight, 0 for out-of-bounds taps (padding_mode='zeros')
+};
+
+__device__ __forceinline__ Tap4 make_taps(float gx, float gy, int W, int H) {
+    // ATen grid_sampler_unnormalize (align_corners): ((coord + 1) / 2) * (size - 1)
+    const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    const float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float xe = x0f + 1.f, ye = y0f + 1.f;
+    Tap4 t;
+    const float wnw = (xe - ix) * (ye - iy), wne = (ix - x0f) * (ye - iy);
+    const float wsw = (xe - ix) * (iy - y0f), wse = (ix - x0f) * (iy - y0f);
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    t.off[0] = cy0 * W + cx0; t.w[0] = (vx0 && vy0) ? wnw : 0.f;
+    t.off[1] = cy0 * W + cx1; t.w[1] = (vx1 && vy0) ? wne : 0.f;
+    t.off[2] = cy1 * W + cx0; t.w[2] = (vx0 && vy1) ? wsw : 0.f;
+    t.off[3] = cy1 * W + cx1; t.w[3] = (vx1 && vy1) ? wse : 0.f;
+    return t;
+}
+
+// project_coord (models.py:28-36): [x y z 1] @ T(4x3); uv = XY / Z; 2(uv - .5); clamp [-1,1]
+__device__ __forceinline__ void project(const float* T, float x, float y, float z, float& gx, float& gy) {
+    const float X = x * T[0] + y * T[3] + z * T[6] + T[9];
+    const float Y = x * T[1] + y * T[4] + z * T[7] + T[10];
+    const float Z = x * T[2] + y * T[5] + z * T[8] + T[11];
+    gx = fminf(fmaxf(2.f * (X / Z - 0.5f), -1.f), 1.f);
+    gy = fminf(fmaxf(2.f * (Y / Z - 0.5f), -1.f), 1.f);
+}
+
+// torch.linspace(start,end,steps)[i] as ATen computes it (symmetric halves)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    const float step = (end - start) / (float)(steps - 1);
+    return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+// LayerNorm over the 128 channels of a row held as y[8] (f32x4) by the 4 lanes sharing l&15
+__device__ __forceinline__ void layer_norm_row(f32x4 (&y)[8], const float* gamma, const float* beta, int g) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (y[j][0] + y[j][1]) + (y[j][2] + y[j][3]);
+    const float mean = quad_sum(s) * (1.f / 128.f);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = y[j][i] - mean;
+            v += d * d;
+        }
+    const float rstd = 1.f / sqrtf(quad_sum(v) * (1.f / 128.f) + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f32x4 ga = ld4(gamma + 16 * j + 4 * g), be = ld4(beta + 16 * j + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[j][i] = (y[j][i] - mean) * rstd * ga[i] + be[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: query prologue + pyramid sampling + fc_p/fc_s  ->  X[group][T][16][128]
+//     levels 0-2: fc_s already folded into 128-channel maps -> pure weighted gather-accumulate
+//     levels 3-4: 96 raw channels sampled straight into MFMA B fragments, times Ws34 (LDS) on MFMA
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_ws34[8 * 6 * 256];  // 48 KiB
+    for (int i = threadIdx.x; i < 8 * 6 * 64; i += 256) st4(s_ws34 + 4 * i, ld4(a.ws34 + 4 * i));
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int T = a.n_slices + 1;
+    const int S = a.size;
+
+    for (long gi = blockIdx.x; gi < a.g_count; gi += gridDim.x) {
+        const long grp = a.g_begin + gi;
+        const int b = (int)(grp / a.groups_per_batch);
+        long q = (grp % a.groups_per_batch) * S3D_GROUP + m;
+        if (q >= a.n_qry) q = a.n_qry - 1;  // padded rows recompute the last query; never stored to sdf
+        float x, y, z;
+        if (a.qry) {
+            const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
+            x = p[0]; y = p[1]; z = p[2];
+        } else {  // dense grid: x slowest, z fastest (common.py:145-164)
+            const long nn = (long)a.nx * a.nx;
+            const int ixg = (int)(q / nn), iyg = (int)((q / a.nx) % a.nx), izg = (int)(q % a.nx);
+            x = a.box * linspace_at(-0.5f, 0.5f, a.nx, ixg);
+            y = a.box * linspace_at(-0.5f, 0.5f, a.nx, iyg);
+            z = a.box * linspace_at(-0.5f, 0.5f, a.nx, izg);
+        }
+        if (a.flip_yz) {  // mode='test' (models.py:53-56)
+            y = -y; z = -z;
+        } else if (a.rot) {  // qry @ obj_rot_mat (models.py:58-60)
+            const float* R = a.rot + b * 9;
+            const float rx = x * R[0] + y * R[3] + z * R[6];
+            const float ry = x * R[1] + y * R[4] + z * R[7];
+            const float rz = x * R[2] + y * R[5] + z * R[8];
+            x = rx; y = ry; z = rz;
+        }
+        float gx, gy;
+        project(a.trans + b * 12, x, y, z, gx, gy);
+
+        for (int t = wave; t < T; t += 4) {
+            f32x4 acc[8];
+            if (t == 0) {  // fc_p (models.py:79)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = 16 * j + 4 * g + i;
+                        acc[j][i] = a.fcp_w[c * 3 + 0] * x + a.fcp_w[c * 3 + 1] * y + a.fcp_w[c * 3 + 2] * z +
+                                    a.fcp_b[c];
+                    }
+            } else {
+                const long img = (long)b * a.n_slices + (t - 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = ld4(a.fcs_b + 16 * j + 4 * g);
+                // levels 0..2: projected maps (img, H, W, 128)
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {
+                    const int W = S >> (4 - l);
+                    const Tap4 tp = make_taps(gx, gy, W, W);
+                    const float* base = a.proj[l] + img * (long)W * W * 128 + 4 * g;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float* p = base + (long)tp.off[k] * 128;
+                        const float w = tp.w[k];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] += ld4(p + 16 * j) * w;
+                    }
+                }
+                // levels 3,4: raw 64 + 32 channels -> B fragments of a K=96 GEMM with Ws34
+                f32x4 braw[6];
+                {
+                    const int W = S >> 1;
+                    const Tap4 tp = make_taps(gx, gy, W, W);
+                    const float* base = a.fine[0] + img * (long)W * W * 64 + 4 * g;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        f32x4 v = zero4();
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v += ld4(base + (long)tp.off[k] * 64 + 16 * u) * tp.w[k];
+                        braw[u] = v;
+                    }
+                }
+                {
+                    const int W = S;
+                    const Tap4 tp = make_taps(gx, gy, W, W);
+                    const float* base = a.fine[1] + img * (long)W * W * 32 + 4 * g;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        f32x4 v = zero4();
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v += ld4(base + (long)tp.off[k] * 32 + 16 * u) * tp.w[k];
+                        braw[4 + u] = v;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        acc[j] = mfma4(ld4(s_ws34 + ((j * 6 + u) * 64 + lane) * 4), braw[u], acc[j]);
+            }
+            float* o = a.X + ((gi * T + t) * S3D_GROUP + m) * 128 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(o + 16 * j, acc[j]);
+        }
+    }
+}
+
+int launch_sample_tokens(const SampleArgs& a, hipStream_t stream) {
+    S3D_CHECK_ARG(a.size % 16 == 0 && a.size >= 16, "sample: size %d", a.size);
+    S3D_CHECK_ARG(a.n_slices >= 1 && a.n_slices + 1 <= S3D_N_TOKENS_MAX, "sample: n_slices %d", a.n_slices);
+    const long blocks = a.g_count < 2048 ? a.g_count : 2048;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL(sample_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: self-attention block of one encoder layer:  X <- LN1(X + out_proj(MHA(X)))
+//     one workgroup (4 waves) per group of 16 queries; wave w owns token tiles t = w, w+4, w+8, w+12.
+//     per head: QKV_h on MFMA -> LDS -> per-(query,token) softmax attention on VALU -> LDS ->
+//     out_proj partial sums on MFMA (accumulated over heads in registers).
+// ---------------------------------------------------------------------------------------------
+#define QKV_LD 100   // floats per row of the per-head QKV buffer (96 + pad: conflict-free b128 rows)
+#define OH_LD 36     // floats per row of the per-head attention output buffer (32 + pad)
+#define ATT_MAXT 4   // token tiles per wave (T <= 16)
+
+template <bool LAST>
+__global__ __launch_bounds__(256) void attn_layer_kernel(float* X, float* x0_out, long groups, int T,
+                                                         const LayerPtrs w) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_qkv = smem;                                   // [T*16][QKV_LD]
+    float* s_oh = smem + S3D_N_TOKENS_MAX * 16 * QKV_LD;   // [T*16][OH_LD]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const float scale = 0.17677669529663687f;  // 1/sqrt(32)
+
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        float* Xg = X + grp * T * S3D_GROUP * 128;
+        // B fragments of the owned token tiles
+        f32x4 xb[ATT_MAXT][8];
+#pragma unroll
+        for (int ti = 0; ti < ATT_MAXT; ++ti) {
+            const int t = wave + 4 * ti;
+            if (t < T) {
+                const float* p = Xg + (t * S3D_GROUP + m) * 128 + 4 * g;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xb[ti][u] = ld4(p + 16 * u);
+            }
+        }
+        f32x4 acc_o[LAST ? 1 : ATT_MAXT][8];
+#pragma unroll
+        for (int ti = 0; ti < (LAST ? 1 : ATT_MAXT); ++ti)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc_o[ti][j] = zero4();
+
+#pragma unroll 1
+        for (int h = 0; h < 4; ++h) {
+            // ---- QKV_h = X Wqkv_h^T + b  (6 column tiles of 16: Q0 Q1 K0 K1 V0 V1) ----
+#pragma unroll
+            for (int ti = 0; ti < ATT_MAXT; ++ti) {
+                const int t = wave + 4 * ti;
+                if (t >= T) continue;
+#pragma unroll
+                for (int jj = 0; jj < 6; ++jj) {
+                    if (LAST && jj < 2 && t != 0) continue;  // Q only for token 0 in the last layer
+                    const int jg = (jj >> 1) * 8 + h * 2 + (jj & 1);
+                    f32x4 c = zero4();
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) c = mfma4(ld4(frag_ptr(w.inw, jg, u, 8, lane)), xb[ti][u], c);
+                    c += ld4(w.inb + 16 * jg + 4 * g);
+                    st4(s_qkv + (t * S3D_GROUP + m) * QKV_LD + 16 * jj + 4 * g, c);
+                }
+            }
+            __syncthreads();
+            // ---- softmax(q k^T / sqrt(32)) v  per (query ql, token tq): one thread each ----
+            {
+                const int ql = threadIdx.x & 15, tq = threadIdx.x >> 4;
+                if (tq < (LAST ? 1 : T)) {
+                    const float* qrow = s_qkv + (tq * S3D_GROUP + ql) * QKV_LD;
+                    f32x4 qv[8];
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) qv[d] = ld4(qrow + 4 * d);
+                    float sc[S3D_N_TOKENS_MAX];
+                    float mx = -1e30f;
+#pragma unroll
+                    for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk) {
+                        if (tk < T) {
+                            const float* krow = s_qkv + (tk * S3D_GROUP + ql) * QKV_LD + 32;
+                            float s = 0.f;
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) {
+                                const f32x4 kv = ld4(krow + 4 * d);
+                                s += qv[d][0] * kv[0] + qv[d][1] * kv[1] + qv[d][2] * kv[2] + qv[d][3] * kv[3];
+                            }
+                            sc[tk] = s * scale;
+                            mx = fmaxf(mx, sc[tk]);
+                        }
+                    }
+                    float den = 0.f;
+#pragma unroll
+                    for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
+                        if (tk < T) {
+                            sc[tk] = expf(sc[tk] - mx);
+                            den += sc[tk];
+                        }
+                    const float inv = 1.f / den;
+                    f32x4 ov[8];
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) ov[d] = zero4();
+#pragma unroll
+                    for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
+                        if (tk < T) {
+                            const float* vrow = s_qkv + (tk * S3D_GROUP + ql) * QKV_LD + 64;
+                            const float p = sc[tk] * inv;
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) ov[d] += ld4(vrow + 4 * d) * p;
+                        }
+                    float* orow = s_oh + (tq * S3D_GROUP + ql) * OH_LD;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) st4(orow + 4 * d, ov[d]);
+                }
+            }
+            __syncthreads();
+            // ---- out_proj partial: acc_o += Wo[:, 32h:32h+32] * O_h^T ----
+#pragma unroll
+            for (int ti = 0; ti < (LAST ? 1 : ATT_MAXT); ++ti) {
+                const int t = wave + 4 * ti;
+                if (t >= (LAST ? 1 : T)) continue;
+#pragma unroll
+                for (int u2 = 0; u2 < 2; ++u2) {
+                    const f32x4 ob = ld4(s_oh + (t * S3D_GROUP + m) * OH_LD + 16 * u2 + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        acc_o[ti][j] = mfma4(ld4(frag_ptr(w.outw, j, h * 2 + u2, 8, lane)), ob, acc_o[ti][j]);
+                }
+            }
+            // the next head's s_qkv writes are fenced from this head's attention reads by the barrier
+            // above; its s_oh writes are fenced from these reads by the next head's first barrier.
+        }
+        // ---- residual + LayerNorm1, store ----
+#pragma unroll
+        for (int ti = 0; ti < (LAST ? 1 : ATT_MAXT); ++ti) {
+            const int t = wave + 4 * ti;
+            if (t >= (LAST ? 1 : T)) continue;
+            f32x4 y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = acc_o[ti][j] + ld4(w.outb + 16 * j + 4 * g) + xb[ti][j];
+            layer_norm_row(y, w.ln1g, w.ln1b, g);
+            float* o = LAST ? x0_out + (grp * S3D_GROUP + m) * 128 + 4 * g
+                            : Xg + (t * S3D_GROUP + m) * 128 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(o + 16 * j, y[j]);
+        }
+        __syncthreads();  // LDS reuse by the next group
+    }
+}
+
+int launch_attn_layer(float* X, float* x0_out, long groups, int T, const LayerPtrs& w, hipStream_t stream) {
+    S3D_CHECK_ARG(T >= 2 && T <= S3D_N_TOKENS_MAX, "attn: T %d", T);
+    if (groups <= 0) return 0;
+    const size_t lds = (size_t)S3D_N_TOKENS_MAX * 16 * (QKV_LD + OH_LD) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)attn_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        hipFuncSetAttribute((const void*)attn_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr_set = true;
+    }
+    const long blocks = groups < 4096 ? groups : 4096;
+    if (x0_out)
+        hipLaunchKernelGGL(attn_layer_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, X, x0_out,
+                           groups, T, w);
+    else
+        hipLaunchKernelGGL(attn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, X, x0_out,
+                           groups, T, w);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: feed-forward block:  X <- LN2(X + W2 relu(W1 X + b1) + b2)   [+ fc_out when FINAL]
+//     rows are independent: a workgroup takes 256 rows (4 waves x 4 row tiles).  The activation row
+//     tile lives in registers as B fragments for the whole kernel; W1/W2 stream through LDS in
+//     32-hidden-unit chunks (double buffered); the hidden tile never leaves the register file: the D
+//     registers of GEMM1 (relu'd) are the B operand of GEMM2.
+// ---------------------------------------------------------------------------------------------
+#define FFN_R 4
+#define FFN_CHUNK_FLOATS 8192   // 16 KiB of W1 fragments + 16 KiB of W2 fragments
+
+template <bool FINAL>
+__global__ __launch_bounds__(256) void ffn_layer_kernel(float* X, long rows, const LayerPtrs w,
+                                                        const float* fco_w, const float* fco_b,
+                                                        float* sdf_out, float sign, long groups_per_batch,
+                                                        long n_qry, long g_begin) {
+    __shared__ __attribute__((aligned(16))) float s_w[2][FFN_CHUNK_FLOATS];  // 64 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * (FFN_R * 16);
+
+    f32x4 xb[FFN_R][8], acc[FFN_R][8];
+#pragma unroll
+    for (int r = 0; r < FFN_R; ++r) {
+        long row = row0 + r * 16 + m;
+        if (row >= rows) row = rows - 1;
+        const float* p = X + row * 128 + 4 * g;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            xb[r][u] = ld4(p + 16 * u);
+            acc[r][u] = zero4();
+        }
+    }
+    // stage chunk 0
+    f32x4 pre[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pre[i] = ld4(w.w1 + (i * 256 + threadIdx.x) * 4);
+        pre[4 + i] = ld4(w.w2 + (i * 256 + threadIdx.x) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        st4(&s_w[0][(i * 256 + threadIdx.x) * 4], pre[i]);
+        st4(&s_w[0][4096 + (i * 256 + threadIdx.x) * 4], pre[4 + i]);
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < S3D_FFN_NCHUNK; ++c) {
+        const float* sw = s_w[c & 1];
+        if (c + 1 < S3D_FFN_NCHUNK) {
+            const float* g1 = w.w1 + (size_t)(c + 1) * 4096;
+            const float* g2 = w.w2 + (size_t)(c + 1) * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pre[i] = ld4(g1 + (i * 256 + threadIdx.x) * 4);
+                pre[4 + i] = ld4(g2 + (i * 256 + threadIdx.x) * 4);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f32x4 hd[FFN_R];
+#pragma unroll
+            for (int r = 0; r < FFN_R; ++r) hd[r] = zero4();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 wa = ld4(sw + ((a * 8 + u) * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < FFN_R; ++r) hd[r] = mfma4(wa, xb[r][u], hd[r]);
+            }
+            const f32x4 b1 = ld4(w.b1 + c * S3D_FFN_CHUNK + 16 * a + 4 * g);
+#pragma unroll
+            for (int r = 0; r < FFN_R; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hd[r][i] = fmaxf(hd[r][i] + b1[i], 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 wb = ld4(sw + 4096 + ((j * 2 + a) * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < FFN_R; ++r) acc[r][j] = mfma4(wb, hd[r], acc[r][j]);
+            }
+        }
+        if (c + 1 < S3D_FFN_NCHUNK) {
+            float* dw = s_w[(c + 1) & 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                st4(dw + (i * 256 + threadIdx.x) * 4, pre[i]);
+                st4(dw + 4096 + (i * 256 + threadIdx.x) * 4, pre[4 + i]);
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int r = 0; r < FFN_R; ++r) {
+        const long row = row0 + r * 16 + m;
+        f32x4 y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = acc[r][j] + ld4(w.b2 + 16 * j + 4 * g) + xb[r][j];
+        layer_norm_row(y, w.ln2g, w.ln2b, g);
+        if (FINAL) {  // fc_out (models.py:84) on the token-0 row of query (group, m)
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 wo = ld4(fco_w + 16 * j + 4 * g);
+                s += y[j][0] * wo[0] + y[j][1] * wo[1] + y[j][2] * wo[2] + y[j][3] * wo[3];
+            }
+            s = quad_sum(s) + fco_b[0];
+            if (g == 0 && row < rows) {
+                const long grp = g_begin + row / S3D_GROUP;
+                const long b = grp / groups_per_batch;
+                const long q = (grp % groups_per_batch) * S3D_GROUP + (row % S3D_GROUP);
+                if (q < n_qry) sdf_out[b * n_qry + q] = sign * s;
+            }
+        } else if (row < rows) {
+            float* o = X + row * 128 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(o + 16 * j, y[j]);
+        }
+    }
+}
+
+int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w, const float* fco_b,
+                     float* sdf_out, float sign, long groups_per_batch, long n_qry, long g_begin, int prec,
+                     hipStream_t stream) {
+    S3D_CHECK_ARG(prec == S3D_PREC_F32, "ffn: precision mode %d not built", prec);
+    if (rows <= 0) return 0;
+    const long blocks = (rows + 4 * FFN_R * 16 - 1) / (4 * FFN_R * 16);
+    if (sdf_out)
+        hipLaunchKernelGGL(ffn_layer_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, X, rows, w,
+                           fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+    else
+        hipLaunchKernelGGL(ffn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, X, rows, w,
+                           fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone helper ops of the module API
+// ---------------------------------------------------------------------------------------------
+__global__ void project_coord_kernel(const float* coords, const float* trans, float* out, int batch,
+                                     long n_qry) {
+    const long total = (long)batch * n_qry;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n_qry);
+        float gx, gy;
+        project(trans + b * 12, coords[i * 3], coords[i * 3 + 1], coords[i * 3 + 2], gx, gy);
+        out[i * 2] = gx;
+        out[i * 2 + 1] = gy;
+    }
+}
+
+int launch_project_coord(const float* coords, const float* trans, float* out, int batch, long n_qry,
+                         hipStream_t stream) {
+    const long total = (long)batch * n_qry;
+    if (total <= 0) return 0;
+    const long blocks = (total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096;
+    hipLaunchKernelGGL(project_coord_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, coords, trans, out,
+                       batch, n_qry);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// sample_from_planes on a channels-last plane: one thread per (point, 4 channels); consecutive lanes
+// read consecutive 16 B of a tap's C-vector and write consecutive 16 B of the output row.
+__global__ void sample_planes_kernel(const float* __restrict__ plane, const float* __restrict__ grid,
+                                     float* __restrict__ out, int n, int h, int w, int c, long mpts) {
+    const int c4 = c >> 2;
+    const long total = (long)n * mpts * c4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(idx % c4) * 4;
+        const long pt = idx / c4;
+        const int ni = (int)(pt / mpts);
+        const Tap4 tp = make_taps(grid[pt * 2], grid[pt * 2 + 1], w, h);
+        const float* base = plane + (long)ni * h * w * c + cc;
+        f32x4 v = zero4();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v += ld4(base + (long)tp.off[k] * c) * tp.w[k];
+        st4(out + pt * c + cc, v);
+    }
+}
+
+int launch_sample_planes(const float* plane, const float* grid, float* out, int n, int h, int w, int c, long m,
+                         hipStream_t stream) {
+    S3D_CHECK_ARG(c % 4 == 0 && c > 0, "sample_planes: C %d must be a multiple of 4", c);
+    const long total = (long)n * m * (c / 4);
+    if (total <= 0) return 0;
+    const long blocks = (total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384;
+    hipLaunchKernelGGL(sample_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, plane, grid, out, n,
+                       h, w, c, m);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,45 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import os
+
+import numpy as np
+import torch
+
+from slice3d_amd.weights import seeded_array
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+GOLDEN_CASES = ("g1_c1_s64_n4_q1000_train", "g2_s64_n12_q2048_test", "g3_s32_n12_q512_b2_train",
+                "g4_s128_n12_q256_test")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    b, s, q, ns, seed = [int(v) for v in g["meta"]]
+    g.update(batch=b, size=s, n_qry=q, n_slices=ns, seed=seed, mode=str(g["mode"]))
+    return g
+
+
+def golden_feed(g, device="cpu"):
+    fd = {k: torch.from_numpy(g[k]).to(device) for k in
+          ("img_input", "qry_norot", "obj_rot_mat", "trans_mat_wo_rot_tp")}
+    if "img_slices" in g:
+        fd["img_slices"] = torch.from_numpy(g["img_slices"]).to(device)
+    return fd
+
+
+def reference_state_dict_shapes(n_slices=12):
+    """Key -> shape table of the reference Slices3DRegModel state_dict (244 tensors), derived from
+    SURVEY.md 8(a)/8(b); test_state_dict.py checks the package's model reproduces it exactly."""
+    from slice3d_amd.models import Slices3DRegModel
+    m = Slices3DRegModel(n_slices=n_slices, backend="none")
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def seeded_sd_from_shapes(shapes, seed=0, dtype=torch.float32):
+    sd = {}
+    for k, shp in shapes.items():
+        a = seeded_array(k, shp, seed)
+        t = torch.from_numpy(a)
+        sd[k] = t.to(dtype) if t.is_floating_point() else t
+    return sd
