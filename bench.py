@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""bench.py — occupancy query-points/s of the Slice3D regression hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): one object per step = reg_slices U-Net encode of a 256x256 image
+into the 12-slice feature pyramid + decode of 100 000 query points (project -> sample 12x5 planes ->
+fc_p/fc_s -> 3-layer transformer -> fc_out), inputs resident in HBM, fp32 (the parity mode).
+N GPUs = N independent objects (one process per GPU, no data-path collective): weak scaling.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+FFN_FLOP_PER_ROW = 2 * 2 * 128 * 2048   # two 128x2048 GEMMs, 2 FLOP/MAC (FFN = 88 %)
+F_MIN_PER_QUERY = 35.96e6           # exact decoder FLOPs/query with last-layer pruning
+
+
+def cpu_baseline(sd, fd, n_slices, n_sample, gpu_sdf):
+    """Oracle (CPU port of the reference path) timed on the host cores for a bounded sample."""
+    from oracle import ref_cpu
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    fd_cpu = {k: v.cpu() for k, v in fd.items()}
+    with torch.no_grad():
+        t0 = time.time()
+        feats, _ = ref_cpu.unet_forward(sd, fd_cpu["img_input"], n_slices)
+        t_unet = time.time() - t0
+        qry = ref_cpu.rotate_queries(fd_cpu, "test")[:, :n_sample]
+        ref_cpu.decode_points(sd, feats, qry[:, :512], fd_cpu["trans_mat_wo_rot_tp"], n_slices)  # warm-up
+        t0 = time.time()
+        sdf = ref_cpu.decode_points(sd, feats, qry, fd_cpu["trans_mat_wo_rot_tp"], n_slices)
+        t_dec = time.time() - t0
+    n_qry = fd_cpu["qry_norot"].shape[1]
+    per_q = t_dec / n_sample
+    err = float((gpu_sdf[:, :n_sample].cpu() - sdf).abs().max())
+    return {
+        "value": n_qry / (t_unet + per_q * n_qry), "unit": "query-points/s", "cores": cores, "kind": "port",
+        "sample": "oracle/ref_cpu.py (torch-CPU fp32 restatement of the reference path): U-Net once at 256^2 "
+                  "(%.2f s) + %d of the %d queries decoded (%.1f us/query); value = Q/(t_unet+Q*t_query)"
+                  % (t_unet, n_sample, n_qry, per_q * 1e6),
+        "decoder_only_qps": 1.0 / per_q,
+    }, err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--img-size", type=int, default=256)
+    ap.add_argument("--n-qry", type=int, default=100000)
+    ap.add_argument("--n-slices", type=int, default=12)
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="queries timed on the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from slice3d_amd import _lib
+    from slice3d_amd.models import Slices3DRegModel
+    from slice3d_amd.synth import make_feed_dict
+    from slice3d_amd.weights import load_seeded
+
+    model = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="test")
+    load_seeded(model, 0)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model.cuda().eval()
+    fd = make_feed_dict(1, args.img_size, args.n_qry, args.n_slices, seed=1234 + rank, with_slices=False,
+                        device="cuda")
+    lib = _lib.load()
+
+    def step():
+        code = model.encode(fd)                       # U-Net + latent maps, once per object
+        return model.decode_sdf(fd["qry_norot"], code)  # 100k queries
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    lib.s3d_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stage_ms, counts = {}, {}
+    for i, name in enumerate(_lib.PROF_NAMES):
+        ms, n = C.c_double(), C.c_long()
+        lib.s3d_prof_read(i, C.byref(ms), C.byref(n))
+        stage_ms[name] = ms.value / args.steps
+        counts[name] = n.value
+    lib.s3d_prof_enable(0)
+
+    if rank == 0:
+        q_total = args.n_qry * world * args.steps
+        n_tok = args.n_slices + 1
+        ffn_launches = max(counts["ffn_layer"], 1)
+        ffn_ms = stage_ms["ffn_layer"] * args.steps / ffn_launches
+        ffn_flops = n_tok * args.n_qry * FFN_FLOP_PER_ROW          # algorithmic FLOPs of one launch
+        achieved = ffn_flops / (ffn_ms * 1e-3) / 1e12
+        decode_ms = sum(stage_ms[k] for k in ("sample_tokens", "attn_layer", "ffn_layer", "ffn_final"))
+        res = {
+            "metric": "occupancy query-points/sec (U-Net encode + per-query decode, 256^2 x 12 slices)",
+            "value": q_total / dt, "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "reg_slices regression inference, %d^2 x %d slices, %d query points/object, "
+                                   "1 object per GPU per step (BASELINE configs[1], fp32 parity mode)"
+                                   % (args.img_size, args.n_slices, args.n_qry),
+                       "img_size": args.img_size, "n_slices": args.n_slices, "n_qry": args.n_qry,
+                       "objects_per_step": world, "parallelism": "objects x%d (no collective)" % world},
+            "roofline": {"kernel": "ffn_layer_kernel<false> (decoder FFN 128->2048->128 + residual + LN2)",
+                         "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": ffn_ms, "launches": counts["ffn_layer"],
+                         "alg_flop_per_launch": ffn_flops},
+            "stage_ms_per_step": stage_ms,
+            "decode_tflops_fmin": args.n_qry * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,
+            "train_samples_per_s": None,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            base, err = cpu_baseline(sd_cpu, fd, args.n_slices, min(args.cpu_sample, args.n_qry), out)
+            res["cpu_baseline"] = base
+            res["parity_vs_oracle"] = {"max_abs_err": err, "n": min(args.cpu_sample, args.n_qry), "tol": 1e-4}
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,22 @@ int s3d_decode_grid_fwd(const void* head_packed, const S3dLatent* latent, const 
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Measurement hook (no reference counterpart): when enabled, the launches of each kernel family are
+ * bracketed with hipEvents on the caller's stream; s3d_prof_read waits for them and returns the summed
+ * duration and the number of launches since s3d_prof_enable(1).  bench.py uses it to time the
+ * dominant kernel inside its timed region.
+ * ------------------------------------------------------------------------------------------- */
+#define S3D_PROF_UNET 0          /* whole s3d_unet_encode_fwd */
+#define S3D_PROF_LATENT 1        /* s3d_latent_build */
+#define S3D_PROF_SAMPLE 2        /* sample_tokens_kernel */
+#define S3D_PROF_ATTN 3          /* attn_layer_kernel (all layers) */
+#define S3D_PROF_FFN 4           /* ffn_layer_kernel, full-row layers */
+#define S3D_PROF_FFN_FINAL 5     /* ffn_layer_kernel, token-0 rows of the last layer (+fc_out) */
+#define S3D_PROF_N 6
+int s3d_prof_enable(int on);
+int s3d_prof_read(int id, double* total_ms, long* count);
+
+/* ---------------------------------------------------------------------------------------------
  * Stand-alone ops of the module's helper API
  * ------------------------------------------------------------------------------------------- */
 /* project_coord (models.py:28-36): coords (B,Q,3), trans (B,4,3) -> out (B,Q,2) */

@@ -13,6 +13,8 @@ N_LEVELS = 5
 N_LAYERS = 3
 PREC_F32 = 0
 PREC_BF16X3 = 1
+PROF_UNET, PROF_LATENT, PROF_SAMPLE, PROF_ATTN, PROF_FFN, PROF_FFN_FINAL = range(6)
+PROF_NAMES = ("unet_encode", "latent_build", "sample_tokens", "attn_layer", "ffn_layer", "ffn_final")
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -65,6 +67,8 @@ SYMBOLS = {
     "s3d_decode_points_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _vp, _vp, _i, _vp, _i, _l, _i, _i,
                                    _vp, _sz, _vp]),
     "s3d_decode_grid_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _i, _f, _vp, _i, _i, _vp, _sz, _vp]),
+    "s3d_prof_enable": (_i, [_i]),
+    "s3d_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "s3d_project_coord_fwd": (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     "s3d_sample_planes_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _vp]),
     "s3d_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

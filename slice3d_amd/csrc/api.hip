@@ -19,6 +19,56 @@ void s3d_set_error(const char* fmt, ...) {
 extern "C" int s3d_version(void) { return S3D_VERSION; }
 extern "C" const char* s3d_last_error(void) { return g_err; }
 
+// ---------------------------------------------------------------------------------------------
+// optional event profiler: brackets the tracked launches with hipEvents ON THE CALLER'S STREAM so
+// bench.py can report per-kernel durations measured live inside its timed region.
+// ---------------------------------------------------------------------------------------------
+static bool g_prof = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[S3D_PROF_N];
+
+struct ProfScope {
+    int id;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(int id_, hipStream_t st_) : id(id_), st(st_) {
+        if (!g_prof) return;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, st);
+        g_prof_ev[id].push_back({a, b});
+    }
+};
+
+extern "C" int s3d_prof_enable(int on) {
+    for (int i = 0; i < S3D_PROF_N; ++i) {
+        for (auto& e : g_prof_ev[i]) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        g_prof_ev[i].clear();
+    }
+    g_prof = on != 0;
+    return 0;
+}
+
+extern "C" int s3d_prof_read(int id, double* total_ms, long* count) {
+    S3D_CHECK_ARG(id >= 0 && id < S3D_PROF_N && total_ms && count, "prof_read: bad argument");
+    double tot = 0;
+    for (auto& e : g_prof_ev[id]) {
+        (void)hipEventSynchronize(e.second);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e.first, e.second);
+        tot += ms;
+    }
+    *total_ms = tot;
+    *count = (long)g_prof_ev[id].size();
+    return 0;
+}
+
 #define TRY(x)              \
     do {                    \
         int rc__ = (x);     \
@@ -223,6 +273,7 @@ extern "C" int s3d_unet_encode_fwd(const void* packed, const float* img, const S
     const float* base = (const float*)packed;
     float* ws = (float*)workspace;
 
+    ProfScope prof_(S3D_PROF_UNET, st);
     TRY(launch_nchw_to_nhwc(img, ws + W.in16, B, 3, S, S, 16, st));
     // ---- VGG16-BN encoder (unet_custom.py:43-47) ----
     const float* cur = ws + W.in16;
@@ -402,6 +453,7 @@ extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, 
                   "latent_build: latent.fine must alias pyramid levels 3,4");
     const HeadLayout H = head_layout();
     const float* b = (const float*)head_packed;
+    ProfScope prof_(S3D_PROF_LATENT, st);
     const int lc[3] = {512, 256, 128};
     for (int l = 0; l < 3; ++l) {
         const int r = (pyr->size / 16) << l;
@@ -479,11 +531,18 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
         sa.qry = qry; sa.rot = rot; sa.trans = trans; sa.flip_yz = flip_yz;
         sa.n_qry = n_qry; sa.groups_per_batch = gpb; sa.g_begin = g0; sa.g_count = gc;
         sa.nx = nx; sa.box = box; sa.X = X;
-        TRY(launch_sample_tokens(sa, st));
+        {
+            ProfScope prof_(S3D_PROF_SAMPLE, st);
+            TRY(launch_sample_tokens(sa, st));
+        }
         for (int l = 0; l < S3D_N_LAYERS; ++l) {
             const LayerPtrs lp = layer_ptrs(b, H, l);
             const bool last = l == S3D_N_LAYERS - 1;
-            TRY(launch_attn_layer(X, last ? X0 : nullptr, gc, T, lp, st));
+            {
+                ProfScope prof_(S3D_PROF_ATTN, st);
+                TRY(launch_attn_layer(X, last ? X0 : nullptr, gc, T, lp, st));
+            }
+            ProfScope prof_(last ? S3D_PROF_FFN_FINAL : S3D_PROF_FFN, st);
             if (!last)
                 TRY(launch_ffn_layer(X, gc * T * S3D_GROUP, lp, nullptr, nullptr, nullptr, 1.f, gpb, n_qry, g0,
                                      prec, st));

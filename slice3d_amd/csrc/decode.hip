@@ -351,9 +351,9 @@ int launch_attn_layer(float* X, float* x0_out, long groups, int T, const LayerPt
     const size_t lds = (size_t)S3D_N_TOKENS_MAX * 16 * (QKV_LD + OH_LD) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)attn_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)attn_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-        hipFuncSetAttribute((const void*)attn_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)attn_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         attr_set = true;
     }

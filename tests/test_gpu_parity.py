@@ -1,0 +1,206 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+ (1) the committed golden vectors captured from the real reference,
+ (2) the CPU oracle on fresh seeded inputs (incl. BASELINE's full 256^2 x 12-slice size),
+ (3) size-independent properties (chunk invariance, permutation equivariance, batch-major order,
+     dense-grid == explicit make_3d_grid queries).
+Tolerance: 1e-4 absolute on sdf / occupancy logits (BASELINE.json north_star); images 1e-4."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, GOLDEN_CASES, golden_feed, load_golden, seeded_sd_from_shapes
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _shapes(n_slices):
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(GOLDEN, "state_dict_keys.json"))).items()}
+    shapes["slices_generator.emds.weight"] = (n_slices, 128)
+    return shapes
+
+
+_models = {}
+
+
+def get_model(n_slices, mode):
+    from slice3d_amd.models import Slices3DRegModel
+    from slice3d_amd.weights import load_seeded
+    key = (n_slices, mode)
+    if key not in _models:
+        m = Slices3DRegModel(n_slices=n_slices, mode=mode)
+        load_seeded(m, 0)
+        _models[key] = m.cuda().eval()
+    return _models[key]
+
+
+def to_gpu(fd):
+    return {k: v.cuda() for k, v in fd.items()}
+
+
+def test_native_library_is_loaded():
+    from slice3d_amd import _lib
+    lib = _lib.load()
+    assert lib.s3d_version() >= 100
+    maps = open("/proc/self/maps").read()
+    assert "libslice3d_hip.so" in maps
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_forward_matches_reference_golden(name):
+    g = load_golden(name)
+    model = get_model(g["n_slices"], g["mode"])
+    fd = golden_feed(g)
+    fd.pop("img_slices", None)
+    qry_before = fd["qry_norot"].clone()
+    out = model(to_gpu(fd))
+    torch.cuda.synchronize()
+    err = np.abs(out["sdf_pred"].cpu().numpy() - g["sdf_pred"]).max()
+    assert err < TOL, err
+    rec = out["slices_rec"][:, :, ::4, ::4].cpu().numpy()
+    assert np.abs(rec - g["slices_rec_strided"]).max() < TOL
+    assert out["slices_rec"].shape == (g["batch"], 3 * g["n_slices"], g["size"], g["size"])
+    assert torch.equal(fd["qry_norot"], qry_before)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_pyramid_matches_reference_golden(name):
+    g = load_golden(name)
+    model = get_model(g["n_slices"], g["mode"])
+    feats, rec = model.slices_generator(torch.from_numpy(g["img_input"]).cuda())
+    for l, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(g["pyr%d_shape" % l])
+        got = f.reshape(-1)[torch.from_numpy(g["pyr%d_idx" % l]).cuda()].cpu().numpy()
+        ref = g["pyr%d_val" % l]
+        assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_helper_ops_match_golden():
+    g = load_golden("g3_s32_n12_q512_b2_train")
+    model = get_model(12, "train")
+    from oracle import ref_cpu
+    fd = golden_feed(g)
+    qr = ref_cpu.rotate_queries(fd, "train")
+    pts = model.project_coord(qr.cuda(), fd["trans_mat_wo_rot_tp"].cuda())
+    assert np.abs(pts.cpu().numpy() - g["img_pts"]).max() < 1e-6
+    feats, _ = model.slices_generator(fd["img_input"].cuda())
+    b, q, ns = g["batch"], g["n_qry"], 12
+    pts_t = torch.from_numpy(g["img_pts"]).view(b, 1, q, 2).expand(-1, ns, -1, -1).reshape(b * ns, q, 2)
+    s2 = model.sample_from_planes(feats[2], pts_t[:, :16].contiguous().cuda())
+    assert s2.shape == (b * ns, 1, 16, 128)
+    assert np.abs(s2.squeeze(1).cpu().numpy() - g["sample_l2"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("b,s,q,ns,mode", [(1, 64, 1500, 12, "test"), (3, 48, 257, 12, "train"),
+                                           (1, 96, 33, 7, "train"), (2, 16, 1, 12, "test"),
+                                           (1, 32, 16, 1, "train")])
+def test_forward_matches_oracle(b, s, q, ns, mode):
+    """Ragged / edge shapes: Q not a multiple of 16, Q=1, 1 and 7 slices, 16^2 images, B=3."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    model = get_model(ns, mode)
+    sd = seeded_sd_from_shapes(_shapes(ns))
+    fd = make_feed_dict(b, s, q, ns, seed=100 + q, with_slices=False)
+    out = model(to_gpu(fd))
+    ref = ref_cpu.forward(sd, fd, mode=mode, n_slices=ns, with_vgg=False)
+    assert (out["sdf_pred"].cpu() - ref["sdf_pred"]).abs().max() < TOL
+    assert (out["slices_rec"].cpu() - ref["slices_rec"]).abs().max() < TOL
+
+
+def test_full_size_256_matches_oracle():
+    """BASELINE configs[1] shape: 256^2 x 12 slices; 100k queries decoded on the GPU, a 4096-query
+    subset checked against the oracle (the oracle needs ~2 s for the U-Net + ~1 s for 4096 queries)."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    model = get_model(12, "test")
+    sd = seeded_sd_from_shapes(_shapes(12))
+    fd = make_feed_dict(1, 256, 100000, 12, seed=2024, with_slices=False)
+    out = model(to_gpu(fd))
+    sdf = out["sdf_pred"].cpu()
+    assert sdf.shape == (1, 100000) and torch.isfinite(sdf).all()
+    idx = torch.from_numpy(np.random.default_rng(0).choice(100000, 4096, replace=False))
+    fd_sub = dict(fd)
+    fd_sub["qry_norot"] = fd["qry_norot"][:, idx]
+    feats, rec = ref_cpu.unet_forward(sd, fd["img_input"], 12)
+    qr = ref_cpu.rotate_queries(fd_sub, "test")
+    ref = ref_cpu.decode_points(sd, feats, qr, fd["trans_mat_wo_rot_tp"], 12)
+    assert (sdf[:, idx] - ref).abs().max() < TOL
+    assert (out["slices_rec"].cpu().view(12, 3, 256, 256) - rec).abs().max() < TOL
+
+
+def test_chunk_invariance_and_permutation():
+    """Queries are independent given the pyramid: decoding in one call, in chunks (Generator3D's
+    eval_points pattern) or in a permuted order gives the same value per query, bit for bit."""
+    from slice3d_amd.synth import make_feed_dict
+    model = get_model(12, "test")
+    fd = to_gpu(make_feed_dict(1, 64, 5000, 12, seed=9, with_slices=False))
+    code = model.encode(fd)
+    full = model.decode_sdf(fd["qry_norot"], code)
+    parts = [model.decode_sdf(fd["qry_norot"][:, s:s + 1234].contiguous(), code) for s in range(0, 5000, 1234)]
+    assert torch.equal(full, torch.cat(parts, 1))
+    perm = torch.randperm(5000, device="cuda")
+    permuted = model.decode_sdf(fd["qry_norot"][:, perm].contiguous(), code)
+    assert torch.equal(full[:, perm], permuted)
+
+
+def test_batch_items_are_independent():
+    from slice3d_amd.synth import make_feed_dict
+    model = get_model(12, "train")
+    fd = to_gpu(make_feed_dict(2, 32, 100, 12, seed=4, with_slices=False))
+    both = model(fd)["sdf_pred"]
+    for b in range(2):
+        one = model({k: v[b:b + 1].contiguous() for k, v in fd.items()})["sdf_pred"]
+        assert torch.equal(both[b:b + 1], one)
+
+
+def test_dense_grid_equals_explicit_grid_queries():
+    """s3d_decode_grid_fwd (in-kernel coordinates) == decode of make_3d_grid points, negated."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    model = get_model(12, "test")
+    fd = to_gpu(make_feed_dict(1, 64, 16, 12, seed=21, with_slices=False))
+    code = model.encode(fd)
+    nx = 20
+    grid = model.decode_grid(code, nx)
+    pts = ref_cpu.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3).unsqueeze(0).cuda()
+    explicit = -model.decode_sdf(pts, code)
+    assert grid.shape == (nx, nx, nx)
+    assert (grid.reshape(1, -1) - explicit).abs().max() < 1e-5
+
+
+def test_encode_decode_api_and_logits_sign():
+    from slice3d_amd.synth import make_feed_dict
+    model = get_model(12, "test")
+    fd = to_gpu(make_feed_dict(1, 32, 64, 12, seed=2, with_slices=False))
+    c = model.encode(fd)
+    d = model.decode(fd["qry_norot"], c)
+    assert torch.equal(d.logits, -d.sdf)
+    assert torch.equal(d.sdf, model(fd)["sdf_pred"])
+
+
+def test_repack_after_weight_update():
+    from slice3d_amd.synth import make_feed_dict
+    from slice3d_amd.models import Slices3DRegModel
+    from slice3d_amd.weights import load_seeded
+    m = load_seeded(Slices3DRegModel(n_slices=12, mode="test"), 0).cuda().eval()
+    fd = to_gpu(make_feed_dict(1, 32, 64, 12, seed=2, with_slices=False))
+    a = m(fd)["sdf_pred"].clone()
+    with torch.no_grad():
+        m.fc_out[0].bias.add_(0.5)
+    b = m(fd)["sdf_pred"]
+    assert torch.allclose(b, a + 0.5, atol=1e-6)
+
+
+def test_error_codes_are_loud():
+    from slice3d_amd import _lib
+    from slice3d_amd.synth import make_feed_dict
+    model = get_model(12, "test")
+    bad = to_gpu(make_feed_dict(1, 40, 8, 12, with_slices=False))   # 40 is not a multiple of 16
+    with pytest.raises(ValueError):
+        model(bad)
+    lib = _lib.load()
+    rc = lib.s3d_unet_encode_fwd(None, None, None, None, 1, 64, 12, None, 0, None)
+    assert rc == -1 and b"null" in lib.s3d_last_error()

@@ -1,0 +1,124 @@
+"""CPU tests: the oracle (oracle/ref_cpu.py) is pinned against the reference's own outputs —
+the committed golden vectors (tests/golden/*.npz, produced by tests/golden/make_golden.py from the
+imported reference) and, when /root/reference is present, the live reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, GOLDEN_CASES, golden_feed, load_golden, seeded_sd_from_shapes
+from oracle import ref_cpu
+from oracle.ref_import import reference_available
+
+ORACLE_TOL = 1e-4     # north_star tolerance on sdf / logits
+ORACLE_TIGHT = 3e-5   # what two fp32 evaluations of this network actually differ by (see synth.py)
+
+
+def _shapes(n_slices):
+    shapes = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    shapes = {k: tuple(v) for k, v in shapes.items()}
+    shapes["slices_generator.emds.weight"] = (n_slices, 128)
+    return shapes
+
+
+@pytest.fixture(scope="module", params=GOLDEN_CASES)
+def case(request):
+    g = load_golden(request.param)
+    sd = seeded_sd_from_shapes(_shapes(g["n_slices"]))
+    return g, sd
+
+
+def test_oracle_matches_golden_outputs(case):
+    g, sd = case
+    fd = golden_feed(g)
+    out = ref_cpu.forward(sd, fd, mode=g["mode"], n_slices=g["n_slices"], with_vgg="img_slices" in fd)
+    assert out["sdf_pred"].shape == g["sdf_pred"].shape
+    err = np.abs(out["sdf_pred"].numpy() - g["sdf_pred"]).max()
+    assert err < ORACLE_TIGHT, err
+    rec = out["slices_rec"][:, :, ::4, ::4].numpy()
+    assert np.abs(rec - g["slices_rec_strided"]).max() < 2e-5
+    if "img_slices" in fd:
+        assert abs(float(out["vgg_loss"]) - float(g["vgg_loss"])) < 1e-6 * max(1.0, abs(float(g["vgg_loss"])))
+
+
+def test_oracle_pyramid_and_projection(case):
+    g, sd = case
+    fd = golden_feed(g)
+    feats, _ = ref_cpu.unet_forward(sd, fd["img_input"], g["n_slices"])
+    for l, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(g["pyr%d_shape" % l])
+        got = f.reshape(-1)[torch.from_numpy(g["pyr%d_idx" % l])].numpy()
+        assert np.abs(got - g["pyr%d_val" % l]).max() < 1e-4 * max(1.0, np.abs(g["pyr%d_val" % l]).max())
+    qr = ref_cpu.rotate_queries(fd, g["mode"])
+    pts = ref_cpu.project_coord(qr, fd["trans_mat_wo_rot_tp"])
+    assert np.abs(pts.numpy() - g["img_pts"]).max() < 1e-6
+    # the clamp of project_coord must be active for part of the queries
+    assert (np.abs(g["img_pts"]) == 1.0).any()
+
+
+@pytest.mark.parametrize("name", ["g2_s64_n12_q2048_test", "g3_s32_n12_q512_b2_train"])
+def test_oracle_stage_tensors(name):
+    g = load_golden(name)
+    sd = seeded_sd_from_shapes(_shapes(g["n_slices"]))
+    fd = golden_feed(g)
+    ns, b, q = g["n_slices"], g["batch"], g["n_qry"]
+    feats, _ = ref_cpu.unet_forward(sd, fd["img_input"], ns)
+    qr = ref_cpu.rotate_queries(fd, g["mode"])
+    pts = ref_cpu.project_coord(qr, fd["trans_mat_wo_rot_tp"])
+    pts_t = pts.view(b, 1, q, 2).expand(-1, ns, -1, -1).reshape(b * ns, q, 2)
+    s2 = ref_cpu.sample_from_planes(feats[2], pts_t[:, :16]).squeeze(1)
+    assert np.abs(s2.numpy() - g["sample_l2"]).max() < 2e-5
+    s2m = ref_cpu.bilinear_sample_manual(feats[2], pts_t[:, :16])
+    assert np.abs(s2m.numpy() - g["sample_l2"]).max() < 2e-5     # independent gather restatement
+    tok = ref_cpu.sample_pyramid(feats, pts, ns)
+    sdf, layers = ref_cpu.decode_tokens(sd, tok, qr, return_layers=True)
+    n = g["fc_s_rows"].shape[0]
+    assert np.abs(layers[0][:n, 1:, :].numpy() - g["fc_s_rows"]).max() < 5e-5
+    assert np.abs(layers[0][:n, 0, :].numpy() - g["fc_p_rows"]).max() < 1e-5
+    for i in range(3):
+        assert np.abs(layers[i + 1][:n, 0, :].numpy() - g["layer%d_tok0" % i]).max() < 5e-5
+
+
+def test_make_3d_grid_golden():
+    z = np.load(os.path.join(GOLDEN, "make_3d_grid.npz"))
+    for n in (2, 4, 5):
+        got = ref_cpu.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (n,) * 3).numpy()
+        assert np.array_equal(got, z["grid%d" % n])
+
+
+def test_losses_restatement():
+    torch.manual_seed(0)
+    x = {"sdf_pred": torch.randn(2, 50), "slices_rec": torch.rand(2, 6, 8, 8), "vgg_loss": torch.tensor(0.3)}
+    gt = {"sdf": torch.randn(2, 50), "img_slices": torch.rand(2, 6, 8, 8)}
+    lp, li, lv = ref_cpu.cal_loss_pred(x, gt)
+    assert torch.isclose(lp, (x["sdf_pred"] - gt["sdf"]).abs().mean())
+    assert torch.isclose(li, (x["slices_rec"] - gt["img_slices"]).abs().mean())
+    acc = ref_cpu.cal_acc(x, gt)
+    want = ((x["sdf_pred"] >= 0) == (gt["sdf"] >= 0)).float().mean()
+    assert torch.isclose(acc, want)
+
+
+def test_eval_points_matches_forward():
+    g = load_golden("g4_s128_n12_q256_test")
+    sd = seeded_sd_from_shapes(_shapes(12))
+    fd = golden_feed(g)
+    vals = ref_cpu.eval_points(sd, fd, 12, chunk_size=100)
+    assert vals.shape == (g["n_qry"],)
+    assert np.abs(vals.numpy() + g["sdf_pred"][0]).max() < ORACLE_TIGHT   # eval_points returns -sdf
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference not present (GPU box)")
+def test_oracle_matches_live_reference():
+    from oracle.ref_import import build_reference_model
+    from slice3d_amd.synth import make_feed_dict
+    for (b, s, q, ns, mode) in [(1, 32, 333, 12, "train"), (1, 48, 200, 12, "test"), (2, 32, 100, 4, "train")]:
+        model = build_reference_model(ns, mode)
+        fd = make_feed_dict(b, s, q, ns, seed=77)
+        with torch.no_grad():
+            ref = model({k: v.clone() for k, v in fd.items()})
+        out = ref_cpu.forward(model.state_dict(), fd, mode=mode, n_slices=ns)
+        assert (ref["sdf_pred"] - out["sdf_pred"]).abs().max() < ORACLE_TIGHT
+        assert (ref["slices_rec"] - out["slices_rec"]).abs().max() < 2e-5
+        assert abs(float(ref["vgg_loss"] - out["vgg_loss"])) < 1e-6
