@@ -148,6 +148,24 @@ int s3d_decode_grid_fwd(const void* head_packed, const S3dLatent* latent, const 
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * VGG19 perceptual loss — replaces VGGPerceptualLoss.forward / VGG19Feats.forward
+ * (reg_slices/src/vgg_perceptual_loss.py:29-70) as called at models.py:90-92.
+ * Taps are what the reference actually compares: torchvision's in-place ReLU makes taps 1-4 post-ReLU,
+ * tap 5 (conv5_2) pre-ReLU.  loss_out[0] = 0.001 * sum_i w_i * mean|x_i - y_i|.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    S3dConvParams conv[14];       /* vgg19.features convs 0,2,5,7,10,12,14,16,19,21,23,25,28,30 (bn NULL) */
+    const float* mean;            /* (3) ImageNet mean buffer  vgg_perceptual_loss.py:47 */
+    const float* std;             /* (3) */
+} S3dVggParams;
+size_t s3d_vgg_packed_bytes(void);
+int s3d_vgg_pack(const S3dVggParams* params_host, void* packed, size_t packed_bytes, void* stream);
+size_t s3d_vgg_workspace_bytes(int n_img, int size);
+/* pred, target: (n_img,3,S,S) NCHW in [-1,1]; S multiple of 16. */
+int s3d_vgg_loss_fwd(const void* packed, const float* pred, const float* target, int n_img, int size,
+                     float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement hook (no reference counterpart): when enabled, the launches of each kernel family are
  * bracketed with hipEvents on the caller's stream; s3d_prof_read waits for them and returns the summed
  * duration and the number of launches since s3d_prof_enable(1).  bench.py uses it to time the
@@ -159,7 +177,8 @@ int s3d_decode_grid_fwd(const void* head_packed, const S3dLatent* latent, const 
 #define S3D_PROF_ATTN 3          /* attn_layer_kernel (all layers) */
 #define S3D_PROF_FFN 4           /* ffn_layer_kernel, full-row layers */
 #define S3D_PROF_FFN_FINAL 5     /* ffn_layer_kernel, token-0 rows of the last layer (+fc_out) */
-#define S3D_PROF_N 6
+#define S3D_PROF_VGG 6           /* whole s3d_vgg_loss_fwd */
+#define S3D_PROF_N 7
 int s3d_prof_enable(int on);
 int s3d_prof_read(int id, double* total_ms, long* count);
 

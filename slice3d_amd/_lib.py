@@ -13,8 +13,8 @@ N_LEVELS = 5
 N_LAYERS = 3
 PREC_F32 = 0
 PREC_BF16X3 = 1
-PROF_UNET, PROF_LATENT, PROF_SAMPLE, PROF_ATTN, PROF_FFN, PROF_FFN_FINAL = range(6)
-PROF_NAMES = ("unet_encode", "latent_build", "sample_tokens", "attn_layer", "ffn_layer", "ffn_final")
+PROF_UNET, PROF_LATENT, PROF_SAMPLE, PROF_ATTN, PROF_FFN, PROF_FFN_FINAL, PROF_VGG = range(7)
+PROF_NAMES = ("unet_encode", "latent_build", "sample_tokens", "attn_layer", "ffn_layer", "ffn_final", "vgg_loss")
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -46,6 +46,10 @@ class S3dHeadParams(C.Structure):
                 ("fc_out_w", C.c_void_p), ("fc_out_b", C.c_void_p)]
 
 
+class S3dVggParams(C.Structure):
+    _fields_ = [("conv", S3dConvParams * 14), ("mean", C.c_void_p), ("std", C.c_void_p)]
+
+
 class S3dLatent(C.Structure):
     _fields_ = [("proj", C.c_void_p * 3), ("fine", C.c_void_p * 2), ("n_img", C.c_int),
                 ("size", C.c_int)]
@@ -67,6 +71,10 @@ SYMBOLS = {
     "s3d_decode_points_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _vp, _vp, _i, _vp, _i, _l, _i, _i,
                                    _vp, _sz, _vp]),
     "s3d_decode_grid_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _i, _f, _vp, _i, _i, _vp, _sz, _vp]),
+    "s3d_vgg_packed_bytes": (_sz, []),
+    "s3d_vgg_pack": (_i, [C.POINTER(S3dVggParams), _vp, _sz, _vp]),
+    "s3d_vgg_workspace_bytes": (_sz, [_i, _i]),
+    "s3d_vgg_loss_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "s3d_prof_enable": (_i, [_i]),
     "s3d_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "s3d_project_coord_fwd": (_i, [_vp, _vp, _vp, _i, _l, _vp]),

@@ -362,6 +362,130 @@ extern "C" int s3d_unet_encode_fwd(const void* packed, const float* img, const S
 }
 
 // =============================================================================================
+// VGG19 perceptual loss
+// =============================================================================================
+static const int kVggCin[14] = {3, 64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512};
+static const int kVggCout[14] = {64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+static const int kVggPoolAfter[14] = {0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0};  // after convs 2,7,16,25
+static const int kVggTap[14] = {0, 1, 0, 2, 0, 3, 0, 0, 0, 4, 0, 0, 0, 5};        // convs 2,7,12,21,30
+static const float kVggW[5] = {1.0f / 2.6f, 1.0f / 4.8f, 1.0f / 3.7f, 1.0f / 5.6f, 10.0f / 1.5f};
+
+struct VggLayout {
+    PackedConv conv[14];
+    size_t mean, stdv, total;
+};
+static VggLayout vgg_layout() {
+    VggLayout L;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += (n + 3) / 4 * 4;
+        return o;
+    };
+    for (int i = 0; i < 14; ++i) {
+        L.conv[i].cout_pad = kVggCout[i];
+        L.conv[i].KU = 9 * pad16(kVggCin[i]) / 16;
+        L.conv[i].w = take((size_t)kVggCout[i] * L.conv[i].KU * 16);
+        L.conv[i].scale = take(kVggCout[i]);
+        L.conv[i].shift = take(kVggCout[i]);
+    }
+    L.mean = take(4);
+    L.stdv = take(4);
+    L.total = off;
+    return L;
+}
+
+extern "C" size_t s3d_vgg_packed_bytes(void) { return vgg_layout().total * sizeof(float); }
+
+extern "C" int s3d_vgg_pack(const S3dVggParams* P, void* packed, size_t packed_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    S3D_CHECK_ARG(P && packed, "vgg_pack: null argument");
+    const VggLayout L = vgg_layout();
+    if (packed_bytes < L.total * sizeof(float)) {
+        s3d_set_error("vgg_pack: packed buffer %zu < %zu bytes", packed_bytes, L.total * sizeof(float));
+        return S3D_E_WORKSPACE;
+    }
+    float* base = (float*)packed;
+    for (int i = 0; i < 14; ++i) {
+        TRY(pack_conv3(P->conv[i].w, base + L.conv[i].w, kVggCout[i], kVggCout[i], kVggCin[i], 0, kVggCin[i],
+                       L.conv[i].KU, 0, 9, st));
+        TRY(launch_fold_bn(P->conv[i].b, nullptr, base + L.conv[i].scale, base + L.conv[i].shift, kVggCout[i],
+                           kVggCout[i], 1, 0, st));
+    }
+    if (hipMemcpyAsync(base + L.mean, P->mean, 3 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(base + L.stdv, P->std, 3 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        s3d_set_error("vgg_pack: memcpy failed");
+        return (int)hipErrorUnknown;
+    }
+    return 0;
+}
+
+struct VggWs {
+    size_t in16, a, b, partial, total;
+};
+static VggWs vgg_ws(int n_img, int S) {
+    VggWs W;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += (n + 63) / 64 * 64;
+        return o;
+    };
+    const size_t px = (size_t)2 * n_img * S * S;
+    W.in16 = take(px * 16);
+    W.a = take(px * 64);
+    W.b = take(px * 64);
+    W.partial = take(4096);
+    W.total = off;
+    return W;
+}
+extern "C" size_t s3d_vgg_workspace_bytes(int n_img, int size) { return vgg_ws(n_img, size).total * sizeof(float); }
+
+extern "C" int s3d_vgg_loss_fwd(const void* packed, const float* pred, const float* target, int n_img, int S,
+                                float* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    S3D_CHECK_ARG(packed && pred && target && loss_out && workspace, "vgg_loss: null argument");
+    S3D_CHECK_ARG(n_img >= 1 && S >= 16 && S % 16 == 0, "vgg_loss: n_img=%d S=%d", n_img, S);
+    const VggLayout L = vgg_layout();
+    const VggWs W = vgg_ws(n_img, S);
+    if (workspace_bytes < W.total * sizeof(float)) {
+        s3d_set_error("vgg_loss: workspace %zu < %zu bytes", workspace_bytes, W.total * sizeof(float));
+        return S3D_E_WORKSPACE;
+    }
+    ProfScope prof_(S3D_PROF_VGG, st);
+    const float* base = (const float*)packed;
+    float* ws = (float*)workspace;
+    if (hipMemsetAsync(loss_out, 0, sizeof(float), st) != hipSuccess) return (int)hipErrorUnknown;
+    TRY(launch_vgg_prep(pred, target, base + L.mean, base + L.stdv, ws + W.in16, n_img, S, st));
+    const int N2 = 2 * n_img;
+    const float* cur = ws + W.in16;
+    int curC = 16, res = S, flip = 0;
+    float* pp[2] = {ws + W.a, ws + W.b};
+    for (int i = 0; i < 14; ++i) {
+        ConvLaunch c = conv_desc(base, L.conv[i], N2, res, res, 3, i == 13 ? S3D_ACT_NONE : S3D_ACT_RELU);
+        c.nsrc = 1;
+        c.src[0] = plain_src(cur, curC);
+        c.out = pp[flip];
+        TRY(launch_conv(c, st));
+        cur = pp[flip];
+        curC = kVggCout[i];
+        flip ^= 1;
+        if (kVggTap[i]) {
+            const long half = (long)n_img * res * res * curC;
+            TRY(launch_l1_diff(cur, cur + half, half, 0.001f * kVggW[kVggTap[i] - 1] / (float)half, ws + W.partial,
+                               loss_out, st));
+        }
+        if (kVggPoolAfter[i]) {
+            TRY(launch_bn_relu_pool(cur, nullptr, nullptr, pp[flip], N2, res, res, curC, st));
+            cur = pp[flip];
+            flip ^= 1;
+            res /= 2;
+        }
+    }
+    return 0;
+}
+
+// =============================================================================================
 // head
 // =============================================================================================
 HeadLayout head_layout() {

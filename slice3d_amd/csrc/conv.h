@@ -61,3 +61,9 @@ int launch_bn_relu_pool(const float* in, const float* scale, const float* shift,
                         int w, int c, hipStream_t stream);
 int launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int cpad, hipStream_t stream);
 int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, hipStream_t stream);
+
+// VGG-loss helpers (conv.hip)
+int launch_vgg_prep(const float* pred, const float* target, const float* mean, const float* stdv, float* out,
+                    int n_img, int size, hipStream_t stream);   // -> (2*n_img, S, S, 16) NHWC, normalised
+int launch_l1_diff(const float* a, const float* b, long n, float scale, float* partial, float* loss_acc,
+                   hipStream_t stream);                         // loss_acc[0] += scale * sum|a-b| (deterministic)

@@ -253,7 +253,8 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ in, const float* _
         r /= wo;
         const int y = (int)(r % ho);
         const int ni = (int)(r / ho);
-        const f32x4 sc = ld4(scale + cc), sh = ld4(shift + cc);
+        const f32x4 sc = scale ? ld4(scale + cc) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh = shift ? ld4(shift + cc) : zero4();
         f32x4 best;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -325,6 +326,80 @@ int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w,
     const long total = (long)n * c * h * w;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, stream, in, out, n, c, h, w);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VGG perceptual loss helpers (vgg_perceptual_loss.py:53-60): ((x+1)/2 - mean)/std, both image sets
+// stacked along the batch so every VGG19 conv runs once on 2*n_img images.
+// ---------------------------------------------------------------------------------------------
+__global__ void vgg_prep_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                const float* __restrict__ mean, const float* __restrict__ stdv,
+                                float* __restrict__ out, int n_img, int size) {
+    const long hw = (long)size * size;
+    const long total = 2L * n_img * hw;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const long ni = idx / hw, r = idx - ni * hw;
+        const float* src = ni < n_img ? pred + ni * 3 * hw : target + (ni - n_img) * 3 * hw;
+        f32x4 v = zero4();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = ((src[c * hw + r] + 1.f) / 2.f - mean[c]) / stdv[c];
+        float* o = out + idx * 16;
+        st4(o, v);
+        st4(o + 4, zero4());
+        st4(o + 8, zero4());
+        st4(o + 12, zero4());
+    }
+}
+
+int launch_vgg_prep(const float* pred, const float* target, const float* mean, const float* stdv, float* out,
+                    int n_img, int size, hipStream_t stream) {
+    const long total = 2L * n_img * size * size;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(vgg_prep_kernel, dim3(blocks), dim3(256), 0, stream, pred, target, mean, stdv, out, n_img,
+                       size);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+#define L1_BLOCKS 1024
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         long n4, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 x = ld4(a + 4 * i), y = ld4(b + 4 * i);
+        s += (fabsf(x[0] - y[0]) + fabsf(x[1] - y[1])) + (fabsf(x[2] - y[2]) + fabsf(x[3] - y[3]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ partial, int n, float scale,
+                                                       float* __restrict__ acc) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) acc[0] += scale * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+int launch_l1_diff(const float* a, const float* b, long n, float scale, float* partial, float* loss_acc,
+                   hipStream_t stream) {
+    S3D_CHECK_ARG(n % 4 == 0, "l1_diff: n must be a multiple of 4");
+    const long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < L1_BLOCKS ? (n4 + 255) / 256 : L1_BLOCKS);
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, stream, a, b, n4, partial);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, scale, loss_acc);
     S3D_LAUNCH_CHECK();
     return 0;
 }

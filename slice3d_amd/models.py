@@ -269,6 +269,16 @@ class Slices3DRegModel(nn.Module):
         nb = lib.s3d_head_packed_bytes()
         self._head_packed = torch.empty(nb, dtype=torch.uint8, device=dev)
         _lib.check(lib.s3d_head_pack(C.byref(hp), self._head_packed.data_ptr(), nb, self._stream()), "s3d_head_pack")
+        vp = _lib.S3dVggParams()
+        vgg = self.vggptlossfunc.vgg
+        for i, (idx, _, _) in enumerate(_VGG19_CONVS):
+            vp.conv[i] = self._conv_params(getattr(getattr(vgg, _slice_of(idx, _VGG19_SLICES)), str(idx)))
+        self._vgg_mean = self.vggptlossfunc.mean.reshape(3).contiguous()
+        self._vgg_std = self.vggptlossfunc.std.reshape(3).contiguous()
+        vp.mean, vp.std = self._vgg_mean.data_ptr(), self._vgg_std.data_ptr()
+        nb = lib.s3d_vgg_packed_bytes()
+        self._vgg_packed = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.s3d_vgg_pack(C.byref(vp), self._vgg_packed.data_ptr(), nb, self._stream()), "s3d_vgg_pack")
         self._packed_key = self._params_key()
 
     def _ensure_packed(self):
@@ -418,4 +428,15 @@ class Slices3DRegModel(nn.Module):
         return ret
 
     def vgg_loss(self, slices_rec_flat, img_slices):
-        raise NotImplementedError("VGG19 perceptual loss kernels are not built yet")
+        """VGGPerceptualLoss(slices_rec, img_slices)['pt_c_loss'] * 0.001 (models.py:90-92)."""
+        lib = self._require_lib()
+        self._ensure_packed()
+        pred = self._f32(slices_rec_flat)
+        n, _, s, _ = pred.shape
+        tgt = self._f32(img_slices).reshape(n, 3, s, s)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        nb = lib.s3d_vgg_workspace_bytes(n, s)
+        ws = self._workspace("vgg", nb)
+        _lib.check(lib.s3d_vgg_loss_fwd(self._vgg_packed.data_ptr(), pred.data_ptr(), tgt.data_ptr(), n, s,
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "s3d_vgg_loss_fwd")
+        return out

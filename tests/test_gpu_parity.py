@@ -54,7 +54,6 @@ def test_forward_matches_reference_golden(name):
     g = load_golden(name)
     model = get_model(g["n_slices"], g["mode"])
     fd = golden_feed(g)
-    fd.pop("img_slices", None)
     qry_before = fd["qry_norot"].clone()
     out = model(to_gpu(fd))
     torch.cuda.synchronize()
@@ -129,6 +128,28 @@ def test_full_size_256_matches_oracle():
     ref = ref_cpu.decode_points(sd, feats, qr, fd["trans_mat_wo_rot_tp"], 12)
     assert (sdf[:, idx] - ref).abs().max() < TOL
     assert (out["slices_rec"].cpu().view(12, 3, 256, 256) - rec).abs().max() < TOL
+
+
+@pytest.mark.parametrize("name", ["g1_c1_s64_n4_q1000_train", "g3_s32_n12_q512_b2_train"])
+def test_vgg_loss_matches_reference_golden(name):
+    """Full reference forward contract incl. vgg_loss (models.py:86-94)."""
+    g = load_golden(name)
+    model = get_model(g["n_slices"], g["mode"])
+    out = model(to_gpu(golden_feed(g)))
+    want = float(g["vgg_loss"])
+    assert abs(float(out["vgg_loss"]) - want) < 2e-5 * abs(want) + 1e-8, (float(out["vgg_loss"]), want)
+
+
+def test_vgg_loss_matches_oracle_128():
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    model = get_model(12, "train")
+    sd = seeded_sd_from_shapes(_shapes(12))
+    fd = make_feed_dict(1, 128, 64, 12, seed=31)
+    out = model(to_gpu(fd))
+    ref = ref_cpu.forward(sd, fd, mode="train", n_slices=12)
+    assert abs(float(out["vgg_loss"]) - float(ref["vgg_loss"])) < 2e-5 * float(ref["vgg_loss"])
+    assert float(model.vgg_loss(fd["img_slices"].view(12, 3, 128, 128).cuda(), fd["img_slices"].cuda())) == 0.0
 
 
 def test_chunk_invariance_and_permutation():
