@@ -166,6 +166,35 @@ int s3d_vgg_loss_fwd(const void* packed, const float* pred, const float* target,
                      float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training step — replaces train_step (reg_slices/train.py:41-53): train-mode forward (batch-statistic
+ * BatchNorm with the running-stat update, unet_parts.py:17,20), the three losses of cal_loss_pred
+ * (train.py:29-39) + cal_acc (train.py:21-27), backward of everything, and Adam (train.py:136).
+ * Gradients are written into caller-owned buffers laid out like the parameters: `unet_grad` / `head_grad`
+ * are the same structs with every pointer replaced by the gradient buffer of that tensor (bn[0], bn[1] =
+ * d gamma, d beta; bn[2], bn[3] ignored).  BatchNorm running_mean / running_var are updated IN PLACE
+ * through unet->...bn[2], bn[3].  losses_out[4] = {L1(sdf), L1(slices), vgg_loss (x0.001), sign accuracy}.
+ * The caller all-reduces the gradient buffers across ranks (data parallel) between this call and
+ * s3d_adam_step.  Only dropout_p == 0 is built in this round.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* img;          /* (B,3,S,S)            img_input            */
+    const float* img_slices;   /* (B,3*n_slices,S,S)   img_slices           */
+    const float* qry;          /* (B,Q,3)              qry_norot            */
+    const float* rot;          /* (B,3,3)              obj_rot_mat          */
+    const float* trans;        /* (B,4,3)              trans_mat_wo_rot_tp  */
+    const float* sdf;          /* (B,Q)                sdf                  */
+} S3dTrainBatch;
+size_t s3d_train_workspace_bytes(int batch, int size, long n_qry, int n_slices);
+int s3d_train_fwd_bwd(const S3dUNetParams* unet, const S3dHeadParams* head, const S3dVggParams* vgg,
+                      const S3dUNetParams* unet_grad, const S3dHeadParams* head_grad,
+                      const S3dTrainBatch* batch, int batch_size, int size, long n_qry, int n_slices,
+                      float dropout_p, unsigned long long seed, float* losses_out, float* sdf_pred_out,
+                      float* slices_rec_out, void* workspace, size_t workspace_bytes, void* stream);
+/* torch.optim.Adam defaults semantics (no weight decay, no amsgrad); step counts from 1. */
+int s3d_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                  float eps, int step, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement hook (no reference counterpart): when enabled, the launches of each kernel family are
  * bracketed with hipEvents on the caller's stream; s3d_prof_read waits for them and returns the summed
  * duration and the number of launches since s3d_prof_enable(1).  bench.py uses it to time the

@@ -49,6 +49,30 @@ _VGG19_TAP_CONVS = (2, 7, 12, 21, 30)
 _VGG19_W = (1.0 / 2.6, 1.0 / 4.8, 1.0 / 3.7, 1.0 / 5.6, 10.0 / 1.5)
 
 
+class TrainState:
+    """Train-mode switches for the restatement: batch-statistic BatchNorm (with the running-stat update
+    torch performs, momentum 0.1, unbiased variance) and dropout probability (the reference trains with
+    nn.TransformerEncoderLayer's default 0.1; parity runs pin it to 0).  `new_stats` collects the
+    updated running statistics keyed like the state_dict."""
+
+    def __init__(self, dropout=0.0):
+        self.dropout = dropout
+        self.new_stats = {}
+
+
+def _bn(x, sd, prefix, train=None):
+    if train is None:
+        return _bn_eval(x, sd, prefix)
+    n = x.numel() // x.shape[1]
+    mu = x.mean(dim=(0, 2, 3))
+    var = x.var(dim=(0, 2, 3), unbiased=False)
+    with torch.no_grad():
+        train.new_stats[prefix + ".running_mean"] = 0.9 * sd[prefix + ".running_mean"] + 0.1 * mu
+        train.new_stats[prefix + ".running_var"] = 0.9 * sd[prefix + ".running_var"] + 0.1 * var * n / max(n - 1, 1)
+    xh = (x - mu.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + BN_EPS)
+    return xh * sd[prefix + ".weight"].view(1, -1, 1, 1) + sd[prefix + ".bias"].view(1, -1, 1, 1)
+
+
 def _bn_eval(x, sd, prefix):
     w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
     m, v = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
@@ -60,7 +84,7 @@ def _bn_eval(x, sd, prefix):
 # --------------------------------------------------------------------------------------------------
 # U-Net  (unet_custom.py:40-69)
 # --------------------------------------------------------------------------------------------------
-def unet_encoder(sd, x, pfx="slices_generator."):
+def unet_encoder(sd, x, pfx="slices_generator.", train=None):
     """VGG16-BN encoder; returns the five PRE-BN tap tensors x1..x5."""
     taps = []
     h = x
@@ -71,7 +95,7 @@ def unet_encoder(sd, x, pfx="slices_generator."):
             taps.append(h)
         if ci == 40:
             break  # down5_ (BN-ReLU-pool) output is never used (unet_custom.py:48)
-        h = torch.relu(_bn_eval(h, sd, f"{pfx}{_VGG16_BN_OWNER[ci]}.{ci + 1}"))
+        h = torch.relu(_bn(h, sd, f"{pfx}{_VGG16_BN_OWNER[ci]}.{ci + 1}", train))
         if ci in _VGG16_POOL_AFTER_BN_OF:
             h = F.max_pool2d(h, 2, 2)
     return taps
@@ -82,24 +106,24 @@ def _expand_bs(x, n_slices):
     return x.view(b, 1, c, h, w).expand(-1, n_slices, -1, -1, -1).reshape(b * n_slices, c, h, w)
 
 
-def _double_conv(sd, x, prefix):
+def _double_conv(sd, x, prefix, train=None):
     h = F.conv2d(x, sd[prefix + ".0.weight"], None, padding=1)
-    h = torch.relu(_bn_eval(h, sd, prefix + ".1"))
+    h = torch.relu(_bn(h, sd, prefix + ".1", train))
     h = F.conv2d(h, sd[prefix + ".3.weight"], None, padding=1)
-    return torch.relu(_bn_eval(h, sd, prefix + ".4"))
+    return torch.relu(_bn(h, sd, prefix + ".4", train))
 
 
-def _up(sd, x1, x2, prefix):
+def _up(sd, x1, x2, prefix, train=None):
     """Up.forward (unet_parts.py:55-75): ConvT 2x2 s2, pad to skip size, cat [skip, up], DoubleConv."""
     x1 = F.conv_transpose2d(x1, sd[prefix + ".up.weight"], sd[prefix + ".up.bias"], stride=2)
     dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
     x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
-    return _double_conv(sd, torch.cat([x2, x1], dim=1), prefix + ".conv.double_conv")
+    return _double_conv(sd, torch.cat([x2, x1], dim=1), prefix + ".conv.double_conv", train)
 
 
-def unet_forward(sd, x, n_slices=12, pfx="slices_generator."):
+def unet_forward(sd, x, n_slices=12, pfx="slices_generator.", train=None):
     """-> (feats[5] each (B*n_slices, C_l, H_l, W_l) NCHW, slices_rec (B*n_slices, 3, S, S))."""
-    x1, x2, x3, x4, x5 = unet_encoder(sd, x, pfx)
+    x1, x2, x3, x4, x5 = unet_encoder(sd, x, pfx, train)
     b, _, h5, w5 = x5.shape
     emb = sd[pfx + "emds.weight"]  # (n_slices, 128)
     emb_tile = emb.view(1, n_slices, -1, 1, 1).expand(b, n_slices, emb.shape[1], h5, w5)
@@ -111,7 +135,7 @@ def unet_forward(sd, x, n_slices=12, pfx="slices_generator."):
     for i, skip in zip((1, 2, 3, 4), (x4, x3, x2, x1)):
         proj = F.conv2d(_expand_bs(skip, n_slices), sd[f"{pfx}trans_up{i}.weight"],
                         sd[f"{pfx}trans_up{i}.bias"])
-        h = _up(sd, h, proj, f"{pfx}up{i}")
+        h = _up(sd, h, proj, f"{pfx}up{i}", train)
         feats.append(h)
     out = torch.tanh(F.conv2d(h, sd[pfx + "outc.conv.weight"], sd[pfx + "outc.conv.bias"]))
     return feats, out
@@ -164,7 +188,7 @@ def layer_norm(x, w, b):
     return (x - mu) / torch.sqrt(var + LN_EPS) * w + b
 
 
-def transformer_layer(sd, x, prefix):
+def transformer_layer(sd, x, prefix, dropout=0.0):
     """One post-LN nn.TransformerEncoderLayer(d=128, nhead=4, ffn=2048, relu), eval mode
     (models.py:18-19).  x: (R, L, 128)."""
     r, l, d = x.shape
@@ -175,12 +199,16 @@ def transformer_layer(sd, x, prefix):
     k = k.view(r, l, N_HEADS, hd).transpose(1, 2)
     v = v.view(r, l, N_HEADS, hd).transpose(1, 2)
     att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
+    att = F.dropout(att, dropout, training=dropout > 0)           # MHA dropout on attention weights
     o = (att @ v).transpose(1, 2).reshape(r, l, d)
     o = o @ sd[prefix + ".self_attn.out_proj.weight"].t() + sd[prefix + ".self_attn.out_proj.bias"]
-    x = layer_norm(x + o, sd[prefix + ".norm1.weight"], sd[prefix + ".norm1.bias"])
+    x = layer_norm(x + F.dropout(o, dropout, training=dropout > 0), sd[prefix + ".norm1.weight"],
+                   sd[prefix + ".norm1.bias"])
     hdn = torch.relu(x @ sd[prefix + ".linear1.weight"].t() + sd[prefix + ".linear1.bias"])
+    hdn = F.dropout(hdn, dropout, training=dropout > 0)
     f = hdn @ sd[prefix + ".linear2.weight"].t() + sd[prefix + ".linear2.bias"]
-    return layer_norm(x + f, sd[prefix + ".norm2.weight"], sd[prefix + ".norm2.bias"])
+    return layer_norm(x + F.dropout(f, dropout, training=dropout > 0), sd[prefix + ".norm2.weight"],
+                      sd[prefix + ".norm2.bias"])
 
 
 def sample_pyramid(feats, img_pts, n_slices):
@@ -193,7 +221,7 @@ def sample_pyramid(feats, img_pts, n_slices):
     return agg.view(b, n_slices, q, c).permute(0, 2, 1, 3).reshape(b * q, n_slices, c)
 
 
-def decode_tokens(sd, tokens_slices, qry_rot, return_layers=False):
+def decode_tokens(sd, tokens_slices, qry_rot, return_layers=False, dropout=0.0):
     """fc_p / fc_s / 3-layer transformer / fc_out (models.py:79-84).
     tokens_slices: (B*Q, n_slices, 992) sampled features; qry_rot (B,Q,3) -> sdf (B,Q)."""
     b, q, _ = qry_rot.shape
@@ -202,7 +230,7 @@ def decode_tokens(sd, tokens_slices, qry_rot, return_layers=False):
     x = torch.cat([feat_qry.view(b * q, 1, D_MODEL), feat_slice], 1)
     layers = [x]
     for i in range(3):
-        x = transformer_layer(sd, x, f"att_decoder.layers.{i}")
+        x = transformer_layer(sd, x, f"att_decoder.layers.{i}", dropout)
         layers.append(x)
     tok0 = x[:, 0, :].view(b, q, D_MODEL)
     sdf = (tok0 @ sd["fc_out.0.weight"].t() + sd["fc_out.0.bias"]).squeeze(-1)
@@ -284,6 +312,32 @@ def forward(sd, feed_dict, mode="train", n_slices=12, with_vgg=True):
         tgt = feed_dict["img_slices"].view(b * n_slices, 3, s1, s2)
         ret["vgg_loss"] = vgg_perceptual_loss(sd, slices_rec, tgt) * 0.001
     return ret
+
+
+def forward_train(sd, feed_dict, n_slices=12, dropout=0.0):
+    """Slices3DRegModel.forward in TRAIN mode (batch-stat BN, dropout) + the losses of train.py:41-47,
+    differentiable w.r.t. the tensors of `sd` that require grad.  Returns (loss, parts, out, TrainState)."""
+    ts = TrainState(dropout)
+    img = feed_dict["img_input"]
+    b, _, s1, s2 = img.shape
+    qry_rot = torch.bmm(feed_dict["qry_norot"], feed_dict["obj_rot_mat"])
+    feats, slices_rec = unet_forward(sd, img, n_slices, train=ts)
+    img_pts = project_coord(qry_rot, feed_dict["trans_mat_wo_rot_tp"])
+    tok = sample_pyramid(feats, img_pts, n_slices)
+    sdf = decode_tokens(sd, tok, qry_rot, dropout=dropout)
+    tgt = feed_dict["img_slices"].view(b * n_slices, 3, s1, s2)
+    out = {"sdf_pred": sdf, "slices_rec": slices_rec.view(b, n_slices * 3, s1, s2),
+           "vgg_loss": vgg_perceptual_loss(sd, slices_rec, tgt) * 0.001}
+    lp, li, lv = cal_loss_pred(out, feed_dict)
+    return lp + li + lv, (lp, li, lv), out, ts
+
+
+def adam_step(p, g, m, v, step, lr=3e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam (no weight decay, no amsgrad) single-tensor update; step counts from 1."""
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    denom = torch.sqrt(v) / math.sqrt(1 - b2 ** step) + eps
+    return p - (lr / (1 - b1 ** step)) * m / denom, m, v
 
 
 def cal_loss_pred(x, gt):

@@ -50,6 +50,10 @@ class S3dVggParams(C.Structure):
     _fields_ = [("conv", S3dConvParams * 14), ("mean", C.c_void_p), ("std", C.c_void_p)]
 
 
+class S3dTrainBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("img", "img_slices", "qry", "rot", "trans", "sdf")]
+
+
 class S3dLatent(C.Structure):
     _fields_ = [("proj", C.c_void_p * 3), ("fine", C.c_void_p * 2), ("n_img", C.c_int),
                 ("size", C.c_int)]
@@ -75,6 +79,11 @@ SYMBOLS = {
     "s3d_vgg_pack": (_i, [C.POINTER(S3dVggParams), _vp, _sz, _vp]),
     "s3d_vgg_workspace_bytes": (_sz, [_i, _i]),
     "s3d_vgg_loss_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "s3d_train_workspace_bytes": (_sz, [_i, _i, _l, _i]),
+    "s3d_train_fwd_bwd": (_i, [C.POINTER(S3dUNetParams), C.POINTER(S3dHeadParams), C.POINTER(S3dVggParams),
+                               C.POINTER(S3dUNetParams), C.POINTER(S3dHeadParams), C.POINTER(S3dTrainBatch),
+                               _i, _i, _l, _i, _f, C.c_ulonglong, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "s3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _i, _vp]),
     "s3d_prof_enable": (_i, [_i]),
     "s3d_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "s3d_project_coord_fwd": (_i, [_vp, _vp, _vp, _i, _l, _vp]),

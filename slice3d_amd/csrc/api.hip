@@ -4,8 +4,11 @@
 
 #include <vector>
 
+#include <math.h>
+
 #include "conv.h"
 #include "decode.h"
+#include "train.h"
 
 static thread_local char g_err[512] = "";
 
@@ -722,3 +725,5 @@ extern "C" int s3d_nhwc_to_nchw(const float* in, float* out, int n, int c, int h
     S3D_CHECK_ARG(in && out, "nhwc_to_nchw: null argument");
     return launch_nhwc_to_nchw(in, out, n, c, h, w, (hipStream_t)stream);
 }
+
+#include "api_train.inc"

@@ -68,4 +68,10 @@ void s3d_set_error(const char* fmt, ...);
         }                                                             \
     } while (0)
 
+#define TRY_RET(x)               \
+    do {                         \
+        int rc__ = (x);          \
+        if (rc__) return rc__;   \
+    } while (0)
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -19,7 +19,9 @@ struct ConvLaunch {
     ConvSrc src[2];
     int nsrc;
     int N, H, W;         // images and spatial size of the output grid (= input grid, "same" padding)
-    int ks;              // 1 or 3
+    int ks;              // 1, 3 (pad 1) or 2 (pad 0; with stride 2 = the data-gradient of ConvTranspose2d 2x2 s2)
+    int stride;          // 0/1 = 1; 2: input pixel = 2*out + tap offset, input grid is (Hin, Win)
+    int Hin, Win;        // input spatial size (0 = same as H, W)
     int CoutPad;         // GEMM N, multiple of 16 (padded rows of the packed weight are zero)
     const float* wpk;    // packed A fragments [CoutPad/16][KU][64][4]
     int KU;              // total K chunks = sum over sources of ks*ks*C/16
@@ -30,16 +32,24 @@ struct ConvLaunch {
     int out_mode;
     int cout_store;      // channels actually stored (NHWC/NCHW), or Ct of a ConvT (CoutPad = 4*Ct)
     int out_cstride;     // channel stride of the NHWC output tensor
+    const float* residual;  // NHWC mode only: v += residual[same index] (after activation)
+    int out_accumulate;  // NHWC mode only: out += v
 };
 
 int launch_conv(const ConvLaunch& a, hipStream_t stream);
 
 // weight / epilogue packers (device kernels behind them)
-enum { S3D_PACK_LINEAR = 0, S3D_PACK_CONV = 1, S3D_PACK_CONVT = 2 };
+enum { S3D_PACK_LINEAR = 0, S3D_PACK_CONV = 1, S3D_PACK_CONVT = 2, S3D_PACK_CONV_DGRAD = 3,
+       S3D_PACK_CONVT_DGRAD = 4, S3D_PACK_LINEAR_T = 5 };
 // dst fragment image rows [0, n_pad) x chunks [u_off, u_off + ku_seg) of a KU_total-wide image.
 //  LINEAR: elem(n,k) = src[n*ld + k]                      (k < k_valid)
 //  CONV:   k = tap*cseg + c ; elem = src[(n*cin_tot + cin_begin + c)*taps + tap]  (c < cseg_valid)
 //  CONVT:  n = q*ct + co ; elem(n, k=ci) = src[(ci*ct + co)*4 + q]                (ci < k_valid)
+//  CONV_DGRAD (data gradient of a ks x ks "same" conv = conv of dY with the flipped, transposed weight):
+//          n = ci - cin_begin ; k = tap*cseg + co ; elem = src[((co*cin_tot + cin_begin + n)*taps) + taps-1-tap]
+//  CONVT_DGRAD (data gradient of ConvTranspose2d 2x2 s2 = 2x2 stride-2 conv of dY):
+//          n = ci ; k = q*ct + co ; elem = src[(n*ct + co)*4 + q]
+//  LINEAR_T: elem(n,k) = src[k*ld + n]
 struct PackArgs {
     const float* src;
     float* dst;

@@ -26,6 +26,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvLaunc
     const int blk_co = blockIdx.x % n_co_blk;
     const long blk_px = blockIdx.x / n_co_blk;
     const int HW = a.H * a.W;
+    const int stride = a.stride > 1 ? a.stride : 1;
+    const int Hin = a.Hin ? a.Hin : a.H, Win = a.Win ? a.Win : a.W;
+    constexpr int PAD = KS == 3 ? 1 : 0;
 
     int pn[MT], py[MT], px[MT];
     bool pv[MT];
@@ -54,15 +57,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvLaunc
         const int cu = S.C >> 4;
 #pragma unroll 1
         for (int tap = 0; tap < KS * KS; ++tap) {
-            const int dy = tap / KS - KS / 2, dx = tap % KS - KS / 2;
+            const int dy = tap / KS - PAD, dx = tap % KS - PAD;
             const float* bp[MT];
             bool ok[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int y = py[mt] + dy, x = px[mt] + dx;
-                ok[mt] = pv[mt] && y >= 0 && y < a.H && x >= 0 && x < a.W;
+                const int y = py[mt] * stride + dy, x = px[mt] * stride + dx;
+                ok[mt] = pv[mt] && y >= 0 && y < Hin && x >= 0 && x < Win;
                 const int ni = (S.bmod ? pn[mt] % S.bmod : pn[mt]) / S.bdiv;
-                const long off = S.sbcast ? (long)ni * S.C : ((long)(ni * a.H + y) * a.W + x) * S.C;
+                const long off = S.sbcast ? (long)ni * S.C : ((long)(ni * Hin + y) * Win + x) * S.C;
                 bp[mt] = S.p + (ok[mt] ? off : 0) + 4 * g;
             }
             const float* wp = frag_ptr(a.wpk, jt0, ubase + tap * cu, a.KU, lane);
@@ -101,8 +104,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvLaunc
             }
             if (a.out_mode == S3D_OUT_NHWC) {
                 if (co < a.cout_store) {  // cout_store is a multiple of 4 in this mode
-                    float* o = a.out + ((long)(pn[mt] * a.H + py[mt]) * a.W + px[mt]) * a.out_cstride + co;
-                    st4(o, v);
+                    const long oi = ((long)(pn[mt] * a.H + py[mt]) * a.W + px[mt]) * a.out_cstride + co;
+                    if (a.residual) v += ld4(a.residual + oi);
+                    if (a.out_accumulate) v += ld4(a.out + oi);
+                    st4(a.out + oi, v);
                 }
             } else if (a.out_mode == S3D_OUT_CONVT) {
                 const int ct = a.cout_store;  // multiple of 16: a lane's 4 channels share a quadrant
@@ -131,6 +136,8 @@ static int launch_cfg(const ConvLaunch& a, hipStream_t stream) {
     dim3 grid((unsigned)nblk), block(WM * WN * 64);
     if (a.ks == 3)
         hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, WM, WN, 3>), grid, block, 0, stream, a);
+    else if (a.ks == 2)
+        hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, WM, WN, 2>), grid, block, 0, stream, a);
     else
         hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, WM, WN, 1>), grid, block, 0, stream, a);
     S3D_LAUNCH_CHECK();
@@ -138,7 +145,7 @@ static int launch_cfg(const ConvLaunch& a, hipStream_t stream) {
 }
 
 int launch_conv(const ConvLaunch& a, hipStream_t stream) {
-    S3D_CHECK_ARG(a.ks == 1 || a.ks == 3, "conv: ks must be 1 or 3");
+    S3D_CHECK_ARG(a.ks >= 1 && a.ks <= 3, "conv: ks must be 1, 2 or 3");
     S3D_CHECK_ARG(a.CoutPad % 16 == 0 && a.CoutPad > 0, "conv: CoutPad %d", a.CoutPad);
     for (int s = 0; s < a.nsrc; ++s)
         S3D_CHECK_ARG(a.src[s].C % 16 == 0 && a.src[s].bdiv >= 1, "conv: bad source %d", s);
@@ -185,9 +192,18 @@ __global__ void pack_frag_kernel(const PackArgs a) {
             } else if (a.kind == S3D_PACK_CONV) {
                 const int tap = k / a.cseg, c = k - tap * a.cseg;
                 if (c < a.cseg_valid) v = a.src[((long)n * a.cin_tot + a.cin_begin + c) * a.taps + tap];
-            } else {
+            } else if (a.kind == S3D_PACK_CONVT) {
                 const int q = n / a.ct, co = n - q * a.ct;
                 if (k < a.k_valid) v = a.src[((long)k * a.ct + co) * 4 + q];
+            } else if (a.kind == S3D_PACK_CONV_DGRAD) {
+                const int tap = k / a.cseg, co = k - tap * a.cseg;
+                if (co < a.cseg_valid)
+                    v = a.src[((long)co * a.cin_tot + a.cin_begin + n) * a.taps + (a.taps - 1 - tap)];
+            } else if (a.kind == S3D_PACK_CONVT_DGRAD) {
+                const int q = k / a.ct, co = k - q * a.ct;
+                if (q < 4) v = a.src[((long)n * a.ct + co) * 4 + q];
+            } else {  // LINEAR_T
+                if (k < a.k_valid) v = a.src[(long)k * a.ld + n];
             }
         }
         long fi;

@@ -44,6 +44,7 @@ struct SampleArgs {
     int nx;
     float box;
     float* X;            // out [g_count][T][16][128]
+    float* raw_out;      // optional (training): sampled level-3/4 features [g_count][T][16][96], token-0 rows zero
 };
 
 int launch_sample_tokens(const SampleArgs& a, hipStream_t stream);
@@ -54,6 +55,9 @@ int launch_attn_layer(float* X, float* x0_out, long groups, int T, const LayerPt
 int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w, const float* fco_b,
                      float* sdf_out, float sign, long groups_per_batch, long n_qry, long g_begin, int prec,
                      hipStream_t stream);
+// training forward: y = LN2(u), u = x + FFN(x) with x read from Xin, y -> Yout, u -> Uout (pre-LN, saved)
+int launch_ffn_layer_train(const float* Xin, float* Yout, float* Uout, long rows, const LayerPtrs& w,
+                           hipStream_t stream);
 
 int launch_project_coord(const float* coords, const float* trans, float* out, int batch, long n_qry,
                          hipStream_t stream);

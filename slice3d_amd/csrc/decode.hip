@@ -185,10 +185,20 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
                         acc[j] = mfma4(ld4(s_ws34 + ((j * 6 + u) * 64 + lane) * 4), braw[u], acc[j]);
+                if (a.raw_out) {
+                    float* ro = a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 96 + 4 * g;
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) st4(ro + 16 * u, braw[u]);
+                }
             }
             float* o = a.X + ((gi * T + t) * S3D_GROUP + m) * 128 + 4 * g;
 #pragma unroll
             for (int j = 0; j < 8; ++j) st4(o + 16 * j, acc[j]);
+            if (a.raw_out && t == 0) {
+                float* ro = a.raw_out + ((gi * T) * S3D_GROUP + m) * 96 + 4 * g;
+#pragma unroll
+                for (int u = 0; u < 6; ++u) st4(ro + 16 * u, zero4());
+            }
         }
     }
 }
@@ -379,8 +389,8 @@ int launch_attn_layer(float* X, float* x0_out, long groups, int T, const LayerPt
 #define FFN_CHUNK_FLOATS 8192   // 16 KiB of W1 fragments + 16 KiB of W2 fragments
 
 template <bool FINAL>
-__global__ __launch_bounds__(256) void ffn_layer_kernel(float* X, long rows, const LayerPtrs w,
-                                                        const float* fco_w, const float* fco_b,
+__global__ __launch_bounds__(256) void ffn_layer_kernel(const float* X, float* Yout, float* Uout, long rows,
+                                                        const LayerPtrs w, const float* fco_w, const float* fco_b,
                                                         float* sdf_out, float sign, long groups_per_batch,
                                                         long n_qry, long g_begin) {
     __shared__ __attribute__((aligned(16))) float s_w[2][FFN_CHUNK_FLOATS];  // 64 KiB
@@ -466,6 +476,11 @@ __global__ __launch_bounds__(256) void ffn_layer_kernel(float* X, long rows, con
         f32x4 y[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) y[j] = acc[r][j] + ld4(w.b2 + 16 * j + 4 * g) + xb[r][j];
+        if (!FINAL && Uout && row < rows) {
+            float* uo = Uout + row * 128 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(uo + 16 * j, y[j]);
+        }
         layer_norm_row(y, w.ln2g, w.ln2b, g);
         if (FINAL) {  // fc_out (models.py:84) on the token-0 row of query (group, m)
             float s = 0.f;
@@ -482,7 +497,7 @@ __global__ __launch_bounds__(256) void ffn_layer_kernel(float* X, long rows, con
                 if (q < n_qry) sdf_out[b * n_qry + q] = sign * s;
             }
         } else if (row < rows) {
-            float* o = X + row * 128 + 4 * g;
+            float* o = Yout + row * 128 + 4 * g;
 #pragma unroll
             for (int j = 0; j < 8; ++j) st4(o + 16 * j, y[j]);
         }
@@ -496,11 +511,21 @@ int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w
     if (rows <= 0) return 0;
     const long blocks = (rows + 4 * FFN_R * 16 - 1) / (4 * FFN_R * 16);
     if (sdf_out)
-        hipLaunchKernelGGL(ffn_layer_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, X, rows, w,
-                           fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+        hipLaunchKernelGGL(ffn_layer_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, X, X, nullptr, rows,
+                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
     else
-        hipLaunchKernelGGL(ffn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, X, rows, w,
-                           fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+        hipLaunchKernelGGL(ffn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, X, X, nullptr, rows,
+                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_ffn_layer_train(const float* Xin, float* Yout, float* Uout, long rows, const LayerPtrs& w,
+                           hipStream_t stream) {
+    if (rows <= 0) return 0;
+    const long blocks = (rows + 4 * FFN_R * 16 - 1) / (4 * FFN_R * 16);
+    hipLaunchKernelGGL(ffn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, Xin, Yout, Uout, rows,
+                       w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L);
     S3D_LAUNCH_CHECK();
     return 0;
 }

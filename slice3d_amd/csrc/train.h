@@ -1,0 +1,96 @@
+// train.h — internal interface of the backward / train-mode kernels (train.hip).
+#pragma once
+#include "conv.h"
+#include "decode.h"
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of a convolution / linear layer:
+//   dW[n][(tap, c)] (+)= sum over output pixels p of dY[p][n] * X[pixel(p, tap)][c]
+// (contraction over PIXELS on fp32 MFMA; partial sums per pixel split, then a deterministic reduce
+//  that writes straight into the PyTorch parameter layout selected by `out_kind`).
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* dy;      // (Nimg, H, W, dy_cstride) NHWC; channels [dy_coff, dy_coff + N) are used
+    int dy_cstride, dy_coff, N;
+    ConvSrc x;            // activation source (same addressing rules as the forward conv)
+    int x_coff, Cx;       // channels [x_coff, x_coff + Cx) of the source are this K segment
+    int Nimg, H, W;       // dY grid
+    int ks, stride, Hin, Win;
+    // output mapping (same index formulas as the packers):
+    float* out;
+    int out_kind;         // S3D_PACK_LINEAR: out[n*ld + k]; S3D_PACK_CONV: out[((n*cin_tot+cin_begin+c)*taps)+tap];
+                          // S3D_PACK_CONVT: rows n = ci, k = (q, co): out[(n*ct + co)*4 + q]
+    int ld, cin_tot, cin_begin, ct;
+    int accumulate;       // 1: out += result
+    float* partial;       // workspace
+    size_t partial_floats;
+};
+int launch_wgrad(const WgradArgs& a, hipStream_t stream);
+size_t wgrad_partial_floats(long P, int N, int Ktot);
+
+// column sums over rows/pixels: out[c] (+)= sum_p in[p*cstride + coff + c]
+int launch_colsum(const float* in, long P, int cstride, int coff, int C, float* out, int accumulate,
+                  float* partial, hipStream_t stream);
+
+// ---- BatchNorm2d, train mode (NHWC, statistics over all pixels of all images) ----
+// stats: mean[c], rstd[c] (biased variance), and the running-stat update torch does (momentum .1, unbiased)
+int launch_bn_stats(const float* z, long P, int C, float* mean, float* rstd, float* running_mean,
+                    float* running_var, float* partial, hipStream_t stream);
+// y = relu(gamma*(z-mean)*rstd + beta)            (pool = 0)
+// y = maxpool2x2(relu(...))                       (pool = 1; z is (N,H,W,C), y is (N,H/2,W/2,C))
+int launch_bn_apply(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    float* y, int n, int h, int w, int c, int pool, hipStream_t stream);
+// backward of y = relu(bn(z)) [+ maxpool]: given dy (grid of y), writes dz (grid of z), dgamma, dbeta.
+int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  const float* dy, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c, int pool,
+                  float* partial, hipStream_t stream);
+
+// ---- misc elementwise ----
+int launch_axpy(float* y, const float* x, float alpha, long n, hipStream_t stream);            // y += alpha*x
+int launch_slice_sum(const float* in, float* out, int batch, int ns, long per_img, int accumulate,
+                     hipStream_t stream);                                                      // out[b] (+)= sum_s in[b*ns+s]
+int launch_tanh_bwd(const float* y_nchw, const float* dy_nchw, float* dz_nhwc, int n, int c, int h, int w, int cpad,
+                    hipStream_t stream);   // dz[n,y,x,c] = dy*(1-y^2), NCHW -> NHWC(cpad), zero padded
+// L1 loss: loss_acc[0] += scale*sum|a-b|; grad[i] (+)= scale*sign(a-b)
+int launch_l1_fwd_bwd(const float* a, const float* b, long n, float scale, float* grad, int accumulate_grad,
+                      float* partial, float* loss_acc, hipStream_t stream);
+int launch_relu_mask_bwd(const float* y, float* dy, long n, hipStream_t stream);              // dy *= (y > 0)
+int launch_pool_bwd(const float* y, const float* dyp, float* dy, int n, int h, int w, int c, hipStream_t stream);
+int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                float bc1, float bc2, hipStream_t stream);
+
+// ---- decoder backward pieces ----
+// LayerNorm backward over rows of 128: du = LN'(u; gamma) dy ; dgamma/dbeta (+)= column sums
+int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du, long rows, float* dgamma,
+                  float* dbeta, int accumulate, float* partial, hipStream_t stream);
+int launch_ln_fwd(const float* u, const float* gamma, const float* beta, float* y, long rows, hipStream_t stream);
+// attention core on stored QKV [groups][T][16][384] (q | k | v, 4 heads x 32): O [groups][T][16][128]
+int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, hipStream_t stream);
+int launch_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, long groups, int T, hipStream_t stream);
+// d(hidden) *= (a > 0) ; a <- relu(a)   (FFN backward on a row block)
+int launch_relu_bwd_inplace(float* a, float* dh, long n, hipStream_t stream);
+
+// ---- train2.hip ----
+struct SampleBwdArgs {
+    const float* dX;         // [groups][T][16][128]
+    float* dproj[3];         // zero-initialised by the caller; (n_img, H_l, W_l, 128)
+    float* dfine[2];         // d pyramid levels 3, 4 (accumulated into)
+    const float* ws34_t;     // fragment image of Ws34^T: [6][8] tiles (LINEAR_T pack of fc_s[:, 896:992])
+    const float *qry, *rot, *trans;
+    int flip_yz, size, n_slices;
+    long n_qry, groups_per_batch, groups;
+};
+int launch_sample_bwd(const SampleBwdArgs& a, hipStream_t stream);
+int launch_tok0_copy(float* full, float* compact, long groups, int T, int dir, int width, hipStream_t stream);
+int launch_fc_out_fwd(const float* x, const float* w, const float* b, float* sdf, long rows, long gpb, long n_qry,
+                      hipStream_t stream);
+int launch_fc_out_bwd(const float* x, const float* w, const float* dsdf, float* dx, float* t, long rows, long gpb,
+                      long n_qry, hipStream_t stream);
+int launch_scalar_reduce(const float* a, const float* b, long n, int mode, float scale, float* out, int accumulate,
+                         float* partial, hipStream_t stream);
+int launch_vgg_prep_bwd(const float* din16, const float* stdv, float* drec, int n_img, int size, hipStream_t stream);
+int launch_qry_rot_rows(const float* qry, const float* rot, int flip_yz, long n_qry, long gpb, long groups,
+                        float* out, hipStream_t stream);
+int launch_copy_cols(const float* src, float* dst, int rows, int csrc, int cdst, hipStream_t stream);
+int launch_emb_grad(const float* dF0, const float* w, float* demds, int B, int ns, int npix, hipStream_t stream);
+#define CS_CHUNKS_MAX 512

@@ -1,0 +1,902 @@
+// train.hip — backward / train-mode kernels (gfx950, fp32).
+//
+// Together with the forward engines (conv.hip, decode.hip) these implement train_step of the reference
+// (reg_slices/train.py:41-53): train-mode BatchNorm (unet_parts.py:17,20 and the VGG16-BN encoder),
+// loss gradients (train.py:29-39), the backward of every op of models.py:48-94 and Adam
+// (train.py:136, torch.optim.Adam defaults).  Data gradients of convolutions / linears reuse the
+// forward implicit-GEMM engine with transposed weight packs; this file adds the weight-gradient GEMM
+// (contraction over pixels), reductions, normalisation backward, the attention core and optimiser.
+#include "train.h"
+
+// =============================================================================================
+// weight gradient:  dW[n][k] = sum_p dY[p][n] * X[pix(p,tap)][c]      (k = tap*Cx + c)
+// One MFMA step contracts 4 pixels (k-slot g <-> pixel 4*it+g).  Channel <-> lane mapping is
+// interleaved (channel = T*x + j for operand tile j, x = l&15) so each lane loads T consecutive
+// channels of ONE pixel with a single 4/8/16-byte load and a wave's load of a pixel quad is
+// 4 x (16*T*4) contiguous bytes.
+// =============================================================================================
+template <int T>
+__device__ __forceinline__ void load_vec(const float* p, bool ok, int valid, float (&v)[T]) {
+    // valid = number of usable channels starting at p (may be <= 0 or >= T)
+    if (ok && valid >= T) {
+        if (T == 4) {
+            const f32x4 t = ld4(p);
+            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j) v[j] = p[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < T; ++j) v[j] = (ok && j < valid) ? p[j] : 0.f;
+    }
+}
+
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, int n_cblk, int taps, long P,
+                                                    int steps_per_wave, int Ktot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    int bx = blockIdx.x;
+    const int cb = bx % n_cblk;
+    bx /= n_cblk;
+    const int tap = bx % taps;
+    const int nb = bx / taps;
+    const int split = blockIdx.y * 4 + wave;
+    const int KS = a.ks, PAD = a.ks == 3 ? 1 : 0;
+    const int stride = a.stride > 1 ? a.stride : 1;
+    const int Hin = a.Hin ? a.Hin : a.H, Win = a.Win ? a.Win : a.W;
+    const int dyo = tap / KS - PAD, dxo = tap % KS - PAD;
+    const int n0 = nb * 16 * TN + TN * x, c0 = cb * 16 * TK + TK * x;
+    const int HW = a.H * a.W;
+
+    f32x4 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = zero4();
+
+    const long p_begin = (long)split * steps_per_wave * 4;
+#pragma unroll 2
+    for (int it = 0; it < steps_per_wave; ++it) {
+        const long p = p_begin + (long)it * 4 + g;
+        const bool pv = p < P;
+        const long pc = pv ? p : 0;
+        const int img = (int)(pc / HW);
+        const int r = (int)(pc - (long)img * HW);
+        const int y = r / a.W, xx = r - y * a.W;
+        float av[TN], bv[TK];
+        load_vec<TN>(a.dy + pc * a.dy_cstride + a.dy_coff + n0, pv, a.N - n0, av);
+        const int yi = y * stride + dyo, xi = xx * stride + dxo;
+        const bool ok = pv && yi >= 0 && yi < Hin && xi >= 0 && xi < Win;
+        const int ni = (a.x.bmod ? img % a.x.bmod : img) / a.x.bdiv;
+        const long off = a.x.sbcast ? (long)ni * a.x.C : ((long)(ni * Hin + (ok ? yi : 0)) * Win + (ok ? xi : 0)) * a.x.C;
+        load_vec<TK>(a.x.p + off + a.x_coff + c0, ok, a.Cx - c0, bv);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TK; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    // D[row = 4g+reg <-> x_n][col = l&15 <-> x_k]
+    float* part = a.partial + (size_t)split * a.N * Ktot;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int n = nb * 16 * TN + TN * (4 * g + reg) + i;
+                const int c = cb * 16 * TK + TK * x + j;
+                if (n < a.N && c < a.Cx) part[(size_t)n * Ktot + tap * a.Cx + c] = acc[i][j][reg];
+            }
+}
+
+__global__ void wgrad_reduce_kernel(const WgradArgs a, int nsplit, int Ktot) {
+    const long total = (long)a.N * Ktot;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += a.partial[(size_t)sp * total + idx];
+        const int n = (int)(idx / Ktot), k = (int)(idx - (long)n * Ktot);
+        long o;
+        if (a.out_kind == S3D_PACK_LINEAR) {
+            o = (long)n * a.ld + k;
+        } else if (a.out_kind == S3D_PACK_CONV) {
+            const int tap = k / a.Cx, c = k - tap * a.Cx;
+            if (a.cin_begin + c >= a.cin_tot) continue;  // padded input channels (3 -> 16)
+            o = ((long)n * a.cin_tot + a.cin_begin + c) * (a.ks * a.ks) + tap;
+        } else {  // CONVT: n = ci, k = q*ct + co
+            const int q = k / a.ct, co = k - q * a.ct;
+            o = ((long)n * a.ct + co) * 4 + q;
+        }
+        a.out[o] = a.accumulate ? a.out[o] + s : s;
+    }
+}
+
+static void wgrad_plan(long P, int N, int Cx, int taps, int& TN, int& TK, int& n_nblk, int& n_cblk, int& splits_y,
+                       int& steps_per_wave) {
+    TN = N >= 64 ? 4 : N >= 32 ? 2 : 1;
+    TK = Cx >= 64 ? 4 : Cx >= 32 ? 2 : 1;
+    n_nblk = (N + 16 * TN - 1) / (16 * TN);
+    n_cblk = (Cx + 16 * TK - 1) / (16 * TK);
+    const long total_steps = (P + 3) / 4;
+    const long tiles = (long)n_nblk * n_cblk * taps;
+    long sy = (2048 + tiles - 1) / tiles;                       // aim at >= 2048 workgroups
+    const long max_by_steps = (total_steps + 4 * 16 - 1) / (4 * 16);  // >= 16 MFMA steps per wave
+    if (sy > max_by_steps) sy = max_by_steps;
+    const long cap = (64L << 20) / ((long)N * Cx * taps * 4);   // partial buffer <= 64 Mi floats
+    if (sy > cap) sy = cap;
+    if (sy < 1) sy = 1;
+    splits_y = (int)sy;
+    steps_per_wave = (int)((total_steps + sy * 4 - 1) / (sy * 4));
+}
+
+size_t wgrad_partial_floats(long P, int N, int Ktot) {
+    // upper bound used by workspace planners: plan with the whole K as one segment
+    int TN, TK, nn, nc, sy, spw;
+    wgrad_plan(P, N, Ktot, 1, TN, TK, nn, nc, sy, spw);
+    return (size_t)sy * 4 * N * Ktot;
+}
+
+int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
+    S3D_CHECK_ARG(a.ks >= 1 && a.ks <= 3 && a.N > 0 && a.Cx > 0, "wgrad: bad dims");
+    S3D_CHECK_ARG(a.dy_cstride % 4 == 0 && a.dy_coff % 4 == 0 && a.x.C % 4 == 0 && a.x_coff % 4 == 0,
+                  "wgrad: channel strides/offsets must be multiples of 4");
+    const long P = (long)a.Nimg * a.H * a.W;
+    const int taps = a.ks * a.ks;
+    int TN, TK, n_nblk, n_cblk, sy, spw;
+    wgrad_plan(P, a.N, a.Cx, taps, TN, TK, n_nblk, n_cblk, sy, spw);
+    const int Ktot = taps * a.Cx;
+    const size_t need = (size_t)sy * 4 * a.N * Ktot;
+    if (need > a.partial_floats) {
+        s3d_set_error("wgrad: partial workspace %zu < %zu floats", a.partial_floats, need);
+        return S3D_E_WORKSPACE;
+    }
+    dim3 grid((unsigned)(n_nblk * taps * n_cblk), (unsigned)sy), block(256);
+#define WG_CASE(tn, tk) \
+    if (TN == tn && TK == tk) hipLaunchKernelGGL((wgrad_kernel<tn, tk>), grid, block, 0, stream, a, n_cblk, taps, P, spw, Ktot)
+    WG_CASE(4, 4); WG_CASE(4, 2); WG_CASE(4, 1); WG_CASE(2, 4); WG_CASE(2, 2); WG_CASE(2, 1);
+    WG_CASE(1, 4); WG_CASE(1, 2); WG_CASE(1, 1);
+#undef WG_CASE
+    S3D_LAUNCH_CHECK();
+    const long total = (long)a.N * Ktot;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a, sy * 4, Ktot);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
+// column reductions (deterministic two-stage).  mode 0: sum x ; 1: sum (x-m[c])^2 ;
+// 2: two sums at once: sum g and sum g*(z-m[c])*r[c]   (BN backward; g in `in`, z in `in2`)
+// =============================================================================================
+#define CS_CHUNKS CS_CHUNKS_MAX
+template <int MODE>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, const float* __restrict__ in2,
+                                                     long P, int cstride, int coff, int C,
+                                                     const float* __restrict__ m, const float* __restrict__ r,
+                                                     float* __restrict__ partial, long rows_per_chunk) {
+    const int c4n = C >> 2;
+    const long r0 = (long)blockIdx.x * rows_per_chunk;
+    long r1 = r0 + rows_per_chunk;
+    if (r1 > P) r1 = P;
+    for (int cq = threadIdx.x; cq < c4n; cq += 256) {
+        const int c = cq * 4;
+        f32x4 s = zero4(), s2 = zero4();
+        f32x4 mv = zero4(), rv = zero4();
+        if (MODE >= 1) mv = ld4(m + c);
+        if (MODE == 2) rv = ld4(r + c);
+        for (long p = r0; p < r1; ++p) {
+            const f32x4 v = ld4(in + p * cstride + coff + c);
+            if (MODE == 0) {
+                s += v;
+            } else if (MODE == 1) {
+                const f32x4 d = v - mv;
+                s += d * d;
+            } else {
+                const f32x4 z = ld4(in2 + p * cstride + coff + c);
+                s += v;
+                s2 += v * ((z - mv) * rv);
+            }
+        }
+        st4(partial + ((size_t)blockIdx.x * C + c), s);
+        if (MODE == 2) st4(partial + ((size_t)(gridDim.x + blockIdx.x) * C + c), s2);
+    }
+}
+
+// final: out[c] (+)= scale * sum over chunks
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nchunks, int C, float scale,
+                                    float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * C + c];
+    s *= scale;
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+static int colsum_chunks(long P, long& rows_per_chunk) {
+    long n = P < CS_CHUNKS ? P : CS_CHUNKS;
+    if (n < 1) n = 1;
+    rows_per_chunk = (P + n - 1) / n;
+    return (int)((P + rows_per_chunk - 1) / rows_per_chunk);
+}
+
+int launch_colsum(const float* in, long P, int cstride, int coff, int C, float* out, int accumulate, float* partial,
+                  hipStream_t stream) {
+    S3D_CHECK_ARG(C % 4 == 0 && cstride % 4 == 0 && coff % 4 == 0, "colsum: C/stride must be multiples of 4");
+    if (P <= 0) return 0;
+    long rpc;
+    const int n = colsum_chunks(P, rpc);
+    hipLaunchKernelGGL((colsum_kernel<0>), dim3(n), dim3(256), 0, stream, in, nullptr, P, cstride, coff, C, nullptr,
+                       nullptr, partial, rpc);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, n, C, 1.f, out,
+                       accumulate);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
+// BatchNorm2d train mode
+// =============================================================================================
+__global__ void bn_finalize_kernel(const float* __restrict__ var_sum, long P, int C, float* __restrict__ rstd,
+                                   const float* __restrict__ mean, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float var = var_sum[c] / (float)P;
+    rstd[c] = 1.f / sqrtf(var + 1e-5f);
+    if (running_mean) {
+        running_mean[c] = 0.9f * running_mean[c] + 0.1f * mean[c];
+        const float unb = P > 1 ? var * (float)P / (float)(P - 1) : var;
+        running_var[c] = 0.9f * running_var[c] + 0.1f * unb;
+    }
+}
+
+int launch_bn_stats(const float* z, long P, int C, float* mean, float* rstd, float* running_mean,
+                    float* running_var, float* partial, hipStream_t stream) {
+    S3D_CHECK_ARG(C % 4 == 0 && P > 0, "bn_stats: bad dims");
+    long rpc;
+    const int n = colsum_chunks(P, rpc);
+    hipLaunchKernelGGL((colsum_kernel<0>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, nullptr, nullptr,
+                       partial, rpc);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, n, C,
+                       1.f / (float)P, mean, 0);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL((colsum_kernel<1>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, mean, nullptr,
+                       partial, rpc);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, n, C, 1.f, rstd, 0);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, rstd, P, C, rstd, mean,
+                       running_mean, running_var);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+__device__ __forceinline__ f32x4 bn_relu4(const f32x4 z, const f32x4 mu, const f32x4 rs, const f32x4 ga,
+                                          const f32x4 be) {
+    f32x4 y = (z - mu) * rs * ga + be;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = fmaxf(y[i], 0.f);
+    return y;
+}
+
+template <bool POOL>
+__global__ void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ y, int n, int h, int w, int c) {
+    const int c4 = c >> 2;
+    const int ho = POOL ? h >> 1 : h, wo = POOL ? w >> 1 : w;
+    const long total = (long)n * ho * wo * c4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(idx % c4) * 4;
+        const f32x4 mu = ld4(mean + cc), rs = ld4(rstd + cc), ga = ld4(gamma + cc), be = ld4(beta + cc);
+        if (!POOL) {
+            st4(y + idx * 4, bn_relu4(ld4(z + idx * 4), mu, rs, ga, be));
+        } else {
+            long r = idx / c4;
+            const int x = (int)(r % wo);
+            r /= wo;
+            const int yy = (int)(r % ho);
+            const int ni = (int)(r / ho);
+            f32x4 best;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 v = bn_relu4(ld4(z + ((long)(ni * h + 2 * yy + (t >> 1)) * w + 2 * x + (t & 1)) * c + cc),
+                                         mu, rs, ga, be);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) best[i] = t == 0 ? v[i] : fmaxf(best[i], v[i]);
+            }
+            st4(y + idx * 4, best);
+        }
+    }
+}
+
+int launch_bn_apply(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    float* y, int n, int h, int w, int c, int pool, hipStream_t stream) {
+    S3D_CHECK_ARG(c % 4 == 0 && (!pool || (h % 2 == 0 && w % 2 == 0)), "bn_apply: bad dims");
+    const long total = (long)n * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (c / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (pool)
+        hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(blocks), dim3(256), 0, stream, z, mean, rstd, gamma, beta, y,
+                           n, h, w, c);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(blocks), dim3(256), 0, stream, z, mean, rstd, gamma, beta, y,
+                           n, h, w, c);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// g = dL/d(bn output) on the z grid: relu mask (+ max-pool routing to the first maximum of the window)
+template <bool POOL>
+__global__ void bn_bwd_g_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ dy,
+                                float* __restrict__ g, int n, int h, int w, int c) {
+    const int c4 = c >> 2;
+    const int ho = POOL ? h >> 1 : h, wo = POOL ? w >> 1 : w;
+    const long total = (long)n * ho * wo * c4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(idx % c4) * 4;
+        const f32x4 mu = ld4(mean + cc), rs = ld4(rstd + cc), ga = ld4(gamma + cc), be = ld4(beta + cc);
+        const f32x4 d = ld4(dy + idx * 4);
+        if (!POOL) {
+            const f32x4 y = bn_relu4(ld4(z + idx * 4), mu, rs, ga, be);
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = y[i] > 0.f ? d[i] : 0.f;
+            st4(g + idx * 4, o);
+        } else {
+            long r = idx / c4;
+            const int x = (int)(r % wo);
+            r /= wo;
+            const int yy = (int)(r % ho);
+            const int ni = (int)(r / ho);
+            f32x4 v[4];
+            int arg[4] = {0, 0, 0, 0};
+            f32x4 best;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v[t] = bn_relu4(ld4(z + ((long)(ni * h + 2 * yy + (t >> 1)) * w + 2 * x + (t & 1)) * c + cc), mu, rs,
+                                ga, be);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (t == 0 || v[t][i] > best[i]) {
+                        best[i] = v[t][i];
+                        arg[i] = t;
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (arg[i] == t && best[i] > 0.f) ? d[i] : 0.f;
+                st4(g + ((long)(ni * h + 2 * yy + (t >> 1)) * w + 2 * x + (t & 1)) * c + cc, o);
+            }
+        }
+    }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                    float* __restrict__ g_dz, long P, int c) {
+    const int c4 = c >> 2;
+    const long total = P * c4;
+    const float invP = 1.f / (float)P;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(idx % c4) * 4;
+        const f32x4 mu = ld4(mean + cc), rs = ld4(rstd + cc), ga = ld4(gamma + cc);
+        const f32x4 sb = ld4(dbeta + cc), sg = ld4(dgamma + cc);
+        const f32x4 xh = (ld4(z + idx * 4) - mu) * rs;
+        const f32x4 g = ld4(g_dz + idx * 4);
+        st4(g_dz + idx * 4, ga * rs * (g - sb * invP - xh * (sg * invP)));
+    }
+}
+
+int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  const float* dy, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c, int pool,
+                  float* partial, hipStream_t stream) {
+    S3D_CHECK_ARG(c % 4 == 0, "bn_bwd: C %% 4");
+    const long P = (long)n * h * w;
+    const long tot_g = (long)n * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (c / 4);
+    const int bg = (int)((tot_g + 255) / 256 < 8192 ? (tot_g + 255) / 256 : 8192);
+    if (pool)
+        hipLaunchKernelGGL((bn_bwd_g_kernel<true>), dim3(bg), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy, dz,
+                           n, h, w, c);
+    else
+        hipLaunchKernelGGL((bn_bwd_g_kernel<false>), dim3(bg), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy,
+                           dz, n, h, w, c);
+    S3D_LAUNCH_CHECK();
+    long rpc;
+    const int nch = colsum_chunks(P, rpc);
+    hipLaunchKernelGGL((colsum_kernel<2>), dim3(nch), dim3(256), 0, stream, dz, z, P, c, 0, c, mean, rstd, partial,
+                       rpc);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, partial, nch, c, 1.f, dbeta,
+                       0);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, partial + (size_t)nch * c,
+                       nch, c, 1.f, dgamma, 0);
+    S3D_LAUNCH_CHECK();
+    const long tot = P * (c / 4);
+    const int ba = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, dbeta, dgamma, dz, P,
+                       c);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
+// elementwise
+// =============================================================================================
+static inline int ew_blocks(long n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] += alpha * x[i];
+}
+int launch_axpy(float* y, const float* x, float alpha, long n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, x, alpha, n);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void slice_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int batch, int ns,
+                                 long per_img, int accumulate) {
+    const long total = (long)batch * per_img;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / per_img, r = i - b * per_img;
+        float s = 0.f;
+        for (int k = 0; k < ns; ++k) s += in[(b * ns + k) * per_img + r];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+int launch_slice_sum(const float* in, float* out, int batch, int ns, long per_img, int accumulate,
+                     hipStream_t stream) {
+    hipLaunchKernelGGL(slice_sum_kernel, dim3(ew_blocks((long)batch * per_img)), dim3(256), 0, stream, in, out, batch,
+                       ns, per_img, accumulate);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dz,
+                                int n, int c, int h, int w, int cpad) {
+    const long total = (long)n * h * w * cpad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(idx % cpad);
+        long r = idx / cpad;
+        const int x = (int)(r % w);
+        r /= w;
+        const int yy = (int)(r % h);
+        const int ni = (int)(r / h);
+        float v = 0.f;
+        if (cc < c) {
+            const long s = ((long)(ni * c + cc) * h + yy) * w + x;
+            v = dy[s] * (1.f - y[s] * y[s]);
+        }
+        dz[idx] = v;
+    }
+}
+int launch_tanh_bwd(const float* y, const float* dy, float* dz, int n, int c, int h, int w, int cpad,
+                    hipStream_t stream) {
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks((long)n * h * w * cpad)), dim3(256), 0, stream, y, dy, dz, n, c,
+                       h, w, cpad);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+#define L1B 1024
+__global__ __launch_bounds__(256) void l1_fb_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                    float scale, float* __restrict__ grad, int acc_grad,
+                                                    float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        s += fabsf(d);
+        if (grad) {
+            const float gsign = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+            grad[i] = acc_grad ? grad[i] + gsign : gsign;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void scalar_final_kernel(const float* __restrict__ partial, int n, float scale,
+                                                           float* __restrict__ acc) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) acc[0] += scale * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+int launch_l1_fwd_bwd(const float* a, const float* b, long n, float scale, float* grad, int accumulate_grad,
+                      float* partial, float* loss_acc, hipStream_t stream) {
+    if (n <= 0) return 0;
+    const int blocks = (int)((n + 255) / 256 < L1B ? (n + 255) / 256 : L1B);
+    hipLaunchKernelGGL(l1_fb_kernel, dim3(blocks), dim3(256), 0, stream, a, b, n, scale, grad, accumulate_grad,
+                       partial);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, scale, loss_acc);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void relu_mask_bwd_kernel(const float* __restrict__ y, float* __restrict__ dy, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        if (!(y[i] > 0.f)) dy[i] = 0.f;
+}
+int launch_relu_mask_bwd(const float* y, float* dy, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, dy, n);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// max-pool 2x2 backward: y (N,H,W,C) pre-pool, dyp (N,H/2,W/2,C) -> dy (N,H,W,C), first maximum wins
+__global__ void pool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dyp, float* __restrict__ dy,
+                                int n, int h, int w, int c) {
+    const int c4 = c >> 2, ho = h >> 1, wo = w >> 1;
+    const long total = (long)n * ho * wo * c4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(idx % c4) * 4;
+        long r = idx / c4;
+        const int x = (int)(r % wo);
+        r /= wo;
+        const int yy = (int)(r % ho);
+        const int ni = (int)(r / ho);
+        const f32x4 d = ld4(dyp + idx * 4);
+        f32x4 v[4], best;
+        int arg[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            v[t] = ld4(y + ((long)(ni * h + 2 * yy + (t >> 1)) * w + 2 * x + (t & 1)) * c + cc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (t == 0 || v[t][i] > best[i]) {
+                    best[i] = v[t][i];
+                    arg[i] = t;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = arg[i] == t ? d[i] : 0.f;
+            st4(dy + ((long)(ni * h + 2 * yy + (t >> 1)) * w + 2 * x + (t & 1)) * c + cc, o);
+        }
+    }
+}
+int launch_pool_bwd(const float* y, const float* dyp, float* dy, int n, int h, int w, int c, hipStream_t stream) {
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_blocks((long)n * (h / 2) * (w / 2) * (c / 4))), dim3(256), 0, stream, y,
+                       dyp, dy, n, h, w, c);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// torch.optim.Adam (no weight decay / amsgrad); bc1 = 1-b1^t, bc2 = 1-b2^t
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2) {
+    const float step = lr / bc1, rbc2 = 1.f / sqrtf(bc2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) * rbc2 + eps);
+    }
+}
+int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                float bc1, float bc2, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void relu_bwd_inplace_kernel(float* __restrict__ a, float* __restrict__ dh, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = a[i];
+        if (v > 0.f) {
+        } else {
+            a[i] = 0.f;
+            dh[i] = 0.f;
+        }
+    }
+}
+int launch_relu_bwd_inplace(float* a, float* dh, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(relu_bwd_inplace_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, a, dh, n);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
+// LayerNorm over rows of 128 (32 lanes x float4 per row; a wave handles 2 rows per pass)
+// =============================================================================================
+__device__ __forceinline__ float half_sum(float v) {  // sum over the 32 lanes sharing lane>>5
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ u, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     long rows) {
+    const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const f32x4 ga = ld4(gamma + 4 * l), be = ld4(beta + 4 * l);
+    for (long row = (long)blockIdx.x * 8 + sub; row < rows; row += (long)gridDim.x * 8) {
+        const f32x4 v = ld4(u + row * 128 + 4 * l);
+        const float mean = half_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / 128.f);
+        const f32x4 d = v - mean;
+        const float var = half_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 128.f);
+        const float rstd = 1.f / sqrtf(var + 1e-5f);
+        st4(y + row * 128 + 4 * l, d * rstd * ga + be);
+    }
+}
+int launch_ln_fwd(const float* u, const float* gamma, const float* beta, float* y, long rows, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    const long nb = (rows + 7) / 8 < 4096 ? (rows + 7) / 8 : 4096;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, u, gamma, beta, y, rows);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+#define LN_BLOCKS 1024
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dy, float* __restrict__ du, long rows,
+                                                     float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float s_g[8][128], s_b[8][128];
+    const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const f32x4 ga = ld4(gamma + 4 * l);
+    f32x4 dg = zero4(), db = zero4();
+    for (long row = (long)blockIdx.x * 8 + sub; row < rows; row += (long)gridDim.x * 8) {
+        const f32x4 v = ld4(u + row * 128 + 4 * l);
+        const f32x4 g = ld4(dy + row * 128 + 4 * l);
+        const float mean = half_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / 128.f);
+        const f32x4 d = v - mean;
+        const float var = half_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 128.f);
+        const float rstd = 1.f / sqrtf(var + 1e-5f);
+        const f32x4 xh = d * rstd;
+        const f32x4 gx = g * ga;
+        const float m1 = half_sum((gx[0] + gx[1]) + (gx[2] + gx[3])) * (1.f / 128.f);
+        const float m2 = half_sum(gx[0] * xh[0] + gx[1] * xh[1] + gx[2] * xh[2] + gx[3] * xh[3]) * (1.f / 128.f);
+        st4(du + row * 128 + 4 * l, (gx - m1 - xh * m2) * rstd);
+        dg += g * xh;
+        db += g;
+    }
+    st4(&s_g[sub][4 * l], dg);
+    st4(&s_b[sub][4 * l], db);
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a += s_g[k][threadIdx.x];
+            b += s_b[k][threadIdx.x];
+        }
+        partial[(size_t)blockIdx.x * 256 + threadIdx.x] = a;
+        partial[(size_t)blockIdx.x * 256 + 128 + threadIdx.x] = b;
+    }
+}
+int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du, long rows, float* dgamma,
+                  float* dbeta, int accumulate, float* partial, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    const int nb = (int)((rows + 7) / 8 < LN_BLOCKS ? (rows + 7) / 8 : LN_BLOCKS);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, u, gamma, dy, du, rows, partial);
+    S3D_LAUNCH_CHECK();
+    // partial rows are [block][256] = dgamma(128) | dbeta(128)
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, stream, partial, nb, 256, 1.f, partial + (size_t)nb * 256, 0);
+    S3D_LAUNCH_CHECK();
+    float* fin = partial + (size_t)nb * 256;
+    if (accumulate) {
+        TRY_RET(launch_axpy(dgamma, fin, 1.f, 128, stream));
+        TRY_RET(launch_axpy(dbeta, fin + 128, 1.f, 128, stream));
+    } else {
+        if (hipMemcpyAsync(dgamma, fin, 128 * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+            hipMemcpyAsync(dbeta, fin + 128, 128 * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+            s3d_set_error("ln_bwd: memcpy failed");
+            return (int)hipErrorUnknown;
+        }
+    }
+    return 0;
+}
+
+// =============================================================================================
+// attention core on stored QKV: [groups][T][16 queries][384 = q|k|v, head h at cols 32h..32h+31]
+// one workgroup of 64*T threads per group: thread = (query ql, head h, token tq)
+// =============================================================================================
+#define ATT_SCALE 0.17677669529663687f
+
+__global__ void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, long groups, int T) {
+    const int tid = threadIdx.x;
+    const int ql = tid & 15, h = (tid >> 4) & 3, tq = tid >> 6;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const float* base = qkv + grp * T * 16 * 384;
+        const float* qrow = base + (tq * 16 + ql) * 384 + 32 * h;
+        f32x4 qv[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) qv[d] = ld4(qrow + 4 * d);
+        float sc[S3D_N_TOKENS_MAX];
+        float mx = -1e30f;
+#pragma unroll
+        for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
+            if (tk < T) {
+                const float* krow = base + (tk * 16 + ql) * 384 + 128 + 32 * h;
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const f32x4 kv = ld4(krow + 4 * d);
+                    s += qv[d][0] * kv[0] + qv[d][1] * kv[1] + qv[d][2] * kv[2] + qv[d][3] * kv[3];
+                }
+                sc[tk] = s * ATT_SCALE;
+                mx = fmaxf(mx, sc[tk]);
+            }
+        float den = 0.f;
+#pragma unroll
+        for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
+            if (tk < T) {
+                sc[tk] = expf(sc[tk] - mx);
+                den += sc[tk];
+            }
+        const float inv = 1.f / den;
+        f32x4 ov[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) ov[d] = zero4();
+#pragma unroll
+        for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
+            if (tk < T) {
+                const float* vrow = base + (tk * 16 + ql) * 384 + 256 + 32 * h;
+                const float p = sc[tk] * inv;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) ov[d] += ld4(vrow + 4 * d) * p;
+            }
+        float* orow = o + (grp * T * 16 + tq * 16 + ql) * 128 + 32 * h;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) st4(orow + 4 * d, ov[d]);
+    }
+}
+
+int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, hipStream_t stream) {
+    if (groups <= 0) return 0;
+    const long nb = groups < 8192 ? groups : 8192;
+    hipLaunchKernelGGL(attn_core_fwd_kernel, dim3((unsigned)nb), dim3(64 * T), 0, stream, qkv, o, groups, T);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward: phase A (thread = (ql,h,tq)): P row, dS row -> LDS, dQ row -> global;
+//           phase B (thread = (ql,h,tk)): dK[tk] = sum_tq dS[tq][tk] Q[tq] * scale, dV[tk] = sum_tq P[tq][tk] dO[tq]
+__global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                     float* __restrict__ dqkv, long groups, int T) {
+    extern __shared__ float smem[];  // P [64][T][T] then dS [64][T][T]
+    const int tid = threadIdx.x;
+    const int ql = tid & 15, h = (tid >> 4) & 3, tt = tid >> 6;
+    const int pair = tid & 63;
+    float* sP = smem + (pair * T + tt) * T;
+    float* sS = smem + 64 * T * T + (pair * T + tt) * T;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const float* base = qkv + grp * T * 16 * 384;
+        const float* dob = d_o + grp * T * 16 * 128;
+        float* dbase = dqkv + grp * T * 16 * 384;
+        {  // phase A, tq = tt
+            const float* qrow = base + (tt * 16 + ql) * 384 + 32 * h;
+            const float* dorow = dob + (tt * 16 + ql) * 128 + 32 * h;
+            f32x4 qv[8], dov[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                qv[d] = ld4(qrow + 4 * d);
+                dov[d] = ld4(dorow + 4 * d);
+            }
+            float sc[S3D_N_TOKENS_MAX], dp[S3D_N_TOKENS_MAX];
+            float mx = -1e30f;
+#pragma unroll
+            for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
+                if (tk < T) {
+                    const float* krow = base + (tk * 16 + ql) * 384 + 128 + 32 * h;
+                    const float* vrow = krow + 128;
+                    float s = 0.f, e = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {
+                        const f32x4 kv = ld4(krow + 4 * d), vv = ld4(vrow + 4 * d);
+                        s += qv[d][0] * kv[0] + qv[d][1] * kv[1] + qv[d][2] * kv[2] + qv[d][3] * kv[3];
+                        e += dov[d][0] * vv[0] + dov[d][1] * vv[1] + dov[d][2] * vv[2] + dov[d][3] * vv[3];
+                    }
+                    sc[tk] = s * ATT_SCALE;
+                    dp[tk] = e;
+                    mx = fmaxf(mx, sc[tk]);
+                }
+            float den = 0.f;
+#pragma unroll
+            for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
+                if (tk < T) {
+                    sc[tk] = expf(sc[tk] - mx);
+                    den += sc[tk];
+                }
+            const float inv = 1.f / den;
+            float dot = 0.f;
+#pragma unroll
+            for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
+                if (tk < T) {
+                    sc[tk] *= inv;
+                    dot += sc[tk] * dp[tk];
+                }
+            f32x4 dq[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) dq[d] = zero4();
+#pragma unroll
+            for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
+                if (tk < T) {
+                    const float ds = sc[tk] * (dp[tk] - dot);
+                    sP[tk] = sc[tk];
+                    sS[tk] = ds;
+                    const float* krow = base + (tk * 16 + ql) * 384 + 128 + 32 * h;
+                    const float w = ds * ATT_SCALE;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) dq[d] += ld4(krow + 4 * d) * w;
+                }
+            float* dqrow = dbase + (tt * 16 + ql) * 384 + 32 * h;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) st4(dqrow + 4 * d, dq[d]);
+        }
+        __syncthreads();
+        {  // phase B, tk = tt
+            f32x4 dk[8], dv[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                dk[d] = zero4();
+                dv[d] = zero4();
+            }
+            for (int tq = 0; tq < T; ++tq) {
+                const float p = smem[(pair * T + tq) * T + tt];
+                const float ds = smem[64 * T * T + (pair * T + tq) * T + tt] * ATT_SCALE;
+                const float* qrow = base + (tq * 16 + ql) * 384 + 32 * h;
+                const float* dorow = dob + (tq * 16 + ql) * 128 + 32 * h;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    dk[d] += ld4(qrow + 4 * d) * ds;
+                    dv[d] += ld4(dorow + 4 * d) * p;
+                }
+            }
+            float* dkrow = dbase + (tt * 16 + ql) * 384 + 128 + 32 * h;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                st4(dkrow + 4 * d, dk[d]);
+                st4(dkrow + 128 + 4 * d, dv[d]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, long groups, int T, hipStream_t stream) {
+    if (groups <= 0) return 0;
+    const size_t lds = (size_t)2 * 64 * T * T * sizeof(float);  // <= 86.5 KiB at T = 13
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_core_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * 64 * 13 * 13 * 4);
+        attr_set = true;
+    }
+    const long nb = groups < 8192 ? groups : 8192;
+    hipLaunchKernelGGL(attn_core_bwd_kernel, dim3((unsigned)nb), dim3(64 * T), lds, stream, qkv, d_o, dqkv, groups, T);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,331 @@
+// train2.hip — decoder-specific backward kernels: pyramid-sampling backward (scatter-add), token-0
+// gather/scatter, fc_out, metrics, VGG input-normalisation backward.
+#include "train.h"
+
+// ---- copies between the token tensor [groups][T][16][128] and its compact token-0 rows [groups*16][128]
+__global__ void tok0_copy_kernel(float* __restrict__ full, float* __restrict__ compact, long groups, int T,
+                                 int dir, int width) {
+    const int w4 = width >> 2;
+    const long total = groups * 16 * w4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % w4) * 4;
+        const long row = idx / w4;
+        const long grp = row >> 4, ql = row & 15;
+        float* f = full + ((grp * T) * 16 + ql) * width + c;
+        float* k = compact + row * width + c;
+        if (dir == 0) st4(k, ld4(f)); else st4(f, ld4(k));
+    }
+}
+int launch_tok0_copy(float* full, float* compact, long groups, int T, int dir, int width, hipStream_t stream) {
+    const long total = groups * 16 * (width / 4);
+    if (total <= 0) return 0;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(tok0_copy_kernel, dim3(blocks), dim3(256), 0, stream, full, compact, groups, T, dir, width);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fc_out on compact token-0 rows: sdf[b*Q+q] = x[row].w + b ; backward d x = dsdf*w, t = dsdf*x
+__global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ sdf,
+                                                         long rows, long gpb, long n_qry) {
+    const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const f32x4 wv = ld4(w + 4 * l);
+    for (long row = (long)blockIdx.x * 8 + sub; row < rows; row += (long)gridDim.x * 8) {
+        const f32x4 v = ld4(x + row * 128 + 4 * l);
+        float s = v[0] * wv[0] + v[1] * wv[1] + v[2] * wv[2] + v[3] * wv[3];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const long grp = row >> 4, bb = grp / gpb, q = (grp % gpb) * 16 + (row & 15);
+        if (l == 0 && q < n_qry) sdf[bb * n_qry + q] = s + b[0];
+    }
+}
+__global__ __launch_bounds__(256) void fc_out_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ dsdf, float* __restrict__ dx,
+                                                         float* __restrict__ t, long rows, long gpb, long n_qry) {
+    const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const f32x4 wv = ld4(w + 4 * l);
+    for (long row = (long)blockIdx.x * 8 + sub; row < rows; row += (long)gridDim.x * 8) {
+        const long grp = row >> 4, bb = grp / gpb, q = (grp % gpb) * 16 + (row & 15);
+        const float d = q < n_qry ? dsdf[bb * n_qry + q] : 0.f;
+        st4(dx + row * 128 + 4 * l, wv * d);
+        st4(t + row * 128 + 4 * l, ld4(x + row * 128 + 4 * l) * d);
+    }
+}
+int launch_fc_out_fwd(const float* x, const float* w, const float* b, float* sdf, long rows, long gpb, long n_qry,
+                      hipStream_t stream) {
+    const long nb = (rows + 7) / 8 < 4096 ? (rows + 7) / 8 : 4096;
+    hipLaunchKernelGGL(fc_out_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, w, b, sdf, rows, gpb, n_qry);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+int launch_fc_out_bwd(const float* x, const float* w, const float* dsdf, float* dx, float* t, long rows, long gpb,
+                      long n_qry, hipStream_t stream) {
+    const long nb = (rows + 7) / 8 < 4096 ? (rows + 7) / 8 : 4096;
+    hipLaunchKernelGGL(fc_out_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, w, dsdf, dx, t, rows, gpb,
+                       n_qry);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- scalar reductions: mode 0: sum x ; mode 1: count[(a>=0)==(b>=0)]
+__global__ __launch_bounds__(256) void scalar_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             long n, int mode, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        s += mode == 0 ? a[i] : (((a[i] >= 0.f) == (b[i] >= 0.f)) ? 1.f : 0.f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void scalar_final2_kernel(const float* __restrict__ partial, int n, float scale,
+                                                            float* __restrict__ out, int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = scale * ((red[0] + red[1]) + (red[2] + red[3]));
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+int launch_scalar_reduce(const float* a, const float* b, long n, int mode, float scale, float* out, int accumulate,
+                         float* partial, hipStream_t stream) {
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(scalar_partial_kernel, dim3(blocks), dim3(256), 0, stream, a, b, n, mode, partial);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scalar_final2_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, scale, out, accumulate);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- VGG input normalisation backward: d rec[n][c][y][x] += d in16[n][y][x][c] * 0.5 / std[c]
+__global__ void vgg_prep_bwd_kernel(const float* __restrict__ din16, const float* __restrict__ stdv,
+                                    float* __restrict__ drec, int n_img, int size) {
+    const long hw = (long)size * size;
+    const long total = (long)n_img * 3 * hw;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx % hw;
+        const int c = (int)((idx / hw) % 3);
+        const long ni = idx / (3 * hw);
+        drec[idx] += din16[(ni * hw + r) * 16 + c] * (0.5f / stdv[c]);
+    }
+}
+int launch_vgg_prep_bwd(const float* din16, const float* stdv, float* drec, int n_img, int size,
+                        hipStream_t stream) {
+    const long total = (long)n_img * 3 * size * size;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(vgg_prep_bwd_kernel, dim3(blocks), dim3(256), 0, stream, din16, stdv, drec, n_img, size);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- rotated query coordinates of the token-0 rows, padded to 4 columns: [groups*16][4] = (x,y,z,0)
+__global__ void qry_rot_rows_kernel(const float* __restrict__ qry, const float* __restrict__ rot, int flip_yz,
+                                    long n_qry, long gpb, long groups, float* __restrict__ out) {
+    const long total = groups * 16;
+    for (long row = (long)blockIdx.x * blockDim.x + threadIdx.x; row < total; row += (long)gridDim.x * blockDim.x) {
+        const long grp = row >> 4, b = grp / gpb, q = (grp % gpb) * 16 + (row & 15);
+        f32x4 v = zero4();
+        if (q < n_qry) {
+            const float* p = qry + (b * n_qry + q) * 3;
+            float x = p[0], y = p[1], z = p[2];
+            if (flip_yz) {
+                y = -y; z = -z;
+            } else if (rot) {
+                const float* R = rot + b * 9;
+                const float rx = x * R[0] + y * R[3] + z * R[6];
+                const float ry = x * R[1] + y * R[4] + z * R[7];
+                const float rz = x * R[2] + y * R[5] + z * R[8];
+                x = rx; y = ry; z = rz;
+            }
+            v[0] = x; v[1] = y; v[2] = z;
+        }
+        st4(out + row * 4, v);
+    }
+}
+int launch_qry_rot_rows(const float* qry, const float* rot, int flip_yz, long n_qry, long gpb, long groups,
+                        float* out, hipStream_t stream) {
+    const long total = groups * 16;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(qry_rot_rows_kernel, dim3(blocks), dim3(256), 0, stream, qry, rot, flip_yz, n_qry, gpb, groups,
+                       out);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
+// sampling backward: dX0 [groups][T][16][128] -> scatter-add into d(latent maps)
+//   levels 0-2 (fc_s folded, 128 ch): dG_l[tap pixel][c] += w_tap * dtok[c]
+//   levels 3-4: d raw34 = Ws34^T dtok (MFMA, Ws34^T fragments in LDS) then scatter with the tap weights
+// fp32 hardware atomics (global_atomic_add_f32): summation order is not deterministic.
+// =============================================================================================
+struct Tap4b {
+    int off[4];
+    float w[4];
+};
+__device__ __forceinline__ Tap4b make_taps_b(float gx, float gy, int W, int H) {
+    const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    const float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float xe = x0f + 1.f, ye = y0f + 1.f;
+    Tap4b t;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    t.off[0] = cy0 * W + cx0; t.w[0] = (vx0 && vy0) ? (xe - ix) * (ye - iy) : 0.f;
+    t.off[1] = cy0 * W + cx1; t.w[1] = (vx1 && vy0) ? (ix - x0f) * (ye - iy) : 0.f;
+    t.off[2] = cy1 * W + cx0; t.w[2] = (vx0 && vy1) ? (xe - ix) * (iy - y0f) : 0.f;
+    t.off[3] = cy1 * W + cx1; t.w[3] = (vx1 && vy1) ? (ix - x0f) * (iy - y0f) : 0.f;
+    return t;
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, const f32x4 v) {
+    unsafeAtomicAdd(p + 0, v[0]);
+    unsafeAtomicAdd(p + 1, v[1]);
+    unsafeAtomicAdd(p + 2, v[2]);
+    unsafeAtomicAdd(p + 3, v[3]);
+}
+
+__global__ __launch_bounds__(256) void sample_bwd_kernel(const SampleBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_wt[6 * 8 * 256];  // Ws34^T fragment image [6][8], 48 KiB
+    for (int i = threadIdx.x; i < 6 * 8 * 64; i += 256) st4(s_wt + 4 * i, ld4(a.ws34_t + 4 * i));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int T = a.n_slices + 1, S = a.size;
+    for (long gi = blockIdx.x; gi < a.groups; gi += gridDim.x) {
+        const int b = (int)(gi / a.groups_per_batch);
+        const long q = (gi % a.groups_per_batch) * S3D_GROUP + m;
+        const bool qv = q < a.n_qry;
+        const long qc = qv ? q : a.n_qry - 1;
+        const float* p = a.qry + ((long)b * a.n_qry + qc) * 3;
+        float x = p[0], y = p[1], z = p[2];
+        if (a.flip_yz) {
+            y = -y; z = -z;
+        } else if (a.rot) {
+            const float* R = a.rot + b * 9;
+            const float rx = x * R[0] + y * R[3] + z * R[6];
+            const float ry = x * R[1] + y * R[4] + z * R[7];
+            const float rz = x * R[2] + y * R[5] + z * R[8];
+            x = rx; y = ry; z = rz;
+        }
+        const float* Tm = a.trans + b * 12;
+        const float X = x * Tm[0] + y * Tm[3] + z * Tm[6] + Tm[9];
+        const float Y = x * Tm[1] + y * Tm[4] + z * Tm[7] + Tm[10];
+        const float Z = x * Tm[2] + y * Tm[5] + z * Tm[8] + Tm[11];
+        const float gx = fminf(fmaxf(2.f * (X / Z - 0.5f), -1.f), 1.f);
+        const float gy = fminf(fmaxf(2.f * (Y / Z - 0.5f), -1.f), 1.f);
+        for (int t = 1 + wave; t < T; t += 4) {
+            const long img = (long)b * a.n_slices + (t - 1);
+            const float* dp = a.dX + ((gi * T + t) * S3D_GROUP + m) * 128 + 4 * g;
+            f32x4 dt[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dt[j] = qv ? ld4(dp + 16 * j) : zero4();
+            // d raw34 = Ws34^T dtok  (6 output tiles of 16 channels, K = 128)
+            f32x4 draw[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                f32x4 c = zero4();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) c = mfma4(ld4(s_wt + ((u * 8 + j) * 64 + lane) * 4), dt[j], c);
+                draw[u] = c;
+            }
+            if (!qv) continue;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const int W = S >> (4 - l);
+                const Tap4b tp = make_taps_b(gx, gy, W, W);
+                float* base = a.dproj[l] + img * (long)W * W * 128 + 4 * g;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (tp.w[k] == 0.f) continue;
+                    float* o = base + (long)tp.off[k] * 128;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) atomic_add4(o + 16 * j, dt[j] * tp.w[k]);
+                }
+            }
+            {
+                const int W = S >> 1;
+                const Tap4b tp = make_taps_b(gx, gy, W, W);
+                float* base = a.dfine[0] + img * (long)W * W * 64 + 4 * g;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (tp.w[k] == 0.f) continue;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) atomic_add4(base + (long)tp.off[k] * 64 + 16 * u, draw[u] * tp.w[k]);
+                }
+            }
+            {
+                const int W = S;
+                const Tap4b tp = make_taps_b(gx, gy, W, W);
+                float* base = a.dfine[1] + img * (long)W * W * 32 + 4 * g;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (tp.w[k] == 0.f) continue;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        atomic_add4(base + (long)tp.off[k] * 32 + 16 * u, draw[4 + u] * tp.w[k]);
+                }
+            }
+        }
+    }
+}
+
+int launch_sample_bwd(const SampleBwdArgs& a, hipStream_t stream) {
+    if (a.groups <= 0) return 0;
+    const long blocks = a.groups < 4096 ? a.groups : 4096;
+    hipLaunchKernelGGL(sample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- copy the first `cdst` columns of a [rows][csrc] matrix into a dense [rows][cdst] matrix
+__global__ void copy_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int csrc,
+                                 int cdst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * cdst) dst[i] = src[(i / cdst) * csrc + i % cdst];
+}
+int launch_copy_cols(const float* src, float* dst, int rows, int csrc, int cdst, hipStream_t stream) {
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((rows * cdst + 255) / 256), dim3(256), 0, stream, src, dst, rows, csrc,
+                       cdst);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- slice-embedding gradient (unet_custom.py:52-57): F0[b*ns+s] = W_a x5[b] + W_b emds[s] + bias
+//      d emds[s][e] = sum_co W[co][512+e] * (sum over b, pixels of dF0[b*ns+s][pix][co])
+__global__ __launch_bounds__(256) void emb_grad_kernel(const float* __restrict__ dF0, const float* __restrict__ w,
+                                                       float* __restrict__ demds, int B, int ns, int npix) {
+    __shared__ float v[512];
+    const int s = blockIdx.x;
+    for (int co = threadIdx.x; co < 512; co += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float* p = dF0 + ((long)(b * ns + s) * npix) * 512 + co;
+            for (int k = 0; k < npix; ++k) acc += p[(long)k * 512];
+        }
+        v[co] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float acc = 0.f;
+        for (int co = 0; co < 512; ++co) acc += v[co] * w[(long)co * 640 + 512 + threadIdx.x];
+        demds[s * 128 + threadIdx.x] = acc;
+    }
+}
+int launch_emb_grad(const float* dF0, const float* w, float* demds, int B, int ns, int npix, hipStream_t stream) {
+    hipLaunchKernelGGL(emb_grad_kernel, dim3(ns), dim3(256), 0, stream, dF0, w, demds, B, ns, npix);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}

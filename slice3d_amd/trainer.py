@@ -1,0 +1,167 @@
+"""Training step on the HIP path — host side of reg_slices/train.py:41-53 (train_step) and :136 (Adam).
+
+`HipTrainer.train_step(batch)` = zero_grad -> model(batch) in train mode -> the three losses -> backward
+-> (all-reduce of gradients across ranks) -> Adam step, all inside libslice3d_hip.so
+(s3d_train_fwd_bwd + s3d_adam_step).  PyTorch owns the parameter / gradient / optimiser-state memory and
+runs the RCCL all-reduce; gradients are exposed as `param.grad` views into one flat buffer.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .models import _VGG16_CFG, _VGG16_SLICES, _VGG19_CONVS, _VGG19_SLICES, _slice_of
+
+
+class HipTrainer:
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, dropout=0.0, process_group=None):
+        self.model = model
+        self.lib = _lib.load()
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.dropout = dropout
+        self.group = process_group
+        self.step = 0
+        dev = model.fc_p.weight.device
+        if dev.type != "cuda":
+            raise _lib.S3dError("move the model to the GPU before building a HipTrainer")
+        # trainable tensors = everything the forward touches (reference: 14 tensors never get a grad —
+        # the dead att_layer.* twin and down5_.41.* — and vggptlossfunc.* is frozen)
+        self.names, self.params = [], []
+        for k, p in model.named_parameters():
+            if k.startswith("att_layer.") or k.startswith("vggptlossfunc.") or ".down5_." in k:
+                continue
+            self.names.append(k)
+            self.params.append(p)
+        n_total = sum(p.numel() for p in self.params)
+        self.grad_flat = torch.zeros(n_total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros_like(self.grad_flat)
+        self.exp_avg_sq = torch.zeros_like(self.grad_flat)
+        self.offsets, off = {}, 0
+        for k, p in zip(self.names, self.params):
+            self.offsets[k] = off
+            p.grad = self.grad_flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self._losses = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._ws = None
+
+    # -- struct builders ------------------------------------------------------------------------
+    def _gptr(self, t):
+        return t.grad.data_ptr() if t.grad is not None else None
+
+    def _conv(self, conv, bn, grad):
+        cp = _lib.S3dConvParams()
+        pick = (lambda t: self._gptr(t)) if grad else (lambda t: t.data_ptr())
+        cp.w = pick(conv.weight)
+        cp.b = pick(conv.bias) if conv.bias is not None else None
+        if bn is not None:
+            cp.bn[0], cp.bn[1] = pick(bn.weight), pick(bn.bias)
+            if not grad:
+                cp.bn[2], cp.bn[3] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        return cp
+
+    def _unet_struct(self, grad):
+        g = self.model.slices_generator
+        up = _lib.S3dUNetParams()
+        seqs = {name: getattr(g, name) for name, _, _ in _VGG16_SLICES}
+        for i, (idx, _, _) in enumerate(_VGG16_CFG):
+            conv = getattr(seqs[_slice_of(idx, _VGG16_SLICES)], str(idx))
+            bn = getattr(seqs[_slice_of(idx + 1, _VGG16_SLICES)], str(idx + 1)) if i < 12 else None
+            up.enc[i] = self._conv(conv, bn, grad)
+        up.trans_c = self._conv(g.trans_c, None, grad)
+        for i in range(4):
+            u = getattr(g, "up%d" % (i + 1))
+            dc = u.conv.double_conv
+            up.trans_up[i] = self._conv(getattr(g, "trans_up%d" % (i + 1)), None, grad)
+            up.up_t[i] = self._conv(u.up, None, grad)
+            up.up_c1[i] = self._conv(getattr(dc, "0"), getattr(dc, "1"), grad)
+            up.up_c2[i] = self._conv(getattr(dc, "3"), getattr(dc, "4"), grad)
+        up.outc = self._conv(g.outc.conv, None, grad)
+        up.emds = self._gptr(g.emds.weight) if grad else g.emds.weight.data_ptr()
+        up.n_slices = self.model.n_slices
+        return up
+
+    def _head_struct(self, grad):
+        m = self.model
+        pick = (lambda t: self._gptr(t)) if grad else (lambda t: t.data_ptr())
+        hp = _lib.S3dHeadParams()
+        hp.fc_p_w, hp.fc_p_b = pick(m.fc_p.weight), pick(m.fc_p.bias)
+        hp.fc_s_w, hp.fc_s_b = pick(m.fc_s.weight), pick(m.fc_s.bias)
+        for i, layer in enumerate(m.att_decoder.layers):
+            lp = hp.layer[i]
+            lp.in_proj_w, lp.in_proj_b = pick(layer.self_attn.in_proj_weight), pick(layer.self_attn.in_proj_bias)
+            lp.out_proj_w, lp.out_proj_b = pick(layer.self_attn.out_proj.weight), pick(layer.self_attn.out_proj.bias)
+            lp.lin1_w, lp.lin1_b = pick(layer.linear1.weight), pick(layer.linear1.bias)
+            lp.lin2_w, lp.lin2_b = pick(layer.linear2.weight), pick(layer.linear2.bias)
+            lp.norm1_w, lp.norm1_b = pick(layer.norm1.weight), pick(layer.norm1.bias)
+            lp.norm2_w, lp.norm2_b = pick(layer.norm2.weight), pick(layer.norm2.bias)
+        hp.fc_out_w, hp.fc_out_b = pick(m.fc_out[0].weight), pick(m.fc_out[0].bias)
+        return hp
+
+    def _vgg_struct(self):
+        vp = _lib.S3dVggParams()
+        vgg = self.model.vggptlossfunc.vgg
+        for i, (idx, _, _) in enumerate(_VGG19_CONVS):
+            conv = getattr(getattr(vgg, _slice_of(idx, _VGG19_SLICES)), str(idx))
+            vp.conv[i].w, vp.conv[i].b = conv.weight.data_ptr(), conv.bias.data_ptr()
+        self._mean = self.model.vggptlossfunc.mean.reshape(3).contiguous()
+        self._std = self.model.vggptlossfunc.std.reshape(3).contiguous()
+        vp.mean, vp.std = self._mean.data_ptr(), self._std.data_ptr()
+        return vp
+
+    # -- one step ---------------------------------------------------------------------------------
+    def forward_backward(self, batch, want_outputs=False):
+        """Train-mode forward + losses + backward; fills param.grad.  Returns the device tensor
+        [loss_pred, loss_img, loss_vgg, acc] (and sdf_pred / slices_rec if asked)."""
+        m, lib = self.model, self.lib
+        dev = self.grad_flat.device
+        f = lambda k: batch[k].to(device=dev, dtype=torch.float32).contiguous()
+        img, sl, qry, rot, tm, sdf = (f(k) for k in ("img_input", "img_slices", "qry_norot", "obj_rot_mat",
+                                                       "trans_mat_wo_rot_tp", "sdf"))
+        b, _, s, _ = img.shape
+        q, ns = qry.shape[1], m.n_slices
+        tb = _lib.S3dTrainBatch()
+        tb.img, tb.img_slices, tb.qry = img.data_ptr(), sl.data_ptr(), qry.data_ptr()
+        tb.rot, tb.trans, tb.sdf = rot.data_ptr(), tm.data_ptr(), sdf.data_ptr()
+        nb = lib.s3d_train_workspace_bytes(b, s, q, ns)
+        if self._ws is None or self._ws.numel() < nb:
+            self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        sdf_pred = torch.empty((b, q), dtype=torch.float32, device=dev) if want_outputs else None
+        rec = torch.empty((b * ns, 3, s, s), dtype=torch.float32, device=dev) if want_outputs else None
+        u, h, v = self._unet_struct(False), self._head_struct(False), self._vgg_struct()
+        du, dh = self._unet_struct(True), self._head_struct(True)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.s3d_train_fwd_bwd(C.byref(u), C.byref(h), C.byref(v), C.byref(du), C.byref(dh), C.byref(tb),
+                                         b, s, q, ns, float(self.dropout), 0, self._losses.data_ptr(),
+                                         sdf_pred.data_ptr() if want_outputs else None,
+                                         rec.data_ptr() if want_outputs else None,
+                                         self._ws.data_ptr(), self._ws.numel(), stream), "s3d_train_fwd_bwd")
+        m._packed_key = None   # BN running statistics changed in place: eval-mode packs are stale
+        if want_outputs:
+            return self._losses, sdf_pred, rec.view(b, ns * 3, s, s)
+        return self._losses
+
+    def all_reduce_grads(self):
+        """Data-parallel exchange step: mean of the gradients over ranks (one flat 83 MB bucket)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.grad_flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.grad_flat.div_(dist.get_world_size(self.group))
+
+    def adam_step(self):
+        self.step += 1
+        stream = C.c_void_p(torch.cuda.current_stream(self.grad_flat.device).cuda_stream)
+        for k, p in zip(self.names, self.params):
+            off, n = self.offsets[k], p.numel()
+            _lib.check(self.lib.s3d_adam_step(p.data_ptr(), self.grad_flat[off:].data_ptr(),
+                                              self.exp_avg[off:].data_ptr(), self.exp_avg_sq[off:].data_ptr(), n,
+                                              self.lr, self.betas[0], self.betas[1], self.eps, self.step, stream),
+                       "s3d_adam_step")
+        self.model._packed_key = None
+
+    def train_step(self, batch):
+        """train.py:41-53 — returns python floats (loss_pred, loss_img, loss_img_vgg, acc)."""
+        losses = self.forward_backward(batch)
+        self.all_reduce_grads()
+        self.adam_step()
+        lp, li, lv, acc = losses.tolist()    # the reference's 4 .item() syncs, as one
+        return lp, li, lv, acc

@@ -86,6 +86,50 @@ def run_case(name, batch, size, n_qry, n_slices, mode, seed, with_stages=False, 
                                                       float(out["vgg_loss"]), os.path.getsize(path) / 1024))
 
 
+def train_case(name, batch, size, n_qry, n_slices, seed):
+    """G4: one train-mode forward/backward of the REAL reference (dropout forced to 0 so the run is
+    deterministic; BatchNorm uses batch statistics) with the losses of train.py:41-47."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    model = build_reference_model(n_slices=n_slices, mode="train", seed=0)
+    model.train()
+    for mod in model.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, nn.MultiheadAttention):
+            mod.dropout = 0.0
+    fd = make_feed_dict(batch, size, n_qry, n_slices, seed=seed)
+    out = model({k: v.clone() for k, v in fd.items()})
+    lp = F.l1_loss(out["sdf_pred"], fd["sdf"])
+    li = F.l1_loss(out["slices_rec"], fd["img_slices"])
+    lv = out["vgg_loss"]
+    (lp + li + lv).backward()
+    acc = ((out["sdf_pred"] >= 0) == (fd["sdf"] >= 0)).float().sum(dim=-1) / out["sdf_pred"].shape[1]
+    rec = {"meta": np.array([batch, size, n_qry, n_slices, seed], dtype=np.int64),
+           "losses": np.array([float(lp), float(li), float(lv), float(acc.mean())], dtype=np.float64),
+           "sdf_pred": out["sdf_pred"].detach().numpy()}
+    for k in ("img_input", "img_slices", "qry_norot", "sdf", "obj_rot_mat", "trans_mat_wo_rot_tp"):
+        rec[k] = fd[k].numpy()
+    rng = np.random.default_rng(7)
+    names = []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        g = p.grad.reshape(-1)
+        idx = rng.integers(0, g.numel(), 32)
+        rec["gn:" + k] = np.array([float(g.norm()), float(g.abs().max())])
+        rec["gi:" + k] = idx
+        rec["gv:" + k] = g[torch.from_numpy(idx)].numpy()
+    rec["grad_names"] = np.array(names)
+    for k, v in model.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            rec["bn:" + k] = v.numpy()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("%-34s losses %s  %d grads  %.1f KB" % (name, rec["losses"], len(names), os.path.getsize(path) / 1024))
+
+
 def grid_case():
     sys.path.insert(0, REG_SLICES)
     from src_convonet.common import make_3d_grid
@@ -107,3 +151,4 @@ if __name__ == "__main__":
     # 128^2 (the reference's released resolution), few queries
     run_case("g4_s128_n12_q256_test", 1, 128, 256, 12, "test", seed=14, store_slices=False)
     grid_case()
+    train_case("g5_train_s32_n12_q128_b2", 2, 32, 128, 12, seed=15)
