@@ -15,6 +15,11 @@ from helpers import GOLDEN, load_golden, seeded_sd_from_shapes
 
 pytestmark = pytest.mark.gpu
 
+# conv biases directly in front of a train-mode BatchNorm: their exact gradient is 0 (BN removes the
+# mean), what both implementations produce is rounding noise
+PRE_BN_BIASES = {"slices_generator.%s.bias" % k for k in
+                 ("down1.0", "down2.7", "down3.14", "down3.17", "down4.24", "down4.27", "down5.34", "down5.37")}
+
 
 def _shapes(n_slices):
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(GOLDEN, "state_dict_keys.json"))).items()}
@@ -49,8 +54,8 @@ def test_train_step_matches_reference_golden():
         k = str(k)
         g = sd[k].grad.reshape(-1).cpu().numpy()
         norm, gmax = z["gn:" + k]
-        if gmax < 1e-6:     # conv biases in front of a train-mode BN: gradient is rounding noise
-            assert np.abs(g).max() < 1e-5
+        if k in PRE_BN_BIASES:
+            assert np.abs(g).max() < 1e-4
             continue
         assert abs(np.linalg.norm(g) - norm) < 2e-2 * norm, (k, np.linalg.norm(g), norm)
         idx, val = z["gi:" + k], z["gv:" + k]
@@ -84,7 +89,10 @@ def test_train_grads_match_oracle_autograd(b, s, q, ns):
         if k not in tr.offsets:
             continue
         ref = sd[k].grad
-        if ref is None or float(ref.abs().max()) < 1e-6:
+        if k in PRE_BN_BIASES:
+            assert float(p.grad.abs().max()) < 1e-4
+            continue
+        if ref is None:
             continue
         g = p.grad.cpu()
         rel = float((g - ref).norm() / ref.norm())
