@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--n-qry", type=int, default=100000)
     ap.add_argument("--n-slices", type=int, default=12)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=3, help="timed training steps for train_samples_per_s (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,6 +135,29 @@ def main():
         counts[name] = n.value
     lib.s3d_prof_enable(0)
 
+    # ---- secondary metric: training samples/s (train.py:41-53 train_step, B = 1 object per GPU) ----
+    train_ms = None
+    if args.train_steps > 0:
+        from slice3d_amd.trainer import HipTrainer
+        tmodel = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="train")
+        load_seeded(tmodel, 0)
+        tmodel.cuda()
+        trainer = HipTrainer(tmodel)
+        tfd = make_feed_dict(1, args.img_size, args.n_qry, args.n_slices, seed=4321 + rank, device="cuda")
+        trainer.train_step(tfd)                      # warm-up (allocates the ~25 GB activation workspace)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.train_steps):
+            tl = trainer.train_step(tfd)
+        barrier()
+        tdt = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([tdt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tdt = float(t.item())
+        train_ms = tdt / args.train_steps * 1e3
+        del trainer, tmodel
+
     if rank == 0:
         q_total = args.n_qry * world * args.steps
         n_tok = args.n_slices + 1
@@ -169,7 +193,11 @@ def main():
                          "alg_flop_per_launch": ffn_flops},
             "stage_ms_per_step": stage_ms,
             "decode_tflops_fmin": args.n_qry * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,
-            "train_samples_per_s": None,
+            "train_samples_per_s": (world / (train_ms * 1e-3)) if train_ms else None,
+            "train_ms_per_step": train_ms,
+            "train_config": "train_step (fwd + 3 losses + bwd + grad all-reduce + Adam), B=1 object/GPU, %d^2 x %d slices, "
+                            "Q=%d, fp32, dropout 0 (the reference trains with 0.1; dropout kernels are not built yet)"
+                            % (args.img_size, args.n_slices, args.n_qry),
         }
         if world == 1 and args.cpu_sample > 0:
             base, err = cpu_baseline(sd_cpu, fd, args.n_slices, min(args.cpu_sample, args.n_qry), out)

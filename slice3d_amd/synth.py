@@ -60,3 +60,24 @@ def make_feed_dict(batch, img_size, n_qry, n_slices=12, seed=0, smooth=True, wit
     fd["obj_rot_mat"] = f32(rotation_az_el())[None].repeat(batch, 1, 1).contiguous()
     fd["trans_mat_wo_rot_tp"] = f32(TRANS_MAT_WO_ROT_TP)[None].repeat(batch, 1, 1).contiguous()
     return fd
+
+
+class SyntheticSlice3DDataset(torch.utils.data.Dataset):
+    """Stand-in for Slice3DDataset (datasets.py:14-179) with the same per-sample tensor contract
+    (no batch dimension): deterministic in (split, index), sharded over ranks like a DistributedSampler."""
+
+    def __init__(self, length, img_size, n_qry, n_slices=12, split="train", rank=0, world=1):
+        self.indices = list(range(rank, length, world))
+        self.img_size, self.n_qry, self.n_slices = img_size, n_qry, n_slices
+        self.base = {"train": 0, "val": 1 << 20, "test": 2 << 20}[split]
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __getitem__(self, i):
+        fd = make_feed_dict(1, self.img_size, self.n_qry, self.n_slices, seed=self.base + self.indices[i])
+        return {k: v[0] for k, v in fd.items()}
+
+
+def collate(samples):
+    return {k: torch.stack([s[k] for s in samples]) for k in samples[0]}

@@ -158,6 +158,31 @@ class HipTrainer:
                        "s3d_adam_step")
         self.model._packed_key = None
 
+    def state_dict(self):
+        """Optimiser state in torch.optim.Adam's checkpoint layout ('opt' entry of train.py:174-176)."""
+        state = {}
+        for i, (k, p) in enumerate(zip(self.names, self.params)):
+            off, n = self.offsets[k], p.numel()
+            state[i] = {"step": torch.tensor(float(self.step)),
+                        "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
+        return {"state": state, "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps,
+                                                  "weight_decay": 0, "amsgrad": False,
+                                                  "params": list(range(len(self.params)))}],
+                "param_names": list(self.names)}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        for i, (k, p) in enumerate(zip(self.names, self.params)):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            off, n = self.offsets[k], p.numel()
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step = int(st["step"])
+
     def train_step(self, batch):
         """train.py:41-53 — returns python floats (loss_pred, loss_img, loss_img_vgg, acc)."""
         losses = self.forward_backward(batch)
