@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--n-qry", type=int, default=100000)
     ap.add_argument("--n-slices", type=int, default=12)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--prec", default="f32", choices=["f32", "f16x3"], help="arithmetic mode of the decoder GEMMs")
     ap.add_argument("--train-steps", type=int, default=3, help="timed training steps for train_samples_per_s (0 = skip)")
     args = ap.parse_args()
 
@@ -97,7 +98,7 @@ def main():
     from slice3d_amd.synth import make_feed_dict
     from slice3d_amd.weights import load_seeded
 
-    model = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="test")
+    model = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="test", prec=args.prec)
     load_seeded(model, 0)
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model.cuda().eval()

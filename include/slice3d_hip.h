@@ -41,7 +41,8 @@ extern "C" {
 
 /* arithmetic mode of the MFMA contractions (argument `prec`) */
 #define S3D_PREC_F32 0           /* v_mfma_f32_16x16x4_f32: exact fp32, the parity mode */
-#define S3D_PREC_BF16X3 1        /* 3x bf16 MFMA on hi/lo splits (~fp32 products), decode FFN only */
+#define S3D_PREC_F16X3 1         /* fp32 operands split into f16 hi+lo, 3 f16 MFMAs per product (22-bit
+                                    significands, fp32 accumulate): fp32-class results; decoder FFN */
 
 int s3d_version(void);
 const char* s3d_last_error(void);           /* thread-local, valid until the next failing call */

@@ -518,6 +518,7 @@ HeadLayout head_layout() {
         H.L[l].b2 = take(128);
         H.L[l].ln2g = take(128);
         H.L[l].ln2b = take(128);
+        H.L[l].wf16 = take((size_t)S3D_FFN_NCHUNK * 8192);
     }
     H.fco_w = take(128);
     H.fco_b = take(4);
@@ -565,6 +566,7 @@ extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed
         TRY(copy_vec(b + H.L[l].b2, p.lin2_b, 128, st));
         TRY(copy_vec(b + H.L[l].ln2g, p.norm2_w, 128, st));
         TRY(copy_vec(b + H.L[l].ln2b, p.norm2_b, 128, st));
+        TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wf16, st));
     }
     TRY(copy_vec(b + H.fco_w, P->fc_out_w, 128, st));
     TRY(copy_vec(b + H.fco_b, P->fc_out_b, 1, st));
@@ -625,6 +627,7 @@ static LayerPtrs layer_ptrs(const float* b, const HeadLayout& H, int l) {
     p.inw = b + H.L[l].inw; p.inb = b + H.L[l].inb; p.outw = b + H.L[l].outw; p.outb = b + H.L[l].outb;
     p.ln1g = b + H.L[l].ln1g; p.ln1b = b + H.L[l].ln1b; p.w1 = b + H.L[l].w1; p.b1 = b + H.L[l].b1;
     p.w2 = b + H.L[l].w2; p.b2 = b + H.L[l].b2; p.ln2g = b + H.L[l].ln2g; p.ln2b = b + H.L[l].ln2b;
+    p.wf16 = b + H.L[l].wf16;
     return p;
 }
 
@@ -635,7 +638,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
     S3D_CHECK_ARG(batch >= 1 && n_qry >= 1, "decode: batch=%d n_qry=%ld", batch, n_qry);
     S3D_CHECK_ARG(ns >= 1 && ns <= 12, "decode: n_slices %d", ns);
     S3D_CHECK_ARG(lat->n_img == batch * ns, "decode: latent has %d images, expected %d", lat->n_img, batch * ns);
-    S3D_CHECK_ARG(prec == S3D_PREC_F32, "decode: precision mode %d not built", prec);
+    S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3, "decode: precision mode %d not built", prec);
     const DecodeWs W = decode_ws(batch, n_qry, ns);
     if (workspace_bytes < W.total * sizeof(float)) {
         s3d_set_error("decode: workspace %zu < %zu bytes", workspace_bytes, W.total * sizeof(float));

@@ -14,6 +14,7 @@ struct HeadLayout {
     struct {
         size_t inw, inb, outw, outb, ln1g, ln1b;
         size_t w1, b1, w2, b2, ln2g, ln2b;   // w1: [128 tiles][8] image; w2: chunked [64][8][2] image
+        size_t wf16;                         // f16 hi/lo chunk image of lin1/lin2 (64 x 32 KiB), decode_f16.hip
     } L[S3D_N_LAYERS];
     size_t fco_w, fco_b;
     size_t total;
@@ -21,7 +22,7 @@ struct HeadLayout {
 HeadLayout head_layout();
 
 struct LayerPtrs {
-    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b, *wf16;
 };
 
 struct SampleArgs {
@@ -63,3 +64,9 @@ int launch_project_coord(const float* coords, const float* trans, float* out, in
                          hipStream_t stream);
 int launch_sample_planes(const float* plane, const float* grid, float* out, int n, int h, int w, int c, long m,
                          hipStream_t stream);
+
+// decode_f16.hip
+int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
+                           const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
+                           long g_begin, hipStream_t stream);
+int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream);

@@ -1,0 +1,230 @@
+// decode_f16.hip — split-precision ("f16x3") variant of the decoder FFN kernel.
+//
+// Every fp32 operand x is split as x = hi + lo with hi = f16(x), lo = f16(x - hi)  (22 significant bits),
+// and each product is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32
+// accumulation: products of two f16 values are exact in fp32, the dropped lo*lo term is < 2^-22 relative,
+// so the result is fp32-class (measured against the fp32 path in tests) at 3 MFMAs of 16 cycles per
+// 16x16x32 block instead of 8 MFMAs of 32 cycles — 5.3x fewer matrix-pipe cycles than the f32 kernel.
+//
+// Structure is that of ffn_layer_kernel (decode.hip): 256 rows per workgroup, activations live in
+// registers as B fragments (now f16 hi/lo pairs), W1/W2 stream through LDS in 32-hidden-unit chunks,
+// the hidden tile never leaves registers.  For K=32 MFMAs a lane (m = l&15, g = l>>4) owns the 8
+// consecutive channels {32u + 8g .. +7}; the output-channel permutation of W2's rows is chosen so that
+// GEMM2's D registers land on exactly those channels again (residual, LayerNorm, 32-byte stores).
+#include "decode.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const _Float16 h = (_Float16)x[t];
+        hi[t] = h;
+        lo[t] = (_Float16)(x[t] - (float)h);
+    }
+}
+__device__ __forceinline__ f32x4 mfma3(const half8 ah, const half8 al, const half8 bh, const half8 bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ half8 ldh8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
+__device__ __forceinline__ float quad_sum16(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+#define F16_R 4
+#define F16_CHUNK_HALFS 16384   // 32 KiB: W1 hi | W1 lo | W2 hi | W2 lo, 4096 halfs each
+
+template <bool FINAL>
+__global__ __launch_bounds__(256) void ffn_layer_f16x3_kernel(const float* X, float* Yout, long rows,
+                                                              const _Float16* wimg, const LayerPtrs w,
+                                                              const float* fco_w, const float* fco_b,
+                                                              float* sdf_out, float sign, long groups_per_batch,
+                                                              long n_qry, long g_begin) {
+    __shared__ __attribute__((aligned(16))) _Float16 s_w[2][F16_CHUNK_HALFS];  // 64 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * (F16_R * 16);
+
+    half8 xh[F16_R][4], xl[F16_R][4];
+    f32x4 acc[F16_R][8];
+#pragma unroll
+    for (int r = 0; r < F16_R; ++r) {
+        long row = row0 + r * 16 + m;
+        if (row >= rows) row = rows - 1;
+        const float* p = X + row * 128 + 8 * g;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
+            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            split8(v, xh[r][u], xl[r][u]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
+    }
+    // stage chunk 0: 32 KiB = 2048 x 16 B, 8 per thread
+    f32x4 pre[8];
+    const f32x4* gsrc = reinterpret_cast<const f32x4*>(wimg);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pre[i] = gsrc[i * 256 + threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reinterpret_cast<f32x4*>(s_w[0])[i * 256 + threadIdx.x] = pre[i];
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < S3D_FFN_NCHUNK; ++c) {
+        const _Float16* sw = s_w[c & 1];
+        if (c + 1 < S3D_FFN_NCHUNK) {
+            const f32x4* gs = gsrc + (size_t)(c + 1) * 2048;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pre[i] = gs[i * 256 + threadIdx.x];
+        }
+        // GEMM1: hidden^T[32][16 rows] = W1_c x^T ; two 16-row tiles a, K = 128 = 4 x 32
+        float hv[F16_R][8];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f32x4 hd[F16_R];
+#pragma unroll
+            for (int r = 0; r < F16_R; ++r) hd[r] = zero4();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const half8 wh = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8);
+                const half8 wl = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) hd[r] = mfma3(wh, wl, xh[r][u], xl[r][u], hd[r]);
+            }
+            const f32x4 b1 = ld4(w.b1 + c * S3D_FFN_CHUNK + 16 * a + 4 * g);
+#pragma unroll
+            for (int r = 0; r < F16_R; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[r][4 * a + i] = fmaxf(hd[r][i] + b1[i], 0.f);
+        }
+        half8 hh[F16_R], hl[F16_R];
+#pragma unroll
+        for (int r = 0; r < F16_R; ++r) split8(hv[r], hh[r], hl[r]);
+        // GEMM2: acc^T[128][16 rows] += W2_c hidden^T, K = 32
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const half8 wh = ldh8(sw + 8192 + (j * 64 + lane) * 8);
+            const half8 wl = ldh8(sw + 12288 + (j * 64 + lane) * 8);
+#pragma unroll
+            for (int r = 0; r < F16_R; ++r) acc[r][j] = mfma3(wh, wl, hh[r], hl[r], acc[r][j]);
+        }
+        if (c + 1 < S3D_FFN_NCHUNK) {
+            f32x4* dw = reinterpret_cast<f32x4*>(s_w[(c + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dw[i * 256 + threadIdx.x] = pre[i];
+        }
+        __syncthreads();
+    }
+
+    // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
+#pragma unroll
+    for (int r = 0; r < F16_R; ++r) {
+        const long row = row0 + r * 16 + m;
+        f32x4 y[8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
+            const f32x4 b2 = ld4(w.b2 + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 4 * (j & 1) + i;
+                y[j][i] = acc[r][j][i] + b2[i] + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
+                s += y[j][i];
+            }
+        }
+        const float mean = quad_sum16(s) * (1.f / 128.f);
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = y[j][i] - mean;
+                v += d * d;
+            }
+        const float rstd = 1.f / sqrtf(quad_sum16(v) * (1.f / 128.f) + 1e-5f);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
+            const f32x4 ga = ld4(w.ln2g + col), be = ld4(w.ln2b + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[j][i] = (y[j][i] - mean) * rstd * ga[i] + be[i];
+            if (FINAL) {
+                const f32x4 wo = ld4(fco_w + col);
+                dot += y[j][0] * wo[0] + y[j][1] * wo[1] + y[j][2] * wo[2] + y[j][3] * wo[3];
+            } else if (row < rows) {
+                st4(Yout + row * 128 + col, y[j]);
+            }
+        }
+        if (FINAL) {
+            dot = quad_sum16(dot) + fco_b[0];
+            if (g == 0 && row < rows) {
+                const long grp = g_begin + row / S3D_GROUP;
+                const long b = grp / groups_per_batch;
+                const long q = (grp % groups_per_batch) * S3D_GROUP + (row % S3D_GROUP);
+                if (q < n_qry) sdf_out[b * n_qry + q] = sign * dot;
+            }
+        }
+    }
+}
+
+int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
+                           const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
+                           long g_begin, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    const long blocks = (rows + 4 * F16_R * 16 - 1) / (4 * F16_R * 16);
+    const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
+    if (sdf_out)
+        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, X, X, rows, img,
+                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+    else
+        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, X, X, rows, img,
+                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// pack lin1 (2048,128) / lin2 (128,2048) into the per-chunk f16 hi/lo fragment image
+__global__ void pack_ffn_f16x3_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                      _Float16* __restrict__ out) {
+    // one thread per (chunk, which, frag, lane): writes 8 hi halfs and 8 lo halfs
+    const int total = S3D_FFN_NCHUNK * 2 * 8 * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, frag = (idx >> 6) & 7, which = (idx >> 9) & 1, c = idx >> 10;
+        const int r = lane & 15, g = lane >> 4;
+        float v[8];
+        if (which == 0) {      // W1 fragment (a, u) = (frag>>2, frag&3): row = hidden unit, k = 32u + 8g + t
+            const int a = frag >> 2, u = frag & 3;
+            const float* p = w1 + (size_t)(32 * c + 16 * a + r) * 128 + 32 * u + 8 * g;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = p[t];
+        } else {               // W2 fragment j = frag: row = permuted output channel, k-slot t -> hidden unit
+            const int j = frag;
+            const int n = 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3);
+            const float* p = w2 + (size_t)n * S3D_FFN + 32 * c;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = p[t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)];
+        }
+        _Float16* dst = out + (size_t)c * F16_CHUNK_HALFS + which * 8192 + (frag * 64 + lane) * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const _Float16 h = (_Float16)v[t];
+            dst[t] = h;
+            dst[4096 + t] = (_Float16)(v[t] - (float)h);
+        }
+    }
+}
+
+int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_ffn_f16x3_kernel, dim3(256), dim3(256), 0, stream, w1, w2,
+                       reinterpret_cast<_Float16*>(out));
+    S3D_LAUNCH_CHECK();
+    return 0;
+}

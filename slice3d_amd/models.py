@@ -173,7 +173,7 @@ class Slices3DRegModel(nn.Module):
         self.vggptlossfunc = VGGPerceptualLoss()
         self.n_slices = n_slices
         self.backend = backend
-        self.prec = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3}[prec]
+        self.prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}[prec]
         import weakref
         self.slices_generator._owner = weakref.ref(self)
         # engine state (never part of state_dict)

@@ -248,3 +248,23 @@ def test_generator3d_mise_and_dense_paths():
         assert mesh.vertices.min() >= -0.5 - 1e-6 and mesh.vertices.max() <= 0.5 + 1e-6
         assert mesh.faces.max() < len(mesh.vertices)
     assert "time (eval points)" in stats and "time (marching cubes)" in stats
+
+
+def test_f16x3_mode_is_fp32_class():
+    """prec='f16x3' (decoder FFN on 3 f16 MFMAs per product, operands split hi+lo) must meet the same
+    1e-4 gate against the oracle and sit within fp32 rounding of the f32 mode."""
+    from oracle import ref_cpu
+    from slice3d_amd.models import Slices3DRegModel
+    from slice3d_amd.synth import make_feed_dict
+    from slice3d_amd.weights import load_seeded
+    m16 = load_seeded(Slices3DRegModel(n_slices=12, mode="test", prec="f16x3"), 0).cuda().eval()
+    m32 = get_model(12, "test")
+    sd = seeded_sd_from_shapes(_shapes(12))
+    fd = make_feed_dict(1, 64, 3000, 12, seed=55, with_slices=False)
+    a = m16(to_gpu(fd))["sdf_pred"].cpu()
+    b = m32(to_gpu(fd))["sdf_pred"].cpu()
+    ref = ref_cpu.forward(sd, fd, mode="test", n_slices=12, with_vgg=False)["sdf_pred"]
+    print("f16x3 vs f32: %.3e   f16x3 vs oracle: %.3e   f32 vs oracle: %.3e" %
+          (float((a - b).abs().max()), float((a - ref).abs().max()), float((b - ref).abs().max())))
+    assert (a - ref).abs().max() < TOL
+    assert (a - b).abs().max() < 2e-5
