@@ -519,6 +519,7 @@ HeadLayout head_layout() {
         H.L[l].ln2g = take(128);
         H.L[l].ln2b = take(128);
         H.L[l].wf16 = take((size_t)S3D_FFN_NCHUNK * 8192);
+        H.L[l].af16 = take((size_t)(96 + 32) * 512);
     }
     H.fco_w = take(128);
     H.fco_b = take(4);
@@ -567,6 +568,7 @@ extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed
         TRY(copy_vec(b + H.L[l].ln2g, p.norm2_w, 128, st));
         TRY(copy_vec(b + H.L[l].ln2b, p.norm2_b, 128, st));
         TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wf16, st));
+        TRY(launch_pack_attn_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].af16, st));
     }
     TRY(copy_vec(b + H.fco_w, P->fc_out_w, 128, st));
     TRY(copy_vec(b + H.fco_b, P->fc_out_b, 1, st));
@@ -628,6 +630,7 @@ static LayerPtrs layer_ptrs(const float* b, const HeadLayout& H, int l) {
     p.ln1g = b + H.L[l].ln1g; p.ln1b = b + H.L[l].ln1b; p.w1 = b + H.L[l].w1; p.b1 = b + H.L[l].b1;
     p.w2 = b + H.L[l].w2; p.b2 = b + H.L[l].b2; p.ln2g = b + H.L[l].ln2g; p.ln2b = b + H.L[l].ln2b;
     p.wf16 = b + H.L[l].wf16;
+    p.af16 = b + H.L[l].af16;
     return p;
 }
 
@@ -670,7 +673,10 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
             const bool last = l == S3D_N_LAYERS - 1;
             {
                 ProfScope prof_(S3D_PROF_ATTN, st);
-                TRY(launch_attn_layer(X, last ? X0 : nullptr, gc, T, lp, st));
+                if (prec == S3D_PREC_F16X3)
+                    TRY(launch_attn_layer_f16x3(X, last ? X0 : nullptr, gc, T, lp, st));
+                else
+                    TRY(launch_attn_layer(X, last ? X0 : nullptr, gc, T, lp, st));
             }
             ProfScope prof_(last ? S3D_PROF_FFN_FINAL : S3D_PROF_FFN, st);
             if (!last)
