@@ -36,11 +36,13 @@ __device__ __forceinline__ float quad_sum16(float v) {
     return v;
 }
 
-#define F16_R 4
+#define F16_R 2
+#define F16_WAVES 8
+#define F16_THREADS (F16_WAVES * 64)
 #define F16_CHUNK_HALFS 16384   // 32 KiB: W1 hi | W1 lo | W2 hi | W2 lo, 4096 halfs each
 
 template <bool FINAL>
-__global__ __launch_bounds__(256) void ffn_layer_f16x3_kernel(const float* X, float* Yout, long rows,
+__global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const float* X, float* Yout, long rows,
                                                               const _Float16* wimg, const LayerPtrs w,
                                                               const float* fco_w, const float* fco_b,
                                                               float* sdf_out, float sign, long groups_per_batch,
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void ffn_layer_f16x3_kernel(const float* X, fl
     __shared__ __attribute__((aligned(16))) _Float16 s_w[2][F16_CHUNK_HALFS];  // 64 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
-    const long row0 = ((long)blockIdx.x * 4 + wave) * (F16_R * 16);
+    const long row0 = ((long)blockIdx.x * F16_WAVES + wave) * (F16_R * 16);
 
     half8 xh[F16_R][4], xl[F16_R][4];
     f32x4 acc[F16_R][8];
@@ -66,13 +68,14 @@ __global__ __launch_bounds__(256) void ffn_layer_f16x3_kernel(const float* X, fl
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
     }
-    // stage chunk 0: 32 KiB = 2048 x 16 B, 8 per thread
-    f32x4 pre[8];
+    // stage chunk 0: 32 KiB = 2048 x 16 B
+    constexpr int NPRE = 2048 / F16_THREADS;
+    f32x4 pre[NPRE];
     const f32x4* gsrc = reinterpret_cast<const f32x4*>(wimg);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pre[i] = gsrc[i * 256 + threadIdx.x];
+    for (int i = 0; i < NPRE; ++i) pre[i] = gsrc[i * F16_THREADS + threadIdx.x];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) reinterpret_cast<f32x4*>(s_w[0])[i * 256 + threadIdx.x] = pre[i];
+    for (int i = 0; i < NPRE; ++i) reinterpret_cast<f32x4*>(s_w[0])[i * F16_THREADS + threadIdx.x] = pre[i];
     __syncthreads();
 
 #pragma unroll 1
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void ffn_layer_f16x3_kernel(const float* X, fl
         if (c + 1 < S3D_FFN_NCHUNK) {
             const f32x4* gs = gsrc + (size_t)(c + 1) * 2048;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) pre[i] = gs[i * 256 + threadIdx.x];
+            for (int i = 0; i < NPRE; ++i) pre[i] = gs[i * F16_THREADS + threadIdx.x];
         }
         // GEMM1: hidden^T[32][16 rows] = W1_c x^T ; two 16-row tiles a, K = 128 = 4 x 32
         float hv[F16_R][8];
@@ -94,8 +97,14 @@ __global__ __launch_bounds__(256) void ffn_layer_f16x3_kernel(const float* X, fl
             for (int u = 0; u < 4; ++u) {
                 const half8 wh = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8);
                 const half8 wl = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
+                // three product kinds, each swept over the independent row tiles (no back-to-back
+                // dependent MFMAs on one accumulator)
 #pragma unroll
-                for (int r = 0; r < F16_R; ++r) hd[r] = mfma3(wh, wl, xh[r][u], xl[r][u], hd[r]);
+                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[r][u], hd[r], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[r][u], hd[r], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[r][u], hd[r], 0, 0, 0);
             }
             const f32x4 b1 = ld4(w.b1 + c * S3D_FFN_CHUNK + 16 * a + 4 * g);
 #pragma unroll
@@ -112,12 +121,16 @@ __global__ __launch_bounds__(256) void ffn_layer_f16x3_kernel(const float* X, fl
             const half8 wh = ldh8(sw + 8192 + (j * 64 + lane) * 8);
             const half8 wl = ldh8(sw + 12288 + (j * 64 + lane) * 8);
 #pragma unroll
-            for (int r = 0; r < F16_R; ++r) acc[r][j] = mfma3(wh, wl, hh[r], hl[r], acc[r][j]);
+            for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl[r], acc[r][j], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh[r], acc[r][j], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh[r], acc[r][j], 0, 0, 0);
         }
         if (c + 1 < S3D_FFN_NCHUNK) {
             f32x4* dw = reinterpret_cast<f32x4*>(s_w[(c + 1) & 1]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dw[i * 256 + threadIdx.x] = pre[i];
+            for (int i = 0; i < NPRE; ++i) dw[i * F16_THREADS + threadIdx.x] = pre[i];
         }
         __syncthreads();
     }
@@ -179,13 +192,13 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
                            long g_begin, hipStream_t stream) {
     if (rows <= 0) return 0;
-    const long blocks = (rows + 4 * F16_R * 16 - 1) / (4 * F16_R * 16);
+    const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
     const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
     if (sdf_out)
-        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, X, X, rows, img,
+        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
                            w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
     else
-        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, X, X, rows, img,
+        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
                            w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
     S3D_LAUNCH_CHECK();
     return 0;
