@@ -42,7 +42,7 @@ extern "C" {
 /* arithmetic mode of the MFMA contractions (argument `prec`) */
 #define S3D_PREC_F32 0           /* v_mfma_f32_16x16x4_f32: exact fp32, the parity mode */
 #define S3D_PREC_F16X3 1         /* fp32 operands split into f16 hi+lo, 3 f16 MFMAs per product (22-bit
-                                    significands, fp32 accumulate): fp32-class results; decoder FFN */
+                                    significands, fp32 accumulate): fp32-class results; conv / attention / FFN */
 
 int s3d_version(void);
 const char* s3d_last_error(void);           /* thread-local, valid until the next failing call */
@@ -92,7 +92,7 @@ size_t s3d_unet_workspace_bytes(int batch, int size, int n_slices);
  * reconstructed slice images (B*n_slices,3,S,S) NCHW (tanh output, models.py:65-66).
  * S must be a multiple of 16. */
 int s3d_unet_encode_fwd(const void* packed, const float* img, const S3dPyramid* out,
-                        float* slices_rec, int batch, int size, int n_slices,
+                        float* slices_rec, int batch, int size, int n_slices, int prec,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -131,7 +131,7 @@ typedef struct {
     int size;
 } S3dLatent;
 
-int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, const S3dLatent* out, void* stream);
+int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, const S3dLatent* out, int prec, void* stream);
 
 size_t s3d_decode_workspace_bytes(int batch, long n_qry, int n_slices);
 /* qry (B,Q,3); rot (B,3,3) or NULL; trans (B,4,3) = trans_mat_wo_rot_tp; flip_yz != 0 selects the

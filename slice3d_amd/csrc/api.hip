@@ -89,6 +89,7 @@ static const int kUpC[4] = {512, 256, 128, 64};  // input channels of up1..4; Ct
 
 struct PackedConv {
     size_t w, scale, shift;  // float offsets
+    size_t w16;              // split-precision (f16 hi/lo) image, same size as w
     int cout_pad, KU;
 };
 struct UNetLayout {
@@ -113,6 +114,7 @@ static UNetLayout unet_layout(int n_slices) {
         pc.cout_pad = cout_pad;
         pc.KU = KU;
         pc.w = take((size_t)cout_pad * KU * 16);
+        pc.w16 = take((size_t)cout_pad * KU * 16);
         pc.scale = take(cout_pad);
         pc.shift = take(cout_pad);
     };
@@ -139,8 +141,9 @@ static UNetLayout unet_layout(int n_slices) {
 extern "C" size_t s3d_unet_packed_bytes(int n_slices) { return unet_layout(n_slices).total * sizeof(float); }
 
 static int pack_conv3(const float* w, float* dst, int cout, int cout_pad, int cin_tot, int cin_begin, int cseg,
-                      int KU_total, int u_off, int taps, hipStream_t st) {
+                      int KU_total, int u_off, int taps, hipStream_t st, int f16 = 0) {
     PackArgs a = {};
+    a.f16 = f16;
     a.src = w; a.dst = dst; a.kind = S3D_PACK_CONV;
     a.n_valid = cout; a.n_pad = cout_pad;
     a.KU_total = KU_total; a.u_off = u_off;
@@ -149,8 +152,10 @@ static int pack_conv3(const float* w, float* dst, int cout, int cout_pad, int ci
     return launch_pack(a, st);
 }
 
-static int pack_linear(const float* w, float* dst, int n, int n_pad, int k, int ld, int chunk_ku, hipStream_t st) {
+static int pack_linear(const float* w, float* dst, int n, int n_pad, int k, int ld, int chunk_ku, hipStream_t st,
+                       int f16 = 0) {
     PackArgs a = {};
+    a.f16 = f16;
     a.src = w; a.dst = dst; a.kind = S3D_PACK_LINEAR;
     a.n_valid = n; a.n_pad = n_pad;
     a.KU_total = pad16(k) / 16; a.u_off = 0; a.ku_seg = a.KU_total;
@@ -172,6 +177,9 @@ extern "C" int s3d_unet_pack(const S3dUNetParams* P, void* packed, size_t packed
         const PackedConv& pc = L.enc[i];
         TRY(pack_conv3(P->enc[i].w, base + pc.w, kEncCout[i], pc.cout_pad, kEncCin[i], 0, kEncCin[i], pc.KU, 0, 9,
                        st));
+        if (kEncCin[i] % 32 == 0)
+            TRY(pack_conv3(P->enc[i].w, base + pc.w16, kEncCout[i], pc.cout_pad, kEncCin[i], 0, kEncCin[i], pc.KU, 0,
+                           9, st, 1));
         if (kEncTap[i])  // raw conv output is the skip tensor: bias only
             TRY(launch_fold_bn(P->enc[i].b, nullptr, base + pc.scale, base + pc.shift, kEncCout[i], pc.cout_pad, 1,
                                0, st));
@@ -184,10 +192,12 @@ extern "C" int s3d_unet_pack(const S3dUNetParams* P, void* packed, size_t packed
         TRY(launch_fold_bn(nullptr, P->enc[tapi[i]].bn, base + L.pool_scale[i], base + L.pool_shift[i],
                            kEncCout[tapi[i]], kEncCout[tapi[i]], 1, 0, st));
     TRY(pack_linear(P->trans_c.w, base + L.trans_c.w, 512, 512, 640, 640, 0, st));
+    TRY(pack_linear(P->trans_c.w, base + L.trans_c.w16, 512, 512, 640, 640, 0, st, 1));
     TRY(launch_fold_bn(P->trans_c.b, nullptr, base + L.trans_c.scale, base + L.trans_c.shift, 512, 512, 1, 0, st));
     for (int i = 0; i < 4; ++i) {
         const int C = kUpC[i], Ct = C / 2;
         TRY(pack_linear(P->trans_up[i].w, base + L.trans_up[i].w, Ct, Ct, C, C, 0, st));
+        TRY(pack_linear(P->trans_up[i].w, base + L.trans_up[i].w16, Ct, Ct, C, C, 0, st, 1));
         TRY(launch_fold_bn(P->trans_up[i].b, nullptr, base + L.trans_up[i].scale, base + L.trans_up[i].shift, Ct,
                            Ct, 1, 0, st));
         {  // ConvTranspose2d weight [Cin][Ct][2][2] -> GEMM rows n = q*Ct + co
@@ -196,19 +206,25 @@ extern "C" int s3d_unet_pack(const S3dUNetParams* P, void* packed, size_t packed
             a.n_valid = 4 * Ct; a.n_pad = 4 * Ct; a.KU_total = C / 16; a.u_off = 0; a.ku_seg = C / 16;
             a.k_valid = C; a.ct = Ct;
             TRY(launch_pack(a, st));
+            a.f16 = 1; a.dst = base + L.up_t[i].w16;
+            TRY(launch_pack(a, st));
             TRY(launch_fold_bn(P->up_t[i].b, nullptr, base + L.up_t[i].scale, base + L.up_t[i].shift, Ct, 4 * Ct, 4,
                                0, st));
         }
         // DoubleConv conv0 on cat([skip_proj, up]) (unet_parts.py:73): two K segments
         TRY(pack_conv3(P->up_c1[i].w, base + L.up_c1[i].w, Ct, Ct, C, 0, Ct, L.up_c1[i].KU, 0, 9, st));
         TRY(pack_conv3(P->up_c1[i].w, base + L.up_c1[i].w, Ct, Ct, C, Ct, Ct, L.up_c1[i].KU, 9 * Ct / 16, 9, st));
+        TRY(pack_conv3(P->up_c1[i].w, base + L.up_c1[i].w16, Ct, Ct, C, 0, Ct, L.up_c1[i].KU, 0, 9, st, 1));
+        TRY(pack_conv3(P->up_c1[i].w, base + L.up_c1[i].w16, Ct, Ct, C, Ct, Ct, L.up_c1[i].KU, 9 * Ct / 16, 9, st, 1));
         TRY(launch_fold_bn(nullptr, P->up_c1[i].bn, base + L.up_c1[i].scale, base + L.up_c1[i].shift, Ct, Ct, 1, 0,
                            st));
         TRY(pack_conv3(P->up_c2[i].w, base + L.up_c2[i].w, Ct, Ct, Ct, 0, Ct, L.up_c2[i].KU, 0, 9, st));
+        TRY(pack_conv3(P->up_c2[i].w, base + L.up_c2[i].w16, Ct, Ct, Ct, 0, Ct, L.up_c2[i].KU, 0, 9, st, 1));
         TRY(launch_fold_bn(nullptr, P->up_c2[i].bn, base + L.up_c2[i].scale, base + L.up_c2[i].shift, Ct, Ct, 1, 0,
                            st));
     }
     TRY(pack_linear(P->outc.w, base + L.outc.w, 3, 16, 32, 32, 0, st));
+    TRY(pack_linear(P->outc.w, base + L.outc.w16, 3, 16, 32, 32, 0, st, 1));
     TRY(launch_fold_bn(P->outc.b, nullptr, base + L.outc.scale, base + L.outc.shift, 3, 16, 1, 0, st));
     hipError_t e = hipMemcpyAsync(base + L.emds, P->emds, (size_t)P->n_slices * 128 * sizeof(float),
                                   hipMemcpyDeviceToDevice, st);
@@ -249,8 +265,10 @@ extern "C" size_t s3d_unet_workspace_bytes(int batch, int size, int n_slices) {
     return unet_ws(batch, size, n_slices).total * sizeof(float);
 }
 
+static int g_desc_prec = S3D_PREC_F32;   // set by the entry point that builds descriptors (host, single stream)
 static ConvLaunch conv_desc(const float* base, const PackedConv& pc, int N, int H, int W, int ks, int act) {
     ConvLaunch c = {};
+    c.wpk16 = g_desc_prec == S3D_PREC_F16X3 ? (const void*)(base + pc.w16) : nullptr;
     c.N = N; c.H = H; c.W = W; c.ks = ks;
     c.CoutPad = pc.cout_pad; c.wpk = base + pc.w; c.KU = pc.KU;
     c.scale = base + pc.scale; c.shift = base + pc.shift;
@@ -260,9 +278,11 @@ static ConvLaunch conv_desc(const float* base, const PackedConv& pc, int N, int 
 static ConvSrc plain_src(const float* p, int C) { return ConvSrc{p, C, 1, 0, 0}; }
 
 extern "C" int s3d_unet_encode_fwd(const void* packed, const float* img, const S3dPyramid* out,
-                                   float* slices_rec, int B, int S, int ns, void* workspace,
+                                   float* slices_rec, int B, int S, int ns, int prec, void* workspace,
                                    size_t workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3, "unet_encode: precision mode %d", prec);
+    struct PrecScope { PrecScope(int p) { g_desc_prec = p; } ~PrecScope() { g_desc_prec = S3D_PREC_F32; } } ps_(prec);
     S3D_CHECK_ARG(packed && img && out && workspace, "unet_encode: null argument");
     S3D_CHECK_ARG(B >= 1 && S >= 16 && S % 16 == 0, "unet_encode: B=%d S=%d (S must be a multiple of 16)", B, S);
     S3D_CHECK_ARG(ns >= 1 && ns <= 12, "unet_encode: n_slices %d", ns);
@@ -389,6 +409,7 @@ static VggLayout vgg_layout() {
         L.conv[i].cout_pad = kVggCout[i];
         L.conv[i].KU = 9 * pad16(kVggCin[i]) / 16;
         L.conv[i].w = take((size_t)kVggCout[i] * L.conv[i].KU * 16);
+        L.conv[i].w16 = 0;
         L.conv[i].scale = take(kVggCout[i]);
         L.conv[i].shift = take(kVggCout[i]);
     }
@@ -504,6 +525,7 @@ HeadLayout head_layout() {
     H.fcs_b = take(128);
     const int lc[3] = {512, 256, 128};
     for (int l = 0; l < 3; ++l) H.wproj[l] = take((size_t)128 * lc[l]);
+    for (int l = 0; l < 3; ++l) H.wproj16[l] = take((size_t)128 * lc[l]);
     H.ws34 = take(128 * 96);
     for (int l = 0; l < S3D_N_LAYERS; ++l) {
         H.L[l].inw = take(384 * 128);
@@ -552,6 +574,7 @@ extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed
     TRY(copy_vec(b + H.fcs_b, P->fc_s_b, 128, st));
     const int lc[3] = {512, 256, 128}, lo[3] = {0, 512, 768};
     for (int l = 0; l < 3; ++l) TRY(pack_linear(P->fc_s_w + lo[l], b + H.wproj[l], 128, 128, lc[l], 992, 0, st));
+    for (int l = 0; l < 3; ++l) TRY(pack_linear(P->fc_s_w + lo[l], b + H.wproj16[l], 128, 128, lc[l], 992, 0, st, 1));
     TRY(pack_linear(P->fc_s_w + 896, b + H.ws34, 128, 128, 96, 992, 0, st));
     for (int l = 0; l < S3D_N_LAYERS; ++l) {
         const S3dLayerParams& p = P->layer[l];
@@ -575,7 +598,7 @@ extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed
     return 0;
 }
 
-extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, const S3dLatent* out,
+extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, const S3dLatent* out, int prec,
                                 void* stream) {
     hipStream_t st = (hipStream_t)stream;
     S3D_CHECK_ARG(head_packed && pyr && out, "latent_build: null argument");
@@ -591,6 +614,7 @@ extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, 
         ConvLaunch c = {};
         c.N = pyr->n_img; c.H = r; c.W = r; c.ks = 1;
         c.CoutPad = 128; c.wpk = b + H.wproj[l]; c.KU = lc[l] / 16;
+        c.wpk16 = prec == S3D_PREC_F16X3 ? (const void*)(b + H.wproj16[l]) : nullptr;
         c.scale = nullptr; c.shift = nullptr;  // identity epilogue: fc_s bias is added by the sampler
         c.act = S3D_ACT_NONE; c.out_mode = S3D_OUT_NHWC; c.cout_store = 128; c.out_cstride = 128;
         c.nsrc = 1;

@@ -25,6 +25,8 @@ struct ConvLaunch {
     int CoutPad;         // GEMM N, multiple of 16 (padded rows of the packed weight are zero)
     const float* wpk;    // packed A fragments [CoutPad/16][KU][64][4]
     int KU;              // total K chunks = sum over sources of ks*ks*C/16
+    const void* wpk16;   // optional split-precision image: f16 hi/lo fragment pairs [CoutPad/16][KU/2][2][64][8]
+                         // (K chunks of 32); used when non-NULL and every source has C % 32 == 0
     const float* scale;  // [CoutPad]  y = acc*scale + shift   (BN folded / bias)
     const float* shift;  // [CoutPad]
     int act;
@@ -59,6 +61,7 @@ struct PackArgs {
     int ld, k_valid;
     int taps, cseg, cseg_valid, cin_tot, cin_begin;
     int ct;
+    int f16;       // 1: write the f16 hi/lo pair image for 32-deep K chunks instead of the fp32 image
     int chunk_ku;  // LINEAR only: if > 0 the image is stored [k-chunk group][row tile][chunk_ku] (FFN W2 staging order)
 };
 int launch_pack(const PackArgs& a, hipStream_t stream);

@@ -13,6 +13,52 @@
 // MFMA per (MT|NT)-fold reuse, so the operand streams fit the L1/L2 path at this precision.
 #include "conv.h"
 
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvLaunch& a, f32x4 (&acc)[MT][NT], const int (&pn)[MT],
+                                              const int (&py)[MT], const int (&px)[MT], const bool (&pv)[MT],
+                                              int jt0, int g) {
+    // epilogue: lane owns channels co..co+3 of pixel (pn,py,px)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = (jt0 + nt) * 16 + 4 * g;
+        const f32x4 sc = a.scale ? ld4(a.scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh = a.shift ? ld4(a.shift + co) : zero4();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!pv[mt]) continue;
+            f32x4 v = acc[mt][nt] * sc + sh;
+            if (a.act == S3D_ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            } else if (a.act == S3D_ACT_TANH) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = tanhf(v[i]);
+            }
+            if (a.out_mode == S3D_OUT_NHWC) {
+                if (co < a.cout_store) {  // cout_store is a multiple of 4 in this mode
+                    const long oi = ((long)(pn[mt] * a.H + py[mt]) * a.W + px[mt]) * a.out_cstride + co;
+                    if (a.residual) v += ld4(a.residual + oi);
+                    if (a.out_accumulate) v += ld4(a.out + oi);
+                    st4(a.out + oi, v);
+                }
+            } else if (a.out_mode == S3D_OUT_CONVT) {
+                const int ct = a.cout_store;  // multiple of 16: a lane's 4 channels share a quadrant
+                const int q = co / ct, c = co - q * ct;
+                if (q < 4) {
+                    const int oy = 2 * py[mt] + (q >> 1), ox = 2 * px[mt] + (q & 1);
+                    float* o = a.out + ((long)(pn[mt] * 2 * a.H + oy) * (2 * a.W) + ox) * ct + c;
+                    st4(o, v);
+                }
+            } else {  // NCHW, arbitrary cout_store
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (co + i < a.cout_store)
+                        a.out[((long)(pn[mt] * a.cout_store + co + i) * a.H + py[mt]) * a.W + px[mt]] = v[i];
+            }
+        }
+    }
+}
+
 template <int MT, int NT, int WM, int WN, int KS>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvLaunch a) {
     const int lane = threadIdx.x & 63;
@@ -85,46 +131,107 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvLaunc
         ubase += KS * KS * cu;
     }
 
-    // epilogue: lane owns channels co..co+3 of pixel (pn,py,px)
+    conv_epilogue<MT, NT>(a, acc, pn, py, px, pv, jt0, g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-precision variant: same tiling, 32-deep K chunks, A = pre-packed f16 hi/lo fragment pairs,
+// B = fp32 activations split into hi/lo on the fly, 3 f16 MFMAs per product (see decode_f16.hip).
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 chalf8 __attribute__((ext_vector_type(8)));
+
+template <int MT, int NT, int WM, int WN, int KS>
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const ConvLaunch a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int m = lane & 15, g = lane >> 4;
+    constexpr int PIX_WG = WM * MT * 16;
+    constexpr int CO_WG = WN * NT * 16;
+    const long P = (long)a.N * a.H * a.W;
+    const int n_co_blk = a.CoutPad / CO_WG;
+    const int blk_co = blockIdx.x % n_co_blk;
+    const long blk_px = blockIdx.x / n_co_blk;
+    const int HW = a.H * a.W;
+    const int stride = a.stride > 1 ? a.stride : 1;
+    const int Hin = a.Hin ? a.Hin : a.H, Win = a.Win ? a.Win : a.W;
+    constexpr int PAD = KS == 3 ? 1 : 0;
+    const int KU32 = a.KU >> 1;
+    const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wpk16);
+
+    int pn[MT], py[MT], px[MT];
+    bool pv[MT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int co = (jt0 + nt) * 16 + 4 * g;
-        const f32x4 sc = a.scale ? ld4(a.scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
-        const f32x4 sh = a.shift ? ld4(a.shift + co) : zero4();
+    for (int mt = 0; mt < MT; ++mt) {
+        const long p = blk_px * PIX_WG + (long)(wm * MT + mt) * 16 + m;
+        pv[mt] = p < P;
+        const long pc = pv[mt] ? p : 0;
+        pn[mt] = (int)(pc / HW);
+        const int r = (int)(pc - (long)pn[mt] * HW);
+        py[mt] = r / a.W;
+        px[mt] = r - py[mt] * a.W;
+    }
+    f32x4 acc[MT][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (!pv[mt]) continue;
-            f32x4 v = acc[mt][nt] * sc + sh;
-            if (a.act == S3D_ACT_RELU) {
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-            } else if (a.act == S3D_ACT_TANH) {
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero4();
+
+    const int jt0 = blk_co * (CO_WG / 16) + wn * NT;
+    int ubase = 0;
+#pragma unroll 1
+    for (int s = 0; s < a.nsrc; ++s) {
+        const ConvSrc S = a.src[s];
+        const int cu = S.C >> 5;
+#pragma unroll 1
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int dy = tap / KS - PAD, dx = tap % KS - PAD;
+            const float* bp[MT];
+            bool ok[MT];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = tanhf(v[i]);
+            for (int mt = 0; mt < MT; ++mt) {
+                const int y = py[mt] * stride + dy, x = px[mt] * stride + dx;
+                ok[mt] = pv[mt] && y >= 0 && y < Hin && x >= 0 && x < Win;
+                const int ni = (S.bmod ? pn[mt] % S.bmod : pn[mt]) / S.bdiv;
+                const long off = S.sbcast ? (long)ni * S.C : ((long)(ni * Hin + y) * Win + x) * S.C;
+                bp[mt] = S.p + (ok[mt] ? off : 0) + 8 * g;
             }
-            if (a.out_mode == S3D_OUT_NHWC) {
-                if (co < a.cout_store) {  // cout_store is a multiple of 4 in this mode
-                    const long oi = ((long)(pn[mt] * a.H + py[mt]) * a.W + px[mt]) * a.out_cstride + co;
-                    if (a.residual) v += ld4(a.residual + oi);
-                    if (a.out_accumulate) v += ld4(a.out + oi);
-                    st4(a.out + oi, v);
-                }
-            } else if (a.out_mode == S3D_OUT_CONVT) {
-                const int ct = a.cout_store;  // multiple of 16: a lane's 4 channels share a quadrant
-                const int q = co / ct, c = co - q * ct;
-                if (q < 4) {
-                    const int oy = 2 * py[mt] + (q >> 1), ox = 2 * px[mt] + (q & 1);
-                    float* o = a.out + ((long)(pn[mt] * 2 * a.H + oy) * (2 * a.W) + ox) * ct + c;
-                    st4(o, v);
-                }
-            } else {  // NCHW, arbitrary cout_store
+            const _Float16* wp = wimg + ((size_t)jt0 * KU32 + ubase + tap * cu) * 1024 + lane * 8;
+#pragma unroll 1
+            for (int c = 0; c < cu; ++c) {
+                chalf8 bh[MT], bl[MT];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (co + i < a.cout_store)
-                        a.out[((long)(pn[mt] * a.cout_store + co + i) * a.H + py[mt]) * a.W + px[mt]] = v[i];
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f32x4 v0 = ok[mt] ? ld4(bp[mt] + 32 * c) : zero4();
+                    const f32x4 v1 = ok[mt] ? ld4(bp[mt] + 32 * c + 4) : zero4();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const _Float16 h0 = (_Float16)v0[t], h1 = (_Float16)v1[t];
+                        bh[mt][t] = h0; bh[mt][4 + t] = h1;
+                        bl[mt][t] = (_Float16)(v0[t] - (float)h0);
+                        bl[mt][4 + t] = (_Float16)(v1[t] - (float)h1);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const _Float16* f = wp + ((size_t)nt * KU32 + c) * 1024;
+                    const chalf8 wh = *reinterpret_cast<const chalf8*>(f);
+                    const chalf8 wl = *reinterpret_cast<const chalf8*>(f + 512);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[mt], acc[mt][nt], 0, 0, 0);
+                }
             }
         }
+        ubase += KS * KS * cu;
     }
+    conv_epilogue<MT, NT>(a, acc, pn, py, px, pv, jt0, g);
 }
 
 template <int MT, int NT, int WM, int WN>
@@ -134,6 +241,18 @@ static int launch_cfg(const ConvLaunch& a, hipStream_t stream) {
     const long nblk = ((P + PIX_WG - 1) / PIX_WG) * (a.CoutPad / CO_WG);
     S3D_CHECK_ARG(nblk > 0 && nblk < (1L << 31), "conv grid out of range (%ld)", nblk);
     dim3 grid((unsigned)nblk), block(WM * WN * 64);
+    bool f16 = a.wpk16 != nullptr && (a.KU % 2 == 0);
+    for (int s = 0; s < a.nsrc; ++s) f16 = f16 && (a.src[s].C % 32 == 0);
+    if (f16) {
+        if (a.ks == 3)
+            hipLaunchKernelGGL((conv_igemm_f16x3_kernel<MT, NT, WM, WN, 3>), grid, block, 0, stream, a);
+        else if (a.ks == 2)
+            hipLaunchKernelGGL((conv_igemm_f16x3_kernel<MT, NT, WM, WN, 2>), grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL((conv_igemm_f16x3_kernel<MT, NT, WM, WN, 1>), grid, block, 0, stream, a);
+        S3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.ks == 3)
         hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, WM, WN, 3>), grid, block, 0, stream, a);
     else if (a.ks == 2)
@@ -180,11 +299,22 @@ __global__ void pack_frag_kernel(const PackArgs a) {
     const long total = (long)(a.n_pad / 16) * a.ku_seg * 256;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
-        const int e = idx & 3, lane = (idx >> 2) & 63;
-        const long fu = idx >> 8;
-        const int ul = (int)(fu % a.ku_seg), j = (int)(fu / a.ku_seg);
+        int e, lane, ul, j, k;
+        if (!a.f16) {
+            e = idx & 3; lane = (idx >> 2) & 63;
+            const long fu = idx >> 8;
+            ul = (int)(fu % a.ku_seg); j = (int)(fu / a.ku_seg);
+            k = 16 * ul + 4 * (lane >> 4) + e;
+        } else {   // 32-deep chunks: ku_seg is even; lane (r,g) holds k = 32*u32 + 8g + t, t = 0..7
+            const int t = idx & 7;
+            lane = (idx >> 3) & 63;
+            const long fu = idx >> 9;
+            const int u32 = (int)(fu % (a.ku_seg / 2));
+            j = (int)(fu / (a.ku_seg / 2));
+            k = 32 * u32 + 8 * (lane >> 4) + t;
+            ul = u32; e = t;
+        }
         const int n = 16 * j + (lane & 15);
-        const int k = 16 * ul + 4 * (lane >> 4) + e;
         float v = 0.f;
         if (n < a.n_valid) {
             if (a.kind == S3D_PACK_LINEAR) {
@@ -205,6 +335,14 @@ __global__ void pack_frag_kernel(const PackArgs a) {
             } else {  // LINEAR_T
                 if (k < a.k_valid) v = a.src[(long)k * a.ld + n];
             }
+        }
+        if (a.f16) {
+            _Float16* d = reinterpret_cast<_Float16*>(a.dst) +
+                          ((long)j * (a.KU_total / 2) + a.u_off / 2 + ul) * 1024 + lane * 8 + e;
+            const _Float16 h = (_Float16)v;
+            d[0] = h;
+            d[512] = (_Float16)(v - (float)h);
+            continue;
         }
         long fi;
         if (a.chunk_ku > 0)

@@ -10,6 +10,7 @@
 struct HeadLayout {
     size_t fcp_w, fcp_b, fcs_b;
     size_t wproj[3];   // fc_s column blocks of pyramid levels 0..2 as [8][C_l/16] fragment images
+    size_t wproj16[3]; // the same blocks as f16 hi/lo fragment pairs (split-precision mode)
     size_t ws34;       // fc_s columns 896..991 (levels 3,4) as an [8][6] fragment image
     struct {
         size_t inw, inb, outw, outb, ln1g, ln1b;

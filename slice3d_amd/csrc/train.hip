@@ -205,15 +205,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     }
 }
 
-// final: out[c] (+)= scale * sum over chunks
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nchunks, int C, float scale,
-                                    float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * C + c];
-    s *= scale;
-    out[c] = accumulate ? out[c] + s : s;
+// final: out[c] (+)= scale * sum over chunks.  Block = 64 columns x 4 chunk slices (coalesced 256-byte
+// rows, 4-way split of the chunk loop, LDS combine): deterministic.
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nchunks, int C,
+                                                           float scale, float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int k = sl;
+        for (; k + 12 < nchunks; k += 16) {
+            s0 += partial[(size_t)k * C + c];
+            s1 += partial[(size_t)(k + 4) * C + c];
+            s2 += partial[(size_t)(k + 8) * C + c];
+            s3 += partial[(size_t)(k + 12) * C + c];
+        }
+        for (; k < nchunks; k += 4) s0 += partial[(size_t)k * C + c];
+    }
+    red[sl][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        const float s = scale * ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 static int colsum_chunks(long P, long& rows_per_chunk) {
@@ -232,7 +247,7 @@ int launch_colsum(const float* in, long P, int cstride, int coff, int C, float* 
     hipLaunchKernelGGL((colsum_kernel<0>), dim3(n), dim3(256), 0, stream, in, nullptr, P, cstride, coff, C, nullptr,
                        nullptr, partial, rpc);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, n, C, 1.f, out,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, partial, n, C, 1.f, out,
                        accumulate);
     S3D_LAUNCH_CHECK();
     return 0;
@@ -263,13 +278,13 @@ int launch_bn_stats(const float* z, long P, int C, float* mean, float* rstd, flo
     hipLaunchKernelGGL((colsum_kernel<0>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, nullptr, nullptr,
                        partial, rpc);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, n, C,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, partial, n, C,
                        1.f / (float)P, mean, 0);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL((colsum_kernel<1>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, mean, nullptr,
                        partial, rpc);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, n, C, 1.f, rstd, 0);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, partial, n, C, 1.f, rstd, 0);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, rstd, P, C, rstd, mean,
                        running_mean, running_var);
@@ -420,10 +435,10 @@ int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const fl
     hipLaunchKernelGGL((colsum_kernel<2>), dim3(nch), dim3(256), 0, stream, dz, z, P, c, 0, c, mean, rstd, partial,
                        rpc);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, partial, nch, c, 1.f, dbeta,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 63) / 64), dim3(256), 0, stream, partial, nch, c, 1.f, dbeta,
                        0);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, partial + (size_t)nch * c,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 63) / 64), dim3(256), 0, stream, partial + (size_t)nch * c,
                        nch, c, 1.f, dgamma, 0);
     S3D_LAUNCH_CHECK();
     const long tot = P * (c / 4);
@@ -703,7 +718,7 @@ int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, u, gamma, dy, du, rows, partial);
     S3D_LAUNCH_CHECK();
     // partial rows are [block][256] = dgamma(128) | dbeta(128)
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, stream, partial, nb, 256, 1.f, partial + (size_t)nb * 256, 0);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(4), dim3(256), 0, stream, partial, nb, 256, 1.f, partial + (size_t)nb * 256, 0);
     S3D_LAUNCH_CHECK();
     float* fin = partial + (size_t)nb * 256;
     if (accumulate) {

@@ -349,7 +349,8 @@ class Slices3DRegModel(nn.Module):
         ws = self._workspace("unet", nb)
         _lib.check(lib.s3d_unet_encode_fwd(self._unet_packed.data_ptr(), img.data_ptr(), C.byref(pyr),
                                            code.slices_rec_flat.data_ptr() if want_slices else None,
-                                           b, s, ns, ws.data_ptr(), ws.numel(), self._stream()), "s3d_unet_encode_fwd")
+                                           b, s, ns, self.prec, ws.data_ptr(), ws.numel(), self._stream()),
+                   "s3d_unet_encode_fwd")
         if build_latent:
             code.proj = [torch.empty((b * ns, (s // 16) << l, (s // 16) << l, 128), dtype=torch.float32, device=dev)
                          for l in range(3)]
@@ -358,7 +359,8 @@ class Slices3DRegModel(nn.Module):
                 lat.proj[l] = code.proj[l].data_ptr()
             lat.fine[0], lat.fine[1] = code.pyramid[3].data_ptr(), code.pyramid[4].data_ptr()
             lat.n_img, lat.size = b * ns, s
-            _lib.check(lib.s3d_latent_build(self._head_packed.data_ptr(), C.byref(pyr), C.byref(lat), self._stream()),
+            _lib.check(lib.s3d_latent_build(self._head_packed.data_ptr(), C.byref(pyr), C.byref(lat), self.prec,
+                                            self._stream()),
                        "s3d_latent_build")
             code._latent_struct = lat
         for k in ("obj_rot_mat", "trans_mat_wo_rot_tp"):

@@ -223,7 +223,7 @@ def test_error_codes_are_loud():
     with pytest.raises(ValueError):
         model(bad)
     lib = _lib.load()
-    rc = lib.s3d_unet_encode_fwd(None, None, None, None, 1, 64, 12, None, 0, None)
+    rc = lib.s3d_unet_encode_fwd(None, None, None, None, 1, 64, 12, 0, None, 0, None)
     assert rc == -1 and b"null" in lib.s3d_last_error()
 
 
@@ -251,8 +251,8 @@ def test_generator3d_mise_and_dense_paths():
 
 
 def test_f16x3_mode_is_fp32_class():
-    """prec='f16x3' (decoder FFN on 3 f16 MFMAs per product, operands split hi+lo) must meet the same
-    1e-4 gate against the oracle and sit within fp32 rounding of the f32 mode."""
+    """prec='f16x3' (convs, attention projections and FFN on 3 f16 MFMAs per product, operands split
+    hi+lo) must meet the same 1e-4 gate against the oracle and sit within fp32 rounding of the f32 mode."""
     from oracle import ref_cpu
     from slice3d_amd.models import Slices3DRegModel
     from slice3d_amd.synth import make_feed_dict
@@ -267,4 +267,4 @@ def test_f16x3_mode_is_fp32_class():
     print("f16x3 vs f32: %.3e   f16x3 vs oracle: %.3e   f32 vs oracle: %.3e" %
           (float((a - b).abs().max()), float((a - ref).abs().max()), float((b - ref).abs().max())))
     assert (a - ref).abs().max() < TOL
-    assert (a - b).abs().max() < 2e-5
+    assert (a - b).abs().max() < 5e-5      # two fp32-class evaluations (cf. oracle-vs-reference noise, synth.py)

@@ -1,0 +1,12 @@
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slice3d_amd.models import Slices3DRegModel
+from slice3d_amd.trainer import HipTrainer
+from slice3d_amd.weights import load_seeded
+from slice3d_amd.synth import make_feed_dict
+m = load_seeded(Slices3DRegModel(n_slices=12, mode="train"), 0).cuda()
+tr = HipTrainer(m)
+fd = make_feed_dict(1, 256, 100000, 12, seed=1, device="cuda")
+for _ in range(3):
+    print(tr.train_step(fd))
+torch.cuda.synchronize()
