@@ -3,7 +3,9 @@
 
 Workload (BASELINE.json configs[1]): one object per step = reg_slices U-Net encode of a 256x256 image
 into the 12-slice feature pyramid + decode of 100 000 query points (project -> sample 12x5 planes ->
-fc_p/fc_s -> 3-layer transformer -> fc_out), inputs resident in HBM, fp32 (the parity mode).
+fc_p/fc_s -> 3-layer transformer -> fc_out), inputs resident in HBM.  --prec f16x3 (default): fp32 operands
+split into f16 hi+lo and multiplied with 3 f16 MFMAs per product (fp32-class, passes the 1e-4 gate);
+--prec f32: exact fp32 MFMA.
 N GPUs = N independent objects (one process per GPU, no data-path collective): weak scaling.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
@@ -23,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+F16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (spec); 16x16x32 f16 measures 1955
 FFN_FLOP_PER_ROW = 2 * 2 * 128 * 2048   # two 128x2048 GEMMs, 2 FLOP/MAC (FFN = 88 %)
 F_MIN_PER_QUERY = 35.96e6           # exact decoder FLOPs/query with last-layer pruning
 
@@ -78,7 +81,7 @@ def main():
     ap.add_argument("--n-qry", type=int, default=100000)
     ap.add_argument("--n-slices", type=int, default=12)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="queries timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--prec", default="f32", choices=["f32", "f16x3"], help="arithmetic mode of the decoder GEMMs")
+    ap.add_argument("--prec", default="f16x3", choices=["f32", "f16x3"], help="arithmetic mode of the decoder GEMMs")
     ap.add_argument("--train-steps", type=int, default=3, help="timed training steps for train_samples_per_s (0 = skip)")
     args = ap.parse_args()
 
@@ -143,7 +146,7 @@ def main():
         tmodel = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="train")
         load_seeded(tmodel, 0)
         tmodel.cuda()
-        trainer = HipTrainer(tmodel)
+        trainer = HipTrainer(tmodel, dropout=0.1, seed=rank)     # the reference's nn.TransformerEncoderLayer default
         tfd = make_feed_dict(1, args.img_size, args.n_qry, args.n_slices, seed=4321 + rank, device="cuda")
         trainer.train_step(tfd)                      # warm-up (allocates the ~25 GB activation workspace)
         barrier()
@@ -166,13 +169,14 @@ def main():
         ffn_ms = stage_ms["ffn_layer"] * args.steps / ffn_launches
         ffn_flops = n_tok * args.n_qry * FFN_FLOP_PER_ROW          # algorithmic FLOPs of one launch
         achieved = ffn_flops / (ffn_ms * 1e-3) / 1e12
+        peak = F32_MFMA_PEAK_TFLOPS if args.prec == "f32" else F16_MFMA_PEAK_TFLOPS
         traffic = None   # HBM bytes/launch of the dominant kernel from the committed PMC pass of this command
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             wl = pmc["workload"]
-            if (wl["img_size"], wl["n_slices"], wl["n_qry"], wl["prec"]) == (args.img_size, args.n_slices,
-                                                                             args.n_qry, "f32"):
-                traffic = pmc["kernels"]["ffn_layer_kernel<false>"]["hbm_bytes_per_launch"]
+            if (wl["img_size"], wl["n_slices"], wl["n_qry"]) == (args.img_size, args.n_slices, args.n_qry):
+                kname = "ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_kernel<false>"
+                traffic = pmc["kernels"][args.prec][kname]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         decode_ms = sum(stage_ms[k] for k in ("sample_tokens", "attn_layer", "ffn_layer", "ffn_final"))
@@ -180,16 +184,24 @@ def main():
             "metric": "occupancy query-points/sec (U-Net encode + per-query decode, 256^2 x 12 slices)",
             "value": q_total / dt, "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "reg_slices regression inference, %d^2 x %d slices, %d query points/object, "
-                                   "1 object per GPU per step (BASELINE configs[1], fp32 parity mode)"
-                                   % (args.img_size, args.n_slices, args.n_qry),
+                                   "1 object per GPU per step (BASELINE configs[1]); arithmetic: %s"
+                                   % (args.img_size, args.n_slices, args.n_qry,
+                                      "exact fp32 MFMA" if args.prec == "f32" else
+                                      "fp32 operands split into f16 hi+lo, 3 f16 MFMAs per product, fp32 accumulate "
+                                      "(fp32-class accuracy, passes the 1e-4 parity gate)"),
                        "img_size": args.img_size, "n_slices": args.n_slices, "n_qry": args.n_qry,
                        "objects_per_step": world, "parallelism": "objects x%d (no collective)" % world},
-            "roofline": {"kernel": "ffn_layer_kernel<false> (decoder FFN 128->2048->128 + residual + LN2)",
-                         "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_bench_f32_pmc_hbm.md",
+            "roofline": {"kernel": ("ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_kernel<false>")
+                                   + " (decoder FFN 128->2048->128 + residual + LN2)",
+                         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "note": ("algorithmic FLOPs (one product = one MAC); in f16x3 mode each product costs 3 f16 "
+                                  "MFMA MACs, so the matrix pipe executes 3x `achieved`" if args.prec != "f32" else
+                                  "exact fp32 MFMA"),
+                         "mfma_pipe_tflops": achieved * (3 if args.prec != "f32" else 1),
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/",
                          "avg_launch_ms": ffn_ms, "launches": counts["ffn_layer"],
                          "alg_flop_per_launch": ffn_flops},
             "stage_ms_per_step": stage_ms,
@@ -197,7 +209,7 @@ def main():
             "train_samples_per_s": (world / (train_ms * 1e-3)) if train_ms else None,
             "train_ms_per_step": train_ms,
             "train_config": "train_step (fwd + 3 losses + bwd + grad all-reduce + Adam), B=1 object/GPU, %d^2 x %d slices, "
-                            "Q=%d, fp32, dropout 0 (the reference trains with 0.1; dropout kernels are not built yet)"
+                            "Q=%d, fp32 MFMA, dropout 0.1, batch-statistic BatchNorm"
                             % (args.img_size, args.n_slices, args.n_qry),
         }
         if world == 1 and args.cpu_sample > 0:

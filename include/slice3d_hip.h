@@ -175,7 +175,8 @@ int s3d_vgg_loss_fwd(const void* packed, const float* pred, const float* target,
  * d gamma, d beta; bn[2], bn[3] ignored).  BatchNorm running_mean / running_var are updated IN PLACE
  * through unet->...bn[2], bn[3].  losses_out[4] = {L1(sdf), L1(slices), vgg_loss (x0.001), sign accuracy}.
  * The caller all-reduces the gradient buffers across ranks (data parallel) between this call and
- * s3d_adam_step.  Only dropout_p == 0 is built in this round.
+ * s3d_adam_step.  dropout_p is nn.TransformerEncoderLayer's dropout (reference default 0.1); masks are
+ * counter-based functions of (seed, site, element index), regenerated in the backward pass.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     const float* img;          /* (B,3,S,S)            img_input            */
@@ -191,6 +192,12 @@ int s3d_train_fwd_bwd(const S3dUNetParams* unet, const S3dHeadParams* head, cons
                       const S3dTrainBatch* batch, int batch_size, int size, long n_qry, int n_slices,
                       float dropout_p, unsigned long long seed, float* losses_out, float* sdf_pred_out,
                       float* slices_rec_out, void* workspace, size_t workspace_bytes, void* stream);
+/* The dropout mask the kernels use: out[i] = keep(seed, site, idx0+i) ? 1/(1-p) : 0.  site = 4*layer +
+ * {0 attention probabilities [(row*4 + head)*16 + key], 1 attention-block output [row*128 + c],
+ *  2 FFN hidden [row*2048 + unit], 3 FFN output [row*128 + c]}; rows index the token tensor
+ * [group][token][16 queries] (the last layer's FFN sites index its compact token-0 rows). */
+int s3d_dropout_mask(unsigned long long seed, int site, unsigned long long idx0, long n, float p, float* out,
+                     void* stream);
 /* torch.optim.Adam defaults semantics (no weight decay, no amsgrad); step counts from 1. */
 int s3d_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                   float eps, int step, void* stream);

@@ -188,7 +188,7 @@ def layer_norm(x, w, b):
     return (x - mu) / torch.sqrt(var + LN_EPS) * w + b
 
 
-def transformer_layer(sd, x, prefix, dropout=0.0):
+def transformer_layer(sd, x, prefix, dropout=0.0, masks=None):
     """One post-LN nn.TransformerEncoderLayer(d=128, nhead=4, ffn=2048, relu), eval mode
     (models.py:18-19).  x: (R, L, 128)."""
     r, l, d = x.shape
@@ -199,16 +199,18 @@ def transformer_layer(sd, x, prefix, dropout=0.0):
     k = k.view(r, l, N_HEADS, hd).transpose(1, 2)
     v = v.view(r, l, N_HEADS, hd).transpose(1, 2)
     att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
-    att = F.dropout(att, dropout, training=dropout > 0)           # MHA dropout on attention weights
+    # the four dropout sites of nn.TransformerEncoderLayer; `masks` (multipliers 0 or 1/(1-p)) replaces
+    # torch's RNG so a run can be compared with an implementation that draws its own masks
+    drop = (lambda t, key: t * masks[key]) if masks is not None else \
+           (lambda t, key: F.dropout(t, dropout, training=dropout > 0))
+    att = drop(att, "att")                                         # MHA dropout on attention weights
     o = (att @ v).transpose(1, 2).reshape(r, l, d)
     o = o @ sd[prefix + ".self_attn.out_proj.weight"].t() + sd[prefix + ".self_attn.out_proj.bias"]
-    x = layer_norm(x + F.dropout(o, dropout, training=dropout > 0), sd[prefix + ".norm1.weight"],
-                   sd[prefix + ".norm1.bias"])
+    x = layer_norm(x + drop(o, "o"), sd[prefix + ".norm1.weight"], sd[prefix + ".norm1.bias"])
     hdn = torch.relu(x @ sd[prefix + ".linear1.weight"].t() + sd[prefix + ".linear1.bias"])
-    hdn = F.dropout(hdn, dropout, training=dropout > 0)
+    hdn = drop(hdn, "h")
     f = hdn @ sd[prefix + ".linear2.weight"].t() + sd[prefix + ".linear2.bias"]
-    return layer_norm(x + F.dropout(f, dropout, training=dropout > 0), sd[prefix + ".norm2.weight"],
-                      sd[prefix + ".norm2.bias"])
+    return layer_norm(x + drop(f, "f"), sd[prefix + ".norm2.weight"], sd[prefix + ".norm2.bias"])
 
 
 def sample_pyramid(feats, img_pts, n_slices):
@@ -221,7 +223,7 @@ def sample_pyramid(feats, img_pts, n_slices):
     return agg.view(b, n_slices, q, c).permute(0, 2, 1, 3).reshape(b * q, n_slices, c)
 
 
-def decode_tokens(sd, tokens_slices, qry_rot, return_layers=False, dropout=0.0):
+def decode_tokens(sd, tokens_slices, qry_rot, return_layers=False, dropout=0.0, masks=None):
     """fc_p / fc_s / 3-layer transformer / fc_out (models.py:79-84).
     tokens_slices: (B*Q, n_slices, 992) sampled features; qry_rot (B,Q,3) -> sdf (B,Q)."""
     b, q, _ = qry_rot.shape
@@ -230,7 +232,7 @@ def decode_tokens(sd, tokens_slices, qry_rot, return_layers=False, dropout=0.0):
     x = torch.cat([feat_qry.view(b * q, 1, D_MODEL), feat_slice], 1)
     layers = [x]
     for i in range(3):
-        x = transformer_layer(sd, x, f"att_decoder.layers.{i}", dropout)
+        x = transformer_layer(sd, x, f"att_decoder.layers.{i}", dropout, masks[i] if masks is not None else None)
         layers.append(x)
     tok0 = x[:, 0, :].view(b, q, D_MODEL)
     sdf = (tok0 @ sd["fc_out.0.weight"].t() + sd["fc_out.0.bias"]).squeeze(-1)
@@ -314,7 +316,7 @@ def forward(sd, feed_dict, mode="train", n_slices=12, with_vgg=True):
     return ret
 
 
-def forward_train(sd, feed_dict, n_slices=12, dropout=0.0):
+def forward_train(sd, feed_dict, n_slices=12, dropout=0.0, masks=None):
     """Slices3DRegModel.forward in TRAIN mode (batch-stat BN, dropout) + the losses of train.py:41-47,
     differentiable w.r.t. the tensors of `sd` that require grad.  Returns (loss, parts, out, TrainState)."""
     ts = TrainState(dropout)
@@ -324,7 +326,7 @@ def forward_train(sd, feed_dict, n_slices=12, dropout=0.0):
     feats, slices_rec = unet_forward(sd, img, n_slices, train=ts)
     img_pts = project_coord(qry_rot, feed_dict["trans_mat_wo_rot_tp"])
     tok = sample_pyramid(feats, img_pts, n_slices)
-    sdf = decode_tokens(sd, tok, qry_rot, dropout=dropout)
+    sdf = decode_tokens(sd, tok, qry_rot, dropout=dropout, masks=masks)
     tgt = feed_dict["img_slices"].view(b * n_slices, 3, s1, s2)
     out = {"sdf_pred": sdf, "slices_rec": slices_rec.view(b, n_slices * 3, s1, s2),
            "vgg_loss": vgg_perceptual_loss(sd, slices_rec, tgt) * 0.001}

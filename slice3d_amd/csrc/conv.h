@@ -1,6 +1,7 @@
 // conv.h — internal interface of the implicit-GEMM convolution engine (conv.hip).
 #pragma once
 #include "common.h"
+#include "dropout.h"
 
 // One activation source of a convolution.  The K loop walks sources in order, which gives the
 // reference's torch.cat([skip, up], 1) (unet_parts.py:73) without materialising the concat, and
@@ -36,6 +37,7 @@ struct ConvLaunch {
     int out_cstride;     // channel stride of the NHWC output tensor
     const float* residual;  // NHWC mode only: v += residual[same index] (after activation)
     int out_accumulate;  // NHWC mode only: out += v
+    DropCfg drop;        // NHWC mode only: v *= dropout mask (index = output element index), before the residual
 };
 
 int launch_conv(const ConvLaunch& a, hipStream_t stream);

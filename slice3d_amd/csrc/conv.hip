@@ -37,6 +37,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvLaunch& a, f32x4 (&acc)[
             if (a.out_mode == S3D_OUT_NHWC) {
                 if (co < a.cout_store) {  // cout_store is a multiple of 4 in this mode
                     const long oi = ((long)(pn[mt] * a.H + py[mt]) * a.W + px[mt]) * a.out_cstride + co;
+                    if (a.drop.p > 0.f) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] *= s3d_drop(a.drop, (unsigned long long)(oi + i));
+                    }
                     if (a.residual) v += ld4(a.residual + oi);
                     if (a.out_accumulate) v += ld4(a.out + oi);
                     st4(a.out + oi, v);

@@ -1,6 +1,7 @@
 // decode.h — internal interface of the per-query decoder kernels (decode.hip).
 #pragma once
 #include "common.h"
+#include "dropout.h"
 
 #define S3D_GROUP 16          // queries per group = one MFMA row tile per token
 #define S3D_FFN_CHUNK 32      // hidden units staged per LDS chunk
@@ -60,7 +61,7 @@ int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w
                      hipStream_t stream);
 // training forward: y = LN2(u), u = x + FFN(x) with x read from Xin, y -> Yout, u -> Uout (pre-LN, saved)
 int launch_ffn_layer_train(const float* Xin, float* Yout, float* Uout, long rows, const LayerPtrs& w,
-                           hipStream_t stream);
+                           const DropCfg& drop_hidden, const DropCfg& drop_out, hipStream_t stream);
 
 int launch_project_coord(const float* coords, const float* trans, float* out, int batch, long n_qry,
                          hipStream_t stream);

@@ -392,7 +392,7 @@ template <bool FINAL>
 __global__ __launch_bounds__(256) void ffn_layer_kernel(const float* X, float* Yout, float* Uout, long rows,
                                                         const LayerPtrs w, const float* fco_w, const float* fco_b,
                                                         float* sdf_out, float sign, long groups_per_batch,
-                                                        long n_qry, long g_begin) {
+                                                        long n_qry, long g_begin, const DropCfg dh, const DropCfg dq) {
     __shared__ __attribute__((aligned(16))) float s_w[2][FFN_CHUNK_FLOATS];  // 64 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -452,6 +452,15 @@ __global__ __launch_bounds__(256) void ffn_layer_kernel(const float* X, float* Y
             for (int r = 0; r < FFN_R; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hd[r][i] = fmaxf(hd[r][i] + b1[i], 0.f);
+            if (dh.p > 0.f) {   // train-mode dropout on the hidden activations (index = row*2048 + unit)
+#pragma unroll
+                for (int r = 0; r < FFN_R; ++r) {
+                    const unsigned long long base =
+                        (unsigned long long)(row0 + r * 16 + m) * S3D_FFN + c * S3D_FFN_CHUNK + 16 * a + 4 * g;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hd[r][i] *= s3d_drop(dh, base + i);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const f32x4 wb = ld4(sw + 4096 + ((j * 2 + a) * 64 + lane) * 4);
@@ -475,7 +484,14 @@ __global__ __launch_bounds__(256) void ffn_layer_kernel(const float* X, float* Y
         const long row = row0 + r * 16 + m;
         f32x4 y[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = acc[r][j] + ld4(w.b2 + 16 * j + 4 * g) + xb[r][j];
+        for (int j = 0; j < 8; ++j) {
+            f32x4 f = acc[r][j] + ld4(w.b2 + 16 * j + 4 * g);
+            if (dq.p > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] *= s3d_drop(dq, (unsigned long long)row * 128 + 16 * j + 4 * g + i);
+            }
+            y[j] = f + xb[r][j];
+        }
         if (!FINAL && Uout && row < rows) {
             float* uo = Uout + row * 128 + 4 * g;
 #pragma unroll
@@ -515,20 +531,22 @@ int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w
     const long blocks = (rows + 4 * FFN_R * 16 - 1) / (4 * FFN_R * 16);
     if (sdf_out)
         hipLaunchKernelGGL(ffn_layer_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, X, X, nullptr, rows,
-                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, make_drop(0, 0.f, 0),
+                           make_drop(0, 0.f, 0));
     else
         hipLaunchKernelGGL(ffn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, X, X, nullptr, rows,
-                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, make_drop(0, 0.f, 0),
+                           make_drop(0, 0.f, 0));
     S3D_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_ffn_layer_train(const float* Xin, float* Yout, float* Uout, long rows, const LayerPtrs& w,
-                           hipStream_t stream) {
+                           const DropCfg& drop_hidden, const DropCfg& drop_out, hipStream_t stream) {
     if (rows <= 0) return 0;
     const long blocks = (rows + 4 * FFN_R * 16 - 1) / (4 * FFN_R * 16);
     hipLaunchKernelGGL(ffn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, Xin, Yout, Uout, rows,
-                       w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L);
+                       w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, drop_hidden, drop_out);
     S3D_LAUNCH_CHECK();
     return 0;
 }

@@ -65,10 +65,14 @@ int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du
                   float* dbeta, int accumulate, float* partial, hipStream_t stream);
 int launch_ln_fwd(const float* u, const float* gamma, const float* beta, float* y, long rows, hipStream_t stream);
 // attention core on stored QKV [groups][T][16][384] (q | k | v, 4 heads x 32): O [groups][T][16][128]
-int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, hipStream_t stream);
-int launch_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, long groups, int T, hipStream_t stream);
+int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, const DropCfg& drop, hipStream_t stream);
+int launch_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, long groups, int T, const DropCfg& drop,
+                         hipStream_t stream);
 // d(hidden) *= (a > 0) ; a <- relu(a)   (FFN backward on a row block)
-int launch_relu_bwd_inplace(float* a, float* dh, long n, hipStream_t stream);
+int launch_relu_bwd_inplace(float* a, float* dh, long n, long row0, const DropCfg& drop, hipStream_t stream);
+// out[i] = in[i] * mask(idx0 + i)   (out may alias in)
+int launch_dropout_apply(const float* in, float* out, long n, unsigned long long idx0, const DropCfg& drop,
+                         hipStream_t stream);
 
 // ---- train2.hip ----
 struct SampleBwdArgs {

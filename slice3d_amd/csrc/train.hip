@@ -627,18 +627,38 @@ int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, 
     return 0;
 }
 
-__global__ void relu_bwd_inplace_kernel(float* __restrict__ a, float* __restrict__ dh, long n) {
+// a <- dropout(relu(a)), dh <- dh * mask * (a > 0); element i of the block is hidden unit (row0*2048 + i)
+__global__ void relu_bwd_inplace_kernel(float* __restrict__ a, float* __restrict__ dh, long n, long row0,
+                                        const DropCfg drop) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float v = a[i];
         if (v > 0.f) {
+            if (drop.p > 0.f) {
+                const float mk = s3d_drop(drop, (unsigned long long)row0 * S3D_FFN + i);
+                a[i] = v * mk;
+                dh[i] *= mk;
+            }
         } else {
             a[i] = 0.f;
             dh[i] = 0.f;
         }
     }
 }
-int launch_relu_bwd_inplace(float* a, float* dh, long n, hipStream_t stream) {
-    hipLaunchKernelGGL(relu_bwd_inplace_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, a, dh, n);
+int launch_relu_bwd_inplace(float* a, float* dh, long n, long row0, const DropCfg& drop, hipStream_t stream) {
+    hipLaunchKernelGGL(relu_bwd_inplace_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, a, dh, n, row0, drop);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void dropout_apply_kernel(const float* __restrict__ in, float* __restrict__ out, long n,
+                                     unsigned long long idx0, const DropCfg drop) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = (in ? in[i] : 1.f) * s3d_drop(drop, idx0 + i);
+}
+int launch_dropout_apply(const float* in, float* out, long n, unsigned long long idx0, const DropCfg& drop,
+                         hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, in, out, n, idx0, drop);
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -740,7 +760,8 @@ int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du
 // =============================================================================================
 #define ATT_SCALE 0.17677669529663687f
 
-__global__ void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, long groups, int T) {
+__global__ void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, long groups, int T,
+                                     const DropCfg drop) {
     const int tid = threadIdx.x;
     const int ql = tid & 15, h = (tid >> 4) & 3, tq = tid >> 6;
     for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
@@ -779,7 +800,9 @@ __global__ void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __res
         for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
             if (tk < T) {
                 const float* vrow = base + (tk * 16 + ql) * 384 + 256 + 32 * h;
-                const float p = sc[tk] * inv;
+                float p = sc[tk] * inv;
+                if (drop.p > 0.f)   // index = ((row_q * 4 + head) * 16 + key)
+                    p *= s3d_drop(drop, ((unsigned long long)((grp * T + tq) * 16 + ql) * 4 + h) * 16 + tk);
 #pragma unroll
                 for (int d = 0; d < 8; ++d) ov[d] += ld4(vrow + 4 * d) * p;
             }
@@ -789,10 +812,10 @@ __global__ void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __res
     }
 }
 
-int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, hipStream_t stream) {
+int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, const DropCfg& drop, hipStream_t stream) {
     if (groups <= 0) return 0;
     const long nb = groups < 8192 ? groups : 8192;
-    hipLaunchKernelGGL(attn_core_fwd_kernel, dim3((unsigned)nb), dim3(64 * T), 0, stream, qkv, o, groups, T);
+    hipLaunchKernelGGL(attn_core_fwd_kernel, dim3((unsigned)nb), dim3(64 * T), 0, stream, qkv, o, groups, T, drop);
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -800,7 +823,7 @@ int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, hipStre
 // backward: phase A (thread = (ql,h,tq)): P row, dS row -> LDS, dQ row -> global;
 //           phase B (thread = (ql,h,tk)): dK[tk] = sum_tq dS[tq][tk] Q[tq] * scale, dV[tk] = sum_tq P[tq][tk] dO[tq]
 __global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
-                                     float* __restrict__ dqkv, long groups, int T) {
+                                     float* __restrict__ dqkv, long groups, int T, const DropCfg drop) {
     extern __shared__ float smem[];  // P [64][T][T] then dS [64][T][T]
     const int tid = threadIdx.x;
     const int ql = tid & 15, h = (tid >> 4) & 3, tt = tid >> 6;
@@ -847,10 +870,15 @@ __global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float*
                 }
             const float inv = 1.f / den;
             float dot = 0.f;
+            float mk[S3D_N_TOKENS_MAX];
 #pragma unroll
             for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
                 if (tk < T) {
                     sc[tk] *= inv;
+                    mk[tk] = drop.p > 0.f
+                                 ? s3d_drop(drop, ((unsigned long long)((grp * T + tt) * 16 + ql) * 4 + h) * 16 + tk)
+                                 : 1.f;
+                    dp[tk] *= mk[tk];        // d/dP of sum_k (P*mask)[k] V[k]
                     dot += sc[tk] * dp[tk];
                 }
             f32x4 dq[8];
@@ -860,7 +888,7 @@ __global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float*
             for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
                 if (tk < T) {
                     const float ds = sc[tk] * (dp[tk] - dot);
-                    sP[tk] = sc[tk];
+                    sP[tk] = sc[tk] * mk[tk];   // dropped probabilities multiply dO in dV
                     sS[tk] = ds;
                     const float* krow = base + (tk * 16 + ql) * 384 + 128 + 32 * h;
                     const float w = ds * ATT_SCALE;
@@ -901,7 +929,8 @@ __global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float*
     }
 }
 
-int launch_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, long groups, int T, hipStream_t stream) {
+int launch_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, long groups, int T, const DropCfg& drop,
+                         hipStream_t stream) {
     if (groups <= 0) return 0;
     const size_t lds = (size_t)2 * 64 * T * T * sizeof(float);  // <= 86.5 KiB at T = 13
     static bool attr_set = false;
@@ -911,7 +940,8 @@ int launch_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, long g
         attr_set = true;
     }
     const long nb = groups < 8192 ? groups : 8192;
-    hipLaunchKernelGGL(attn_core_bwd_kernel, dim3((unsigned)nb), dim3(64 * T), lds, stream, qkv, d_o, dqkv, groups, T);
+    hipLaunchKernelGGL(attn_core_bwd_kernel, dim3((unsigned)nb), dim3(64 * T), lds, stream, qkv, d_o, dqkv, groups, T,
+                       drop);
     S3D_LAUNCH_CHECK();
     return 0;
 }

@@ -14,13 +14,14 @@ from .models import _VGG16_CFG, _VGG16_SLICES, _VGG19_CONVS, _VGG19_SLICES, _sli
 
 
 class HipTrainer:
-    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, dropout=0.0, process_group=None):
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, dropout=0.0, process_group=None, seed=0):
         self.model = model
         self.lib = _lib.load()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.dropout = dropout
         self.group = process_group
         self.step = 0
+        self.seed, self._calls, self.last_seed = seed, 0, 0
         dev = model.fc_p.weight.device
         if dev.type != "cuda":
             raise _lib.S3dError("move the model to the GPU before building a HipTrainer")
@@ -108,6 +109,12 @@ class HipTrainer:
         vp.mean, vp.std = self._mean.data_ptr(), self._std.data_ptr()
         return vp
 
+    def _next_seed(self):
+        """Fresh dropout seed per call (rank-dependent so data-parallel ranks draw different masks)."""
+        self.last_seed = (self.seed * 1000003 + self.step * 7919 + self._calls) & 0xFFFFFFFFFFFF
+        self._calls += 1
+        return self.last_seed
+
     # -- one step ---------------------------------------------------------------------------------
     def forward_backward(self, batch, want_outputs=False):
         """Train-mode forward + losses + backward; fills param.grad.  Returns the device tensor
@@ -131,7 +138,7 @@ class HipTrainer:
         du, dh = self._unet_struct(True), self._head_struct(True)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.s3d_train_fwd_bwd(C.byref(u), C.byref(h), C.byref(v), C.byref(du), C.byref(dh), C.byref(tb),
-                                         b, s, q, ns, float(self.dropout), 0, self._losses.data_ptr(),
+                                         b, s, q, ns, float(self.dropout), self._next_seed(), self._losses.data_ptr(),
                                          sdf_pred.data_ptr() if want_outputs else None,
                                          rec.data_ptr() if want_outputs else None,
                                          self._ws.data_ptr(), self._ws.numel(), stream), "s3d_train_fwd_bwd")

@@ -99,6 +99,75 @@ def test_train_grads_match_oracle_autograd(b, s, q, ns):
         assert rel < 2e-2, (k, rel)
 
 
+def _hip_dropout_masks(b, q, ns, p, seed):
+    """Rebuild, in the oracle's (query, token, ...) layout, the masks the HIP kernels draw (s3d_dropout_mask)."""
+    import ctypes as C
+    from slice3d_amd import _lib
+    lib = _lib.load()
+    T = ns + 1
+    gpb = (q + 15) // 16
+    G = gpb * b
+    rows, rows0 = G * T * 16, G * 16
+    qi = torch.arange(q)
+    masks = []
+    for l in range(3):
+        def gen(site, n):
+            out = torch.empty(n, dtype=torch.float32, device="cuda")
+            _lib.check(lib.s3d_dropout_mask(seed, 4 * l + site, 0, n, p, out.data_ptr(), None), "s3d_dropout_mask")
+            torch.cuda.synchronize()
+            return out.cpu()
+        # row of (batch bb, query q, token t) in the token tensor
+        row = torch.stack([torch.stack([((bb * gpb + qi // 16) * T + t) * 16 + qi % 16 for t in range(T)], 1)
+                           for bb in range(b)]).reshape(b * q, T)                       # (R, T)
+        m_att = gen(0, rows * 4 * 16).view(rows, 4, 16)[row][:, :, :, :T].permute(0, 2, 1, 3)   # (R, 4, Tq, Tk)
+        m_o = gen(1, rows * 128).view(rows, 128)[row]                                             # (R, T, 128)
+        if l < 2:
+            m_h = gen(2, rows * 2048).view(rows, 2048)[row]
+            m_f = gen(3, rows * 128).view(rows, 128)[row]
+        else:   # the last layer's FFN runs on the compact token-0 rows; other tokens are never consumed
+            row0 = torch.cat([(bb * gpb + qi // 16) * 16 + qi % 16 for bb in range(b)])
+            m_h = torch.ones(b * q, T, 2048)
+            m_f = torch.ones(b * q, T, 128)
+            m_h[:, 0] = gen(2, rows0 * 2048).view(rows0, 2048)[row0]
+            m_f[:, 0] = gen(3, rows0 * 128).view(rows0, 128)[row0]
+        masks.append({"att": m_att, "o": m_o, "h": m_h, "f": m_f})
+    return masks
+
+
+def test_dropout_matches_oracle_with_identical_masks():
+    """Train step with dropout 0.1: the oracle is run with the very masks the kernels generate
+    (counter-based, exported through s3d_dropout_mask), so losses and gradients must agree as at p = 0."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    b, s, q, ns, p = 1, 32, 40, 12, 0.1
+    m, tr = make_trainer(ns)
+    tr.dropout = p
+    fd = make_feed_dict(b, s, q, ns, seed=321)
+    losses = tr.forward_backward({k: v.cuda() for k, v in fd.items()})
+    got = losses.cpu().numpy()
+    masks = _hip_dropout_masks(b, q, ns, p, tr.last_seed)
+    keep = float(masks[0]["h"].gt(0).float().mean())
+    assert abs(keep - (1 - p)) < 0.01, keep
+    assert float(masks[0]["h"].max()) == pytest.approx(1 / (1 - p))
+    sd = seeded_sd_from_shapes(_shapes(ns))
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and not k.startswith("vggptlossfunc"):
+            v.requires_grad_(True)
+    loss, parts, out, ts = ref_cpu.forward_train(sd, fd, ns, p, masks=masks)
+    loss.backward()
+    for i in range(3):
+        assert abs(got[i] - float(parts[i])) < 2e-5 * abs(float(parts[i])) + 1e-7, (i, got[i], float(parts[i]))
+    for k, prm in m.named_parameters():
+        if k not in tr.offsets or k in PRE_BN_BIASES or sd[k].grad is None:
+            continue
+        rel = float((prm.grad.cpu() - sd[k].grad).norm() / sd[k].grad.norm())
+        assert rel < 2e-2, (k, rel)
+    # and the dropout run differs from the p = 0 run (the masks are really applied)
+    tr.dropout = 0.0
+    l0 = tr.forward_backward({k: v.cuda() for k, v in fd.items()}).cpu().numpy()
+    assert abs(l0[0] - got[0]) > 1e-4
+
+
 def test_adam_step_matches_torch_adam():
     m, tr = make_trainer(12)
     torch.manual_seed(0)
