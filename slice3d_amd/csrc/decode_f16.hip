@@ -364,6 +364,8 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
                         sc[tk] = s;
                         mx = fmaxf(mx, s);
                     }
+                    // keep the scheduler from hoisting all 26 K-row reads (104 VGPRs) ahead of the math
+                    if ((tk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
                 float den = 0.f;
 #pragma unroll
@@ -385,6 +387,7 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
                             o8[i] += p * v0[i];
                             o8[4 + i] += p * v1[i];
                         }
+                        if ((tk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                     }
                 half8 oh, ol;
                 split8(o8, oh, ol);
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
                     const _Float16* f = g_out + h * A16_WO_HALFS + (j * 1024) + lane * 8;   // L1/L2-resident
                     acc_o[ti][j] = mfma3(ldh8(f), ldh8(f + 512), oh, ol, acc_o[ti][j]);
                 }
+                __builtin_amdgcn_sched_barrier(0);   // do not interleave the two tiles' attention (register pressure)
             }
             __syncthreads();   // K_h/V_h reads done; W_in_{h+1} has landed (vmcnt is drained at the barrier)
         }
@@ -434,6 +438,7 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
                 for (int i = 0; i < 4; ++i) r[i] = (y[j][i] - mean) * rstd * ga[i] + be[i];
                 st4(o + col, r);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();   // LDS weight buffers are restaged for the next group
     }
