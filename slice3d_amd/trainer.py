@@ -149,10 +149,8 @@ class HipTrainer:
 
     def all_reduce_grads(self):
         """Data-parallel exchange step: mean of the gradients over ranks (one flat 83 MB bucket)."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.grad_flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.grad_flat.div_(dist.get_world_size(self.group))
+        from .parallel import all_reduce_mean_
+        all_reduce_mean_(self.grad_flat, self.group)
 
     def adam_step(self):
         self.step += 1

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from slice3d_amd.parallel import decode_points_sharded, object_indices, shard_range
+from slice3d_amd.parallel import all_reduce_mean_, decode_points_sharded, object_indices, shard_range
 
 
 def test_shard_range_tiles_exactly():
@@ -56,6 +56,44 @@ def test_query_parallel_decode_gloo_world2(n_qry):
     ret = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_qry, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=10) == 1.0
+
+
+def _grad_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # per-rank "gradients" of a flat bucket: the all-reduced bucket must equal the mean over shards
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(10007, generator=g)
+    want = sum(torch.randn(10007, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
+    all_reduce_mean_(flat)
+    ok = torch.allclose(flat, want, atol=1e-6)
+    # identical parameters after an identical Adam update on every rank (oracle restatement of Adam)
+    from oracle.ref_cpu import adam_step
+    p0 = torch.linspace(-1, 1, 10007)
+    p1, m1, v1 = adam_step(p0, flat, torch.zeros_like(p0), torch.zeros_like(p0), 1)
+    gathered = [torch.empty_like(p1) for _ in range(world)]
+    dist.all_gather(gathered, p1)
+    ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
+    t = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        ret.put(float(t))
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_gloo_world2():
+    """C3 exchange step on CPU: mean of per-shard gradients, replicas stay bit-identical after Adam."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, ret)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
