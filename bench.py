@@ -146,7 +146,7 @@ def main():
         tmodel = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="train")
         load_seeded(tmodel, 0)
         tmodel.cuda()
-        trainer = HipTrainer(tmodel, dropout=0.1, seed=rank)     # the reference's nn.TransformerEncoderLayer default
+        trainer = HipTrainer(tmodel, dropout=0.1, seed=rank, prec=args.prec)   # dropout: the reference's default
         tfd = make_feed_dict(1, args.img_size, args.n_qry, args.n_slices, seed=4321 + rank, device="cuda")
         trainer.train_step(tfd)                      # warm-up (allocates the ~25 GB activation workspace)
         barrier()
@@ -209,7 +209,7 @@ def main():
             "train_samples_per_s": (world / (train_ms * 1e-3)) if train_ms else None,
             "train_ms_per_step": train_ms,
             "train_config": "train_step (fwd + 3 losses + bwd + grad all-reduce + Adam), B=1 object/GPU, %d^2 x %d slices, "
-                            "Q=%d, fp32 MFMA, dropout 0.1, batch-statistic BatchNorm"
+                            "Q=%d, dropout 0.1, batch-statistic BatchNorm; forward/dgrad GEMMs in --prec, weight gradients fp32 MFMA"
                             % (args.img_size, args.n_slices, args.n_qry),
         }
         if world == 1 and args.cpu_sample > 0:

@@ -190,7 +190,7 @@ size_t s3d_train_workspace_bytes(int batch, int size, long n_qry, int n_slices);
 int s3d_train_fwd_bwd(const S3dUNetParams* unet, const S3dHeadParams* head, const S3dVggParams* vgg,
                       const S3dUNetParams* unet_grad, const S3dHeadParams* head_grad,
                       const S3dTrainBatch* batch, int batch_size, int size, long n_qry, int n_slices,
-                      float dropout_p, unsigned long long seed, float* losses_out, float* sdf_pred_out,
+                      float dropout_p, unsigned long long seed, int prec, float* losses_out, float* sdf_pred_out,
                       float* slices_rec_out, void* workspace, size_t workspace_bytes, void* stream);
 /* The dropout mask the kernels use: out[i] = keep(seed, site, idx0+i) ? 1/(1-p) : 0.  site = 4*layer +
  * {0 attention probabilities [(row*4 + head)*16 + key], 1 attention-block output [row*128 + c],

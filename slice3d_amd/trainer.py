@@ -14,11 +14,13 @@ from .models import _VGG16_CFG, _VGG16_SLICES, _VGG19_CONVS, _VGG19_SLICES, _sli
 
 
 class HipTrainer:
-    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, dropout=0.0, process_group=None, seed=0):
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, dropout=0.0, process_group=None, seed=0,
+                 prec="f32"):
         self.model = model
         self.lib = _lib.load()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.dropout = dropout
+        self.prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}[prec]   # conv / linear GEMMs; wgrad stays fp32
         self.group = process_group
         self.step = 0
         self.seed, self._calls, self.last_seed = seed, 0, 0
@@ -138,7 +140,8 @@ class HipTrainer:
         du, dh = self._unet_struct(True), self._head_struct(True)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.s3d_train_fwd_bwd(C.byref(u), C.byref(h), C.byref(v), C.byref(du), C.byref(dh), C.byref(tb),
-                                         b, s, q, ns, float(self.dropout), self._next_seed(), self._losses.data_ptr(),
+                                         b, s, q, ns, float(self.dropout), self._next_seed(), self.prec,
+                                         self._losses.data_ptr(),
                                          sdf_pred.data_ptr() if want_outputs else None,
                                          rec.data_ptr() if want_outputs else None,
                                          self._ws.data_ptr(), self._ws.numel(), stream), "s3d_train_fwd_bwd")
