@@ -271,7 +271,8 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
                                                                const _Float16* wimg, const LayerPtrs w) {
     extern __shared__ __attribute__((aligned(16))) float smem16[];
     _Float16* s_win = reinterpret_cast<_Float16*>(smem16);                  // 24 fragment pairs, 48 KiB
-    float* s_k = smem16 + A16_WIN_HALFS / 2;                                // [T*16][AKV_LD]
+    float* s_q = smem16 + A16_WIN_HALFS / 2;                                // [T*16][AKV_LD]; O_h overwrites it
+    float* s_k = s_q + S3D_N_TOKENS_MAX * 16 * AKV_LD;
     float* s_v = s_k + S3D_N_TOKENS_MAX * 16 * AKV_LD;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -307,8 +308,8 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
 
 #pragma unroll 1
         for (int h = 0; h < 4; ++h) {
-            float q8[A16_MAXT][8];
-            // ---- projections: part p (0 Q, 1 K, 2 V), half jj: lane (m,g) gets head dims 8g + 4jj + i ----
+            // ---- phase 1: projections.  part p (0 Q, 1 K, 2 V), half jj: lane (m,g) gets head dims 8g+4jj+i;
+            //      all three go to LDS as fp32 rows [token][query][32 dims] (padded to AKV_LD) ----
 #pragma unroll 1
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -329,66 +330,73 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
                         }
                     }
                     const f32x4 bias = ld4(w.inb + p * 128 + 32 * h + 8 * g + 4 * jj);
+                    float* dstb = p == 0 ? s_q : (p == 1 ? s_k : s_v);
 #pragma unroll
                     for (int ti = 0; ti < A16_MAXT; ++ti) {
                         const int t = wave + 8 * ti;
                         if (t >= T) continue;
-                        const f32x4 v = d[ti] + bias;
-                        if (p == 0) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) q8[ti][4 * jj + i] = v[i];
-                        } else {
-                            st4((p == 1 ? s_k : s_v) + (t * S3D_GROUP + m) * AKV_LD + 8 * g + 4 * jj, v);
-                        }
+                        if (LAST && p == 0 && t != 0) continue;
+                        st4(dstb + (t * S3D_GROUP + m) * AKV_LD + 8 * g + 4 * jj, d[ti] + bias);
                     }
                 }
             }
-            __syncthreads();   // K_h / V_h complete; every wave is done with W_in_h
+            __syncthreads();   // Q_h / K_h / V_h complete; every wave is done with W_in_h
             // W_in_h is dead: start the DMA of the next head's in_proj fragments under the attention phase
             if (h < 3) dma_kib(g_in + (h + 1) * A16_WIN_HALFS, s_win, 48, wave, lane);
-            // ---- 13-key softmax attention by the MFMA lanes; out_proj partial on MFMA ----
+            // ---- phase 2a: softmax attention of queries 2*wave, 2*wave+1 on fp32 MFMA.
+            //      lane (r, g): S^T = K Q^T  -> lane (tq = r, g) holds scores of keys 4g..4g+3;
+            //      O^T = V^T P^T with that very register as B operand; O overwrites Q in LDS ----
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) {
+                const int mq = 2 * wave + qi;
+                const int r = m;                                  // token index carried by this lane (tq or tk)
+                const int rc = r < T ? r : T - 1;                 // rows >= T do not exist: read a valid row, use 0
+                const float* krow = s_k + (rc * S3D_GROUP + mq) * AKV_LD + 4 * g;
+                const float* qrow = s_q + (rc * S3D_GROUP + mq) * AKV_LD + 4 * g;
+                const bool rv = r < T;
+                f32x4 k0 = ld4(krow), k1 = ld4(krow + 16), q0 = ld4(qrow), q1 = ld4(qrow + 16);
+                if (!rv) {
+                    k0 = zero4(); k1 = zero4(); q0 = zero4(); q1 = zero4();
+                }
+                f32x4 sacc = mfma4(k0, q0, zero4());              // MFMA always runs wave-wide, outside any branch
+                sacc = mfma4(k1, q1, sacc);
+                float e[4];
+                float mx = -1e30f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    e[i] = (4 * g + i < T) ? sacc[i] * scale : -1e30f;
+                    mx = fmaxf(mx, e[i]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float den = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    e[i] = (4 * g + i < T) ? __expf(e[i] - mx) : 0.f;
+                    den += e[i];
+                }
+                den = quad_sum16(den);
+                const float inv = 1.f / den;
+                const f32x4 pb = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    f32x4 va;                                      // A: lane (d = r, g) holds V[key 4g+i][d]
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        va[i] = (4 * g + i < T) ? s_v[((4 * g + i) * S3D_GROUP + mq) * AKV_LD + 16 * dt + r] : 0.f;
+                    const f32x4 o = mfma4(va, pb, zero4());        // lane (tq = r, g): dims 16dt + 4g + i
+                    if (r < (LAST ? 1 : T)) st4(s_q + (r * S3D_GROUP + mq) * AKV_LD + 16 * dt + 4 * g, o);
+                }
+            }
+            __syncthreads();   // O_h (in the Q buffer) visible to the tile owners
+            // ---- phase 2b: out_proj partial sums on f16x3 MFMA, accumulated over heads in registers ----
 #pragma unroll
             for (int ti = 0; ti < A16_MAXT; ++ti) {
                 const int t = wave + 8 * ti;
                 if (t >= (LAST ? 1 : T)) continue;
-                float sc[S3D_N_TOKENS_MAX];
-                float mx = -1e30f;
-#pragma unroll
-                for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk) {
-                    if (tk < T) {
-                        const float* kr = s_k + (tk * S3D_GROUP + m) * AKV_LD + 8 * g;
-                        const f32x4 k0 = ld4(kr), k1 = ld4(kr + 4);
-                        float s = q8[ti][0] * k0[0] + q8[ti][1] * k0[1] + q8[ti][2] * k0[2] + q8[ti][3] * k0[3] +
-                                  q8[ti][4] * k1[0] + q8[ti][5] * k1[1] + q8[ti][6] * k1[2] + q8[ti][7] * k1[3];
-                        s = quad_sum16(s) * scale;
-                        sc[tk] = s;
-                        mx = fmaxf(mx, s);
-                    }
-                    // keep the scheduler from hoisting all 26 K-row reads (104 VGPRs) ahead of the math
-                    if ((tk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-                float den = 0.f;
-#pragma unroll
-                for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
-                    if (tk < T) {
-                        sc[tk] = __expf(sc[tk] - mx);
-                        den += sc[tk];
-                    }
-                const float inv = 1.f / den;
-                float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
-                    if (tk < T) {
-                        const float* vr = s_v + (tk * S3D_GROUP + m) * AKV_LD + 8 * g;
-                        const f32x4 v0 = ld4(vr), v1 = ld4(vr + 4);
-                        const float p = sc[tk] * inv;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            o8[i] += p * v0[i];
-                            o8[4 + i] += p * v1[i];
-                        }
-                        if ((tk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                    }
+                const float* orow = s_q + (t * S3D_GROUP + m) * AKV_LD + 8 * g;
+                const f32x4 o0 = ld4(orow), o1 = ld4(orow + 4);
+                const float o8[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
                 half8 oh, ol;
                 split8(o8, oh, ol);
 #pragma unroll
@@ -396,9 +404,8 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
                     const _Float16* f = g_out + h * A16_WO_HALFS + (j * 1024) + lane * 8;   // L1/L2-resident
                     acc_o[ti][j] = mfma3(ldh8(f), ldh8(f + 512), oh, ol, acc_o[ti][j]);
                 }
-                __builtin_amdgcn_sched_barrier(0);   // do not interleave the two tiles' attention (register pressure)
             }
-            __syncthreads();   // K_h/V_h reads done; W_in_{h+1} has landed (vmcnt is drained at the barrier)
+            __syncthreads();   // Q/K/V buffers free for the next head; W_in_{h+1} has landed
         }
         // ---- residual + LayerNorm1 (columns 32*(j>>1) + 8g + 4*(j&1) + i), store ----
 #pragma unroll
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
 
 int launch_attn_layer_f16x3(float* X, float* x0_out, long groups, int T, const LayerPtrs& w, hipStream_t stream) {
     if (groups <= 0) return 0;
-    const size_t lds = (size_t)A16_WIN_HALFS * 2 + (size_t)2 * S3D_N_TOKENS_MAX * 16 * AKV_LD * 4;   // 107 KiB
+    const size_t lds = (size_t)A16_WIN_HALFS * 2 + (size_t)3 * S3D_N_TOKENS_MAX * 16 * AKV_LD * 4;   // 136 KiB
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_layer_f16x3_kernel<false>,
