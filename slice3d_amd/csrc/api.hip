@@ -631,8 +631,9 @@ extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, 
 #define S3D_CHUNK_GROUPS 16384  // 262144 queries per pass: X = 16384*13*16*128*4 B = 1.74 GB
 
 struct DecodeWs {
-    size_t X, X0, total;
+    size_t X, X0, perm, sortws, total;
 };
+#define S3D_SORT_MIN_QUERIES 4096   // below this the sort costs more than the locality buys
 static DecodeWs decode_ws(int batch, long n_qry, int ns) {
     const long gpb = (n_qry + S3D_GROUP - 1) / S3D_GROUP;
     long g = gpb * batch;
@@ -640,7 +641,9 @@ static DecodeWs decode_ws(int batch, long n_qry, int ns) {
     DecodeWs W;
     W.X = 0;
     W.X0 = (size_t)g * (ns + 1) * S3D_GROUP * 128;
-    W.total = W.X0 + (size_t)g * S3D_GROUP * 128;
+    W.perm = W.X0 + (size_t)g * S3D_GROUP * 128;
+    W.sortws = W.perm + (size_t)batch * n_qry;
+    W.total = W.sortws + (size_t)batch * (65536 + n_qry);
     return W;
 }
 
@@ -678,6 +681,13 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
     const int T = ns + 1;
     const long gpb = (n_qry + S3D_GROUP - 1) / S3D_GROUP;
     const long G = gpb * batch;
+    const int* perm = nullptr;
+    if (qry && n_qry >= S3D_SORT_MIN_QUERIES) {   // scattered queries: sort by projected pixel for L2 locality
+        int* pm = (int*)((float*)workspace + W.perm);
+        TRY(launch_query_sort(qry, flip_yz ? nullptr : rot, trans, flip_yz, batch, n_qry, pm,
+                              (int*)((float*)workspace + W.sortws), st));
+        perm = pm;
+    }
     for (long g0 = 0; g0 < G; g0 += S3D_CHUNK_GROUPS) {
         const long gc = G - g0 < S3D_CHUNK_GROUPS ? G - g0 : S3D_CHUNK_GROUPS;
         SampleArgs sa = {};
@@ -687,7 +697,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
         sa.fcp_w = b + H.fcp_w; sa.fcp_b = b + H.fcp_b; sa.fcs_b = b + H.fcs_b; sa.ws34 = b + H.ws34;
         sa.qry = qry; sa.rot = rot; sa.trans = trans; sa.flip_yz = flip_yz;
         sa.n_qry = n_qry; sa.groups_per_batch = gpb; sa.g_begin = g0; sa.g_count = gc;
-        sa.nx = nx; sa.box = box; sa.X = X;
+        sa.nx = nx; sa.box = box; sa.X = X; sa.perm = perm;
         {
             ProfScope prof_(S3D_PROF_SAMPLE, st);
             TRY(launch_sample_tokens(sa, st));
@@ -705,10 +715,10 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
             ProfScope prof_(last ? S3D_PROF_FFN_FINAL : S3D_PROF_FFN, st);
             if (!last)
                 TRY(launch_ffn_layer(X, gc * T * S3D_GROUP, lp, nullptr, nullptr, nullptr, 1.f, gpb, n_qry, g0,
-                                     prec, st));
+                                     prec, nullptr, st));
             else
                 TRY(launch_ffn_layer(X0, gc * S3D_GROUP, lp, b + H.fco_w, b + H.fco_b, out, sign, gpb, n_qry, g0,
-                                     prec, st));
+                                     prec, perm, st));
         }
     }
     return 0;

@@ -48,6 +48,7 @@ struct SampleArgs {
     int nx;
     float box;
     float* X;            // out [g_count][T][16][128]
+    const int* perm;     // optional: slot -> query index within the batch item (locality sort), (B, Q) ints
     float* raw_out;      // optional (training): sampled level-3/4 features [g_count][T][16][96], token-0 rows zero
 };
 
@@ -58,7 +59,11 @@ int launch_attn_layer(float* X, float* x0_out, long groups, int T, const LayerPt
 // rows x 128 in place; if sdf_out != NULL: final layer, writes sign*(fc_out(LN2(..))) per row instead.
 int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w, const float* fco_b,
                      float* sdf_out, float sign, long groups_per_batch, long n_qry, long g_begin, int prec,
-                     hipStream_t stream);
+                     const int* perm, hipStream_t stream);
+// image-space locality sort of the queries of each batch item (counting sort on the Morton code of the
+// projected pixel at 256^2): perm[b*Q + slot] = query index.  ws: (B*65536 + B*Q) ints of scratch.
+int launch_query_sort(const float* qry, const float* rot, const float* trans, int flip_yz, int batch, long n_qry,
+                      int* perm, int* ws, hipStream_t stream);
 // training forward: y = LN2(u), u = x + FFN(x) with x read from Xin, y -> Yout, u -> Uout (pre-LN, saved)
 int launch_ffn_layer_train(const float* Xin, float* Yout, float* Uout, long rows, const LayerPtrs& w,
                            const DropCfg& drop_hidden, const DropCfg& drop_out, hipStream_t stream);
@@ -71,7 +76,7 @@ int launch_sample_planes(const float* plane, const float* grid, float* out, int 
 // decode_f16.hip
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
-                           long g_begin, hipStream_t stream);
+                           long g_begin, const int* perm, hipStream_t stream);
 int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream);
 int launch_attn_layer_f16x3(float* X, float* x0_out, long groups, int T, const LayerPtrs& w, hipStream_t stream);
 int launch_pack_attn_f16x3(const float* win, const float* wout, float* out, hipStream_t stream);

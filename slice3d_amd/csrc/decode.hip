@@ -97,11 +97,18 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
     const int T = a.n_slices + 1;
     const int S = a.size;
 
-    for (long gi = blockIdx.x; gi < a.g_count; gi += gridDim.x) {
+    // each block walks a CONTIGUOUS chunk of groups (queries may be locality-sorted), and the blocks that the
+    // dispatcher places on one XCD (b % 8) get adjacent chunks, so neighbouring taps meet in that XCD's L2
+    const long nb = gridDim.x;
+    const long bb = (nb % 8 == 0) ? (long)(blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : (long)blockIdx.x;
+    const long chunk = (a.g_count + nb - 1) / nb;
+    const long g_lo = bb * chunk, g_hi = g_lo + chunk < a.g_count ? g_lo + chunk : a.g_count;
+    for (long gi = g_lo; gi < g_hi; ++gi) {
         const long grp = a.g_begin + gi;
         const int b = (int)(grp / a.groups_per_batch);
         long q = (grp % a.groups_per_batch) * S3D_GROUP + m;
         if (q >= a.n_qry) q = a.n_qry - 1;  // padded rows recompute the last query; never stored to sdf
+        if (a.perm) q = a.perm[(long)b * a.n_qry + q];
         float x, y, z;
         if (a.qry) {
             const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
@@ -140,18 +147,30 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
                 const long img = (long)b * a.n_slices + (t - 1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = ld4(a.fcs_b + 16 * j + 4 * g);
-                // levels 0..2: projected maps (img, H, W, 128)
+                // levels 0..2: projected maps (img, H, W, 128).  Loads are issued 16 at a time (two taps) into
+                // a staging array and only then consumed: left to itself the scheduler keeps ONE 16-byte
+                // load in flight per wave (load, s_waitcnt vmcnt(0), fma, ...), which made this gather 4x slower.
 #pragma unroll
                 for (int l = 0; l < 3; ++l) {
                     const int W = S >> (4 - l);
                     const Tap4 tp = make_taps(gx, gy, W, W);
                     const float* base = a.proj[l] + img * (long)W * W * 128 + 4 * g;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float* p = base + (long)tp.off[k] * 128;
-                        const float w = tp.w[k];
+                    for (int kp = 0; kp < 2; ++kp) {
+                        f32x4 v[2][8];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[j] += ld4(p + 16 * j) * w;
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            const float* p = base + (long)tp.off[2 * kp + k2] * 128;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[k2][j] = ld4(p + 16 * j);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // all 16 loads issued before the first use
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            const float w = tp.w[2 * kp + k2];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[j] += v[k2][j] * w;
+                        }
                     }
                 }
                 // levels 3,4: raw 64 + 32 channels -> B fragments of a K=96 GEMM with Ws34
@@ -160,25 +179,26 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
                     const int W = S >> 1;
                     const Tap4 tp = make_taps(gx, gy, W, W);
                     const float* base = a.fine[0] + img * (long)W * W * 64 + 4 * g;
+                    f32x4 v[4][4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        f32x4 v = zero4();
+                    for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v += ld4(base + (long)tp.off[k] * 64 + 16 * u) * tp.w[k];
-                        braw[u] = v;
-                    }
-                }
-                {
-                    const int W = S;
-                    const Tap4 tp = make_taps(gx, gy, W, W);
-                    const float* base = a.fine[1] + img * (long)W * W * 32 + 4 * g;
+                        for (int u = 0; u < 4; ++u) v[k][u] = ld4(base + (long)tp.off[k] * 64 + 16 * u);
+                    const int W4 = S;
+                    const Tap4 tq = make_taps(gx, gy, W4, W4);
+                    const float* base4 = a.fine[1] + img * (long)W4 * W4 * 32 + 4 * g;
+                    f32x4 v4[4][2];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        f32x4 v = zero4();
+                    for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v += ld4(base + (long)tp.off[k] * 32 + 16 * u) * tp.w[k];
-                        braw[4 + u] = v;
-                    }
+                        for (int u = 0; u < 2; ++u) v4[k][u] = ld4(base4 + (long)tq.off[k] * 32 + 16 * u);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        braw[u] = v[0][u] * tp.w[0] + v[1][u] * tp.w[1] + v[2][u] * tp.w[2] + v[3][u] * tp.w[3];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        braw[4 + u] = v4[0][u] * tq.w[0] + v4[1][u] * tq.w[1] + v4[2][u] * tq.w[2] + v4[3][u] * tq.w[3];
                 }
 #pragma unroll
                 for (int u = 0; u < 6; ++u)
@@ -206,8 +226,9 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
 int launch_sample_tokens(const SampleArgs& a, hipStream_t stream) {
     S3D_CHECK_ARG(a.size % 16 == 0 && a.size >= 16, "sample: size %d", a.size);
     S3D_CHECK_ARG(a.n_slices >= 1 && a.n_slices + 1 <= S3D_N_TOKENS_MAX, "sample: n_slices %d", a.n_slices);
-    const long blocks = a.g_count < 2048 ? a.g_count : 2048;
+    long blocks = a.g_count < 2048 ? a.g_count : 2048;
     if (blocks <= 0) return 0;
+    if (blocks >= 8) blocks -= blocks % 8;
     hipLaunchKernelGGL(sample_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     S3D_LAUNCH_CHECK();
     return 0;
@@ -392,7 +413,8 @@ template <bool FINAL>
 __global__ __launch_bounds__(256) void ffn_layer_kernel(const float* X, float* Yout, float* Uout, long rows,
                                                         const LayerPtrs w, const float* fco_w, const float* fco_b,
                                                         float* sdf_out, float sign, long groups_per_batch,
-                                                        long n_qry, long g_begin, const DropCfg dh, const DropCfg dq) {
+                                                        long n_qry, long g_begin, const DropCfg dh, const DropCfg dq,
+                                                        const int* perm) {
     __shared__ __attribute__((aligned(16))) float s_w[2][FFN_CHUNK_FLOATS];  // 64 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -510,7 +532,7 @@ __global__ __launch_bounds__(256) void ffn_layer_kernel(const float* X, float* Y
                 const long grp = g_begin + row / S3D_GROUP;
                 const long b = grp / groups_per_batch;
                 const long q = (grp % groups_per_batch) * S3D_GROUP + (row % S3D_GROUP);
-                if (q < n_qry) sdf_out[b * n_qry + q] = sign * s;
+                if (q < n_qry) sdf_out[b * n_qry + (perm ? perm[b * n_qry + q] : q)] = sign * s;
             }
         } else if (row < rows) {
             float* o = Yout + row * 128 + 4 * g;
@@ -522,21 +544,21 @@ __global__ __launch_bounds__(256) void ffn_layer_kernel(const float* X, float* Y
 
 int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w, const float* fco_b,
                      float* sdf_out, float sign, long groups_per_batch, long n_qry, long g_begin, int prec,
-                     hipStream_t stream) {
+                     const int* perm, hipStream_t stream) {
     if (prec == S3D_PREC_F16X3)
         return launch_ffn_layer_f16x3(X, rows, w, w.wf16, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin,
-                                      stream);
+                                      perm, stream);
     S3D_CHECK_ARG(prec == S3D_PREC_F32, "ffn: precision mode %d not built", prec);
     if (rows <= 0) return 0;
     const long blocks = (rows + 4 * FFN_R * 16 - 1) / (4 * FFN_R * 16);
     if (sdf_out)
         hipLaunchKernelGGL(ffn_layer_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, X, X, nullptr, rows,
                            w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, make_drop(0, 0.f, 0),
-                           make_drop(0, 0.f, 0));
+                           make_drop(0, 0.f, 0), perm);
     else
         hipLaunchKernelGGL(ffn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, X, X, nullptr, rows,
                            w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, make_drop(0, 0.f, 0),
-                           make_drop(0, 0.f, 0));
+                           make_drop(0, 0.f, 0), perm);
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -546,7 +568,97 @@ int launch_ffn_layer_train(const float* Xin, float* Yout, float* Uout, long rows
     if (rows <= 0) return 0;
     const long blocks = (rows + 4 * FFN_R * 16 - 1) / (4 * FFN_R * 16);
     hipLaunchKernelGGL(ffn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, Xin, Yout, Uout, rows,
-                       w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, drop_hidden, drop_out);
+                       w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, drop_hidden, drop_out, nullptr);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// image-space locality sort of the queries (counting sort, 65536 Morton bins of the projected pixel)
+// ---------------------------------------------------------------------------------------------
+#define QS_BINS 65536
+__device__ __forceinline__ unsigned morton8(unsigned x, unsigned y) {
+    auto spread = [](unsigned v) {
+        v = (v | (v << 4)) & 0x0F0Fu;
+        v = (v | (v << 2)) & 0x3333u;
+        v = (v | (v << 1)) & 0x5555u;
+        return v;
+    };
+    return spread(x) | (spread(y) << 1);
+}
+__global__ void qsort_key_kernel(const float* qry, const float* rot, const float* trans, int flip_yz, int batch,
+                                 long n_qry, int* keys, int* hist) {
+    const long total = (long)batch * n_qry;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n_qry);
+        float x = qry[i * 3], y = qry[i * 3 + 1], z = qry[i * 3 + 2];
+        if (flip_yz) {
+            y = -y; z = -z;
+        } else if (rot) {
+            const float* R = rot + b * 9;
+            const float rx = x * R[0] + y * R[3] + z * R[6];
+            const float ry = x * R[1] + y * R[4] + z * R[7];
+            const float rz = x * R[2] + y * R[5] + z * R[8];
+            x = rx; y = ry; z = rz;
+        }
+        float gx, gy;
+        project(trans + b * 12, x, y, z, gx, gy);
+        const unsigned px = (unsigned)fminf(fmaxf((gx + 1.f) * 127.5f, 0.f), 255.f);
+        const unsigned py = (unsigned)fminf(fmaxf((gy + 1.f) * 127.5f, 0.f), 255.f);
+        const int key = (int)morton8(px, py);
+        keys[i] = key;
+        atomicAdd(&hist[(long)b * QS_BINS + key], 1);
+    }
+}
+// exclusive scan of each batch item's 65536-bin histogram, in place (one 1024-thread block per item)
+__global__ __launch_bounds__(1024) void qsort_scan_kernel(int* hist) {
+    __shared__ int part[1024];
+    int* h = hist + (long)blockIdx.x * QS_BINS;
+    const int t = threadIdx.x;
+    int local[64];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        local[i] = s;
+        s += h[t * 64 + i];
+    }
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const int base = t ? part[t - 1] : 0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) h[t * 64 + i] = base + local[i];
+}
+__global__ void qsort_scatter_kernel(const int* keys, int* offs, int batch, long n_qry, int* perm) {
+    const long total = (long)batch * n_qry;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n_qry);
+        const int pos = atomicAdd(&offs[(long)b * QS_BINS + keys[i]], 1);
+        perm[(long)b * n_qry + pos] = (int)(i - (long)b * n_qry);
+    }
+}
+
+int launch_query_sort(const float* qry, const float* rot, const float* trans, int flip_yz, int batch, long n_qry,
+                      int* perm, int* ws, hipStream_t stream) {
+    int* hist = ws;
+    int* keys = ws + (size_t)batch * QS_BINS;
+    if (hipMemsetAsync(hist, 0, (size_t)batch * QS_BINS * sizeof(int), stream) != hipSuccess) {
+        s3d_set_error("query_sort: memset failed");
+        return (int)hipErrorUnknown;
+    }
+    const long total = (long)batch * n_qry;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(qsort_key_kernel, dim3(blocks), dim3(256), 0, stream, qry, rot, trans, flip_yz, batch, n_qry,
+                       keys, hist);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(qsort_scan_kernel, dim3(batch), dim3(1024), 0, stream, hist);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(qsort_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys, hist, batch, n_qry, perm);
     S3D_LAUNCH_CHECK();
     return 0;
 }

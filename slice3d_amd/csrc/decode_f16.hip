@@ -46,7 +46,7 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
                                                               const _Float16* wimg, const LayerPtrs w,
                                                               const float* fco_w, const float* fco_b,
                                                               float* sdf_out, float sign, long groups_per_batch,
-                                                              long n_qry, long g_begin) {
+                                                              long n_qry, long g_begin, const int* perm) {
     __shared__ __attribute__((aligned(16))) _Float16 s_w[2][F16_CHUNK_HALFS];  // 64 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
                 const long grp = g_begin + row / S3D_GROUP;
                 const long b = grp / groups_per_batch;
                 const long q = (grp % groups_per_batch) * S3D_GROUP + (row % S3D_GROUP);
-                if (q < n_qry) sdf_out[b * n_qry + q] = sign * dot;
+                if (q < n_qry) sdf_out[b * n_qry + (perm ? perm[b * n_qry + q] : q)] = sign * dot;
             }
         }
     }
@@ -190,16 +190,16 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
 
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
-                           long g_begin, hipStream_t stream) {
+                           long g_begin, const int* perm, hipStream_t stream) {
     if (rows <= 0) return 0;
     const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
     const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
     if (sdf_out)
         hipLaunchKernelGGL(ffn_layer_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
-                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
     else
         hipLaunchKernelGGL(ffn_layer_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
-                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin);
+                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
     S3D_LAUNCH_CHECK();
     return 0;
 }
