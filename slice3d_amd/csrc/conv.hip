@@ -203,33 +203,44 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
             const _Float16* wp = wimg + ((size_t)jt0 * KU32 + ubase + tap * cu) * 1024 + lane * 8;
 #pragma unroll 1
             for (int c = 0; c < cu; ++c) {
-                chalf8 bh[MT], bl[MT];
+                // issue every load of this K chunk (2 per activation tile, 2 per weight tile) before the first
+                // use: left alone the scheduler interleaves load / wait / 4 MFMAs and exposes the L2 latency
+                f32x4 v0[MT], v1[MT];
+                chalf8 wh[NT], wl[NT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const f32x4 v0 = ok[mt] ? ld4(bp[mt] + 32 * c) : zero4();
-                    const f32x4 v1 = ok[mt] ? ld4(bp[mt] + 32 * c + 4) : zero4();
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const _Float16 h0 = (_Float16)v0[t], h1 = (_Float16)v1[t];
-                        bh[mt][t] = h0; bh[mt][4 + t] = h1;
-                        bl[mt][t] = (_Float16)(v0[t] - (float)h0);
-                        bl[mt][4 + t] = (_Float16)(v1[t] - (float)h1);
-                    }
+                    v0[mt] = ok[mt] ? ld4(bp[mt] + 32 * c) : zero4();
+                    v1[mt] = ok[mt] ? ld4(bp[mt] + 32 * c + 4) : zero4();
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const _Float16* f = wp + ((size_t)nt * KU32 + c) * 1024;
-                    const chalf8 wh = *reinterpret_cast<const chalf8*>(f);
-                    const chalf8 wl = *reinterpret_cast<const chalf8*>(f + 512);
+                    wh[nt] = *reinterpret_cast<const chalf8*>(f);
+                    wl[nt] = *reinterpret_cast<const chalf8*>(f + 512);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                chalf8 bh[MT], bl[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const _Float16 h0 = (_Float16)v0[mt][t], h1 = (_Float16)v1[mt][t];
+                        bh[mt][t] = h0; bh[mt][4 + t] = h1;
+                        bl[mt][t] = (_Float16)(v0[mt][t] - (float)h0);
+                        bl[mt][4 + t] = (_Float16)(v1[mt][t] - (float)h1);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bl[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], bh[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bh[mt], acc[mt][nt], 0, 0, 0);
                 }
             }
         }

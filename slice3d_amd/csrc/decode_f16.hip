@@ -93,18 +93,22 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
             f32x4 hd[F16_R];
 #pragma unroll
             for (int r = 0; r < F16_R; ++r) hd[r] = zero4();
+            half8 w1h[4], w1l[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const half8 wh = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8);
-                const half8 wl = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
+                w1h[u] = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8);
+                w1l[u] = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
                 // three product kinds, each swept over the independent row tiles (no back-to-back
                 // dependent MFMAs on one accumulator)
 #pragma unroll
-                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[r][u], hd[r], 0, 0, 0);
+                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[u], xl[r][u], hd[r], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[r][u], hd[r], 0, 0, 0);
+                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[u], xh[r][u], hd[r], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[r][u], hd[r], 0, 0, 0);
+                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[u], xh[r][u], hd[r], 0, 0, 0);
             }
             const f32x4 b1 = ld4(w.b1 + c * S3D_FFN_CHUNK + 16 * a + 4 * g);
 #pragma unroll
@@ -117,15 +121,23 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
         for (int r = 0; r < F16_R; ++r) split8(hv[r], hh[r], hl[r]);
         // GEMM2: acc^T[128][16 rows] += W2_c hidden^T, K = 32
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const half8 wh = ldh8(sw + 8192 + (j * 64 + lane) * 8);
-            const half8 wl = ldh8(sw + 12288 + (j * 64 + lane) * 8);
+        for (int jh = 0; jh < 2; ++jh) {
+            half8 w2h[4], w2l[4];
 #pragma unroll
-            for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl[r], acc[r][j], 0, 0, 0);
+            for (int jq = 0; jq < 4; ++jq) {
+                w2h[jq] = ldh8(sw + 8192 + ((4 * jh + jq) * 64 + lane) * 8);
+                w2l[jq] = ldh8(sw + 12288 + ((4 * jh + jq) * 64 + lane) * 8);
+            }
 #pragma unroll
-            for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh[r], acc[r][j], 0, 0, 0);
+            for (int jq = 0; jq < 4; ++jq) {
+                const int j = 4 * jh + jq;
 #pragma unroll
-            for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh[r], acc[r][j], 0, 0, 0);
+                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], hl[r], acc[r][j], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[jq], hh[r], acc[r][j], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], hh[r], acc[r][j], 0, 0, 0);
+            }
         }
         if (c + 1 < S3D_FFN_NCHUNK) {
             f32x4* dw = reinterpret_cast<f32x4*>(s_w[(c + 1) & 1]);
