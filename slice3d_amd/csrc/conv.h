@@ -37,6 +37,9 @@ struct ConvLaunch {
     int out_cstride;     // channel stride of the NHWC output tensor
     const float* residual;  // NHWC mode only: v += residual[same index] (after activation)
     int out_accumulate;  // NHWC mode only: out += v
+    const float* gate;   // NHWC mode only: v = gate[same index] > 0 ? v * gate_scale : 0  (ReLU/dropout backward)
+    float gate_scale;
+    unsigned long long drop_base;  // element index of this launch's out[0] in the dropout counter space
     DropCfg drop;        // NHWC mode only: v *= dropout mask (index = output element index), before the residual
 };
 

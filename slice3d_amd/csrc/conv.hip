@@ -39,7 +39,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvLaunch& a, f32x4 (&acc)[
                     const long oi = ((long)(pn[mt] * a.H + py[mt]) * a.W + px[mt]) * a.out_cstride + co;
                     if (a.drop.p > 0.f) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] *= s3d_drop(a.drop, (unsigned long long)(oi + i));
+                        for (int i = 0; i < 4; ++i) v[i] *= s3d_drop(a.drop, a.drop_base + (unsigned long long)(oi + i));
+                    }
+                    if (a.gate) {
+                        const f32x4 gt = ld4(a.gate + oi);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = gt[i] > 0.f ? v[i] * a.gate_scale : 0.f;
                     }
                     if (a.residual) v += ld4(a.residual + oi);
                     if (a.out_accumulate) v += ld4(a.out + oi);

@@ -74,6 +74,8 @@ int launch_sample_planes(const float* plane, const float* grid, float* out, int 
                          hipStream_t stream);
 
 // decode_f16.hip
+int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, long rows, const LayerPtrs& w,
+                                 const DropCfg& drop_hidden, const DropCfg& drop_out, hipStream_t stream);
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
                            long g_begin, const int* perm, hipStream_t stream);

@@ -41,12 +41,19 @@ __device__ __forceinline__ float quad_sum16(float v) {
 #define F16_THREADS (F16_WAVES * 64)
 #define F16_CHUNK_HALFS 16384   // 32 KiB: W1 hi | W1 lo | W2 hi | W2 lo, 4096 halfs each
 
-template <bool FINAL>
+struct FfnTrainArgs {   // MODE 2 only: pre-LayerNorm output for the backward pass + train-mode dropout
+    float* Uout;
+    DropCfg dh, dq;
+};
+// MODE 0: layer FFN (in place or X -> Yout); 1: last layer + fc_out (FINAL); 2: training forward
+template <int MODE>
 __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const float* X, float* Yout, long rows,
                                                               const _Float16* wimg, const LayerPtrs w,
                                                               const float* fco_w, const float* fco_b,
                                                               float* sdf_out, float sign, long groups_per_batch,
-                                                              long n_qry, long g_begin, const int* perm) {
+                                                              long n_qry, long g_begin, const int* perm,
+                                                              const FfnTrainArgs ta) {
+    constexpr bool FINAL = MODE == 1;
     __shared__ __attribute__((aligned(16))) _Float16 s_w[2][F16_CHUNK_HALFS];  // 64 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -115,6 +122,15 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
             for (int r = 0; r < F16_R; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hv[r][4 * a + i] = fmaxf(hd[r][i] + b1[i], 0.f);
+            if (MODE == 2 && ta.dh.p > 0.f) {   // hidden-unit dropout, counter = row*2048 + unit
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) {
+                    const unsigned long long base =
+                        (unsigned long long)(row0 + r * 16 + m) * S3D_FFN + c * S3D_FFN_CHUNK + 16 * a + 4 * g;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hv[r][4 * a + i] *= s3d_drop(ta.dh, base + i);
+                }
+            }
         }
         half8 hh[F16_R], hl[F16_R];
 #pragma unroll
@@ -160,9 +176,12 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int t = 4 * (j & 1) + i;
-                y[j][i] = acc[r][j][i] + b2[i] + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
+                float f = acc[r][j][i] + b2[i];
+                if (MODE == 2 && ta.dq.p > 0.f) f *= s3d_drop(ta.dq, (unsigned long long)row * 128 + col + i);
+                y[j][i] = f + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
                 s += y[j][i];
             }
+            if (MODE == 2 && row < rows) st4(ta.Uout + row * 128 + col, y[j]);
         }
         const float mean = quad_sum16(s) * (1.f / 128.f);
         float v = 0.f;
@@ -206,12 +225,26 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
     if (rows <= 0) return 0;
     const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
     const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
+    FfnTrainArgs ta = {};
     if (sdf_out)
-        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
-                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
+        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<1>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
+                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta);
     else
-        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
-                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
+        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<0>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
+                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, long rows, const LayerPtrs& w,
+                                 const DropCfg& drop_hidden, const DropCfg& drop_out, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    S3D_CHECK_ARG(w.wf16 != nullptr, "ffn train f16x3: no packed f16 image");
+    const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
+    FfnTrainArgs ta = {Uout, drop_hidden, drop_out};
+    hipLaunchKernelGGL(ffn_layer_f16x3_kernel<2>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, Xin, Yout, rows,
+                       reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L,
+                       nullptr, ta);
     S3D_LAUNCH_CHECK();
     return 0;
 }

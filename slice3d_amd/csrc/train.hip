@@ -177,31 +177,87 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
                                                      long P, int cstride, int coff, int C,
                                                      const float* __restrict__ m, const float* __restrict__ r,
                                                      float* __restrict__ partial, long rows_per_chunk) {
+    // thread = (row lane rl, column quad cq): narrow matrices (C = 64..128) still use all 256 threads
+    __shared__ f32x4 red[256], red2[MODE == 2 ? 256 : 1];
     const int c4n = C >> 2;
+    const int tpr = c4n < 256 ? c4n : 256;
+    const int rl_n = 256 / tpr;
+    const int rl = threadIdx.x / tpr, ct = threadIdx.x - rl * tpr;
     const long r0 = (long)blockIdx.x * rows_per_chunk;
     long r1 = r0 + rows_per_chunk;
     if (r1 > P) r1 = P;
-    for (int cq = threadIdx.x; cq < c4n; cq += 256) {
-        const int c = cq * 4;
+    for (int cq0 = 0; cq0 < c4n; cq0 += tpr) {
+        const int cq = cq0 + ct;
+        const bool active = rl < rl_n && cq < c4n;
+        const int c = (cq < c4n ? cq : 0) * 4;
         f32x4 s = zero4(), s2 = zero4();
         f32x4 mv = zero4(), rv = zero4();
         if (MODE >= 1) mv = ld4(m + c);
         if (MODE == 2) rv = ld4(r + c);
-        for (long p = r0; p < r1; ++p) {
-            const f32x4 v = ld4(in + p * cstride + coff + c);
-            if (MODE == 0) {
-                s += v;
-            } else if (MODE == 1) {
-                const f32x4 d = v - mv;
-                s += d * d;
+        if (active) {
+            const float* src = in + coff + c;
+            if (MODE == 0) {   // 8 independent row streams: 8 loads in flight per thread
+                f32x4 t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = zero4();
+                long p = r0 + rl;
+                for (; p + 7L * rl_n < r1; p += 8L * rl_n) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = ld4(src + (p + (long)k * rl_n) * cstride);
+                    __builtin_amdgcn_sched_barrier(0);   // all 8 loads issued before the first add waits
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] += v[k];
+                }
+                for (; p < r1; p += rl_n) t[0] += ld4(src + p * cstride);
+                s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
             } else {
-                const f32x4 z = ld4(in2 + p * cstride + coff + c);
-                s += v;
-                s2 += v * ((z - mv) * rv);
+                const float* src2 = MODE == 2 ? in2 + coff + c : src;
+                long p = r0 + rl;
+                for (; p + 3L * rl_n < r1; p += 4L * rl_n) {
+                    f32x4 v[4], z[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = ld4(src + (p + (long)k * rl_n) * cstride);
+                        if (MODE == 2) z[k] = ld4(src2 + (p + (long)k * rl_n) * cstride);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (MODE == 1) {
+                            const f32x4 d = v[k] - mv;
+                            s += d * d;
+                        } else {
+                            s += v[k];
+                            s2 += v[k] * ((z[k] - mv) * rv);
+                        }
+                    }
+                }
+                for (; p < r1; p += rl_n) {
+                    const f32x4 v = ld4(src + p * cstride);
+                    if (MODE == 1) {
+                        const f32x4 d = v - mv;
+                        s += d * d;
+                    } else {
+                        const f32x4 z = ld4(src2 + p * cstride);
+                        s += v;
+                        s2 += v * ((z - mv) * rv);
+                    }
+                }
             }
         }
-        st4(partial + ((size_t)blockIdx.x * C + c), s);
-        if (MODE == 2) st4(partial + ((size_t)(gridDim.x + blockIdx.x) * C + c), s2);
+        red[threadIdx.x] = s;
+        if (MODE == 2) red2[threadIdx.x] = s2;
+        __syncthreads();
+        if (rl == 0 && cq < c4n) {
+            for (int k = 1; k < rl_n; ++k) {
+                s += red[k * tpr + ct];
+                if (MODE == 2) s2 += red2[k * tpr + ct];
+            }
+            st4(partial + ((size_t)blockIdx.x * C + c), s);
+            if (MODE == 2) st4(partial + ((size_t)(gridDim.x + blockIdx.x) * C + c), s2);
+        }
+        __syncthreads();
     }
 }
 

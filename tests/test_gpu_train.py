@@ -186,13 +186,16 @@ def test_f16x3_training_gemms_match_fp32():
     for i in range(3):
         assert abs(la[i] - lb[i]) < 2e-5 * abs(la[i]) + 1e-7, (i, la[i], lb[i])
     ga, gb, tr = res["f32"][1], res["f16x3"][1], res["f32"][2]
+    assert float((ga - gb).norm() / ga.norm()) < 2e-2
+    gmax = max(float(ga[tr.offsets[k]:tr.offsets[k] + p.numel()].norm()) for k, p in zip(tr.names, tr.params))
     for k, p in zip(tr.names, tr.params):
         if k in PRE_BN_BIASES:
             continue
         off, n = tr.offsets[k], p.numel()
         a, b = ga[off:off + n], gb[off:off + n]
-        # deepest encoder gradients feel the sign flips of near-zero L1 residuals most (see module docstring)
-        assert float((a - b).norm() / (a.norm() + 1e-30)) < 5e-2, k
+        # shallow encoder gradients feel the sign flips of near-zero L1 residuals most (see module docstring);
+        # the absolute term covers bias gradients that are themselves a near-cancelling sum (|g| ~ 1e-4 gmax)
+        assert float((a - b).norm()) < 5e-2 * float(a.norm()) + 1e-4 * gmax, k
 
 
 def test_adam_step_matches_torch_adam():
