@@ -41,11 +41,14 @@ __device__ __forceinline__ float quad_sum16(float v) {
 #define F16_THREADS (F16_WAVES * 64)
 #define F16_CHUNK_HALFS 16384   // 32 KiB: W1 hi | W1 lo | W2 hi | W2 lo, 4096 halfs each
 
-struct FfnTrainArgs {   // MODE 2 only: pre-LayerNorm output for the backward pass + train-mode dropout
+struct FfnTrainArgs {   // MODE 2: pre-LayerNorm output for the backward pass + train-mode dropout; MODE 3: Hout
     float* Uout;
     DropCfg dh, dq;
+    float* Hout;
+    long row_base;   // row index of X[0] in the dropout counter space (block-wise backward recompute)
 };
-// MODE 0: layer FFN (in place or X -> Yout); 1: last layer + fc_out (FINAL); 2: training forward
+// MODE 0: layer FFN (in place or X -> Yout); 1: last layer + fc_out (FINAL); 2: training forward;
+// 3: backward-pass recompute of the hidden activations only: Hout = dropout(relu(x W1^T + b1)), [rows][2048]
 template <int MODE>
 __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const float* X, float* Yout, long rows,
                                                               const _Float16* wimg, const LayerPtrs w,
@@ -122,13 +125,24 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
             for (int r = 0; r < F16_R; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hv[r][4 * a + i] = fmaxf(hd[r][i] + b1[i], 0.f);
-            if (MODE == 2 && ta.dh.p > 0.f) {   // hidden-unit dropout, counter = row*2048 + unit
+            if (MODE >= 2 && ta.dh.p > 0.f) {   // hidden-unit dropout, counter = row*2048 + unit
 #pragma unroll
                 for (int r = 0; r < F16_R; ++r) {
                     const unsigned long long base =
-                        (unsigned long long)(row0 + r * 16 + m) * S3D_FFN + c * S3D_FFN_CHUNK + 16 * a + 4 * g;
+                        (unsigned long long)(ta.row_base + row0 + r * 16 + m) * S3D_FFN + c * S3D_FFN_CHUNK + 16 * a + 4 * g;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hv[r][4 * a + i] *= s3d_drop(ta.dh, base + i);
+                }
+            }
+        }
+        if (MODE == 3) {
+#pragma unroll
+            for (int r = 0; r < F16_R; ++r) {
+                const long row = row0 + r * 16 + m;
+                if (row < rows) {
+                    float* hp = ta.Hout + row * S3D_FFN + c * S3D_FFN_CHUNK + 4 * g;
+                    st4(hp, f32x4{hv[r][0], hv[r][1], hv[r][2], hv[r][3]});
+                    st4(hp + 16, f32x4{hv[r][4], hv[r][5], hv[r][6], hv[r][7]});
                 }
             }
         }
@@ -137,7 +151,7 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
         for (int r = 0; r < F16_R; ++r) split8(hv[r], hh[r], hl[r]);
         // GEMM2: acc^T[128][16 rows] += W2_c hidden^T, K = 32
 #pragma unroll
-        for (int jh = 0; jh < 2; ++jh) {
+        for (int jh = 0; jh < (MODE == 3 ? 0 : 2); ++jh) {
             half8 w2h[4], w2l[4];
 #pragma unroll
             for (int jq = 0; jq < 4; ++jq) {
@@ -163,6 +177,7 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
         __syncthreads();
     }
 
+    if (MODE == 3) return;
     // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
 #pragma unroll
     for (int r = 0; r < F16_R; ++r) {
@@ -241,7 +256,7 @@ int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, lon
     if (rows <= 0) return 0;
     S3D_CHECK_ARG(w.wf16 != nullptr, "ffn train f16x3: no packed f16 image");
     const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
-    FfnTrainArgs ta = {Uout, drop_hidden, drop_out};
+    FfnTrainArgs ta = {Uout, drop_hidden, drop_out, nullptr, 0};
     hipLaunchKernelGGL(ffn_layer_f16x3_kernel<2>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, Xin, Yout, rows,
                        reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L,
                        nullptr, ta);
@@ -249,9 +264,175 @@ int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, lon
     return 0;
 }
 
+int launch_ffn_hidden_f16x3(const float* Xin, float* Hout, long rows, long row_base, const LayerPtrs& w,
+                            const DropCfg& drop_hidden, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    S3D_CHECK_ARG(w.wf16 != nullptr, "ffn hidden f16x3: no packed f16 image");
+    const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
+    FfnTrainArgs ta = {nullptr, drop_hidden, make_drop(0, 0.f, 0), Hout, row_base};
+    hipLaunchKernelGGL(ffn_layer_f16x3_kernel<3>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, Xin, nullptr, rows,
+                       reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L,
+                       nullptr, ta);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FFN backward, data path:  given dY (gradient w.r.t. the lin2 output) and the stored hidden activations H,
+//   dA = (dY W2) * (H > 0 ? gate_scale : 0)      [rows][2048], written for the weight-gradient GEMMs
+//   dX = dA W1 + Dres                             [rows][128]
+// Same tiling as the forward kernel: dY rows live in registers as f16 hi/lo B fragments, the transposed
+// weights (W2^T chunk as GEMM-1-shaped fragments, W1^T chunk as GEMM-2-shaped fragments; packed by
+// pack_ffn_f16x3_kernel with swapped strides) stream through LDS, dA never re-enters registers from memory.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(F16_THREADS) void ffn_bwd_dx_f16x3_kernel(const float* __restrict__ DY,
+                                                               const float* __restrict__ Dres,
+                                                               const float* __restrict__ H, float* __restrict__ DA,
+                                                               float* __restrict__ DX, long rows,
+                                                               const _Float16* __restrict__ timg, float gate_scale) {
+    __shared__ __attribute__((aligned(16))) _Float16 s_w[2][F16_CHUNK_HALFS];  // 64 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const long row0 = ((long)blockIdx.x * F16_WAVES + wave) * (F16_R * 16);
+
+    half8 yh[F16_R][4], yl[F16_R][4];
+    f32x4 acc[F16_R][8];
+#pragma unroll
+    for (int r = 0; r < F16_R; ++r) {
+        long row = row0 + r * 16 + m;
+        if (row >= rows) row = rows - 1;
+        const float* p = DY + row * 128 + 8 * g;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
+            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            split8(v, yh[r][u], yl[r][u]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
+    }
+    constexpr int NPRE = 2048 / F16_THREADS;
+    f32x4 pre[NPRE];
+    const f32x4* gsrc = reinterpret_cast<const f32x4*>(timg);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) pre[i] = gsrc[i * F16_THREADS + threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) reinterpret_cast<f32x4*>(s_w[0])[i * F16_THREADS + threadIdx.x] = pre[i];
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < S3D_FFN_NCHUNK; ++c) {
+        const _Float16* sw = s_w[c & 1];
+        if (c + 1 < S3D_FFN_NCHUNK) {
+            const f32x4* gs = gsrc + (size_t)(c + 1) * 2048;
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) pre[i] = gs[i * F16_THREADS + threadIdx.x];
+        }
+        // gate: the stored hidden activations of this chunk (lane layout = GEMM output layout)
+        f32x4 hg[F16_R][2];
+#pragma unroll
+        for (int r = 0; r < F16_R; ++r) {
+            long row = row0 + r * 16 + m;
+            if (row >= rows) row = rows - 1;
+            const float* hp = H + row * S3D_FFN + c * S3D_FFN_CHUNK + 4 * g;
+            hg[r][0] = ld4(hp);
+            hg[r][1] = ld4(hp + 16);
+        }
+        // GEMM1': dh^T[32 hidden][16 rows] = W2_c^T dy^T, K = 128
+        float dav[F16_R][8];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f32x4 dd[F16_R];
+#pragma unroll
+            for (int r = 0; r < F16_R; ++r) dd[r] = zero4();
+            half8 wh[4], wl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                wh[u] = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8);
+                wl[u] = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) dd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], yl[r][u], dd[r], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) dd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], yh[r][u], dd[r], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) dd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], yh[r][u], dd[r], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < F16_R; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dav[r][4 * a + i] = hg[r][a][i] > 0.f ? dd[r][i] * gate_scale : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < F16_R; ++r) {
+            const long row = row0 + r * 16 + m;
+            if (row < rows) {
+                float* dp = DA + row * S3D_FFN + c * S3D_FFN_CHUNK + 4 * g;
+                st4(dp, f32x4{dav[r][0], dav[r][1], dav[r][2], dav[r][3]});
+                st4(dp + 16, f32x4{dav[r][4], dav[r][5], dav[r][6], dav[r][7]});
+            }
+        }
+        half8 dh_[F16_R], dl_[F16_R];
+#pragma unroll
+        for (int r = 0; r < F16_R; ++r) split8(dav[r], dh_[r], dl_[r]);
+        // GEMM2': dx^T[128][16 rows] += W1_c^T da^T, K = 32
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            half8 w2h[4], w2l[4];
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {
+                w2h[jq] = ldh8(sw + 8192 + ((4 * jh + jq) * 64 + lane) * 8);
+                w2l[jq] = ldh8(sw + 12288 + ((4 * jh + jq) * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {
+                const int j = 4 * jh + jq;
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], dl_[r], acc[r][j], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[jq], dh_[r], acc[r][j], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], dh_[r], acc[r][j], 0, 0, 0);
+            }
+        }
+        if (c + 1 < S3D_FFN_NCHUNK) {
+            f32x4* dw = reinterpret_cast<f32x4*>(s_w[(c + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) dw[i * F16_THREADS + threadIdx.x] = pre[i];
+        }
+        __syncthreads();
+    }
+    // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
+#pragma unroll
+    for (int r = 0; r < F16_R; ++r) {
+        const long row = row0 + r * 16 + m;
+        if (row >= rows) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
+            st4(DX + row * 128 + col, acc[r][j] + ld4(Dres + row * 128 + col));
+        }
+    }
+}
+
+int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const float* H, float* DA, float* DX, long rows,
+                            const float* timg, float gate_scale, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
+    hipLaunchKernelGGL(ffn_bwd_dx_f16x3_kernel, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, DY, Dres, H, DA, DX,
+                       rows, reinterpret_cast<const _Float16*>(timg), gate_scale);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // pack lin1 (2048,128) / lin2 (128,2048) into the per-chunk f16 hi/lo fragment image
+// Generic strides: element (hidden h, input k) of the GEMM-1-shaped operand is w1[h*s1h + k*s1k], element
+// (output n, hidden h) of the GEMM-2-shaped operand is w2[n*s2n + h*s2h].  Forward image: (lin1, 128, 1),
+// (lin2, 2048, 1); backward ("transposed") image: (lin2, 1, 2048), (lin1, 1, 128).
 __global__ void pack_ffn_f16x3_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
-                                      _Float16* __restrict__ out) {
+                                      _Float16* __restrict__ out, int s1h, int s1k, int s2n, int s2h) {
     // one thread per (chunk, which, frag, lane): writes 8 hi halfs and 8 lo halfs
     const int total = S3D_FFN_NCHUNK * 2 * 8 * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -260,15 +441,15 @@ __global__ void pack_ffn_f16x3_kernel(const float* __restrict__ w1, const float*
         float v[8];
         if (which == 0) {      // W1 fragment (a, u) = (frag>>2, frag&3): row = hidden unit, k = 32u + 8g + t
             const int a = frag >> 2, u = frag & 3;
-            const float* p = w1 + (size_t)(32 * c + 16 * a + r) * 128 + 32 * u + 8 * g;
+            const float* p = w1 + (size_t)(32 * c + 16 * a + r) * s1h + (size_t)(32 * u + 8 * g) * s1k;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = p[t];
+            for (int t = 0; t < 8; ++t) v[t] = p[(size_t)t * s1k];
         } else {               // W2 fragment j = frag: row = permuted output channel, k-slot t -> hidden unit
             const int j = frag;
             const int n = 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3);
-            const float* p = w2 + (size_t)n * S3D_FFN + 32 * c;
+            const float* p = w2 + (size_t)n * s2n + (size_t)(32 * c) * s2h;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = p[t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)];
+            for (int t = 0; t < 8; ++t) v[t] = p[(size_t)(t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)) * s2h];
         }
         _Float16* dst = out + (size_t)c * F16_CHUNK_HALFS + which * 8192 + (frag * 64 + lane) * 8;
 #pragma unroll
@@ -282,7 +463,13 @@ __global__ void pack_ffn_f16x3_kernel(const float* __restrict__ w1, const float*
 
 int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(pack_ffn_f16x3_kernel, dim3(256), dim3(256), 0, stream, w1, w2,
-                       reinterpret_cast<_Float16*>(out));
+                       reinterpret_cast<_Float16*>(out), 128, 1, S3D_FFN, 1);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_ffn_f16x3_kernel, dim3(256), dim3(256), 0, stream, w2, w1,
+                       reinterpret_cast<_Float16*>(out), 1, S3D_FFN, 1, 128);
     S3D_LAUNCH_CHECK();
     return 0;
 }

@@ -168,9 +168,11 @@ def test_dropout_matches_oracle_with_identical_masks():
     assert abs(l0[0] - got[0]) > 1e-4
 
 
-def test_f16x3_training_gemms_match_fp32():
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_f16x3_training_gemms_match_fp32(p_drop):
     """prec='f16x3' routes the forward / data-gradient GEMMs of the train step through the split-precision
-    conv engine (weight gradients stay fp32): losses and gradients must agree with the fp32 run to fp32 noise."""
+    kernels (fused FFN forward / backward, conv engine; weight gradients stay fp32): losses and gradients must
+    agree with the fp32 run to fp32 noise — with dropout too, since both paths draw the same counter-based masks."""
     from slice3d_amd.models import Slices3DRegModel
     from slice3d_amd.synth import make_feed_dict
     from slice3d_amd.trainer import HipTrainer
@@ -179,7 +181,7 @@ def test_f16x3_training_gemms_match_fp32():
     res = {}
     for prec in ("f32", "f16x3"):
         m = load_seeded(Slices3DRegModel(n_slices=12, mode="train"), 0).cuda()
-        tr = HipTrainer(m, prec=prec)
+        tr = HipTrainer(m, prec=prec, dropout=p_drop, seed=5)
         losses = tr.forward_backward(fd).cpu().numpy().copy()
         res[prec] = (losses, tr.grad_flat.cpu().clone(), tr)
     la, lb = res["f32"][0], res["f16x3"][0]
