@@ -22,6 +22,7 @@ struct WgradArgs {
                           // S3D_PACK_CONVT: rows n = ci, k = (q, co): out[(n*ct + co)*4 + q]
     int ld, cin_tot, cin_begin, ct;
     int accumulate;       // 1: out += result
+    int prec;             // S3D_PREC_F16X3: plain 1x1 contractions run on split-precision f16 MFMA (else fp32 MFMA)
     float* partial;       // workspace
     size_t partial_floats;
 };

@@ -97,7 +97,15 @@ __global__ void wgrad_reduce_kernel(const WgradArgs a, int nsplit, int Ktot) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += a.partial[(size_t)sp * total + idx];
+        int sp = 0;
+        for (; sp + 8 <= nsplit; sp += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = a.partial[(size_t)(sp + k) * total + idx];
+            __builtin_amdgcn_sched_barrier(0);   // 8 loads in flight
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; sp < nsplit; ++sp) s += a.partial[(size_t)sp * total + idx];
         const int n = (int)(idx / Ktot), k = (int)(idx - (long)n * Ktot);
         long o;
         if (a.out_kind == S3D_PACK_LINEAR) {
@@ -112,6 +120,152 @@ __global__ void wgrad_reduce_kernel(const WgradArgs a, int nsplit, int Ktot) {
         }
         a.out[o] = a.accumulate ? a.out[o] + s : s;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-precision weight gradient of a plain linear / 1x1 contraction:  dW[n][c] = sum_p dY[p][n] X[p][c].
+// Workgroup tile 128 (n) x 128 (c), 4 waves of 64 x 64; the contraction runs over rows in steps of 32
+// (one v_mfma_f32_16x16x32_f16 K).  The MFMA wants 8 consecutive ROWS per lane for a fixed channel, i.e.
+// the transposed operands: thread (channel, row group) gathers its 8 rows from global (a wave reads 256
+// contiguous bytes per row), splits them into f16 hi/lo and writes two 16-byte words into the
+// [channel][row] LDS tile (80-byte channel stride: conflict-free for both the writes and the fragment
+// reads).  Next step's global loads are issued before the MFMAs of the current one.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 wl_half8 __attribute__((ext_vector_type(8)));
+#define WL_LD 40
+__global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a, int n_cblk, long P,
+                                                              int steps_per_split) {
+    __shared__ __attribute__((aligned(16))) _Float16 s_t[2][2][128 * WL_LD];   // [dy|x][hi|lo], 40 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int ch = tid & 127, rg = tid >> 7;
+    const int cb = blockIdx.x % n_cblk, nb = blockIdx.x / n_cblk;
+    const int n0 = nb * 128, c0 = cb * 128;
+    const int wn = wave & 1, wc = wave >> 1;
+    const bool n_ok = n0 + ch < a.N, c_ok = c0 + ch < a.Cx;
+    const float* dyp = a.dy + a.dy_coff + n0 + (n_ok ? ch : 0);
+    const float* xp = a.x.p + a.x_coff + c0 + (c_ok ? ch : 0);
+    const long dstride = a.dy_cstride, xstride = a.x.C;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = zero4();
+
+    // raw prefetch registers; loads are unconditional (clamped addresses) so that the compiler keeps all 32 in
+    // flight — validity is applied as a 0/1 factor when the values are converted, one step later
+    float pd[2][8], px[2][8];
+    auto gload = [&](long pbase) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                long row = pbase + 16 * ps + 8 * rg + t;
+                row = row < P ? row : P - 1;
+                pd[ps][t] = dyp[row * dstride];
+                px[ps][t] = xp[row * xstride];
+            }
+    };
+    const float nf = n_ok ? 1.f : 0.f, cf = c_ok ? 1.f : 0.f;
+    const long p_begin = (long)blockIdx.y * steps_per_split * 32;
+    gload(p_begin);
+    for (int it = 0; it < steps_per_split; ++it) {
+        const long pb = p_begin + (long)it * 32;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            wl_half8 hi, lo;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float v = pd[ps][t] * (pb + 16 * ps + 8 * rg + t < P ? nf : 0.f);
+                const _Float16 h = (_Float16)v;
+                hi[t] = h;
+                lo[t] = (_Float16)(v - (float)h);
+            }
+            *reinterpret_cast<wl_half8*>(&s_t[0][0][ch * WL_LD + 16 * ps + 8 * rg]) = hi;
+            *reinterpret_cast<wl_half8*>(&s_t[0][1][ch * WL_LD + 16 * ps + 8 * rg]) = lo;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float v = px[ps][t] * (pb + 16 * ps + 8 * rg + t < P ? cf : 0.f);
+                const _Float16 h = (_Float16)v;
+                hi[t] = h;
+                lo[t] = (_Float16)(v - (float)h);
+            }
+            *reinterpret_cast<wl_half8*>(&s_t[1][0][ch * WL_LD + 16 * ps + 8 * rg]) = hi;
+            *reinterpret_cast<wl_half8*>(&s_t[1][1][ch * WL_LD + 16 * ps + 8 * rg]) = lo;
+        }
+        __syncthreads();
+        if (it + 1 < steps_per_split) gload(p_begin + (long)(it + 1) * 32);
+        wl_half8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (64 * wn + 16 * i + m) * WL_LD + 8 * g;
+            ah[i] = *reinterpret_cast<const wl_half8*>(&s_t[0][0][o]);
+            al[i] = *reinterpret_cast<const wl_half8*>(&s_t[0][1][o]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = (64 * wc + 16 * j + m) * WL_LD + 8 * g;
+            bh[j] = *reinterpret_cast<const wl_half8*>(&s_t[1][0][o]);
+            bl[j] = *reinterpret_cast<const wl_half8*>(&s_t[1][1][o]);
+        }
+        // three product kinds, each swept over the 16 independent accumulators
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+    // D[row = 4g+reg <-> n][col = l&15 <-> c]
+    float* part = a.partial + (size_t)blockIdx.y * a.N * a.Cx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int n = n0 + 64 * wn + 16 * i + 4 * g + reg;
+                const int c = c0 + 64 * wc + 16 * j + m;
+                if (n < a.N && c < a.Cx) part[(size_t)n * a.Cx + c] = acc[i][j][reg];
+            }
+}
+
+static bool wgrad_lin_eligible(const WgradArgs& a, long P) {
+    return a.prec == S3D_PREC_F16X3 && a.ks == 1 && a.stride <= 1 && !a.x.sbcast && !a.x.bmod && a.x.bdiv == 1 &&
+           (a.Hin == 0 || a.Hin == a.H) && (a.Win == 0 || a.Win == a.W) && a.N >= 64 && a.Cx >= 64 && P >= 1024;
+}
+
+static int launch_wgrad_lin_f16x3(const WgradArgs& a, long P, hipStream_t stream) {
+    const int n_nblk = (a.N + 127) / 128, n_cblk = (a.Cx + 127) / 128;
+    const long total_steps = (P + 31) / 32;
+    const long tiles = (long)n_nblk * n_cblk;
+    long splits = (1024 + tiles - 1) / tiles;                 // aim at >= 1024 workgroups
+    const long max_by_steps = (total_steps + 7) / 8;          // >= 8 K-steps per workgroup
+    if (splits > max_by_steps) splits = max_by_steps;
+    const long cap = (long)(a.partial_floats / ((size_t)a.N * a.Cx));
+    if (splits > cap) splits = cap;
+    if (splits < 1) {
+        s3d_set_error("wgrad: partial workspace too small for %d x %d", a.N, a.Cx);
+        return S3D_E_WORKSPACE;
+    }
+    const int spw = (int)((total_steps + splits - 1) / splits);
+    splits = (total_steps + spw - 1) / spw;
+    hipLaunchKernelGGL(wgrad_lin_f16x3_kernel, dim3((unsigned)(n_nblk * n_cblk), (unsigned)splits), dim3(256), 0, stream,
+                       a, n_cblk, P, spw);
+    S3D_LAUNCH_CHECK();
+    const long total = (long)a.N * a.Cx;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a, (int)splits, a.Cx);
+    S3D_LAUNCH_CHECK();
+    return 0;
 }
 
 static void wgrad_plan(long P, int N, int Cx, int taps, int& TN, int& TK, int& n_nblk, int& n_cblk, int& splits_y,
@@ -144,6 +298,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     S3D_CHECK_ARG(a.dy_cstride % 4 == 0 && a.dy_coff % 4 == 0 && a.x.C % 4 == 0 && a.x_coff % 4 == 0,
                   "wgrad: channel strides/offsets must be multiples of 4");
     const long P = (long)a.Nimg * a.H * a.W;
+    if (wgrad_lin_eligible(a, P)) return launch_wgrad_lin_f16x3(a, P, stream);
     const int taps = a.ks * a.ks;
     int TN, TK, n_nblk, n_cblk, sy, spw;
     wgrad_plan(P, a.N, a.Cx, taps, TN, TK, n_nblk, n_cblk, sy, spw);
