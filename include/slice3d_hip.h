@@ -225,6 +225,14 @@ int s3d_prof_read(int id, double* total_ms, long* count);
 /* project_coord (models.py:28-36): coords (B,Q,3), trans (B,4,3) -> out (B,Q,2) */
 int s3d_project_coord_fwd(const float* coords, const float* trans, float* out, int batch, long n_qry,
                           void* stream);
+/* Image-space locality order of the queries (no reference counterpart: an execution-order choice of this
+ * library, exposed so hosts / tests can map token-tensor rows back to queries).  Queries of each batch item are
+ * projected exactly like models.py:28-36 (after models.py:53-60's flip / rotation), binned at 256^2 and ordered by
+ * the Morton code of the bin, ascending query index inside a bin: perm_out[b*Q + slot] = query index.
+ * Deterministic.  The decoder and the train step use this order internally for Q >= 4096. */
+size_t s3d_query_sort_workspace_bytes(int batch, long n_qry);
+int s3d_query_sort(const float* qry, const float* rot, const float* trans, int flip_yz, int batch, long n_qry,
+                   int* perm_out, void* workspace, size_t workspace_bytes, void* stream);
 /* sample_from_planes (models.py:38-46) on a channels-last plane: plane (N,H,W,C), grid (N,M,2)
  * -> out (N,M,C); bilinear, zeros padding, align_corners=True.  C % 4 == 0. */
 int s3d_sample_planes_fwd(const float* plane, const float* grid, float* out, int n, int h, int w,

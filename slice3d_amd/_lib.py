@@ -88,6 +88,8 @@ SYMBOLS = {
     "s3d_prof_enable": (_i, [_i]),
     "s3d_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "s3d_project_coord_fwd": (_i, [_vp, _vp, _vp, _i, _l, _vp]),
+    "s3d_query_sort_workspace_bytes": (_sz, [_i, _l]),
+    "s3d_query_sort": (_i, [_vp, _vp, _vp, _i, _i, _l, _vp, _vp, _sz, _vp]),
     "s3d_sample_planes_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _vp]),
     "s3d_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "s3d_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -643,7 +643,7 @@ static DecodeWs decode_ws(int batch, long n_qry, int ns) {
     W.X0 = (size_t)g * (ns + 1) * S3D_GROUP * 128;
     W.perm = W.X0 + (size_t)g * S3D_GROUP * 128;
     W.sortws = W.perm + (size_t)batch * n_qry;
-    W.total = W.sortws + (size_t)batch * (65536 + n_qry);
+    W.total = W.sortws + query_sort_ws_ints(batch, n_qry);
     return W;
 }
 
@@ -750,6 +750,22 @@ extern "C" int s3d_project_coord_fwd(const float* coords, const float* trans, fl
                                      void* stream) {
     S3D_CHECK_ARG(coords && trans && out, "project_coord: null argument");
     return launch_project_coord(coords, trans, out, batch, n_qry, (hipStream_t)stream);
+}
+
+extern "C" size_t s3d_query_sort_workspace_bytes(int batch, long n_qry) {
+    return query_sort_ws_ints(batch, n_qry) * sizeof(int);
+}
+
+extern "C" int s3d_query_sort(const float* qry, const float* rot, const float* trans, int flip_yz, int batch,
+                              long n_qry, int* perm_out, void* workspace, size_t workspace_bytes, void* stream) {
+    S3D_CHECK_ARG(qry && trans && perm_out && workspace, "query_sort: null argument");
+    S3D_CHECK_ARG(batch >= 1 && n_qry >= 1, "query_sort: bad dims");
+    if (workspace_bytes < s3d_query_sort_workspace_bytes(batch, n_qry)) {
+        s3d_set_error("query_sort: workspace %zu < %zu bytes", workspace_bytes,
+                      s3d_query_sort_workspace_bytes(batch, n_qry));
+        return S3D_E_WORKSPACE;
+    }
+    return launch_query_sort(qry, rot, trans, flip_yz, batch, n_qry, perm_out, (int*)workspace, (hipStream_t)stream);
 }
 
 extern "C" int s3d_sample_planes_fwd(const float* plane, const float* grid, float* out, int n, int h, int w,

@@ -61,7 +61,9 @@ int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w
                      float* sdf_out, float sign, long groups_per_batch, long n_qry, long g_begin, int prec,
                      const int* perm, hipStream_t stream);
 // image-space locality sort of the queries of each batch item (counting sort on the Morton code of the
-// projected pixel at 256^2): perm[b*Q + slot] = query index.  ws: (B*65536 + B*Q) ints of scratch.
+// projected pixel at 256^2): perm[b*Q + slot] = query index, ascending query index inside a bin (deterministic).
+// ws: query_sort_ws_ints(B, Q) ints; on return ws[b*65536 + k] = end of bin k in perm[b] (bin/tile ranges).
+size_t query_sort_ws_ints(int batch, long n_qry);
 int launch_query_sort(const float* qry, const float* rot, const float* trans, int flip_yz, int batch, long n_qry,
                       int* perm, int* ws, hipStream_t stream);
 // training forward: y = LN2(u), u = x + FFN(x) with x read from Xin, y -> Yout, u -> Uout (pre-LN, saved)

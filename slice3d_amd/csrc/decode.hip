@@ -643,11 +643,69 @@ __global__ void qsort_scatter_kernel(const int* keys, int* offs, int batch, long
     }
 }
 
+// The atomic scatter leaves the members of one bin in arbitrary order.  Restore ascending query index inside
+// every bin so that the permutation is a pure function of the inputs (reproducible dropout streams, row-wise
+// comparisons against the oracle): bins of <= 32 members (the common case: ~1.5 per bin) are insertion-sorted by
+// one thread; larger bins (clamped border pixels) go to an overflow list and get a workgroup rank sort.
+__global__ void qsort_fix_kernel(const int* __restrict__ ends, int batch, long n_qry, int* __restrict__ perm,
+                                 int* __restrict__ ovf) {
+    const long total = (long)batch * QS_BINS;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / QS_BINS), k = (int)(i % QS_BINS);
+        const int beg = k ? ends[i - 1] : 0, n = ends[i] - beg;
+        if (n <= 1) continue;
+        int* p = perm + (long)b * n_qry + beg;
+        if (n <= 32) {
+            for (int u = 1; u < n; ++u) {
+                const int v = p[u];
+                int w = u - 1;
+                while (w >= 0 && p[w] > v) {
+                    p[w + 1] = p[w];
+                    --w;
+                }
+                p[w + 1] = v;
+            }
+        } else {
+            const int slot = atomicAdd(&ovf[0], 1);
+            ovf[1 + slot] = (int)i;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void qsort_fix_large_kernel(const int* __restrict__ ends, long n_qry,
+                                                              int* __restrict__ perm, int* __restrict__ tmp,
+                                                              const int* __restrict__ ovf) {
+    const int cnt = ovf[0];
+    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const long i = ovf[1 + e];
+        const int b = (int)(i / QS_BINS), k = (int)(i % QS_BINS);
+        const int beg = k ? ends[i - 1] : 0, n = ends[i] - beg;
+        int* p = perm + (long)b * n_qry + beg;
+        int* t = tmp + (long)b * n_qry + beg;
+        for (int u = threadIdx.x; u < n; u += 256) {
+            const int v = p[u];
+            int rank = 0;
+            for (int w = 0; w < n; ++w) rank += p[w] < v;
+            t[rank] = v;
+        }
+        __syncthreads();
+        for (int u = threadIdx.x; u < n; u += 256) p[u] = t[u];
+        __syncthreads();
+    }
+}
+
+// workspace: hist/ends [batch][65536] | keys (later: rank-sort scratch) [batch][n_qry] | overflow list
+size_t query_sort_ws_ints(int batch, long n_qry) {
+    return (size_t)batch * QS_BINS + (size_t)batch * n_qry + (size_t)batch * (n_qry / 32 + 1) + 1;
+}
+
+// perm[b][pos] = original query index; on return ws[b*65536 + k] = END of bin k (start of bin k+1) in perm[b]
 int launch_query_sort(const float* qry, const float* rot, const float* trans, int flip_yz, int batch, long n_qry,
                       int* perm, int* ws, hipStream_t stream) {
     int* hist = ws;
     int* keys = ws + (size_t)batch * QS_BINS;
-    if (hipMemsetAsync(hist, 0, (size_t)batch * QS_BINS * sizeof(int), stream) != hipSuccess) {
+    int* ovf = keys + (size_t)batch * n_qry;
+    if (hipMemsetAsync(hist, 0, (size_t)batch * QS_BINS * sizeof(int), stream) != hipSuccess ||
+        hipMemsetAsync(ovf, 0, sizeof(int), stream) != hipSuccess) {
         s3d_set_error("query_sort: memset failed");
         return (int)hipErrorUnknown;
     }
@@ -659,6 +717,11 @@ int launch_query_sort(const float* qry, const float* rot, const float* trans, in
     hipLaunchKernelGGL(qsort_scan_kernel, dim3(batch), dim3(1024), 0, stream, hist);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(qsort_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys, hist, batch, n_qry, perm);
+    S3D_LAUNCH_CHECK();
+    const int fb = batch * QS_BINS / 256 < 4096 ? batch * QS_BINS / 256 : 4096;
+    hipLaunchKernelGGL(qsort_fix_kernel, dim3(fb), dim3(256), 0, stream, hist, batch, n_qry, perm, ovf);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(qsort_fix_large_kernel, dim3(256), dim3(256), 0, stream, hist, n_qry, perm, keys, ovf);
     S3D_LAUNCH_CHECK();
     return 0;
 }

@@ -84,17 +84,21 @@ struct SampleBwdArgs {
     const float *qry, *rot, *trans;
     int flip_yz, size, n_slices;
     long n_qry, groups_per_batch, groups;
+    const int* perm;         // optional: token rows are in sorted order, perm[b*Q + slot] = query (s3d_query_sort)
+    const int* bin_ends;     // with perm: [B][65536] end offset of every Morton bin (launch_query_sort's ws)
 };
 int launch_sample_bwd(const SampleBwdArgs& a, hipStream_t stream);
 int launch_tok0_copy(float* full, float* compact, long groups, int T, int dir, int width, hipStream_t stream);
+// perm (optional): row slot -> query index within the batch item (sorted token order)
 int launch_fc_out_fwd(const float* x, const float* w, const float* b, float* sdf, long rows, long gpb, long n_qry,
-                      hipStream_t stream);
+                      const int* perm, hipStream_t stream);
 int launch_fc_out_bwd(const float* x, const float* w, const float* dsdf, float* dx, float* t, long rows, long gpb,
-                      long n_qry, hipStream_t stream);
+                      long n_qry, const int* perm, hipStream_t stream);
 int launch_scalar_reduce(const float* a, const float* b, long n, int mode, float scale, float* out, int accumulate,
                          float* partial, hipStream_t stream);
 int launch_vgg_prep_bwd(const float* din16, const float* stdv, float* drec, int n_img, int size, hipStream_t stream);
 int launch_qry_rot_rows(const float* qry, const float* rot, int flip_yz, long n_qry, long gpb, long groups,
+                        const int* perm,
                         float* out, hipStream_t stream);
 int launch_copy_cols(const float* src, float* dst, int rows, int csrc, int cdst, hipStream_t stream);
 int launch_emb_grad(const float* dF0, const float* w, float* demds, int B, int ns, int npix, hipStream_t stream);

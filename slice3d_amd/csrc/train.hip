@@ -967,16 +967,37 @@ int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du
 
 // =============================================================================================
 // attention core on stored QKV: [groups][T][16 queries][384 = q|k|v, head h at cols 32h..32h+31]
-// one workgroup of 64*T threads per group: thread = (query ql, head h, token tq)
+// One workgroup per (group, head); thread = (query ql = tid & 15, token tt = tid >> 4).  The head's K and V
+// rows (T*16 rows of 32 floats) are staged once in LDS (36-float row stride: 16 query lanes hit 16
+// distinct bank quads, the token lanes of a wave broadcast), so every global byte is read once.
 // =============================================================================================
 #define ATT_SCALE 0.17677669529663687f
+#define ATT_LD 36
+#define ATT_THREADS 256
 
-__global__ void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, long groups, int T,
-                                     const DropCfg drop) {
+// rows [T*16][32] of one head (column offset coff in the 384/128-wide source) -> LDS [row][ATT_LD]
+__device__ __forceinline__ void att_stage(const float* __restrict__ src, int src_ld, int coff, int T, float* dst) {
+    for (int i = threadIdx.x; i < T * 16 * 8; i += ATT_THREADS) {
+        const int row = i >> 3, q4 = i & 7;
+        st4(dst + row * ATT_LD + 4 * q4, ld4(src + (long)row * src_ld + coff + 4 * q4));
+    }
+}
+
+__global__ __launch_bounds__(ATT_THREADS) void attn_core_fwd_kernel(const float* __restrict__ qkv,
+                                                                    float* __restrict__ o, long groups, int T,
+                                                                    const DropCfg drop) {
+    __shared__ __attribute__((aligned(16))) float sK[S3D_N_TOKENS_MAX * 16 * ATT_LD], sV[S3D_N_TOKENS_MAX * 16 * ATT_LD];
     const int tid = threadIdx.x;
-    const int ql = tid & 15, h = (tid >> 4) & 3, tq = tid >> 6;
-    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int ql = tid & 15, tq = tid >> 4;
+    for (long task = blockIdx.x; task < groups * 4; task += gridDim.x) {
+        const long grp = task >> 2;
+        const int h = (int)(task & 3);
         const float* base = qkv + grp * T * 16 * 384;
+        __syncthreads();
+        att_stage(base, 384, 128 + 32 * h, T, sK);
+        att_stage(base, 384, 256 + 32 * h, T, sV);
+        __syncthreads();
+        if (tq >= T) continue;
         const float* qrow = base + (tq * 16 + ql) * 384 + 32 * h;
         f32x4 qv[8];
 #pragma unroll
@@ -986,7 +1007,7 @@ __global__ void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __res
 #pragma unroll
         for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
             if (tk < T) {
-                const float* krow = base + (tk * 16 + ql) * 384 + 128 + 32 * h;
+                const float* krow = sK + (tk * 16 + ql) * ATT_LD;
                 float s = 0.f;
 #pragma unroll
                 for (int d = 0; d < 8; ++d) {
@@ -1010,7 +1031,7 @@ __global__ void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __res
 #pragma unroll
         for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
             if (tk < T) {
-                const float* vrow = base + (tk * 16 + ql) * 384 + 256 + 32 * h;
+                const float* vrow = sV + (tk * 16 + ql) * ATT_LD;
                 float p = sc[tk] * inv;
                 if (drop.p > 0.f)   // index = ((row_q * 4 + head) * 16 + key)
                     p *= s3d_drop(drop, ((unsigned long long)((grp * T + tq) * 16 + ql) * 4 + h) * 16 + tk);
@@ -1025,27 +1046,36 @@ __global__ void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __res
 
 int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, const DropCfg& drop, hipStream_t stream) {
     if (groups <= 0) return 0;
-    const long nb = groups < 8192 ? groups : 8192;
-    hipLaunchKernelGGL(attn_core_fwd_kernel, dim3((unsigned)nb), dim3(64 * T), 0, stream, qkv, o, groups, T, drop);
+    S3D_CHECK_ARG(T >= 1 && T <= S3D_N_TOKENS_MAX, "attn core: T %d", T);
+    const long nb = groups * 4 < 16384 ? groups * 4 : 16384;
+    hipLaunchKernelGGL(attn_core_fwd_kernel, dim3((unsigned)nb), dim3(ATT_THREADS), 0, stream, qkv, o, groups, T, drop);
     S3D_LAUNCH_CHECK();
     return 0;
 }
 
-// backward: phase A (thread = (ql,h,tq)): P row, dS row -> LDS, dQ row -> global;
-//           phase B (thread = (ql,h,tk)): dK[tk] = sum_tq dS[tq][tk] Q[tq] * scale, dV[tk] = sum_tq P[tq][tk] dO[tq]
-__global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
-                                     float* __restrict__ dqkv, long groups, int T, const DropCfg drop) {
-    extern __shared__ float smem[];  // P [64][T][T] then dS [64][T][T]
+// backward: phase A (thread = (ql, tq), K/V of the head in LDS): P row, dS row -> LDS, dQ row -> global;
+//           phase B (thread = (ql, tk), Q/dO of the head restaged into the same LDS):
+//           dK[tk] = sum_tq dS[tq][tk] Q[tq] * scale,  dV[tk] = sum_tq P[tq][tk] dO[tq]
+__global__ __launch_bounds__(ATT_THREADS) void attn_core_bwd_kernel(const float* __restrict__ qkv,
+                                                                    const float* __restrict__ d_o,
+                                                                    float* __restrict__ dqkv, long groups, int T,
+                                                                    const DropCfg drop) {
+    __shared__ __attribute__((aligned(16))) float sA[S3D_N_TOKENS_MAX * 16 * ATT_LD], sB[S3D_N_TOKENS_MAX * 16 * ATT_LD];
+    __shared__ float sP[16 * S3D_N_TOKENS_MAX * S3D_N_TOKENS_MAX], sS[16 * S3D_N_TOKENS_MAX * S3D_N_TOKENS_MAX];
     const int tid = threadIdx.x;
-    const int ql = tid & 15, h = (tid >> 4) & 3, tt = tid >> 6;
-    const int pair = tid & 63;
-    float* sP = smem + (pair * T + tt) * T;
-    float* sS = smem + 64 * T * T + (pair * T + tt) * T;
-    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int ql = tid & 15, tt = tid >> 4;
+    const bool act = tt < T;
+    for (long task = blockIdx.x; task < groups * 4; task += gridDim.x) {
+        const long grp = task >> 2;
+        const int h = (int)(task & 3);
         const float* base = qkv + grp * T * 16 * 384;
         const float* dob = d_o + grp * T * 16 * 128;
         float* dbase = dqkv + grp * T * 16 * 384;
-        {  // phase A, tq = tt
+        __syncthreads();
+        att_stage(base, 384, 128 + 32 * h, T, sA);   // K
+        att_stage(base, 384, 256 + 32 * h, T, sB);   // V
+        __syncthreads();
+        if (act) {  // phase A, tq = tt
             const float* qrow = base + (tt * 16 + ql) * 384 + 32 * h;
             const float* dorow = dob + (tt * 16 + ql) * 128 + 32 * h;
             f32x4 qv[8], dov[8];
@@ -1059,8 +1089,8 @@ __global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float*
 #pragma unroll
             for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
                 if (tk < T) {
-                    const float* krow = base + (tk * 16 + ql) * 384 + 128 + 32 * h;
-                    const float* vrow = krow + 128;
+                    const float* krow = sA + (tk * 16 + ql) * ATT_LD;
+                    const float* vrow = sB + (tk * 16 + ql) * ATT_LD;
                     float s = 0.f, e = 0.f;
 #pragma unroll
                     for (int d = 0; d < 8; ++d) {
@@ -1095,13 +1125,15 @@ __global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float*
             f32x4 dq[8];
 #pragma unroll
             for (int d = 0; d < 8; ++d) dq[d] = zero4();
+            float* pP = sP + (ql * T + tt) * T;
+            float* pS = sS + (ql * T + tt) * T;
 #pragma unroll
             for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
                 if (tk < T) {
                     const float ds = sc[tk] * (dp[tk] - dot);
-                    sP[tk] = sc[tk] * mk[tk];   // dropped probabilities multiply dO in dV
-                    sS[tk] = ds;
-                    const float* krow = base + (tk * 16 + ql) * 384 + 128 + 32 * h;
+                    pP[tk] = sc[tk] * mk[tk];   // dropped probabilities multiply dO in dV
+                    pS[tk] = ds * ATT_SCALE;
+                    const float* krow = sA + (tk * 16 + ql) * ATT_LD;
                     const float w = ds * ATT_SCALE;
 #pragma unroll
                     for (int d = 0; d < 8; ++d) dq[d] += ld4(krow + 4 * d) * w;
@@ -1111,7 +1143,10 @@ __global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float*
             for (int d = 0; d < 8; ++d) st4(dqrow + 4 * d, dq[d]);
         }
         __syncthreads();
-        {  // phase B, tk = tt
+        att_stage(base, 384, 32 * h, T, sA);   // Q
+        att_stage(dob, 128, 32 * h, T, sB);    // dO
+        __syncthreads();
+        if (act) {  // phase B, tk = tt
             f32x4 dk[8], dv[8];
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
@@ -1119,10 +1154,10 @@ __global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float*
                 dv[d] = zero4();
             }
             for (int tq = 0; tq < T; ++tq) {
-                const float p = smem[(pair * T + tq) * T + tt];
-                const float ds = smem[64 * T * T + (pair * T + tq) * T + tt] * ATT_SCALE;
-                const float* qrow = base + (tq * 16 + ql) * 384 + 32 * h;
-                const float* dorow = dob + (tq * 16 + ql) * 128 + 32 * h;
+                const float p = sP[(ql * T + tq) * T + tt];
+                const float ds = sS[(ql * T + tq) * T + tt];
+                const float* qrow = sA + (tq * 16 + ql) * ATT_LD;
+                const float* dorow = sB + (tq * 16 + ql) * ATT_LD;
 #pragma unroll
                 for (int d = 0; d < 8; ++d) {
                     dk[d] += ld4(qrow + 4 * d) * ds;
@@ -1136,22 +1171,15 @@ __global__ void attn_core_bwd_kernel(const float* __restrict__ qkv, const float*
                 st4(dkrow + 128 + 4 * d, dv[d]);
             }
         }
-        __syncthreads();
     }
 }
 
 int launch_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, long groups, int T, const DropCfg& drop,
                          hipStream_t stream) {
     if (groups <= 0) return 0;
-    const size_t lds = (size_t)2 * 64 * T * T * sizeof(float);  // <= 86.5 KiB at T = 13
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_core_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * 64 * 13 * 13 * 4);
-        attr_set = true;
-    }
-    const long nb = groups < 8192 ? groups : 8192;
-    hipLaunchKernelGGL(attn_core_bwd_kernel, dim3((unsigned)nb), dim3(64 * T), lds, stream, qkv, d_o, dqkv, groups, T,
+    S3D_CHECK_ARG(T >= 1 && T <= S3D_N_TOKENS_MAX, "attn core: T %d", T);
+    const long nb = groups * 4 < 16384 ? groups * 4 : 16384;
+    hipLaunchKernelGGL(attn_core_bwd_kernel, dim3((unsigned)nb), dim3(ATT_THREADS), 0, stream, qkv, d_o, dqkv, groups, T,
                        drop);
     S3D_LAUNCH_CHECK();
     return 0;

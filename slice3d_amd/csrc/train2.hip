@@ -29,7 +29,8 @@ int launch_tok0_copy(float* full, float* compact, long groups, int T, int dir, i
 // ---- fc_out on compact token-0 rows: sdf[b*Q+q] = x[row].w + b ; backward d x = dsdf*w, t = dsdf*x
 __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, float* __restrict__ sdf,
-                                                         long rows, long gpb, long n_qry) {
+                                                         long rows, long gpb, long n_qry,
+                                                         const int* __restrict__ perm) {
     const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
     const f32x4 wv = ld4(w + 4 * l);
     for (long row = (long)blockIdx.x * 8 + sub; row < rows; row += (long)gridDim.x * 8) {
@@ -38,33 +39,34 @@ __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         const long grp = row >> 4, bb = grp / gpb, q = (grp % gpb) * 16 + (row & 15);
-        if (l == 0 && q < n_qry) sdf[bb * n_qry + q] = s + b[0];
+        if (l == 0 && q < n_qry) sdf[bb * n_qry + (perm ? perm[bb * n_qry + q] : q)] = s + b[0];
     }
 }
 __global__ __launch_bounds__(256) void fc_out_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ dsdf, float* __restrict__ dx,
-                                                         float* __restrict__ t, long rows, long gpb, long n_qry) {
+                                                         float* __restrict__ t, long rows, long gpb, long n_qry,
+                                                         const int* __restrict__ perm) {
     const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
     const f32x4 wv = ld4(w + 4 * l);
     for (long row = (long)blockIdx.x * 8 + sub; row < rows; row += (long)gridDim.x * 8) {
         const long grp = row >> 4, bb = grp / gpb, q = (grp % gpb) * 16 + (row & 15);
-        const float d = q < n_qry ? dsdf[bb * n_qry + q] : 0.f;
+        const float d = q < n_qry ? dsdf[bb * n_qry + (perm ? perm[bb * n_qry + q] : q)] : 0.f;
         st4(dx + row * 128 + 4 * l, wv * d);
         st4(t + row * 128 + 4 * l, ld4(x + row * 128 + 4 * l) * d);
     }
 }
 int launch_fc_out_fwd(const float* x, const float* w, const float* b, float* sdf, long rows, long gpb, long n_qry,
-                      hipStream_t stream) {
+                      const int* perm, hipStream_t stream) {
     const long nb = (rows + 7) / 8 < 4096 ? (rows + 7) / 8 : 4096;
-    hipLaunchKernelGGL(fc_out_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, w, b, sdf, rows, gpb, n_qry);
+    hipLaunchKernelGGL(fc_out_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, w, b, sdf, rows, gpb, n_qry, perm);
     S3D_LAUNCH_CHECK();
     return 0;
 }
 int launch_fc_out_bwd(const float* x, const float* w, const float* dsdf, float* dx, float* t, long rows, long gpb,
-                      long n_qry, hipStream_t stream) {
+                      long n_qry, const int* perm, hipStream_t stream) {
     const long nb = (rows + 7) / 8 < 4096 ? (rows + 7) / 8 : 4096;
     hipLaunchKernelGGL(fc_out_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, w, dsdf, dx, t, rows, gpb,
-                       n_qry);
+                       n_qry, perm);
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -130,13 +132,14 @@ int launch_vgg_prep_bwd(const float* din16, const float* stdv, float* drec, int 
 
 // ---- rotated query coordinates of the token-0 rows, padded to 4 columns: [groups*16][4] = (x,y,z,0)
 __global__ void qry_rot_rows_kernel(const float* __restrict__ qry, const float* __restrict__ rot, int flip_yz,
-                                    long n_qry, long gpb, long groups, float* __restrict__ out) {
+                                    long n_qry, long gpb, long groups, const int* __restrict__ perm,
+                                    float* __restrict__ out) {
     const long total = groups * 16;
     for (long row = (long)blockIdx.x * blockDim.x + threadIdx.x; row < total; row += (long)gridDim.x * blockDim.x) {
         const long grp = row >> 4, b = grp / gpb, q = (grp % gpb) * 16 + (row & 15);
         f32x4 v = zero4();
         if (q < n_qry) {
-            const float* p = qry + (b * n_qry + q) * 3;
+            const float* p = qry + (b * n_qry + (perm ? perm[b * n_qry + q] : q)) * 3;
             float x = p[0], y = p[1], z = p[2];
             if (flip_yz) {
                 y = -y; z = -z;
@@ -153,11 +156,11 @@ __global__ void qry_rot_rows_kernel(const float* __restrict__ qry, const float* 
     }
 }
 int launch_qry_rot_rows(const float* qry, const float* rot, int flip_yz, long n_qry, long gpb, long groups,
-                        float* out, hipStream_t stream) {
+                        const int* perm, float* out, hipStream_t stream) {
     const long total = groups * 16;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(qry_rot_rows_kernel, dim3(blocks), dim3(256), 0, stream, qry, rot, flip_yz, n_qry, gpb, groups,
-                       out);
+                       perm, out);
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -208,7 +211,8 @@ __global__ __launch_bounds__(256) void sample_bwd_kernel(const SampleBwdArgs a) 
         const int b = (int)(gi / a.groups_per_batch);
         const long q = (gi % a.groups_per_batch) * S3D_GROUP + m;
         const bool qv = q < a.n_qry;
-        const long qc = qv ? q : a.n_qry - 1;
+        long qc = qv ? q : a.n_qry - 1;
+        if (a.perm) qc = a.perm[(long)b * a.n_qry + qc];
         const float* p = a.qry + ((long)b * a.n_qry + qc) * 3;
         float x = p[0], y = p[1], z = p[2];
         if (a.flip_yz) {
@@ -282,8 +286,180 @@ __global__ __launch_bounds__(256) void sample_bwd_kernel(const SampleBwdArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tiled variant for locality-sorted queries (a.perm / a.bin_ends from launch_query_sort).
+// One workgroup per (batch item, slice image, 16x16-bin image tile): the tile's queries are one contiguous
+// range of the sorted order, their bilinear taps fall into a small per-level pixel footprint
+// (ceil(16 (W-1)/255) + 2 squared), which is accumulated with LDS atomics and flushed to the global
+// gradient maps once — ~40 global atomics per (query, slice) instead of 1920.
+// ---------------------------------------------------------------------------------------------
+struct SbtGeom {
+    int W[5], C[5], fw[5], off[5];   // level width, channels, footprint width, LDS float offset
+    int total;                       // floats of LDS accumulators
+};
+__device__ __forceinline__ unsigned compact8(unsigned v) {   // even bits of a 16-bit Morton code
+    v &= 0x5555u;
+    v = (v | (v >> 1)) & 0x3333u;
+    v = (v | (v >> 2)) & 0x0F0Fu;
+    v = (v | (v >> 4)) & 0x00FFu;
+    return v;
+}
+struct TapL {
+    int lofs[4];   // LDS pixel index inside the footprint, or -1 -> use gofs
+    int gofs[4];   // global pixel index
+    float w[4];
+};
+__device__ __forceinline__ TapL make_taps_l(float gx, float gy, int W, int ox, int oy, int fw) {
+    const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    const float iy = ((gy + 1.f) / 2.f) * (float)(W - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float xe = x0f + 1.f, ye = y0f + 1.f;
+    const float wx[2] = {xe - ix, ix - x0f}, wy[2] = {ye - iy, iy - y0f};
+    TapL t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x0 + (k & 1), y = y0 + (k >> 1);
+        const bool ok = x >= 0 && x < W && y >= 0 && y < W;
+        t.w[k] = ok ? wx[k & 1] * wy[k >> 1] : 0.f;
+        t.gofs[k] = ok ? y * W + x : 0;
+        const int lx = x - ox, ly = y - oy;
+        t.lofs[k] = (ok && lx >= 0 && lx < fw && ly >= 0 && ly < fw) ? ly * fw + lx : -1;
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdArgs a, const SbtGeom G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_wt = smem;                 // Ws34^T fragment image [6][8], 48 KiB
+    float* s_acc = smem + 6 * 8 * 256;  // per-level footprint accumulators
+    const int tile = blockIdx.x & 255;
+    const int ts = (blockIdx.x >> 8) % a.n_slices;
+    const int b = (blockIdx.x >> 8) / a.n_slices;
+    const int* ends = a.bin_ends + (long)b * 65536;
+    const long qs_lo = tile ? ends[256 * tile - 1] : 0, qs_hi = ends[256 * tile + 255];
+    if (qs_lo >= qs_hi) return;
+    for (int i = threadIdx.x; i < 6 * 8 * 64; i += 512) st4(s_wt + 4 * i, ld4(a.ws34_t + 4 * i));
+    for (int i = threadIdx.x; i < G.total / 4; i += 512) st4(s_acc + 4 * i, zero4());
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int T = a.n_slices + 1, t = ts + 1;
+    const int tx = (int)compact8((unsigned)tile), ty = (int)compact8((unsigned)tile >> 1);
+    int ox[5], oy[5];
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+        ox[l] = 16 * tx * (G.W[l] - 1) / 255;
+        oy[l] = 16 * ty * (G.W[l] - 1) / 255;
+    }
+    const long img = (long)b * a.n_slices + ts;
+    const float* Tm = a.trans + b * 12;
+    for (long gi = qs_lo / 16 + wave; gi * 16 < qs_hi; gi += 8) {
+        const long qs = gi * 16 + m;
+        const bool qv = qs >= qs_lo && qs < qs_hi;
+        const long q = a.perm[(long)b * a.n_qry + (qs < a.n_qry ? qs : a.n_qry - 1)];
+        const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
+        float x = p[0], y = p[1], z = p[2];
+        if (a.flip_yz) {
+            y = -y; z = -z;
+        } else if (a.rot) {
+            const float* R = a.rot + b * 9;
+            const float rx = x * R[0] + y * R[3] + z * R[6];
+            const float ry = x * R[1] + y * R[4] + z * R[7];
+            const float rz = x * R[2] + y * R[5] + z * R[8];
+            x = rx; y = ry; z = rz;
+        }
+        const float X = x * Tm[0] + y * Tm[3] + z * Tm[6] + Tm[9];
+        const float Y = x * Tm[1] + y * Tm[4] + z * Tm[7] + Tm[10];
+        const float Z = x * Tm[2] + y * Tm[5] + z * Tm[8] + Tm[11];
+        const float gx = fminf(fmaxf(2.f * (X / Z - 0.5f), -1.f), 1.f);
+        const float gy = fminf(fmaxf(2.f * (Y / Z - 0.5f), -1.f), 1.f);
+        const float* dp = a.dX + ((((long)b * a.groups_per_batch + gi) * T + t) * S3D_GROUP + m) * 128 + 4 * g;
+        f32x4 dt[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dt[j] = qv ? ld4(dp + 16 * j) : zero4();
+        f32x4 draw[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            f32x4 c = zero4();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c = mfma4(ld4(s_wt + ((u * 8 + j) * 64 + lane) * 4), dt[j], c);
+            draw[u] = c;
+        }
+        if (!qv) continue;
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            const int C = l < 3 ? 128 : (l == 3 ? 64 : 32);
+            const TapL tp = make_taps_l(gx, gy, G.W[l], ox[l], oy[l], G.fw[l]);
+            float* gbase = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + img * (long)G.W[l] * G.W[l] * C + 4 * g;
+            float* lbase = s_acc + G.off[l] + 4 * g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (tp.w[k] == 0.f) continue;
+                const int nv = l < 3 ? 8 : (l == 3 ? 4 : 2);
+                if (tp.lofs[k] >= 0) {   // LDS footprint (ds_add_f32)
+                    float* o = lbase + tp.lofs[k] * C;
+#pragma unroll
+                    for (int j = 0; j < nv; ++j) {
+                        const f32x4 v = (l < 3 ? dt[j] : draw[(l == 3 ? 0 : 4) + j]) * tp.w[k];
+                        atomic_add4(o + 16 * j, v);
+                    }
+                } else {                 // rounding put the tap one pixel outside the footprint: global atomic
+                    float* o = gbase + (long)tp.gofs[k] * C;
+#pragma unroll
+                    for (int j = 0; j < nv; ++j) {
+                        const f32x4 v = (l < 3 ? dt[j] : draw[(l == 3 ? 0 : 4) + j]) * tp.w[k];
+                        atomic_add4(o + 16 * j, v);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // flush the footprints (skip untouched entries)
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+        const int C = G.C[l], fw = G.fw[l], W = G.W[l];
+        float* gmap = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + img * (long)W * W * C;
+        const int c4 = C >> 2, n4 = fw * fw * c4;
+        for (int i = threadIdx.x; i < n4; i += 512) {
+            const f32x4 v = ld4(s_acc + G.off[l] + 4 * i);
+            if (v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f) continue;
+            const int pix = i / c4, c = (i - pix * c4) * 4;
+            const int y = oy[l] + pix / fw, x = ox[l] + pix % fw;
+            if (x < W && y < W) atomic_add4(gmap + ((long)y * W + x) * C + c, v);
+        }
+    }
+}
+
 int launch_sample_bwd(const SampleBwdArgs& a, hipStream_t stream) {
     if (a.groups <= 0) return 0;
+    if (a.perm && a.bin_ends) {
+        SbtGeom G;
+        int off = 0;
+        for (int l = 0; l < 5; ++l) {
+            G.W[l] = a.size >> (4 - l);
+            G.C[l] = l < 3 ? 128 : (l == 3 ? 64 : 32);
+            G.fw[l] = (16 * (G.W[l] - 1) + 254) / 255 + 2;
+            G.off[l] = off;
+            off += G.fw[l] * G.fw[l] * G.C[l];
+        }
+        G.total = off;
+        const size_t lds = (size_t)(6 * 8 * 256 + off) * sizeof(float);
+        if (lds <= 160 * 1024) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)sample_bwd_tiled_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_set = true;
+            }
+            const long batch = a.groups / a.groups_per_batch;
+            hipLaunchKernelGGL(sample_bwd_tiled_kernel, dim3((unsigned)(batch * a.n_slices * 256)), dim3(512), lds,
+                               stream, a, G);
+            S3D_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const long blocks = a.groups < 4096 ? a.groups : 4096;
     hipLaunchKernelGGL(sample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     S3D_LAUNCH_CHECK();

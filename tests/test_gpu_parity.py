@@ -268,3 +268,52 @@ def test_f16x3_mode_is_fp32_class():
           (float((a - b).abs().max()), float((a - ref).abs().max()), float((b - ref).abs().max())))
     assert (a - ref).abs().max() < TOL
     assert (a - b).abs().max() < 5e-5      # two fp32-class evaluations (cf. oracle-vs-reference noise, synth.py)
+
+
+def test_query_sort_is_a_deterministic_locality_permutation():
+    """s3d_query_sort: a permutation of range(Q) per batch item, ordered by the Morton code of the projected
+    256^2 bin with ascending query index inside a bin, identical on every call (the train step's dropout
+    streams and row-wise comparisons rely on that)."""
+    import ctypes as C
+    from slice3d_amd import _lib
+    from slice3d_amd.synth import make_feed_dict
+    lib = _lib.load()
+    b, q = 2, 30000
+    fd = make_feed_dict(b, 32, q, 4, seed=3, device="cuda")
+    qry = fd["qry_norot"].contiguous()
+    # pile many queries onto a few pixels (large bins -> the workgroup rank-sort path) and beyond the clamp
+    qry[0, :5000] = qry[0, 0]
+    qry[1, 100:3000, :2] *= 40.0
+    rot, trans = fd["obj_rot_mat"].contiguous(), fd["trans_mat_wo_rot_tp"].contiguous()
+    nbytes = lib.s3d_query_sort_workspace_bytes(b, q)
+    ws = torch.empty(nbytes // 4 + 1, dtype=torch.int32, device="cuda")
+    perms = []
+    for _ in range(3):
+        perm = torch.empty(b, q, dtype=torch.int32, device="cuda")
+        _lib.check(lib.s3d_query_sort(qry.data_ptr(), rot.data_ptr(), trans.data_ptr(), 0, b, q, perm.data_ptr(),
+                                      ws.data_ptr(), nbytes, None), "s3d_query_sort")
+        torch.cuda.synchronize()
+        perms.append(perm.cpu().long())
+    assert torch.equal(perms[0], perms[1]) and torch.equal(perms[0], perms[2])
+    # reference keys computed with the module's own projection op
+    pts = torch.bmm(qry, rot)
+    g = torch.empty(b, q, 2, device="cuda")
+    _lib.check(lib.s3d_project_coord_fwd(pts.contiguous().data_ptr(), trans.data_ptr(), g.data_ptr(), b, q, None), "proj")
+    g = g.clamp(-1, 1).cpu()
+    px = ((g[..., 0] + 1) * 127.5).clamp(0, 255).long()
+    py = ((g[..., 1] + 1) * 127.5).clamp(0, 255).long()
+
+    def spread(v):
+        v = (v | (v << 4)) & 0x0F0F
+        v = (v | (v << 2)) & 0x3333
+        v = (v | (v << 1)) & 0x5555
+        return v
+    key = spread(px) | (spread(py) << 1)
+    for bb in range(b):
+        pm = perms[0][bb]
+        assert torch.equal(torch.sort(pm).values, torch.arange(q))
+        k = key[bb][pm]
+        comp = k * q + pm                      # (bin, query index) must be strictly increasing
+        # fp rounding of the projection can move a query across a bin edge; allow a handful of such ties
+        bad = int((comp[1:] <= comp[:-1]).sum())
+        assert bad <= 8, bad

@@ -69,7 +69,8 @@ def test_train_step_matches_reference_golden():
     print("worst sampled-gradient error / max|g| = %.2e" % worst)
 
 
-@pytest.mark.parametrize("b,s,q,ns", [(1, 32, 50, 12), (2, 48, 33, 4)])
+# q >= 4096 exercises the locality-sorted token order (s3d_query_sort) and the tiled sampling backward
+@pytest.mark.parametrize("b,s,q,ns", [(1, 32, 50, 12), (2, 48, 33, 4), (2, 32, 4200, 3)])
 def test_train_grads_match_oracle_autograd(b, s, q, ns):
     from oracle import ref_cpu
     from slice3d_amd.synth import make_feed_dict
