@@ -357,7 +357,10 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
     for (long gi = qs_lo / 16 + wave; gi * 16 < qs_hi; gi += 8) {
         const long qs = gi * 16 + m;
         const bool qv = qs >= qs_lo && qs < qs_hi;
-        const long q = a.perm[(long)b * a.n_qry + (qs < a.n_qry ? qs : a.n_qry - 1)];
+        // lanes outside the tile's range carry zero gradients; they borrow a valid neighbour's coordinates so
+        // that they do not break the row-uniformity test below
+        const long qsc = qs < qs_lo ? qs_lo : (qs >= qs_hi ? qs_hi - 1 : qs);
+        const long q = a.perm[(long)b * a.n_qry + qsc];
         const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
         float x = p[0], y = p[1], z = p[2];
         if (a.flip_yz) {
@@ -386,30 +389,64 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
             for (int j = 0; j < 8; ++j) c = mfma4(ld4(s_wt + ((u * 8 + j) * 64 + lane) * 4), dt[j], c);
             draw[u] = c;
         }
-        if (!qv) continue;
 #pragma unroll
         for (int l = 0; l < 5; ++l) {
             const int C = l < 3 ? 128 : (l == 3 ? 64 : 32);
+            const int nv = l < 3 ? 8 : (l == 3 ? 4 : 2);
             const TapL tp = make_taps_l(gx, gy, G.W[l], ox[l], oy[l], G.fw[l]);
             float* gbase = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + img * (long)G.W[l] * G.W[l] * C + 4 * g;
             float* lbase = s_acc + G.off[l] + 4 * g;
+            // Segmented reduction over the lane row: sorted neighbours that share their four tap pixels form
+            // contiguous runs; sum w*d over each run with 4 predicated DPP shifts (Hillis-Steele restricted to
+            // the run) and let the run's last lane issue ONE LDS add per value.  LDS float atomics cost ~3
+            // cycles per lane, so the number of lanes that reach them is what matters.
+            const bool regular = tp.lofs[0] >= 0 && tp.lofs[1] == tp.lofs[0] + 1 && tp.lofs[2] == tp.lofs[0] + G.fw[l] &&
+                                 tp.lofs[3] == tp.lofs[2] + 1;
+            const int key = regular ? tp.lofs[0] : -1 - m;
+            const int key_prev = __builtin_amdgcn_update_dpp(-100, key, 0x111, 0xF, 0xF, false);   // row_shr:1
+            const int key_next = __builtin_amdgcn_update_dpp(-100, key, 0x101, 0xF, 0xF, false);   // row_shl:1
+            const bool head = m == 0 || key_prev != key, tail = m == 15 || key_next != key;
+            // head position of my run: inclusive max-scan of (head ? m : 0)
+            int hp = head ? m : 0;
+            hp = max(hp, __builtin_amdgcn_update_dpp(0, hp, 0x111, 0xF, 0xF, false));
+            hp = max(hp, __builtin_amdgcn_update_dpp(0, hp, 0x112, 0xF, 0xF, false));
+            hp = max(hp, __builtin_amdgcn_update_dpp(0, hp, 0x114, 0xF, 0xF, false));
+            hp = max(hp, __builtin_amdgcn_update_dpp(0, hp, 0x118, 0xF, 0xF, false));
+            const float p1 = hp <= m - 1 ? 1.f : 0.f, p2 = hp <= m - 2 ? 1.f : 0.f, p4 = hp <= m - 4 ? 1.f : 0.f,
+                        p8 = hp <= m - 8 ? 1.f : 0.f;
+            if (regular) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (tp.w[k] == 0.f) continue;
-                const int nv = l < 3 ? 8 : (l == 3 ? 4 : 2);
-                if (tp.lofs[k] >= 0) {   // LDS footprint (ds_add_f32)
+                for (int k = 0; k < 4; ++k) {
                     float* o = lbase + tp.lofs[k] * C;
 #pragma unroll
                     for (int j = 0; j < nv; ++j) {
-                        const f32x4 v = (l < 3 ? dt[j] : draw[(l == 3 ? 0 : 4) + j]) * tp.w[k];
-                        atomic_add4(o + 16 * j, v);
-                    }
-                } else {                 // rounding put the tap one pixel outside the footprint: global atomic
-                    float* o = gbase + (long)tp.gofs[k] * C;
+                        f32x4 v = (l < 3 ? dt[j] : draw[(l == 3 ? 0 : 4) + j]) * tp.w[k];
 #pragma unroll
-                    for (int j = 0; j < nv; ++j) {
-                        const f32x4 v = (l < 3 ? dt[j] : draw[(l == 3 ? 0 : 4) + j]) * tp.w[k];
-                        atomic_add4(o + 16 * j, v);
+                        for (int i = 0; i < 4; ++i) {
+                            float x = v[i];
+                            x = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, false)), p1, x);
+                            x = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, false)), p2, x);
+                            x = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xF, false)), p4, x);
+                            x = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xF, false)), p8, x);
+                            v[i] = x;
+                        }
+                        if (tail) atomic_add4(o + 16 * j, v);
+                    }
+                }
+            } else if (qv) {   // a tap outside the map / footprint: per-tap handling
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (tp.w[k] == 0.f) continue;
+                    if (tp.lofs[k] >= 0) {
+                        float* o = lbase + tp.lofs[k] * C;
+#pragma unroll
+                        for (int j = 0; j < nv; ++j)
+                            atomic_add4(o + 16 * j, (l < 3 ? dt[j] : draw[(l == 3 ? 0 : 4) + j]) * tp.w[k]);
+                    } else {   // rounding put the tap one pixel outside the footprint: global atomic
+                        float* o = gbase + (long)tp.gofs[k] * C;
+#pragma unroll
+                        for (int j = 0; j < nv; ++j)
+                            atomic_add4(o + 16 * j, (l < 3 ? dt[j] : draw[(l == 3 ? 0 : 4) + j]) * tp.w[k]);
                     }
                 }
             }
