@@ -78,11 +78,12 @@ int launch_sample_planes(const float* plane, const float* grid, float* out, int 
 // decode_f16.hip
 int launch_ffn_hidden_f16x3(const float* Xin, float* Hout, long rows, long row_base, const LayerPtrs& w,
                             const DropCfg& drop_hidden, hipStream_t stream);
-int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const float* H, float* DA, float* DX, long rows,
+int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
                             const float* timg, float gate_scale, hipStream_t stream);
 int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipStream_t stream);
-int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, long rows, const LayerPtrs& w,
-                                 const DropCfg& drop_hidden, const DropCfg& drop_out, hipStream_t stream);
+int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
+                                 const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
+                                 hipStream_t stream);
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
                            long g_begin, const int* perm, hipStream_t stream);

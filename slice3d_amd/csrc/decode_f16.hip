@@ -45,6 +45,8 @@ struct FfnTrainArgs {   // MODE 2: pre-LayerNorm output for the backward pass + 
     float* Uout;
     DropCfg dh, dq;
     float* Hout;
+    unsigned* Mout;  // MODE 2: activity bits of the hidden units (post-dropout h > 0): dword [row][g][chunk>>2],
+                     // byte chunk&3, bit 4a+i  <->  hidden unit 32*chunk + 16a + 4g + i
     long row_base;   // row index of X[0] in the dropout counter space (block-wise backward recompute)
 };
 // MODE 0: layer FFN (in place or X -> Yout); 1: last layer + fc_out (FINAL); 2: training forward;
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
     for (int i = 0; i < NPRE; ++i) reinterpret_cast<f32x4*>(s_w[0])[i * F16_THREADS + threadIdx.x] = pre[i];
     __syncthreads();
 
+    unsigned mword[F16_R] = {};
 #pragma unroll 1
     for (int c = 0; c < S3D_FFN_NCHUNK; ++c) {
         const _Float16* sw = s_w[c & 1];
@@ -132,6 +135,20 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
                         (unsigned long long)(ta.row_base + row0 + r * 16 + m) * S3D_FFN + c * S3D_FFN_CHUNK + 16 * a + 4 * g;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hv[r][4 * a + i] *= s3d_drop(ta.dh, base + i);
+                }
+            }
+        }
+        if (MODE == 2 && ta.Mout) {
+#pragma unroll
+            for (int r = 0; r < F16_R; ++r) {
+                unsigned byte = 0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) byte |= (hv[r][t] > 0.f ? 1u : 0u) << t;
+                mword[r] |= byte << (8 * (c & 3));
+                const long row = row0 + r * 16 + m;
+                if ((c & 3) == 3) {
+                    if (row < rows) ta.Mout[row * 64 + g * 16 + (c >> 2)] = mword[r];
+                    mword[r] = 0;
                 }
             }
         }
@@ -251,12 +268,13 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
     return 0;
 }
 
-int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, long rows, const LayerPtrs& w,
-                                 const DropCfg& drop_hidden, const DropCfg& drop_out, hipStream_t stream) {
+int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
+                                 const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
+                                 hipStream_t stream) {
     if (rows <= 0) return 0;
     S3D_CHECK_ARG(w.wf16 != nullptr, "ffn train f16x3: no packed f16 image");
     const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
-    FfnTrainArgs ta = {Uout, drop_hidden, drop_out, nullptr, 0};
+    FfnTrainArgs ta = {Uout, drop_hidden, drop_out, nullptr, Mout, 0};
     hipLaunchKernelGGL(ffn_layer_f16x3_kernel<2>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, Xin, Yout, rows,
                        reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L,
                        nullptr, ta);
@@ -269,7 +287,7 @@ int launch_ffn_hidden_f16x3(const float* Xin, float* Hout, long rows, long row_b
     if (rows <= 0) return 0;
     S3D_CHECK_ARG(w.wf16 != nullptr, "ffn hidden f16x3: no packed f16 image");
     const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
-    FfnTrainArgs ta = {nullptr, drop_hidden, make_drop(0, 0.f, 0), Hout, row_base};
+    FfnTrainArgs ta = {nullptr, drop_hidden, make_drop(0, 0.f, 0), Hout, nullptr, row_base};
     hipLaunchKernelGGL(ffn_layer_f16x3_kernel<3>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, Xin, nullptr, rows,
                        reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L,
                        nullptr, ta);
@@ -278,8 +296,9 @@ int launch_ffn_hidden_f16x3(const float* Xin, float* Hout, long rows, long row_b
 }
 
 // ---------------------------------------------------------------------------------------------
-// FFN backward, data path:  given dY (gradient w.r.t. the lin2 output) and the stored hidden activations H,
-//   dA = (dY W2) * (H > 0 ? gate_scale : 0)      [rows][2048], written for the weight-gradient GEMMs
+// FFN backward, data path:  given dY (gradient w.r.t. the lin2 output) and the activity bits M of the
+// hidden units (forward kernel, FfnTrainArgs::Mout),
+//   dA = (dY W2) * (bit ? gate_scale : 0)        [rows][2048], registers only
 //   dX = dA W1 + Dres                             [rows][128]
 // Same tiling as the forward kernel: dY rows live in registers as f16 hi/lo B fragments, the transposed
 // weights (W2^T chunk as GEMM-1-shaped fragments, W1^T chunk as GEMM-2-shaped fragments; packed by
@@ -287,7 +306,7 @@ int launch_ffn_hidden_f16x3(const float* Xin, float* Hout, long rows, long row_b
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(F16_THREADS) void ffn_bwd_dx_f16x3_kernel(const float* __restrict__ DY,
                                                                const float* __restrict__ Dres,
-                                                               const float* __restrict__ H, float* __restrict__ DA,
+                                                               const unsigned* __restrict__ M,
                                                                float* __restrict__ DX, long rows,
                                                                const _Float16* __restrict__ timg, float gate_scale) {
     __shared__ __attribute__((aligned(16))) _Float16 s_w[2][F16_CHUNK_HALFS];  // 64 KiB
@@ -320,6 +339,7 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_bwd_dx_f16x3_kernel(const flo
     for (int i = 0; i < NPRE; ++i) reinterpret_cast<f32x4*>(s_w[0])[i * F16_THREADS + threadIdx.x] = pre[i];
     __syncthreads();
 
+    unsigned mw[F16_R] = {};
 #pragma unroll 1
     for (int c = 0; c < S3D_FFN_NCHUNK; ++c) {
         const _Float16* sw = s_w[c & 1];
@@ -328,15 +348,14 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_bwd_dx_f16x3_kernel(const flo
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) pre[i] = gs[i * F16_THREADS + threadIdx.x];
         }
-        // gate: the stored hidden activations of this chunk (lane layout = GEMM output layout)
-        f32x4 hg[F16_R][2];
+        // gate: activity bits of this chunk's hidden units (written by the forward kernel), one dword per 4 chunks
+        if ((c & 3) == 0) {
 #pragma unroll
-        for (int r = 0; r < F16_R; ++r) {
-            long row = row0 + r * 16 + m;
-            if (row >= rows) row = rows - 1;
-            const float* hp = H + row * S3D_FFN + c * S3D_FFN_CHUNK + 4 * g;
-            hg[r][0] = ld4(hp);
-            hg[r][1] = ld4(hp + 16);
+            for (int r = 0; r < F16_R; ++r) {
+                long row = row0 + r * 16 + m;
+                if (row >= rows) row = rows - 1;
+                mw[r] = M[row * 64 + g * 16 + (c >> 2)];
+            }
         }
         // GEMM1': dh^T[32 hidden][16 rows] = W2_c^T dy^T, K = 128
         float dav[F16_R][8];
@@ -363,16 +382,8 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_bwd_dx_f16x3_kernel(const flo
 #pragma unroll
             for (int r = 0; r < F16_R; ++r)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dav[r][4 * a + i] = hg[r][a][i] > 0.f ? dd[r][i] * gate_scale : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < F16_R; ++r) {
-            const long row = row0 + r * 16 + m;
-            if (row < rows) {
-                float* dp = DA + row * S3D_FFN + c * S3D_FFN_CHUNK + 4 * g;
-                st4(dp, f32x4{dav[r][0], dav[r][1], dav[r][2], dav[r][3]});
-                st4(dp + 16, f32x4{dav[r][4], dav[r][5], dav[r][6], dav[r][7]});
-            }
+                for (int i = 0; i < 4; ++i)
+                    dav[r][4 * a + i] = ((mw[r] >> (8 * (c & 3) + 4 * a + i)) & 1u) ? dd[r][i] * gate_scale : 0.f;
         }
         half8 dh_[F16_R], dl_[F16_R];
 #pragma unroll
@@ -417,11 +428,11 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_bwd_dx_f16x3_kernel(const flo
     }
 }
 
-int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const float* H, float* DA, float* DX, long rows,
+int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
                             const float* timg, float gate_scale, hipStream_t stream) {
     if (rows <= 0) return 0;
     const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
-    hipLaunchKernelGGL(ffn_bwd_dx_f16x3_kernel, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, DY, Dres, H, DA, DX,
+    hipLaunchKernelGGL(ffn_bwd_dx_f16x3_kernel, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, DY, Dres, M, DX,
                        rows, reinterpret_cast<const _Float16*>(timg), gate_scale);
     S3D_LAUNCH_CHECK();
     return 0;

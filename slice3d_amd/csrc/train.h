@@ -27,6 +27,32 @@ struct WgradArgs {
     size_t partial_floats;
 };
 int launch_wgrad(const WgradArgs& a, hipStream_t stream);
+
+// ---- FFN weight gradients with on-the-fly recomputation of the 2048-wide operand (split precision) ----
+// out[q][hid] = sum_rows D[row][q] * Z[row][hid],  Z[row][hid] = bit(row,hid) ? (R[row] . W[hid] + bias[hid]) * scale : 0
+//   dW2      = ( D = dY,  R = x,  W = lin1 weight, bias = lin1 bias )   out -> lin2 grad [128][2048]
+//   dW1^T    = ( D = x,   R = dY, W = lin2 weight^T, no bias )          out -> lin1 grad [2048][128] (transposed store),
+//              colsum(Z) -> lin1 bias grad
+// bits: activity mask written by the forward FFN kernel.  The [rows][2048] matrices are never materialised.
+struct FfnWgradArgs {
+    const float* D;         // [P][128]
+    const float* R;         // [P][128]
+    const float* wimg;      // f16 hi|lo fragment image of W [2048][128] (launch_pack_ffn_rec_f16x3)
+    const float* bias;      // [2048] or null
+    const unsigned* mask;   // [P][64] dwords
+    float scale;            // value of a kept unit's dropout factor (1/(1-p)), 1 without dropout
+    long P;
+    float* out;             // [128][2048] (transpose_out = 0) or [2048][128] (transpose_out = 1)
+    int transpose_out;
+    float* bias_out;        // [2048] column sums of Z, or null
+    int accumulate;
+    float* partial;         // workspace
+    size_t partial_floats;
+};
+int launch_ffn_wgrad_rec(const FfnWgradArgs& a, hipStream_t stream);
+// W: element (hid, k) at w[hid*sh + k*sk]  ->  image [128 hid tiles][4][64 lanes][8] halfs hi, then lo
+int launch_pack_ffn_rec_f16x3(const float* w, int sh, int sk, float* out, hipStream_t stream);
+#define S3D_FFN_REC_IMG_FLOATS (S3D_FFN * 128)   /* 2 x 2048*128 halfs */
 size_t wgrad_partial_floats(long P, int N, int Ktot);
 
 // column sums over rows/pixels: out[c] (+)= sum_p in[p*cstride + coff + c]

@@ -238,6 +238,291 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
             }
 }
 
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nchunks, int C, float scale,
+                                    float* __restrict__ out, int accumulate);
+
+// ---------------------------------------------------------------------------------------------
+// FFN weight gradients with recomputation (see train.h).  Workgroup = 128 (q) x 128 (hidden) output tile of
+// hidden block blockIdx.x, rows split over blockIdx.y; 4 waves.  Per 32-row step:
+//   1. stage  D^T  (gathered, [q][row]) and  R  (row-major) as f16 hi/lo in LDS, the step's mask dwords too;
+//   2. every wave recomputes 2 hidden tiles x 2 row tiles of Z = R W^T on the MFMA (its 16 W fragments stay in
+//      registers for the whole kernel), applies bias / mask / scale and writes Z^T ([hidden][row], hi/lo) to LDS
+//      — the D registers hold 4 consecutive rows of one hidden unit, i.e. one 8-byte LDS word;
+//   3. the 64 x 64 wave tiles of  out += D^T Z  run from LDS as in wgrad_lin_f16x3_kernel.
+// ---------------------------------------------------------------------------------------------
+#define FWR_XLD 136   // halfs per row of the row-major R tile (128 + 8 pad)
+template <int COLSUM>
+__global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArgs a, int steps_per_split) {
+    __shared__ __attribute__((aligned(16))) _Float16 s_d[2][128 * WL_LD];    // D^T hi|lo       20 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 s_z[2][128 * WL_LD];    // Z^T hi|lo       20 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 s_r[2][32 * FWR_XLD];   // R row-major     17 KiB
+    __shared__ unsigned s_m[128];                                            // [row][g] mask dwords of this block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int hb = blockIdx.x;
+    const int ch = tid & 127, rg = tid >> 7;      // gather role: channel, row group
+    const int rrow = tid >> 3, rcq = tid & 7;     // row-major role: row, channel quad
+    const int wn = wave & 1, wc = wave >> 1;
+    const long P = a.P;
+
+    // this wave's W fragments: hidden tiles 2*wave + e of the block, K = 128 = 4 x 32
+    wl_half8 wh[2][4], wlo[2][4];
+    float bv[2];
+    {
+        const _Float16* img = reinterpret_cast<const _Float16*>(a.wimg);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int tile = hb * 8 + 2 * wave + e;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t o = ((size_t)(tile * 4 + u) * 64 + lane) * 8;
+                wh[e][u] = *reinterpret_cast<const wl_half8*>(img + o);
+                wlo[e][u] = *reinterpret_cast<const wl_half8*>(img + (size_t)S3D_FFN * 128 + o);
+            }
+            bv[e] = a.bias ? a.bias[tile * 16 + m] : 0.f;
+        }
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = zero4();
+    float csum[2] = {0.f, 0.f};
+
+    float pd[2][8];
+    f32x4 pr[4];
+    unsigned pm = 0;
+    auto gload = [&](long pbase) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                long row = pbase + 16 * ps + 8 * rg + t;
+                row = row < P ? row : P - 1;
+                pd[ps][t] = a.D[row * 128 + ch];
+            }
+        long row = pbase + rrow;
+        row = row < P ? row : P - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pr[k] = ld4(a.R + row * 128 + 32 * k + 4 * rcq);
+        if (tid < 128) {
+            long mr = pbase + (tid >> 2);
+            mr = mr < P ? mr : P - 1;
+            pm = a.mask[mr * 64 + (tid & 3) * 16 + hb];
+        }
+    };
+    const long p_begin = (long)blockIdx.y * steps_per_split * 32;
+    gload(p_begin);
+    for (int it = 0; it < steps_per_split; ++it) {
+        const long pb = p_begin + (long)it * 32;
+        // ---- 1. stage D^T, R, mask ----
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            wl_half8 hi, lo;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float v = pd[ps][t] * (pb + 16 * ps + 8 * rg + t < P ? 1.f : 0.f);
+                const _Float16 h = (_Float16)v;
+                hi[t] = h;
+                lo[t] = (_Float16)(v - (float)h);
+            }
+            *reinterpret_cast<wl_half8*>(&s_d[0][ch * WL_LD + 16 * ps + 8 * rg]) = hi;
+            *reinterpret_cast<wl_half8*>(&s_d[1][ch * WL_LD + 16 * ps + 8 * rg]) = lo;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+            half4_t hi, lo;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const _Float16 h = (_Float16)pr[k][t];
+                hi[t] = h;
+                lo[t] = (_Float16)(pr[k][t] - (float)h);
+            }
+            *reinterpret_cast<half4_t*>(&s_r[0][rrow * FWR_XLD + 32 * k + 4 * rcq]) = hi;
+            *reinterpret_cast<half4_t*>(&s_r[1][rrow * FWR_XLD + 32 * k + 4 * rcq]) = lo;
+        }
+        if (tid < 128) s_m[tid] = (pb + (tid >> 2) < P) ? pm : 0u;
+        __syncthreads();
+        if (it + 1 < steps_per_split) gload(pb + 32);
+        // ---- 2. recompute Z tiles (rt, e): D[row 4g+i of tile rt][hidden m of tile e] ----
+        f32x4 z[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) z[rt][e] = zero4();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            wl_half8 xh[2], xl[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int o = (rt * 16 + m) * FWR_XLD + 32 * u + 8 * g;
+                xh[rt] = *reinterpret_cast<const wl_half8*>(&s_r[0][o]);
+                xl[rt] = *reinterpret_cast<const wl_half8*>(&s_r[1][o]);
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], wlo[e][u], z[rt][e], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], wh[e][u], z[rt][e], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], wh[e][u], z[rt][e], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                half4_t hi, lo;
+                // hidden unit (block-local) = 32*wave + 16*e + m  ->  mask byte `wave`, bit 4e + (m & 3), dword g' = m >> 2
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned mw = s_m[(rt * 16 + 4 * g + i) * 4 + (m >> 2)];
+                    const bool on = (mw >> (8 * wave + 4 * e + (m & 3))) & 1u;
+                    const float v = on ? (z[rt][e][i] + bv[e]) * a.scale : 0.f;
+                    if (COLSUM) csum[e] += v;
+                    const _Float16 h = (_Float16)v;
+                    hi[i] = h;
+                    lo[i] = (_Float16)(v - (float)h);
+                }
+                const int o = ((2 * wave + e) * 16 + m) * WL_LD + rt * 16 + 4 * g;
+                *reinterpret_cast<half4_t*>(&s_z[0][o]) = hi;
+                *reinterpret_cast<half4_t*>(&s_z[1][o]) = lo;
+            }
+        __syncthreads();
+        // ---- 3. out tile += D^T Z ----
+        wl_half8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (64 * wn + 16 * i + m) * WL_LD + 8 * g;
+            ah[i] = *reinterpret_cast<const wl_half8*>(&s_d[0][o]);
+            al[i] = *reinterpret_cast<const wl_half8*>(&s_d[1][o]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = (64 * wc + 16 * j + m) * WL_LD + 8 * g;
+            bh[j] = *reinterpret_cast<const wl_half8*>(&s_z[0][o]);
+            bl[j] = *reinterpret_cast<const wl_half8*>(&s_z[1][o]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+    // partial[split][q][hidden]
+    float* part = a.partial + (size_t)blockIdx.y * 128 * S3D_FFN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int q = 64 * wn + 16 * i + 4 * g + reg;
+                const int hid = hb * 128 + 64 * wc + 16 * j + m;
+                part[(size_t)q * S3D_FFN + hid] = acc[i][j][reg];
+            }
+    if (COLSUM) {
+        float* cp = a.partial + (size_t)gridDim.y * 128 * S3D_FFN + (size_t)blockIdx.y * S3D_FFN;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = csum[e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) cp[hb * 128 + (2 * wave + e) * 16 + m] = v;
+        }
+    }
+}
+
+__global__ void ffn_wgrad_rec_reduce_kernel(const float* __restrict__ partial, int nsplit, float* __restrict__ out,
+                                            int transpose_out, int accumulate) {
+    const long total = 128L * S3D_FFN;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        int sp = 0;
+        for (; sp + 8 <= nsplit; sp += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(sp + k) * total + idx];
+            __builtin_amdgcn_sched_barrier(0);
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; sp < nsplit; ++sp) s += partial[(size_t)sp * total + idx];
+        const long q = idx / S3D_FFN, hid = idx - q * S3D_FFN;
+        const long o = transpose_out ? hid * 128 + q : idx;
+        out[o] = accumulate ? out[o] + s : s;
+    }
+}
+
+int launch_ffn_wgrad_rec(const FfnWgradArgs& a, hipStream_t stream) {
+    if (a.P <= 0) return 0;
+    S3D_CHECK_ARG(a.D && a.R && a.wimg && a.mask && a.out && a.partial, "ffn_wgrad_rec: null argument");
+    const long total_steps = (a.P + 31) / 32;
+    long splits = 64;                                          // 16 hidden blocks x 64 = 1024 workgroups
+    const long max_by_steps = (total_steps + 7) / 8;
+    if (splits > max_by_steps) splits = max_by_steps;
+    const long cap = (long)(a.partial_floats / ((size_t)129 * S3D_FFN));
+    if (splits > cap) splits = cap;
+    if (splits < 1) {
+        s3d_set_error("ffn_wgrad_rec: partial workspace too small");
+        return S3D_E_WORKSPACE;
+    }
+    const int spw = (int)((total_steps + splits - 1) / splits);
+    splits = (total_steps + spw - 1) / spw;
+    dim3 grid(S3D_FFN / 128, (unsigned)splits);
+    if (a.bias_out)
+        hipLaunchKernelGGL((ffn_wgrad_rec_kernel<1>), grid, dim3(256), 0, stream, a, spw);
+    else
+        hipLaunchKernelGGL((ffn_wgrad_rec_kernel<0>), grid, dim3(256), 0, stream, a, spw);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ffn_wgrad_rec_reduce_kernel, dim3(1024), dim3(256), 0, stream, a.partial, (int)splits, a.out,
+                       a.transpose_out, a.accumulate);
+    S3D_LAUNCH_CHECK();
+    if (a.bias_out) {
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(S3D_FFN / 64), dim3(256), 0, stream,
+                           a.partial + (size_t)splits * 128 * S3D_FFN, (int)splits, S3D_FFN, 1.f, a.bias_out,
+                           a.accumulate);
+        S3D_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// element (hid, k) = w[hid*sh + k*sk]; lane (hl = l & 15, g = l >> 4) of fragment (tile, u) holds k = 32u + 8g .. +7
+__global__ void pack_ffn_rec_f16x3_kernel(const float* __restrict__ w, int sh, int sk, _Float16* __restrict__ out) {
+    const int total = (S3D_FFN / 16) * 4 * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, u = (idx >> 6) & 3, tile = idx >> 8;
+        const int hid = tile * 16 + (lane & 15), k0 = 32 * u + 8 * (lane >> 4);
+        _Float16* dst = out + (size_t)idx * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float v = w[(size_t)hid * sh + (size_t)(k0 + t) * sk];
+            const _Float16 h = (_Float16)v;
+            dst[t] = h;
+            dst[(size_t)S3D_FFN * 128 + t] = (_Float16)(v - (float)h);
+        }
+    }
+}
+int launch_pack_ffn_rec_f16x3(const float* w, int sh, int sk, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_ffn_rec_f16x3_kernel, dim3(128), dim3(256), 0, stream, w, sh, sk,
+                       reinterpret_cast<_Float16*>(out));
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
 static bool wgrad_lin_eligible(const WgradArgs& a, long P) {
     return a.prec == S3D_PREC_F16X3 && a.ks == 1 && a.stride <= 1 && !a.x.sbcast && !a.x.bmod && a.x.bdiv == 1 &&
            (a.Hin == 0 || a.Hin == a.H) && (a.Win == 0 || a.Win == a.W) && a.N >= 64 && a.Cx >= 64 && P >= 1024;
