@@ -209,7 +209,8 @@ def main():
             "train_samples_per_s": (world / (train_ms * 1e-3)) if train_ms else None,
             "train_ms_per_step": train_ms,
             "train_config": "train_step (fwd + 3 losses + bwd + grad all-reduce + Adam), B=1 object/GPU, %d^2 x %d slices, "
-                            "Q=%d, dropout 0.1, batch-statistic BatchNorm; forward/dgrad GEMMs in --prec, weight gradients fp32 MFMA"
+                            "Q=%d, dropout 0.1, batch-statistic BatchNorm; forward/dgrad GEMMs and linear-layer weight gradients in --prec, "
+                            "3x3-conv weight gradients fp32 MFMA"
                             % (args.img_size, args.n_slices, args.n_qry),
         }
         if world == 1 and args.cpu_sample > 0:
