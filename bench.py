@@ -24,6 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+UNET_GFLOP_256 = 241.97   # encoder 40.09 + 12-slice decoder 201.88 GFLOP at S=256
 F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 F16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (spec); 16x16x32 f16 measures 1955
 FFN_FLOP_PER_ROW = 2 * 2 * 128 * 2048   # two 128x2048 GEMMs, 2 FLOP/MAC (FFN = 88 %)
@@ -139,6 +140,29 @@ def main():
         counts[name] = n.value
     lib.s3d_prof_enable(0)
 
+    # ---- secondary rooflines (north_star): stand-alone feature-sample op (HBM bound) ----
+    sample_roof = None
+    if rank == 0:
+        code = model.encode(fd, build_latent=False)
+        g = model.project_coord(fd["qry_norot"] * torch.tensor([1.0, -1.0, -1.0], device="cuda"),   # mode='test' flip
+                                fd["trans_mat_wo_rot_tp"])
+        model.sample_pyramid(code.pyramid, g)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            feats = model.sample_pyramid(code.pyramid, g)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        ch = sum(p.shape[-1] for p in code.pyramid)
+        alg = args.n_slices * args.n_qry * (ch * 4 + 8) + sum(p.numel() * 4 for p in code.pyramid)
+        sample_roof = {"kernel": "sample_pyramid_kernel (+ locality sort; sample_from_planes x5 + cat semantics, materialises (12,Q,992) fp32)",
+                       "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                       "frac": alg / (ms * 1e-3) / 1e9 / 8000.0, "ms": ms, "alg_bytes": alg,
+                       "note": "algorithmic bytes: output write + grid read + pyramid once; time includes the query sort"}
+        del code, feats
+
     # ---- secondary metric: training samples/s (train.py:41-53 train_step, B = 1 object per GPU) ----
     train_ms = None
     if args.train_steps > 0:
@@ -204,6 +228,14 @@ def main():
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/",
                          "avg_launch_ms": ffn_ms, "launches": counts["ffn_layer"],
                          "alg_flop_per_launch": ffn_flops},
+            "secondary_rooflines": [
+                sample_roof,
+                {"kernel": "U-Net conv stack (conv_igemm_f16x3_kernel family, 33 launches)", "bound": "mfma",
+                 "achieved": UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"],
+                 "peak": peak, "unit": "TFLOP/s",
+                 "frac": UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"] / peak,
+                 "note": "algorithmic FLOPs 241.97 GFLOP/object at 256^2 (SURVEY 8d) / whole unet_encode stage time"},
+            ],
             "stage_ms_per_step": stage_ms,
             "decode_tflops_fmin": args.n_qry * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,
             "train_samples_per_s": (world / (train_ms * 1e-3)) if train_ms else None,

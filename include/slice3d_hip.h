@@ -237,6 +237,15 @@ int s3d_query_sort(const float* qry, const float* rot, const float* trans, int f
  * -> out (N,M,C); bilinear, zeros padding, align_corners=True.  C % 4 == 0. */
 int s3d_sample_planes_fwd(const float* plane, const float* grid, float* out, int n, int h, int w,
                           int c, long m, void* stream);
+/* The reference's feature-sampling block as ONE op (models.py:63-73: five sample_from_planes calls over
+ * feat_list + torch.cat(dim=2)): pyr = channels-last pyramid of B*n_slices images, grid (B,Q,2) projected
+ * coordinates shared by the n_slices images of a batch item -> out (B*n_slices, Q, 992) fp32, channel order
+ * [512 | 256 | 128 | 64 | 32].  HBM-bound on the 3 968-byte row writes (SURVEY.md 8(d) "stand-alone
+ * feature-sample kernel").  workspace: s3d_sample_pyramid_workspace_bytes (point records + the locality order
+ * the points are visited in for Q >= 4096; results do not depend on the order). */
+size_t s3d_sample_pyramid_workspace_bytes(int batch, long n_qry);
+int s3d_sample_pyramid_fwd(const S3dPyramid* pyr, const float* grid, float* out, int batch, int n_slices,
+                           long n_qry, void* workspace, size_t workspace_bytes, void* stream);
 /* layout helpers: (N,C,H,W) <-> (N,H,W,C) */
 int s3d_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, void* stream);
 int s3d_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, void* stream);

@@ -90,6 +90,8 @@ SYMBOLS = {
     "s3d_project_coord_fwd": (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     "s3d_query_sort_workspace_bytes": (_sz, [_i, _l]),
     "s3d_query_sort": (_i, [_vp, _vp, _vp, _i, _i, _l, _vp, _vp, _sz, _vp]),
+    "s3d_sample_pyramid_workspace_bytes": (_sz, [_i, _l]),
+    "s3d_sample_pyramid_fwd": (_i, [C.POINTER(S3dPyramid), _vp, _vp, _i, _i, _l, _vp, _sz, _vp]),
     "s3d_sample_planes_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _vp]),
     "s3d_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "s3d_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -768,6 +768,33 @@ extern "C" int s3d_query_sort(const float* qry, const float* rot, const float* t
     return launch_query_sort(qry, rot, trans, flip_yz, batch, n_qry, perm_out, (int*)workspace, (hipStream_t)stream);
 }
 
+extern "C" size_t s3d_sample_pyramid_workspace_bytes(int batch, long n_qry) {
+    // point records (float4) | permutation | sort scratch
+    return (size_t)batch * n_qry * 16 + ((size_t)batch * n_qry + 4 + query_sort_ws_ints(batch, n_qry)) * sizeof(int);
+}
+
+extern "C" int s3d_sample_pyramid_fwd(const S3dPyramid* pyr, const float* grid, float* out, int batch, int n_slices,
+                                      long n_qry, void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    S3D_CHECK_ARG(pyr && grid && out && workspace, "sample_pyramid: null argument");
+    S3D_CHECK_ARG(batch >= 1 && n_slices >= 1 && n_qry >= 1 && pyr->n_img == batch * n_slices,
+                  "sample_pyramid: pyramid holds %d images, expected %d x %d", pyr ? pyr->n_img : 0, batch, n_slices);
+    S3D_CHECK_ARG(pyr->size % 16 == 0 && pyr->size >= 16, "sample_pyramid: size %d", pyr->size);
+    if (workspace_bytes < s3d_sample_pyramid_workspace_bytes(batch, n_qry)) {
+        s3d_set_error("sample_pyramid: workspace %zu < %zu bytes", workspace_bytes,
+                      s3d_sample_pyramid_workspace_bytes(batch, n_qry));
+        return S3D_E_WORKSPACE;
+    }
+    float* pts = (float*)workspace;
+    const int* perm = nullptr;
+    if (n_qry >= S3D_SORT_MIN_QUERIES) {   // visit the points in image-space locality order
+        int* pm = (int*)(pts + (size_t)batch * n_qry * 4);
+        TRY(launch_query_sort(grid, nullptr, nullptr, 0, batch, n_qry, pm, pm + (size_t)batch * n_qry + 4, st));
+        perm = pm;
+    }
+    return launch_sample_pyramid(pyr->level, grid, perm, pts, out, batch, n_slices, pyr->size, n_qry, st);
+}
+
 extern "C" int s3d_sample_planes_fwd(const float* plane, const float* grid, float* out, int n, int h, int w,
                                      int c, long m, void* stream) {
     S3D_CHECK_ARG(plane && grid && out, "sample_planes: null argument");

@@ -64,6 +64,8 @@ int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w
 // projected pixel at 256^2): perm[b*Q + slot] = query index, ascending query index inside a bin (deterministic).
 // ws: query_sort_ws_ints(B, Q) ints; on return ws[b*65536 + k] = end of bin k in perm[b] (bin/tile ranges).
 size_t query_sort_ws_ints(int batch, long n_qry);
+int launch_sample_pyramid(const float* const* level, const float* grid, const int* perm, float* pts, float* out,
+                          int batch, int n_slices, int size, long n_qry, hipStream_t stream);
 int launch_query_sort(const float* qry, const float* rot, const float* trans, int flip_yz, int batch, long n_qry,
                       int* perm, int* ws, hipStream_t stream);
 // training forward: y = LN2(u), u = x + FFN(x) with x read from Xin, y -> Yout, u -> Uout (pre-LN, saved)

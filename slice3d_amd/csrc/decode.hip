@@ -591,6 +591,15 @@ __global__ void qsort_key_kernel(const float* qry, const float* rot, const float
     const long total = (long)batch * n_qry;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / n_qry);
+        if (!trans) {   // already-projected coordinates: qry = (B, Q, 2) grid in [-1, 1]
+            const float gx = qry[i * 2], gy = qry[i * 2 + 1];
+            const unsigned px = (unsigned)fminf(fmaxf((gx + 1.f) * 127.5f, 0.f), 255.f);
+            const unsigned py = (unsigned)fminf(fmaxf((gy + 1.f) * 127.5f, 0.f), 255.f);
+            const int key = (int)morton8(px, py);
+            keys[i] = key;
+            atomicAdd(&hist[(long)b * QS_BINS + key], 1);
+            continue;
+        }
         float x = qry[i * 3], y = qry[i * 3 + 1], z = qry[i * 3 + 2];
         if (flip_yz) {
             y = -y; z = -z;
@@ -765,11 +774,97 @@ __global__ void sample_planes_kernel(const float* __restrict__ plane, const floa
         const int ni = (int)(pt / mpts);
         const Tap4 tp = make_taps(grid[pt * 2], grid[pt * 2 + 1], w, h);
         const float* base = plane + (long)ni * h * w * c + cc;
-        f32x4 v = zero4();
+        f32x4 t[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v += ld4(base + (long)tp.off[k] * c) * tp.w[k];
-        st4(out + pt * c + cc, v);
+        for (int k = 0; k < 4; ++k) t[k] = ld4(base + (long)tp.off[k] * c);
+        __builtin_amdgcn_sched_barrier(0);   // four taps in flight
+        st4(out + pt * c + cc, (t[0] * tp.w[0] + t[1] * tp.w[1]) + (t[2] * tp.w[2] + t[3] * tp.w[3]));
     }
+}
+
+// Fused form of the reference's five sample_from_planes calls + torch.cat (models.py:66-73): every (slice
+// image, point) gets its 992-channel row [512 | 256 | 128 | 64 | 32] of bilinear samples of the five pyramid
+// levels.  Points are visited in image-space locality order (perm), each row is written once, contiguously:
+// the kernel is bound by the 3 968-byte row write.  thread = (row, channel quad).
+struct SamplePyrArgs {
+    const float* level[5];
+    const float* grid;   // (B, Q, 2)
+    const int* perm;     // (B, Q) or null
+    float4* pts;         // (B, Q) scratch: (gx, gy, original index as int bits, 0) in visiting order
+    float* out;          // (B*ns, Q, 992)
+    int size, n_slices, batch;
+    long n_qry;
+};
+__global__ void sample_pyramid_pts_kernel(const SamplePyrArgs a) {
+    const long total = (long)a.batch * a.n_qry;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / a.n_qry;
+        const int q = a.perm ? a.perm[i] : (int)(i - b * a.n_qry);
+        const float* gp = a.grid + (b * a.n_qry + q) * 2;
+        a.pts[i] = make_float4(gp[0], gp[1], __int_as_float(q), 0.f);
+    }
+}
+__global__ __launch_bounds__(256) void sample_pyramid_kernel(const SamplePyrArgs a) {
+    const long rows = (long)a.batch * a.n_slices * a.n_qry;
+    // a workgroup handles whole rows: 248 quads per row, 256 threads -> thread t < 248 active
+    const int cq = threadIdx.x;
+    if (cq >= 248) return;
+    int l, c0;   // level and first channel inside the level
+    if (cq < 128) { l = 0; c0 = 4 * cq; }
+    else if (cq < 192) { l = 1; c0 = 4 * (cq - 128); }
+    else if (cq < 224) { l = 2; c0 = 4 * (cq - 192); }
+    else if (cq < 240) { l = 3; c0 = 4 * (cq - 224); }
+    else { l = 4; c0 = 4 * (cq - 240); }
+    const int C = 512 >> l, W = (a.size / 16) << l;
+    const float* plane = a.level[l];
+    // row order: (image, point in visiting order): consecutive rows = neighbouring points of ONE image, their
+    // taps meet in L1 / L2.  4 rows per pass: the 4 point records and the 16 tap loads are each one batch.
+    for (long r0 = (long)blockIdx.x * 4; r0 < rows; r0 += (long)gridDim.x * 4) {
+        long img[4];
+        float4 pt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long r = r0 + u < rows ? r0 + u : rows - 1;
+            img[u] = r / a.n_qry;
+            pt[u] = a.pts[(img[u] / a.n_slices) * a.n_qry + (r - img[u] * a.n_qry)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 t[4][4];
+        float w[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const Tap4 tp = make_taps(pt[u].x, pt[u].y, W, W);
+            const float* base = plane + img[u] * (long)W * W * C + c0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[u][k] = ld4(base + (long)tp.off[k] * C);
+                w[u][k] = tp.w[k];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r0 + u < rows)
+                __builtin_nontemporal_store((t[u][0] * w[u][0] + t[u][1] * w[u][1]) + (t[u][2] * w[u][2] + t[u][3] * w[u][3]),
+                                            reinterpret_cast<f32x4*>(a.out + (img[u] * a.n_qry + __float_as_int(pt[u].z)) * 992 + 4 * cq));
+    }
+}
+int launch_sample_pyramid(const float* const* level, const float* grid, const int* perm, float* pts, float* out,
+                          int batch, int n_slices, int size, long n_qry, hipStream_t stream) {
+    SamplePyrArgs a;
+    for (int l = 0; l < 5; ++l) a.level[l] = level[l];
+    a.grid = grid; a.perm = perm; a.pts = reinterpret_cast<float4*>(pts); a.out = out;
+    a.size = size; a.n_slices = n_slices; a.batch = batch; a.n_qry = n_qry;
+    const long rows = (long)batch * n_slices * n_qry;
+    if (rows <= 0) return 0;
+    const long np = (long)batch * n_qry;
+    hipLaunchKernelGGL(sample_pyramid_pts_kernel, dim3((unsigned)((np + 255) / 256 < 4096 ? (np + 255) / 256 : 4096)),
+                       dim3(256), 0, stream, a);
+    S3D_LAUNCH_CHECK();
+    const long blocks = (rows + 3) / 4 < 32768 ? (rows + 3) / 4 : 32768;
+    hipLaunchKernelGGL(sample_pyramid_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    S3D_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_sample_planes(const float* plane, const float* grid, float* out, int n, int h, int w, int c, long m,

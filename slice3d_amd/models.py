@@ -190,11 +190,14 @@ class Slices3DRegModel(nn.Module):
         if self._lib is None:
             raise _lib.S3dError("Slices3DRegModel(backend=%r) cannot compute: the HIP library is required "
                                 "(backend='hip'); there is no CPU fallback in the product path" % self.backend)
-        if self.training:
-            raise NotImplementedError(
-                "train-mode forward (batch-stat BatchNorm, dropout, backward kernels) is not built yet; "
-                "call model.eval() — see DESIGN.md 'next'")
         return self._lib
+
+    def _require_eval(self):
+        if self.training:
+            raise RuntimeError(
+                "this module computes the eval-mode forward (running-stat BatchNorm, no dropout); the train-mode "
+                "step (batch-stat BatchNorm, dropout, backward, Adam) runs through slice3d_amd.trainer.HipTrainer — "
+                "call model.eval() for inference")
 
     def _device(self):
         return self.fc_p.weight.device
@@ -323,12 +326,34 @@ class Slices3DRegModel(nn.Module):
                                              self._stream()), "s3d_sample_planes_fwd")
         return out
 
+    def sample_pyramid(self, pyramid, projected_coordinates):
+        """The reference's sampling block as one HBM-bound op (models.py:63-73): `pyramid` = the five
+        channels-last levels of B*n_slices images (LatentCode.pyramid), projected_coordinates (B,Q,2)
+        -> (B*n_slices, Q, 992), the tensor torch.cat(feat_interp, dim=2) holds in the reference."""
+        lib = self._require_lib()
+        grid = self._f32(projected_coordinates)
+        b, q, _ = grid.shape
+        n_img, s = pyramid[0].shape[0], pyramid[4].shape[1]
+        if n_img % b != 0 or [p.shape[-1] for p in pyramid] != list(LEVEL_CHANNELS):
+            raise ValueError("pyramid does not match the batch / the (512,256,128,64,32) channel layout")
+        pyr = _lib.S3dPyramid()
+        for l in range(5):
+            pyr.level[l] = pyramid[l].data_ptr()
+        pyr.n_img, pyr.size = n_img, s
+        out = torch.empty((n_img, q, sum(LEVEL_CHANNELS)), dtype=torch.float32, device=grid.device)
+        nb = lib.s3d_sample_pyramid_workspace_bytes(b, q)
+        ws = self._workspace("sample_pyramid", nb)
+        _lib.check(lib.s3d_sample_pyramid_fwd(C.byref(pyr), grid.data_ptr(), out.data_ptr(), b, n_img // b, q,
+                                              ws.data_ptr(), nb, self._stream()), "s3d_sample_pyramid_fwd")
+        return out
+
     # ------------------------------------------------------------------------------------------
     # encode / decode
     # ------------------------------------------------------------------------------------------
     def encode(self, feed_dict, want_slices=False, build_latent=True):
         """U-Net slice generator + (optionally) the fc_s-folded latent maps.  Runs once per object."""
         lib = self._require_lib()
+        self._require_eval()
         self._ensure_packed()
         img = self._f32(feed_dict["img_input"])
         b, ch, s, s2 = img.shape
@@ -371,6 +396,7 @@ class Slices3DRegModel(nn.Module):
     def decode_sdf(self, p, c, obj_rot_mat=None, trans_mat_wo_rot_tp=None, mode=None):
         """sdf_pred (B,Q) for query points p (B,Q,3) given a LatentCode (models.py:53-84)."""
         lib = self._require_lib()
+        self._require_eval()
         mode = self.mode if mode is None else mode
         qry = self._f32(p)
         b, q, _ = qry.shape
@@ -402,6 +428,7 @@ class Slices3DRegModel(nn.Module):
     def decode_grid(self, c, nx, box=1.0, trans_mat_wo_rot_tp=None):
         """Dense nx^3 logits (-sdf) with in-kernel grid coordinates (reconstruct.py:135-146); batch 1."""
         lib = self._require_lib()
+        self._require_eval()
         if c.batch != 1:
             raise ValueError("decode_grid expects a single encoded object")
         tm = self._f32(trans_mat_wo_rot_tp) if trans_mat_wo_rot_tp is not None else c.trans_mat_wo_rot_tp

@@ -317,3 +317,23 @@ def test_query_sort_is_a_deterministic_locality_permutation():
         # fp rounding of the projection can move a query across a bin edge; allow a handful of such ties
         bad = int((comp[1:] <= comp[:-1]).sum())
         assert bad <= 8, bad
+
+
+@pytest.mark.parametrize("q", [700, 5000])
+def test_sample_pyramid_matches_grid_sample(q):
+    """s3d_sample_pyramid_fwd == the reference's five sample_from_planes calls + cat (models.py:63-73), with and
+    without the internal locality order (q >= 4096)."""
+    import torch.nn.functional as F
+    from slice3d_amd.models import Slices3DRegModel, LEVEL_CHANNELS
+    b, ns, s = 2, 3, 32
+    g = torch.Generator().manual_seed(11)
+    pyr = [torch.randn(b * ns, (s // 16) << l, (s // 16) << l, LEVEL_CHANNELS[l], generator=g) for l in range(5)]
+    grid = torch.rand(b, q, 2, generator=g) * 2.4 - 1.2
+    grid = grid.clamp(-1, 1)
+    m = Slices3DRegModel(img_size=s, n_slices=ns, mode="test").cuda().eval()
+    got = m.sample_pyramid([p.cuda() for p in pyr], grid.cuda()).cpu()
+    gg = grid.view(b, 1, q, 2).expand(-1, ns, -1, -1).reshape(b * ns, 1, q, 2)
+    want = torch.cat([F.grid_sample(p.permute(0, 3, 1, 2), gg, mode="bilinear", padding_mode="zeros",
+                                    align_corners=True).permute(0, 3, 2, 1).reshape(b * ns, q, -1) for p in pyr], 2)
+    assert got.shape == want.shape == (b * ns, q, 992)
+    assert (got - want).abs().max() < 2e-5
