@@ -30,6 +30,12 @@ __device__ __forceinline__ f32x4 mfma3(const half8 ah, const half8 al, const hal
     return c;
 }
 __device__ __forceinline__ half8 ldh8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
+// global -> LDS copy of one 32 KiB weight chunk by LDS-DMA (1 KiB per wave-instruction, no VGPR staging)
+__device__ __forceinline__ void dma_chunk32k(const _Float16* gsrc, _Float16* ldst, int wave, int lane, int nwaves) {
+    for (int piece = wave; piece < 32; piece += nwaves)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(ldst + piece * 512), 16, 0, 0);
+}
 __device__ __forceinline__ float quad_sum16(float v) {
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -37,7 +43,11 @@ __device__ __forceinline__ float quad_sum16(float v) {
 }
 
 #define F16_R 2
-#define F16_WAVES 8
+// 4 waves = one per SIMD; two workgroups share a CU (2 x 64 KiB LDS, 2 x 256 VGPRs per SIMD lane).  The two
+// waves of a SIMD then belong to DIFFERENT workgroups: while one sits at its per-chunk barrier / LDS latency, the
+// other keeps the matrix pipe busy (with 8-wave workgroups both waves of a SIMD stalled at the same barrier:
+// 37 % of the wave time parked, MFMA pipe 56 % busy — SQ_WAIT_ANY / SQ_VALU_MFMA_BUSY_CYCLES).
+#define F16_WAVES 4
 #define F16_THREADS (F16_WAVES * 64)
 #define F16_CHUNK_HALFS 16384   // 32 KiB: W1 hi | W1 lo | W2 hi | W2 lo, 4096 halfs each
 
@@ -52,7 +62,7 @@ struct FfnTrainArgs {   // MODE 2: pre-LayerNorm output for the backward pass + 
 // MODE 0: layer FFN (in place or X -> Yout); 1: last layer + fc_out (FINAL); 2: training forward;
 // 3: backward-pass recompute of the hidden activations only: Hout = dropout(relu(x W1^T + b1)), [rows][2048]
 template <int MODE>
-__global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const float* X, float* Yout, long rows,
+__global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_kernel(const float* X, float* Yout, long rows,
                                                               const _Float16* wimg, const LayerPtrs w,
                                                               const float* fco_w, const float* fco_b,
                                                               float* sdf_out, float sign, long groups_per_batch,
@@ -80,24 +90,22 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
     }
-    // stage chunk 0: 32 KiB = 2048 x 16 B
-    constexpr int NPRE = 2048 / F16_THREADS;
-    f32x4 pre[NPRE];
-    const f32x4* gsrc = reinterpret_cast<const f32x4*>(wimg);
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) pre[i] = gsrc[i * F16_THREADS + threadIdx.x];
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) reinterpret_cast<f32x4*>(s_w[0])[i * F16_THREADS + threadIdx.x] = pre[i];
+    // stage chunk 0 (LDS-DMA); chunk c+1 is requested at the top of iteration c into the other buffer
+    dma_chunk32k(wimg, s_w[0], wave, lane, F16_WAVES);
     __syncthreads();
 
     unsigned mword[F16_R] = {};
+    // lin1 bias of the NEXT chunk is fetched one iteration ahead and BEFORE the weight prefetch: vmcnt retires
+    // in order, so a bias load issued after the prefetch would make its consumer wait for the whole prefetch
+    f32x4 b1n[2] = {ld4(w.b1 + 4 * g), ld4(w.b1 + 16 + 4 * g)};
 #pragma unroll 1
     for (int c = 0; c < S3D_FFN_NCHUNK; ++c) {
         const _Float16* sw = s_w[c & 1];
+        const f32x4 b1c[2] = {b1n[0], b1n[1]};
         if (c + 1 < S3D_FFN_NCHUNK) {
-            const f32x4* gs = gsrc + (size_t)(c + 1) * 2048;
-#pragma unroll
-            for (int i = 0; i < NPRE; ++i) pre[i] = gs[i * F16_THREADS + threadIdx.x];
+            b1n[0] = ld4(w.b1 + (c + 1) * S3D_FFN_CHUNK + 4 * g);
+            b1n[1] = ld4(w.b1 + (c + 1) * S3D_FFN_CHUNK + 16 + 4 * g);
+            dma_chunk32k(wimg + (size_t)(c + 1) * F16_CHUNK_HALFS, s_w[(c + 1) & 1], wave, lane, F16_WAVES);
         }
         // GEMM1: hidden^T[32][16 rows] = W1_c x^T ; two 16-row tiles a, K = 128 = 4 x 32
         float hv[F16_R][8];
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
 #pragma unroll
                 for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[u], xh[r][u], hd[r], 0, 0, 0);
             }
-            const f32x4 b1 = ld4(w.b1 + c * S3D_FFN_CHUNK + 16 * a + 4 * g);
+            const f32x4 b1 = b1c[a];
 #pragma unroll
             for (int r = 0; r < F16_R; ++r)
 #pragma unroll
@@ -186,12 +194,7 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_layer_f16x3_kernel(const floa
                 for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], hh[r], acc[r][j], 0, 0, 0);
             }
         }
-        if (c + 1 < S3D_FFN_NCHUNK) {
-            f32x4* dw = reinterpret_cast<f32x4*>(s_w[(c + 1) & 1]);
-#pragma unroll
-            for (int i = 0; i < NPRE; ++i) dw[i * F16_THREADS + threadIdx.x] = pre[i];
-        }
-        __syncthreads();
+        __syncthreads();   // chunk c+1 has landed (the barrier drains vmcnt); everyone is done with buffer c & 1
     }
 
     if (MODE == 3) return;
@@ -304,7 +307,7 @@ int launch_ffn_hidden_f16x3(const float* Xin, float* Hout, long rows, long row_b
 // weights (W2^T chunk as GEMM-1-shaped fragments, W1^T chunk as GEMM-2-shaped fragments; packed by
 // pack_ffn_f16x3_kernel with swapped strides) stream through LDS, dA never re-enters registers from memory.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(F16_THREADS) void ffn_bwd_dx_f16x3_kernel(const float* __restrict__ DY,
+__global__ __launch_bounds__(F16_THREADS, 2) void ffn_bwd_dx_f16x3_kernel(const float* __restrict__ DY,
                                                                const float* __restrict__ Dres,
                                                                const unsigned* __restrict__ M,
                                                                float* __restrict__ DX, long rows,
@@ -330,24 +333,15 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_bwd_dx_f16x3_kernel(const flo
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
     }
-    constexpr int NPRE = 2048 / F16_THREADS;
-    f32x4 pre[NPRE];
-    const f32x4* gsrc = reinterpret_cast<const f32x4*>(timg);
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) pre[i] = gsrc[i * F16_THREADS + threadIdx.x];
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) reinterpret_cast<f32x4*>(s_w[0])[i * F16_THREADS + threadIdx.x] = pre[i];
+    dma_chunk32k(timg, s_w[0], wave, lane, F16_WAVES);
     __syncthreads();
 
     unsigned mw[F16_R] = {};
 #pragma unroll 1
     for (int c = 0; c < S3D_FFN_NCHUNK; ++c) {
         const _Float16* sw = s_w[c & 1];
-        if (c + 1 < S3D_FFN_NCHUNK) {
-            const f32x4* gs = gsrc + (size_t)(c + 1) * 2048;
-#pragma unroll
-            for (int i = 0; i < NPRE; ++i) pre[i] = gs[i * F16_THREADS + threadIdx.x];
-        }
+        if (c + 1 < S3D_FFN_NCHUNK)
+            dma_chunk32k(timg + (size_t)(c + 1) * F16_CHUNK_HALFS, s_w[(c + 1) & 1], wave, lane, F16_WAVES);
         // gate: activity bits of this chunk's hidden units (written by the forward kernel), one dword per 4 chunks
         if ((c & 3) == 0) {
 #pragma unroll
@@ -408,12 +402,7 @@ __global__ __launch_bounds__(F16_THREADS) void ffn_bwd_dx_f16x3_kernel(const flo
                 for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], dh_[r], acc[r][j], 0, 0, 0);
             }
         }
-        if (c + 1 < S3D_FFN_NCHUNK) {
-            f32x4* dw = reinterpret_cast<f32x4*>(s_w[(c + 1) & 1]);
-#pragma unroll
-            for (int i = 0; i < NPRE; ++i) dw[i * F16_THREADS + threadIdx.x] = pre[i];
-        }
-        __syncthreads();
+        __syncthreads();   // chunk c+1 has landed (the barrier drains vmcnt); everyone is done with buffer c & 1
     }
     // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
 #pragma unroll
