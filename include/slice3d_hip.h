@@ -167,6 +167,54 @@ int s3d_vgg_loss_fwd(const void* packed, const float* pred, const float* target,
                      float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Slices3DGTModel — reg_slices/src/model_gt.py:12-111 (regression from GIVEN slice images).
+ * Same split as above: encoder once per object, folded latent maps, per-query decode.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    S3dConvParams conv[13];       /* img_encoder (vgg16bn_feats.py:26-40): VGG16-BN convs 0,3,7,10,14,17,20,24,27,30,
+                                     34,37,40 each with the BatchNorm that follows it (conv[12].bn unused) */
+} S3dVgg16BnParams;
+typedef struct {
+    float* level[5];              /* raw conv1_2, conv2_2, conv3_3, conv4_3, conv5_3 outputs, channels-last:
+                                     (n_img, S>>l, S>>l, {64,128,256,512,512}[l]) */
+    int n_img;                    /* B*n_slices */
+    int size;
+} S3dGtPyramid;
+size_t s3d_gt_encoder_packed_bytes(void);
+int s3d_gt_encoder_pack(const S3dVgg16BnParams* params_host, void* packed, size_t packed_bytes, void* stream);
+size_t s3d_gt_encoder_workspace_bytes(int n_img, int size);
+/* img_slices (n_img,3,S,S) NCHW = feed_dict['img_slices'].view(B*n_slices,3,S,S) (model_gt.py:73-76) */
+int s3d_gt_encode_fwd(const void* packed, const float* img_slices, const S3dGtPyramid* out, int n_img, int size,
+                      int prec, void* workspace, size_t workspace_bytes, void* stream);
+
+typedef struct {
+    const float* pts_w[3];  const float* pts_b[3];      /* pts_feat_extractor.{0,2,4}: (32,3) (64,32) (128,64) */
+    const float* local_w[2]; const float* local_b[2];   /* fc_local.{0,2}: (128,1472) (128,128) */
+    S3dLayerParams layer[S3D_N_LAYERS];                 /* att_decoder.layers.{0,1,2} */
+    const float* fc_out_w; const float* fc_out_b;       /* fc_out.0 */
+} S3dGtHeadParams;
+size_t s3d_gt_head_packed_bytes(void);
+int s3d_gt_head_pack(const S3dGtHeadParams* params_host, void* packed, size_t packed_bytes, void* stream);
+/* proj[0..3]: conv5_3, conv4_3, conv3_3, conv2_2 levels with fc_local.0 folded in (n_img, W, W, 128);
+ * fine: the raw conv1_2 level (must alias pyramid level 0). */
+typedef struct {
+    float* proj[4];
+    const float* fine;
+    int n_img;
+    int size;
+} S3dGtLatent;
+int s3d_gt_latent_build(const void* head_packed, const S3dGtPyramid* pyr, const S3dGtLatent* out, int prec,
+                        void* stream);
+size_t s3d_gt_decode_workspace_bytes(int batch, long n_qry, int n_slices);
+int s3d_gt_decode_points_fwd(const void* head_packed, const S3dGtLatent* latent, const float* qry,
+                             const float* rot, const float* trans, int flip_yz, float* sdf_out, int batch,
+                             long n_qry, int n_slices, int prec, void* workspace, size_t workspace_bytes,
+                             void* stream);
+int s3d_gt_decode_grid_fwd(const void* head_packed, const S3dGtLatent* latent, const float* trans, int nx,
+                           float box, float* logits_out, int n_slices, int prec, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Training step — replaces train_step (reg_slices/train.py:41-53): train-mode forward (batch-statistic
  * BatchNorm with the running-stat update, unet_parts.py:17,20), the three losses of cal_loss_pred
  * (train.py:29-39) + cal_acc (train.py:21-27), backward of everything, and Adam (train.py:136).

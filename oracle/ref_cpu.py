@@ -371,3 +371,63 @@ def eval_points(sd, data, n_slices=12, chunk_size=3000):
     qry = rotate_queries(data, "test")
     sdf = decode_points(sd, feats, qry, data["trans_mat_wo_rot_tp"], n_slices, chunk=chunk_size)
     return (-sdf).squeeze(0)
+
+
+# --------------------------------------------------------------------------------------------------
+# Slices3DGTModel  (model_gt.py:59-111, vgg16bn_feats.py:42-57)
+# --------------------------------------------------------------------------------------------------
+_GT_BLOCK = {"down1": "conv1_2", "down2": "conv2_2", "down3": "conv3_3", "down4": "conv4_3", "down5": "conv5_3",
+             "down5_": "conv_last"}
+GT_LEVEL_CHANNELS = (64, 128, 256, 512, 512)   # conv1_2 ... conv5_3, sum = 1472
+
+
+def gt_encoder(sd, x, pfx="img_encoder."):
+    """VGG16BNFeats.forward (vgg16bn_feats.py:42-57): the five RAW conv outputs conv1_2..conv5_3 — the slices
+    [:4] [4:11] [11:21] [21:31] [31:41] end on a conv, the BN/ReLU/pool that follow open the next slice."""
+    taps = []
+    h = x
+    for ci in _VGG16_CONV_IDX:
+        blk = _GT_BLOCK[_VGG16_BLOCK_OF[ci]]
+        h = F.conv2d(h, sd[f"{pfx}{blk}.{ci}.weight"], sd[f"{pfx}{blk}.{ci}.bias"], padding=1)
+        if ci in _VGG16_TAPS:
+            taps.append(h)
+        if ci == 40:
+            break   # conv_last (BN-ReLU-pool) only feeds feat_global, which forward() never uses
+        h = torch.relu(_bn_eval(h, sd, f"{pfx}{_GT_BLOCK[_VGG16_BN_OWNER[ci]]}.{ci + 1}"))
+        if ci in _VGG16_POOL_AFTER_BN_OF:
+            h = F.max_pool2d(h, 2, 2)
+    return taps
+
+
+def gt_decode_points(sd, feats, qry_rot, trans_mat, n_slices, chunk=2048):
+    """model_gt.py:77-106 for a set of (already rotated / flipped) queries."""
+    outs = []
+    b = qry_rot.shape[0]
+    for s in range(0, qry_rot.shape[1], chunk):
+        qr = qry_rot[:, s:s + chunk]
+        q = qr.shape[1]
+        img_pts = project_coord(qr, trans_mat)
+        pts = img_pts.view(b, 1, q, 2).expand(-1, n_slices, -1, -1).reshape(b * n_slices, q, 2)
+        agg = torch.cat([sample_from_planes(f, pts).squeeze(1) for f in feats], dim=2)     # (B*ns, Q, 1472)
+        agg = agg.view(b, n_slices, q, 1472).permute(0, 2, 1, 3).reshape(b, q, n_slices, 1472)
+        h = qr
+        for i in (0, 2, 4):
+            h = torch.relu(h @ sd[f"pts_feat_extractor.{i}.weight"].t() + sd[f"pts_feat_extractor.{i}.bias"])
+        loc = agg
+        for i in (0, 2):
+            loc = torch.relu(loc @ sd[f"fc_local.{i}.weight"].t() + sd[f"fc_local.{i}.bias"])
+        x = torch.cat([h.reshape(b * q, 1, D_MODEL), loc.reshape(b * q, n_slices, D_MODEL)], 1)
+        for i in range(3):
+            x = transformer_layer(sd, x, f"att_decoder.layers.{i}")
+        tok0 = x[:, 0, :].view(b, q, D_MODEL)
+        outs.append((tok0 @ sd["fc_out.0.weight"].t() + sd["fc_out.0.bias"]).squeeze(-1))
+    return torch.cat(outs, 1)
+
+
+def gt_forward(sd, feed_dict, mode="train", n_slices=12):
+    """-> (sdf_pred (B,Q), feats[5] NCHW)."""
+    sl = feed_dict["img_slices"]
+    b, _, hh, ww = sl.shape
+    feats = gt_encoder(sd, sl.reshape(b * n_slices, 3, hh, ww))
+    qry_rot = rotate_queries(feed_dict, mode)
+    return gt_decode_points(sd, feats, qry_rot, feed_dict["trans_mat_wo_rot_tp"], n_slices), feats

@@ -93,3 +93,15 @@ def build_reference_model(n_slices=12, mode="train", img_size=128, seed=0):
     load_seeded(model, seed)
     model.eval()
     return model
+
+
+def build_reference_gt_model(n_slices=12, mode="train", img_size=128, seed=0):
+    """Reference Slices3DGTModel (reg_slices/src/model_gt.py) with name-seeded weights, eval() mode."""
+    import importlib
+    from slice3d_amd.weights import load_seeded
+    import_reference_models()   # installs the stubs and the sys.path entry
+    mg = importlib.import_module("src.model_gt")
+    model = mg.Slices3DGTModel(img_size=img_size, n_slices=n_slices, mode=mode)
+    load_seeded(model, seed)
+    model.eval()
+    return model

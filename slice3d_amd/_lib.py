@@ -54,6 +54,24 @@ class S3dTrainBatch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("img", "img_slices", "qry", "rot", "trans", "sdf")]
 
 
+class S3dVgg16BnParams(C.Structure):
+    _fields_ = [("conv", S3dConvParams * 13)]
+
+
+class S3dGtPyramid(C.Structure):
+    _fields_ = [("level", C.c_void_p * 5), ("n_img", C.c_int), ("size", C.c_int)]
+
+
+class S3dGtHeadParams(C.Structure):
+    _fields_ = [("pts_w", C.c_void_p * 3), ("pts_b", C.c_void_p * 3), ("local_w", C.c_void_p * 2),
+                ("local_b", C.c_void_p * 2), ("layer", S3dLayerParams * N_LAYERS),
+                ("fc_out_w", C.c_void_p), ("fc_out_b", C.c_void_p)]
+
+
+class S3dGtLatent(C.Structure):
+    _fields_ = [("proj", C.c_void_p * 4), ("fine", C.c_void_p), ("n_img", C.c_int), ("size", C.c_int)]
+
+
 class S3dLatent(C.Structure):
     _fields_ = [("proj", C.c_void_p * 3), ("fine", C.c_void_p * 2), ("n_img", C.c_int),
                 ("size", C.c_int)]
@@ -75,6 +93,17 @@ SYMBOLS = {
     "s3d_decode_points_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _vp, _vp, _i, _vp, _i, _l, _i, _i,
                                    _vp, _sz, _vp]),
     "s3d_decode_grid_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _i, _f, _vp, _i, _i, _vp, _sz, _vp]),
+    "s3d_gt_encoder_packed_bytes": (_sz, []),
+    "s3d_gt_encoder_pack": (_i, [C.POINTER(S3dVgg16BnParams), _vp, _sz, _vp]),
+    "s3d_gt_encoder_workspace_bytes": (_sz, [_i, _i]),
+    "s3d_gt_encode_fwd": (_i, [_vp, _vp, C.POINTER(S3dGtPyramid), _i, _i, _i, _vp, _sz, _vp]),
+    "s3d_gt_head_packed_bytes": (_sz, []),
+    "s3d_gt_head_pack": (_i, [C.POINTER(S3dGtHeadParams), _vp, _sz, _vp]),
+    "s3d_gt_latent_build": (_i, [_vp, C.POINTER(S3dGtPyramid), C.POINTER(S3dGtLatent), _i, _vp]),
+    "s3d_gt_decode_workspace_bytes": (_sz, [_i, _l, _i]),
+    "s3d_gt_decode_points_fwd": (_i, [_vp, C.POINTER(S3dGtLatent), _vp, _vp, _vp, _i, _vp, _i, _l, _i, _i,
+                                      _vp, _sz, _vp]),
+    "s3d_gt_decode_grid_fwd": (_i, [_vp, C.POINTER(S3dGtLatent), _vp, _i, _f, _vp, _i, _i, _vp, _sz, _vp]),
     "s3d_vgg_packed_bytes": (_sz, []),
     "s3d_vgg_pack": (_i, [C.POINTER(S3dVggParams), _vp, _sz, _vp]),
     "s3d_vgg_workspace_bytes": (_sz, [_i, _i]),

@@ -560,6 +560,27 @@ static int copy_vec(float* dst, const float* src, size_t n, hipStream_t st) {
     return 0;
 }
 
+static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLayout& H, hipStream_t st) {
+    for (int l = 0; l < S3D_N_LAYERS; ++l) {
+        const S3dLayerParams& p = layers[l];
+        TRY(pack_linear(p.in_proj_w, b + H.L[l].inw, 384, 384, 128, 128, 0, st));
+        TRY(copy_vec(b + H.L[l].inb, p.in_proj_b, 384, st));
+        TRY(pack_linear(p.out_proj_w, b + H.L[l].outw, 128, 128, 128, 128, 0, st));
+        TRY(copy_vec(b + H.L[l].outb, p.out_proj_b, 128, st));
+        TRY(copy_vec(b + H.L[l].ln1g, p.norm1_w, 128, st));
+        TRY(copy_vec(b + H.L[l].ln1b, p.norm1_b, 128, st));
+        TRY(pack_linear(p.lin1_w, b + H.L[l].w1, S3D_FFN, S3D_FFN, 128, 128, 0, st));
+        TRY(copy_vec(b + H.L[l].b1, p.lin1_b, S3D_FFN, st));
+        TRY(pack_linear(p.lin2_w, b + H.L[l].w2, 128, 128, S3D_FFN, S3D_FFN, S3D_FFN_CHUNK / 16, st));
+        TRY(copy_vec(b + H.L[l].b2, p.lin2_b, 128, st));
+        TRY(copy_vec(b + H.L[l].ln2g, p.norm2_w, 128, st));
+        TRY(copy_vec(b + H.L[l].ln2b, p.norm2_b, 128, st));
+        TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wf16, st));
+        TRY(launch_pack_attn_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].af16, st));
+    }
+    return 0;
+}
+
 extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     S3D_CHECK_ARG(P && packed, "head_pack: null argument");
@@ -576,23 +597,7 @@ extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed
     for (int l = 0; l < 3; ++l) TRY(pack_linear(P->fc_s_w + lo[l], b + H.wproj[l], 128, 128, lc[l], 992, 0, st));
     for (int l = 0; l < 3; ++l) TRY(pack_linear(P->fc_s_w + lo[l], b + H.wproj16[l], 128, 128, lc[l], 992, 0, st, 1));
     TRY(pack_linear(P->fc_s_w + 896, b + H.ws34, 128, 128, 96, 992, 0, st));
-    for (int l = 0; l < S3D_N_LAYERS; ++l) {
-        const S3dLayerParams& p = P->layer[l];
-        TRY(pack_linear(p.in_proj_w, b + H.L[l].inw, 384, 384, 128, 128, 0, st));
-        TRY(copy_vec(b + H.L[l].inb, p.in_proj_b, 384, st));
-        TRY(pack_linear(p.out_proj_w, b + H.L[l].outw, 128, 128, 128, 128, 0, st));
-        TRY(copy_vec(b + H.L[l].outb, p.out_proj_b, 128, st));
-        TRY(copy_vec(b + H.L[l].ln1g, p.norm1_w, 128, st));
-        TRY(copy_vec(b + H.L[l].ln1b, p.norm1_b, 128, st));
-        TRY(pack_linear(p.lin1_w, b + H.L[l].w1, S3D_FFN, S3D_FFN, 128, 128, 0, st));
-        TRY(copy_vec(b + H.L[l].b1, p.lin1_b, S3D_FFN, st));
-        TRY(pack_linear(p.lin2_w, b + H.L[l].w2, 128, 128, S3D_FFN, S3D_FFN, S3D_FFN_CHUNK / 16, st));
-        TRY(copy_vec(b + H.L[l].b2, p.lin2_b, 128, st));
-        TRY(copy_vec(b + H.L[l].ln2g, p.norm2_w, 128, st));
-        TRY(copy_vec(b + H.L[l].ln2b, p.norm2_b, 128, st));
-        TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wf16, st));
-        TRY(launch_pack_attn_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].af16, st));
-    }
+    TRY(pack_head_layers(P->layer, b, H, st));
     TRY(copy_vec(b + H.fco_w, P->fc_out_w, 128, st));
     TRY(copy_vec(b + H.fco_b, P->fc_out_b, 1, st));
     return 0;
@@ -812,4 +817,5 @@ extern "C" int s3d_nhwc_to_nchw(const float* in, float* out, int n, int c, int h
     return launch_nhwc_to_nchw(in, out, n, c, h, w, (hipStream_t)stream);
 }
 
+#include "api_gt.inc"
 #include "api_train.inc"

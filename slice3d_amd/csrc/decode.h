@@ -64,6 +64,36 @@ int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w
 // projected pixel at 256^2): perm[b*Q + slot] = query index, ascending query index inside a bin (deterministic).
 // ws: query_sort_ws_ints(B, Q) ints; on return ws[b*65536 + k] = end of bin k in perm[b] (bin/tile ranges).
 size_t query_sort_ws_ints(int batch, long n_qry);
+
+// ---- Slices3DGTModel sampler (model_gt.py:77-96): four fc_local[0]-folded 128-channel maps (pyramid levels
+// conv2_2 .. conv5_3) + the raw 64-channel conv1_2 level through a K=64 MFMA, + bias, ReLU -> slice-token rows.
+// Token-0 rows are written by launch_gt_point_tokens (pts_feat_extractor) after the second fc_local layer.
+struct SampleGtArgs {
+    const float* proj[4];   // [0] = conv5_3 level (S/16) ... [3] = conv2_2 level (S/2); (n_img, W, W, 128)
+    const float* fine;      // conv1_2 level (n_img, S, S, 64)
+    const float* wraw;      // fragment image of fc_local[0].weight[:, 0:64]  [8 j][4 u][64 lanes][4]
+    const float* bias;      // fc_local[0].bias
+    int size, n_slices;
+    const float *qry, *rot, *trans;
+    int flip_yz;
+    long n_qry, groups_per_batch, g_begin, g_count;
+    int nx;
+    float box;
+    float* X;               // out [g_count][T][16][128]; token-0 rows are zero-filled
+    const int* perm;
+};
+int launch_sample_tokens_gt(const SampleGtArgs& a, hipStream_t stream);
+struct GtPointArgs {
+    const float *w0, *b0, *w1, *b1, *w2, *b2;   // pts_feat_extractor Linear(3,32), (32,64), (64,128), each + ReLU
+    const float *qry, *rot;
+    int flip_yz, n_slices;
+    long n_qry, groups_per_batch, g_begin, g_count;
+    int nx;
+    float box;
+    float* X;
+    const int* perm;
+};
+int launch_gt_point_tokens(const GtPointArgs& a, hipStream_t stream);
 int launch_sample_pyramid(const float* const* level, const float* grid, const int* perm, float* pts, float* out,
                           int batch, int n_slices, int size, long n_qry, hipStream_t stream);
 int launch_query_sort(const float* qry, const float* rot, const float* trans, int flip_yz, int batch, long n_qry,

@@ -878,3 +878,185 @@ int launch_sample_planes(const float* plane, const float* grid, float* out, int 
     S3D_LAUNCH_CHECK();
     return 0;
 }
+
+
+// =============================================================================================
+// Slices3DGTModel front end (model_gt.py:77-96)
+// =============================================================================================
+__device__ __forceinline__ void gt_query_xyz(const float* qry, const float* rot, int flip_yz, const int* perm,
+                                             int nx, float box, int b, long q, long n_qry, float& x, float& y,
+                                             float& z) {
+    if (perm) q = perm[(long)b * n_qry + q];
+    if (qry) {
+        const float* p = qry + ((long)b * n_qry + q) * 3;
+        x = p[0]; y = p[1]; z = p[2];
+    } else {
+        const long nn = (long)nx * nx;
+        const int ixg = (int)(q / nn), iyg = (int)((q / nx) % nx), izg = (int)(q % nx);
+        x = box * linspace_at(-0.5f, 0.5f, nx, ixg);
+        y = box * linspace_at(-0.5f, 0.5f, nx, iyg);
+        z = box * linspace_at(-0.5f, 0.5f, nx, izg);
+    }
+    if (flip_yz) {
+        y = -y; z = -z;
+    } else if (rot) {
+        const float* R = rot + b * 9;
+        const float rx = x * R[0] + y * R[3] + z * R[6];
+        const float ry = x * R[1] + y * R[4] + z * R[7];
+        const float rz = x * R[2] + y * R[5] + z * R[8];
+        x = rx; y = ry; z = rz;
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_tokens_gt_kernel(const SampleGtArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_w[8 * 4 * 256];  // 32 KiB: fc_local[0][:, :64] fragments
+    for (int i = threadIdx.x; i < 8 * 4 * 64; i += 256) st4(s_w + 4 * i, ld4(a.wraw + 4 * i));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int T = a.n_slices + 1, S = a.size;
+    const long nb = gridDim.x;
+    const long bb = (nb % 8 == 0) ? (long)(blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : (long)blockIdx.x;
+    const long chunk = (a.g_count + nb - 1) / nb;
+    const long g_lo = bb * chunk, g_hi = g_lo + chunk < a.g_count ? g_lo + chunk : a.g_count;
+    for (long gi = g_lo; gi < g_hi; ++gi) {
+        const long grp = a.g_begin + gi;
+        const int b = (int)(grp / a.groups_per_batch);
+        long q = (grp % a.groups_per_batch) * S3D_GROUP + m;
+        if (q >= a.n_qry) q = a.n_qry - 1;
+        float x, y, z, gx, gy;
+        gt_query_xyz(a.qry, a.rot, a.flip_yz, a.perm, a.nx, a.box, b, q, a.n_qry, x, y, z);
+        project(a.trans + b * 12, x, y, z, gx, gy);
+        for (int t = wave; t < T; t += 4) {
+            f32x4 acc[8];
+            if (t == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = zero4();
+            } else {
+                const long img = (long)b * a.n_slices + (t - 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = ld4(a.bias + 16 * j + 4 * g);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    const int W = S >> (4 - l);
+                    const Tap4 tp = make_taps(gx, gy, W, W);
+                    const float* base = a.proj[l] + img * (long)W * W * 128 + 4 * g;
+#pragma unroll
+                    for (int kp = 0; kp < 2; ++kp) {
+                        f32x4 v[2][8];
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            const float* p = base + (long)tp.off[2 * kp + k2] * 128;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[k2][j] = ld4(p + 16 * j);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            const float w = tp.w[2 * kp + k2];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[j] += v[k2][j] * w;
+                        }
+                    }
+                }
+                f32x4 braw[4];
+                {
+                    const Tap4 tp = make_taps(gx, gy, S, S);
+                    const float* base = a.fine + img * (long)S * S * 64 + 4 * g;
+                    f32x4 v[4][4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[k][u] = ld4(base + (long)tp.off[k] * 64 + 16 * u);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        braw[u] = v[0][u] * tp.w[0] + v[1][u] * tp.w[1] + v[2][u] * tp.w[2] + v[3][u] * tp.w[3];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        acc[j] = mfma4(ld4(s_w + ((j * 4 + u) * 64 + lane) * 4), braw[u], acc[j]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[j][i] = fmaxf(acc[j][i], 0.f);
+            }
+            float* o = a.X + ((gi * T + t) * S3D_GROUP + m) * 128 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(o + 16 * j, acc[j]);
+        }
+    }
+}
+
+int launch_sample_tokens_gt(const SampleGtArgs& a, hipStream_t stream) {
+    S3D_CHECK_ARG(a.size % 16 == 0 && a.size >= 16, "sample_gt: size %d", a.size);
+    S3D_CHECK_ARG(a.n_slices >= 1 && a.n_slices + 1 <= S3D_N_TOKENS_MAX, "sample_gt: n_slices %d", a.n_slices);
+    long blocks = a.g_count < 2048 ? a.g_count : 2048;
+    if (blocks <= 0) return 0;
+    if (blocks >= 8) blocks -= blocks % 8;
+    hipLaunchKernelGGL(sample_tokens_gt_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// pts_feat_extractor (model_gt.py:24-31): thread = (query row, 4 output channels); the three small weight
+// matrices sit in LDS (3*32 + 32*64 + 64*128 floats = 41 KiB)
+__global__ __launch_bounds__(256) void gt_point_tokens_kernel(const GtPointArgs a) {
+    __shared__ float s_w0[32 * 3], s_b0[32], s_w1[64 * 32], s_b1[64], s_w2[128 * 64], s_b2[128];
+    __shared__ float s_h1[8][32], s_h2[8][64];
+    for (int i = threadIdx.x; i < 96; i += 256) s_w0[i] = a.w0[i];
+    for (int i = threadIdx.x; i < 32; i += 256) s_b0[i] = a.b0[i];
+    for (int i = threadIdx.x; i < 2048; i += 256) s_w1[i] = a.w1[i];
+    for (int i = threadIdx.x; i < 64; i += 256) s_b1[i] = a.b1[i];
+    for (int i = threadIdx.x; i < 8192; i += 256) s_w2[i] = a.w2[i];
+    for (int i = threadIdx.x; i < 128; i += 256) s_b2[i] = a.b2[i];
+    __syncthreads();
+    const int T = a.n_slices + 1;
+    const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;   // 8 query rows per pass, 32 threads each
+    const long rows = a.g_count * S3D_GROUP;
+    for (long r0 = (long)blockIdx.x * 8; r0 < rows; r0 += (long)gridDim.x * 8) {
+        const long r = r0 + sub;
+        const bool ok = r < rows;
+        const long gi = (ok ? r : rows - 1) / S3D_GROUP;
+        const int m = (int)((ok ? r : rows - 1) % S3D_GROUP);
+        const long grp = a.g_begin + gi;
+        const int b = (int)(grp / a.groups_per_batch);
+        long q = (grp % a.groups_per_batch) * S3D_GROUP + m;
+        if (q >= a.n_qry) q = a.n_qry - 1;
+        float x, y, z;
+        gt_query_xyz(a.qry, a.rot, a.flip_yz, a.perm, a.nx, a.box, b, q, a.n_qry, x, y, z);
+        s_h1[sub][l] = fmaxf(s_w0[l * 3] * x + s_w0[l * 3 + 1] * y + s_w0[l * 3 + 2] * z + s_b0[l], 0.f);
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int c = l + 32 * o;
+            float s = s_b1[c];
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) s += s_w1[c * 32 + k] * s_h1[sub][k];
+            s_h2[sub][c] = fmaxf(s, 0.f);
+        }
+        __syncthreads();
+        f32x4 out;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * l + i;
+            float s = s_b2[c];
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) s += s_w2[c * 64 + k] * s_h2[sub][k];
+            out[i] = fmaxf(s, 0.f);
+        }
+        if (ok) st4(a.X + ((gi * T) * S3D_GROUP + m) * 128 + 4 * l, out);
+        __syncthreads();
+    }
+}
+
+int launch_gt_point_tokens(const GtPointArgs& a, hipStream_t stream) {
+    if (a.g_count <= 0) return 0;
+    const long rows = a.g_count * S3D_GROUP;
+    const long blocks = (rows + 7) / 8 < 2048 ? (rows + 7) / 8 : 2048;
+    hipLaunchKernelGGL(gt_point_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,61 @@
+"""GPU parity of the Slices3DGTModel path (s3d_gt_* through the C ABI) against the reference goldens and the
+CPU oracle.  Tolerance: 1e-4 absolute on sdf (the north_star gate), as for Slices3DRegModel."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from test_gt_oracle import GT_CASES, gt_feed, gt_shapes
+
+pytestmark = pytest.mark.gpu
+
+
+def make_model(ns, prec, mode):
+    from slice3d_amd.models_gt import Slices3DGTModel
+    from slice3d_amd.weights import load_seeded
+    return load_seeded(Slices3DGTModel(n_slices=ns, mode=mode, prec=prec), 0).cuda().eval()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("case", GT_CASES)
+def test_gt_matches_reference_golden(case, prec):
+    g = load_golden(case)
+    m = make_model(g["n_slices"], prec, g["mode"])
+    fd = gt_feed(g, "cuda")
+    code = m.encode(fd)
+    for l in range(5):   # raw pyramid probes (reference tensors are NCHW)
+        n, c, h, w = [int(v) for v in g["pyr%d_shape" % l]]
+        nchw = code.pyramid[l].permute(0, 3, 1, 2).contiguous().reshape(-1).cpu().numpy()
+        got = nchw[g["pyr%d_idx" % l]]
+        scale = max(1.0, float(np.abs(g["pyr%d_val" % l]).max()))
+        assert np.abs(got - g["pyr%d_val" % l]).max() < 1e-4 * scale, l
+    out = m(fd)["sdf_pred"].cpu().numpy()
+    assert np.abs(out - g["sdf_pred"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("b,s,q,ns,mode", [(1, 32, 70, 12, "train"), (2, 48, 4500, 5, "test")])
+def test_gt_matches_oracle(b, s, q, ns, mode):
+    """Other shapes (ragged query count, fewer slices, the locality-sorted path at q >= 4096) vs the oracle."""
+    from oracle import ref_cpu
+    from helpers import seeded_sd_from_shapes
+    from slice3d_amd.synth import make_feed_dict
+    fd = make_feed_dict(b, s, q, ns, seed=900 + q)
+    sd = seeded_sd_from_shapes(gt_shapes())
+    with torch.no_grad():
+        want, _ = ref_cpu.gt_forward(sd, fd, mode, ns)
+    m = make_model(ns, "f16x3", mode)
+    got = m({k: v.cuda() for k, v in fd.items()})["sdf_pred"].cpu()
+    assert (got - want).abs().max() < 1e-4
+
+
+def test_gt_dense_grid_equals_point_decode():
+    from slice3d_amd.synth import make_feed_dict
+    ns, s, nx = 12, 32, 9
+    fd = {k: v.cuda() for k, v in make_feed_dict(1, s, 8, ns, seed=5).items()}
+    m = make_model(ns, "f16x3", "test")
+    code = m.encode(fd)
+    logits = m.decode_grid(code, nx, box=1.0, trans_mat_wo_rot_tp=fd["trans_mat_wo_rot_tp"])
+    lin = torch.linspace(-0.5, 0.5, nx, device="cuda")
+    pts = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(1, -1, 3)
+    sdf = m.decode_sdf(pts, code, trans_mat_wo_rot_tp=fd["trans_mat_wo_rot_tp"], mode="test")
+    assert (logits + sdf.reshape(-1)).abs().max() < 2e-5
