@@ -21,9 +21,13 @@ from slice3d_amd.synth import SyntheticSlice3DDataset  # noqa: E402
 
 def main():
     args = get_parser().parse_args()
-    if args.name_model != "slicenet":
-        raise SystemExit("only --name_model slicenet is built (DISN / GT-slices models: SURVEY.md section 2)")
-    model = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode=args.mode)
+    if args.name_model == "slicenet":
+        model = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode=args.mode)
+    elif args.name_model == "gtslice":   # regression from given slices (model_gt.py; --from_which_slices gt|gen|gt_rec)
+        from slice3d_amd.models_gt import Slices3DGTModel
+        model = Slices3DGTModel(img_size=args.img_size, n_slices=args.n_slices, mode=args.mode)
+    else:
+        raise SystemExit("--name_model %s is not built (DISN: SURVEY.md section 2, out of scope)" % args.name_model)
     path_ckpt = os.path.join("experiments", args.name_exp, "ckpt", args.name_ckpt)
     if os.path.isfile(path_ckpt):
         model.load_state_dict(torch.load(path_ckpt, map_location="cpu")["model"])     # strict, as the reference
@@ -38,11 +42,14 @@ def main():
                             upsampling_steps=args.mc_up_steps, chunk_size=args.mc_chunk_size,
                             pred_type=args.pred_type)
     if args.name_dataset != "synthetic":
-        raise SystemExit("on-disk datasets (SURVEY.md 8(f-3)) are not built yet; use --name_dataset synthetic")
-    dataset = SyntheticSlice3DDataset(args.synthetic_len, args.img_size, 16, args.n_slices, split="test")
+        from slice3d_amd.datasets import Slice3DDataset
+        dataset = Slice3DDataset(split="test", args=args)
+    else:
+        dataset = SyntheticSlice3DDataset(args.synthetic_len, args.img_size, 16, args.n_slices, split="test")
     with torch.no_grad():
         for idx in range(len(dataset)):
-            path_mesh = os.path.join(path_res, "synthetic_%04d.obj" % idx)
+            shape = dataset.files[idx][1] if hasattr(dataset, "files") else "synthetic_%04d" % idx
+            path_mesh = os.path.join(path_res, shape + ".obj")
             if not args.overwrite_res and os.path.exists(path_mesh):
                 continue
             data = {k: v.unsqueeze(0).cuda() for k, v in dataset[idx].items()}

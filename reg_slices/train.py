@@ -48,8 +48,18 @@ def val_step(model, val_loader, pred_type="sdf"):
 
 
 def make_loaders(args, rank, world):
-    if args.name_dataset != "synthetic":
-        raise SystemExit("on-disk datasets (SURVEY.md 8(f-3)) are not built yet; use --name_dataset synthetic")
+    if args.name_dataset != "synthetic":   # on-disk dataset in the reference's layout (train.py:123-127)
+        from slice3d_amd.datasets import Slice3DDataset
+
+        def disk_loader(split):
+            ds = Slice3DDataset(split=split, args=args)
+            sampler = None
+            if world > 1 and split == "train":   # one shard of the samples per rank (the reference uses DataParallel)
+                sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True)
+            return torch.utils.data.DataLoader(ds, batch_size=args.n_bs, shuffle=(split == "train" and sampler is None),
+                                               sampler=sampler, num_workers=args.n_wk, drop_last=True)
+        return disk_loader("train"), disk_loader("val")
+
     def loader(split):
         ds = SyntheticSlice3DDataset(args.synthetic_len, args.img_size, args.n_qry, args.n_slices, split=split,
                                      rank=rank, world=world)
