@@ -220,7 +220,7 @@ class Slices3DGTModel(nn.Module):
         _lib.check(lib.s3d_gt_decode_grid_fwd(self._head_packed.data_ptr(), C.byref(lat), tm.data_ptr(), nx,
                                               C.c_float(box), out.data_ptr(), self.n_slices, self._prec(),
                                               ws.data_ptr(), nb, self._stream()), "s3d_gt_decode_grid_fwd")
-        return out
+        return out.view(nx, nx, nx)
 
     def forward(self, feed_dict):
         """model_gt.py:59-111 -> {'sdf_pred': (B,Q)}.  Unlike the reference, 'test' mode does not modify

@@ -58,4 +58,5 @@ def test_gt_dense_grid_equals_point_decode():
     lin = torch.linspace(-0.5, 0.5, nx, device="cuda")
     pts = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(1, -1, 3)
     sdf = m.decode_sdf(pts, code, trans_mat_wo_rot_tp=fd["trans_mat_wo_rot_tp"], mode="test")
-    assert (logits + sdf.reshape(-1)).abs().max() < 2e-5
+    assert logits.shape == (nx, nx, nx)
+    assert (logits.reshape(-1) + sdf.reshape(-1)).abs().max() < 2e-5
