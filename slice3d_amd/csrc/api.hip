@@ -542,6 +542,7 @@ HeadLayout head_layout() {
         H.L[l].ln2b = take(128);
         H.L[l].wf16 = take((size_t)S3D_FFN_NCHUNK * 8192);
         H.L[l].af16 = take((size_t)(96 + 32) * 512);
+        H.L[l].aq16 = take((size_t)(96 + 32) * 512);
     }
     H.fco_w = take(128);
     H.fco_b = take(4);
@@ -577,6 +578,7 @@ static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLa
         TRY(copy_vec(b + H.L[l].ln2b, p.norm2_b, 128, st));
         TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wf16, st));
         TRY(launch_pack_attn_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].af16, st));
+        TRY(launch_pack_attn_q_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].aq16, st));
     }
     return 0;
 }
@@ -663,7 +665,16 @@ static LayerPtrs layer_ptrs(const float* b, const HeadLayout& H, int l) {
     p.w2 = b + H.L[l].w2; p.b2 = b + H.L[l].b2; p.ln2g = b + H.L[l].ln2g; p.ln2b = b + H.L[l].ln2b;
     p.wf16 = b + H.L[l].wf16;
     p.af16 = b + H.L[l].af16;
+    p.aq16 = b + H.L[l].aq16;
     return p;
+}
+
+static bool attn_query_major() {   // S3D_ATTN_Q=0 selects the token-major kernel for every layer (A/B timing)
+    static const int on = [] {
+        const char* e = getenv("S3D_ATTN_Q");
+        return e ? atoi(e) : 1;
+    }();
+    return on != 0;
 }
 
 static int decode_impl(const void* head_packed, const S3dLatent* lat, const float* qry, const float* rot,
@@ -712,7 +723,9 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
             const bool last = l == S3D_N_LAYERS - 1;
             {
                 ProfScope prof_(S3D_PROF_ATTN, st);
-                if (prec == S3D_PREC_F16X3)
+                if (prec == S3D_PREC_F16X3 && !last && attn_query_major())
+                    TRY(launch_attn_layer_q(X, gc, T, lp, st));
+                else if (prec == S3D_PREC_F16X3)
                     TRY(launch_attn_layer_f16x3(X, last ? X0 : nullptr, gc, T, lp, st));
                 else
                     TRY(launch_attn_layer(X, last ? X0 : nullptr, gc, T, lp, st));

@@ -17,6 +17,7 @@ struct HeadLayout {
         size_t inw, inb, outw, outb, ln1g, ln1b;
         size_t w1, b1, w2, b2, ln2g, ln2b;   // w1: [128 tiles][8] image; w2: chunked [64][8][2] image
         size_t wf16;                         // f16 hi/lo chunk image of lin1/lin2 (64 x 32 KiB), decode_f16.hip
+        size_t aq16;                         // in_proj / out_proj fragments of the query-major attention kernel
         size_t af16;                         // f16 hi/lo fragment pairs of in_proj (96) and out_proj (32)
     } L[S3D_N_LAYERS];
     size_t fco_w, fco_b;
@@ -25,7 +26,7 @@ struct HeadLayout {
 HeadLayout head_layout();
 
 struct LayerPtrs {
-    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b, *wf16, *af16;
+    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b, *wf16, *af16, *aq16;
 };
 
 struct SampleArgs {
@@ -116,6 +117,8 @@ int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipS
 int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
                                  const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
                                  hipStream_t stream);
+int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream);
+int launch_pack_attn_q_f16x3(const float* win, const float* wout, float* out, hipStream_t stream);
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
                            long g_begin, const int* perm, hipStream_t stream);

@@ -1,0 +1,328 @@
+// decode_attnq.hip — self-attention block of one encoder layer, query-major tiling (split precision):
+//     X <- LN1(X + out_proj(MHA(X)))        X: [group][T tokens][16 queries][128]
+//
+// The 13 tokens of ONE query attend only to each other, so a 16-row MFMA tile is made of the T tokens of a
+// single query (rows T..15 are padding) instead of 16 queries of one token.  Every wave owns two queries of
+// the 16-query group and does everything for them — QKV, the 13x13 attention, out_proj, residual, LayerNorm —
+// without exchanging anything with the other waves:
+//   Q^T, K^T  swapped form   D^T = W X^T   (f16x3 MFMA): lane (token, g) holds head dims {16j + 4g + i}
+//   V         plain form     D   = X W^T   (same fragments, operands exchanged): lane (dim, g) holds tokens 4g+i
+//   S^T = K Q^T   fp32 MFMA 16x16x4: the k-slot of lane g at step (j,i) is dim 16j+4g+i — exactly the Q / K registers
+//   softmax over the keys = registers i and lane groups g of one query column (two shuffles)
+//   O^T = V^T P^T fp32 MFMA: A = the V registers, B = the P registers; result lane (token, g) holds dims 4g+i
+//   out_proj      f16x3 MFMA: O^T registers are its B operand (k-slot 8g+t <-> dim 16(t>>2) + 4g + (t&3), folded
+//                 into the packed W_o columns), accumulated over heads
+// No Q/K/V/O ever touches LDS; LDS holds only the in_proj fragments of the current and the next head (LDS-DMA ring,
+// one barrier per head instead of three barriers + three exchanges).  13 of 16 tile rows are useful (19 % padding);
+// the token-0-pruned last layer keeps the token-major kernel (decode_f16.hip), where pruning skips whole tiles.
+#include "decode.h"
+
+typedef _Float16 half8q __attribute__((ext_vector_type(8)));
+
+#define AQ_WIN_HALFS (24 * 1024)   // per head: 24 fragment pairs (q0,q1,k0,k1,v0,v1) x 4 k-steps, hi|lo = 48 KiB
+#define AQ_WO_HALFS (8 * 1024)     // per head: 8 fragment pairs = 16 KiB
+#define AQ_STEP_HALFS (AQ_WIN_HALFS + AQ_WO_HALFS)   // one ring slot: 64 KiB
+
+__device__ __forceinline__ half8q ldq8(const _Float16* p) { return *reinterpret_cast<const half8q*>(p); }
+__device__ __forceinline__ void splitq8(const float (&x)[8], half8q& hi, half8q& lo) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const _Float16 h = (_Float16)x[t];
+        hi[t] = h;
+        lo[t] = (_Float16)(x[t] - (float)h);
+    }
+}
+__device__ __forceinline__ f32x4 mfma3q(const half8q ah, const half8q al, const half8q bh, const half8q bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ float colsum16(float v) {   // sum over the 4 lane groups g of one column (l & 15)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float colmax16(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups, int T, const _Float16* wimg,
+                                                           const LayerPtrs w) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // 2 x 64 KiB ring: in_proj | out_proj fragments of a head
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const float scale = 0.17677669529663687f;   // 1/sqrt(32)
+    const _Float16* g_in = wimg;
+    const _Float16* g_out = wimg + 4 * AQ_WIN_HALFS;
+    auto dma_head = [&](int h, int buf) {
+        const _Float16* gs = g_in + (size_t)h * AQ_WIN_HALFS;
+        const _Float16* go = g_out + (size_t)h * AQ_WO_HALFS;
+        for (int i = wave; i < 64; i += 8) {
+            const _Float16* src = i < 48 ? gs + i * 512 : go + (i - 48) * 512;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
+                                             (__attribute__((address_space(3))) void*)(s_win + buf * AQ_STEP_HALFS + i * 512),
+                                             16, 0, 0);
+        }
+    };
+    // (group, head) steps form one sequence; the fragments of step s+1 are requested at the start of step s
+    long step = 0;
+    if ((long)blockIdx.x < groups) dma_head(0, 0);
+    const bool row_ok = m < T;
+    const int mt = row_ok ? m : T - 1;   // padding rows read a valid token, their results are never stored
+
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        float* Xg = X + grp * T * S3D_GROUP * 128;
+        f32x4 acc_o[2][8];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc_o[r][j] = zero4();
+#pragma unroll 1
+        for (int h = 0; h < 4; ++h, ++step) {
+            __syncthreads();   // fragments of this step have landed (vmcnt drained); the other buffer is free
+            // biases first: vmcnt retires in order, a load issued after the DMA request would wait for all of it
+            f32x4 bq[2], bk[2];
+            float bv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bq[j] = ld4(w.inb + 32 * h + 16 * j + 4 * g);
+                bk[j] = ld4(w.inb + 128 + 32 * h + 16 * j + 4 * g);
+                bv[j] = w.inb[256 + 32 * h + 16 * j + m];
+            }
+            // the activation fragments are re-read per head (L2) rather than held across heads: 64 registers that
+            // the fragment pipeline below needs; like the biases they are requested ahead of the DMA
+            half8q xh[2][4], xl[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float* p = Xg + (mt * S3D_GROUP + 2 * wave + r) * 128 + 8 * g;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
+                    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                    splitq8(v, xh[r][u], xl[r][u]);
+                }
+            }
+            {
+                const bool more_h = h < 3, more_g = grp + gridDim.x < groups;
+                if (more_h || more_g) dma_head(more_h ? h + 1 : 0, (int)((step + 1) & 1));
+            }
+            const _Float16* sw = s_win + (step & 1) * AQ_STEP_HALFS;
+            // ---- Q^T, K^T (swapped) and V (plain) of both query tiles: 6 x 4 fragment pairs ----
+            f32x4 qd[2][2], kd[2][2], vd[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    qd[r][j] = zero4();
+                    kd[r][j] = zero4();
+                    vd[r][j] = zero4();
+                }
+            // software pipeline over the 8 fragment batches (q,k of k-step u | v of k-step u): the LDS reads of
+            // the next batch are issued before the MFMAs of the current one (sched_barrier pins that order)
+            half8q ah[4], al[4], bh2[2], bl2[2];
+            auto load_qk = [&](int u) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    ah[f] = ldq8(sw + (f * 4 + u) * 1024 + lane * 8);
+                    al[f] = ldq8(sw + (f * 4 + u) * 1024 + 512 + lane * 8);
+                }
+            };
+            auto load_v = [&](int u) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    bh2[f] = ldq8(sw + ((4 + f) * 4 + u) * 1024 + lane * 8);
+                    bl2[f] = ldq8(sw + ((4 + f) * 4 + u) * 1024 + 512 + lane * 8);
+                }
+            };
+            load_qk(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                load_v(u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        qd[r][j] = mfma3q(ah[j], al[j], xh[r][u], xl[r][u], qd[r][j]);
+                        kd[r][j] = mfma3q(ah[2 + j], al[2 + j], xh[r][u], xl[r][u], kd[r][j]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u < 3) load_qk(u + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) vd[r][j] = mfma3q(xh[r][u], xl[r][u], bh2[j], bl2[j], vd[r][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // first half of the out_proj fragments travels under the attention math
+            const _Float16* gw = sw + AQ_WIN_HALFS;
+            half8q wh[4], wl[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                wh[jj] = ldq8(gw + jj * 1024 + lane * 8);
+                wl[jj] = ldq8(gw + jj * 1024 + 512 + lane * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // biases: q,k rows 16j + 4g + i of the head; v column 16j + m
+            half8q oh[2], ol[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    qd[r][j] = (qd[r][j] + bq[j]) * scale;
+                    kd[r][j] = kd[r][j] + bk[j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) vd[r][j][i] += bv[j];
+                }
+                // S^T[tk][tq] = sum_dims K[tk] Q[tq]: lane (tq = m, g) gets keys tk = 4g + i
+                f32x4 s = zero4();
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kd[r][j][i], qd[r][j][i], s, 0, 0, 0);
+                float e[4];
+                float mx = -1e30f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    e[i] = (4 * g + i < T) ? s[i] : -1e30f;
+                    mx = fmaxf(mx, e[i]);
+                }
+                mx = colmax16(mx);
+                float den = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    e[i] = (4 * g + i < T) ? expf(e[i] - mx) : 0.f;
+                    den += e[i];
+                }
+                const float inv = 1.f / colsum16(den);
+                // O^T[d][tq] = sum_tk V[tk][d] P[tq][tk]: A = V registers (lane (d, g): tokens 4g+i), B = P registers
+                f32x4 od[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 o = zero4();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vd[r][j][i], e[i] * inv, o, 0, 0, 0);
+                    od[j] = o;
+                }
+                const float ov[8] = {od[0][0], od[0][1], od[0][2], od[0][3], od[1][0], od[1][1], od[1][2], od[1][3]};
+                splitq8(ov, oh[r], ol[r]);
+            }
+            // ---- out_proj partial sums of this head ----
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc_o[r][jj] = mfma3q(wh[jj], wl[jj], oh[r], ol[r], acc_o[r][jj]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                wh[jj] = ldq8(gw + (4 + jj) * 1024 + lane * 8);
+                wl[jj] = ldq8(gw + (4 + jj) * 1024 + 512 + lane * 8);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc_o[r][4 + jj] = mfma3q(wh[jj], wl[jj], oh[r], ol[r], acc_o[r][4 + jj]);
+        }
+        // ---- residual + LayerNorm1 (columns 32*(j>>1) + 8g + 4*(j&1) + i), store ----
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            f32x4 y[8];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
+                const f32x4 bo = ld4(w.outb + col);
+                const f32x4 xr = ld4(Xg + (mt * S3D_GROUP + 2 * wave + r) * 128 + col);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    y[j][i] = acc_o[r][j][i] + bo[i] + xr[i];
+                    s += y[j][i];
+                }
+            }
+            const float mean = colsum16(s) * (1.f / 128.f);
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float dd = y[j][i] - mean;
+                    v += dd * dd;
+                }
+            const float rstd = 1.f / sqrtf(colsum16(v) * (1.f / 128.f) + 1e-5f);
+            float* o = Xg + (mt * S3D_GROUP + 2 * wave + r) * 128;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
+                const f32x4 ga = ld4(w.ln1g + col), be = ld4(w.ln1b + col);
+                f32x4 rr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rr[i] = (y[j][i] - mean) * rstd * ga[i] + be[i];
+                if (row_ok) st4(o + col, rr);
+            }
+        }
+    }
+}
+
+int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream) {
+    if (groups <= 0) return 0;
+    S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr, "attn_q: T %d", T);
+    const size_t lds = (size_t)2 * AQ_STEP_HALFS * 2;   // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long blocks = groups < 2048 ? groups : 2048;
+    hipLaunchKernelGGL(attn_layer_q_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, X, groups, T,
+                       reinterpret_cast<const _Float16*>(w.aq16), w);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// in_proj (384,128) / out_proj (128,128) -> fragment pairs (hi 512 halfs | lo 512 halfs each) of the query-major kernel
+//   frag = h*24 + (p*2 + j)*4 + u : row = p*128 + 32h + 16j + (l&15), k = 32u + 8g + t          (p = q,k,v)
+//   frag = 96 + h*8 + jc          : row m <-> output channel 32(jc>>1) + 8(m>>2) + 4(jc&1) + (m&3),
+//                                   k-slot 8g + t <-> head dim 16(t>>2) + 4g + (t&3)
+__global__ void pack_attn_q_f16x3_kernel(const float* __restrict__ win, const float* __restrict__ wout,
+                                         _Float16* __restrict__ out) {
+    const int total = (96 + 32) * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, frag = idx >> 6;
+        const int r = lane & 15, g = lane >> 4;
+        float v[8];
+        if (frag < 96) {
+            const int h = frag / 24, f = frag % 24, u = f & 3, j = (f >> 2) & 1, p = f >> 3;
+            const float* src = win + (size_t)(p * 128 + 32 * h + 16 * j + r) * 128 + 32 * u + 8 * g;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = src[t];
+        } else {
+            const int f = frag - 96, jc = f & 7, h = f >> 3;
+            const int n = 32 * (jc >> 1) + 8 * (r >> 2) + 4 * (jc & 1) + (r & 3);
+            const float* src = wout + (size_t)n * 128 + 32 * h;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = src[16 * (t >> 2) + 4 * g + (t & 3)];
+        }
+        _Float16* dst = out + (size_t)frag * 1024 + lane * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const _Float16 hh = (_Float16)v[t];
+            dst[t] = hh;
+            dst[512 + t] = (_Float16)(v[t] - (float)hh);
+        }
+    }
+}
+
+int launch_pack_attn_q_f16x3(const float* win, const float* wout, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_attn_q_f16x3_kernel, dim3(32), dim3(256), 0, stream, win, wout,
+                       reinterpret_cast<_Float16*>(out));
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
