@@ -235,8 +235,9 @@ extern "C" int s3d_unet_pack(const S3dUNetParams* P, void* packed, size_t packed
     return 0;
 }
 
+#define S3D_SPLITK_FLOATS ((size_t)4718592)
 struct UNetWs {
-    size_t in16, a, b, x[5], p[4], proj, up, mid;
+    size_t in16, a, b, x[5], p[4], proj, up, mid, splitk;
     size_t total;
 };
 static UNetWs unet_ws(int B, int S, int ns) {
@@ -257,6 +258,7 @@ static UNetWs unet_ws(int B, int S, int ns) {
     W.proj = take(px * 32);                 // largest skip projection: (B,S,S,32)
     W.up = take(px * ns * 32);              // largest ConvT output: (B*ns,S,S,32)
     W.mid = take(px * ns * 32);
+    W.splitk = take(S3D_SPLITK_FLOATS);   // split-K partials of the few-pixel encoder layers
     W.total = off;
     return W;
 }
@@ -307,6 +309,7 @@ extern "C" int s3d_unet_encode_fwd(const void* packed, const float* img, const S
         ConvLaunch c = conv_desc(base, L.enc[i], B, res, res, 3, kEncTap[i] ? S3D_ACT_NONE : S3D_ACT_RELU);
         c.nsrc = 1;
         c.src[0] = plain_src(cur, curC);
+        c.splitk_ws = ws + W.splitk; c.splitk_floats = S3D_SPLITK_FLOATS;
         float* dst = kEncTap[i] ? ws + W.x[tap_i] : pp[flip];
         c.out = dst;
         TRY(launch_conv(c, st));

@@ -40,6 +40,8 @@ struct ConvLaunch {
     const float* gate;   // NHWC mode only: v = gate[same index] > 0 ? v * gate_scale : 0  (ReLU/dropout backward)
     float gate_scale;
     unsigned long long drop_base;  // element index of this launch's out[0] in the dropout counter space
+    float* splitk_ws;    // optional scratch for split-K partial sums (few-pixel deep layers); NULL = never split
+    size_t splitk_floats;
     DropCfg drop;        // NHWC mode only: v *= dropout mask (index = output element index), before the residual
 };
 

@@ -11,6 +11,7 @@
 // L2-resident); B fragments (activations) are 16-byte per-lane loads from the NHWC tensors, zero for
 // padding taps.  fp32 MFMA runs at 256 FLOP/clk/CU, i.e. one 16-byte operand load feeds 128 cycles of
 // MFMA per (MT|NT)-fold reuse, so the operand streams fit the L1/L2 path at this precision.
+#include <stdlib.h>
 #include "conv.h"
 
 template <int MT, int NT>
@@ -254,6 +255,237 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     conv_epilogue<MT, NT>(a, acc, pn, py, px, pv, jt0, g);
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-staged 3x3 convolution (stride 1, "same"), split precision.
+// A workgroup (4 waves) owns an 8-row x 16-column pixel tile of one image and CO_WG output channels.  Per
+// 32-channel K chunk the (8+2) x (16+2) input halo is fetched ONCE (coalesced 16 B/lane), split into f16 hi/lo
+// ONCE and parked in LDS ([pixel][40 halfs]: an 80-byte pixel stride makes both the staging writes and the
+// 16-lane fragment reads conflict-free); the nine taps then read their B fragments from LDS at shifted pixel
+// offsets.  The direct kernel above loads and splits every input value 9 x (Cout / CO_WG) times instead.
+// Zero padding = zeros written for halo pixels outside the image.  Waves are arranged WP x WC: wave (wp, wc) owns
+// pixel rows {MT*wp .. +MT-1} of the tile and NT = 2 output-channel tiles; weight fragments come straight from
+// the packed image (L2), requested one tap ahead.  The next chunk's halo is in flight under the MFMAs.
+// ---------------------------------------------------------------------------------------------
+#define C3_PXS 40            // halfs per pixel in LDS (32 + 8 pad)
+#define C3_HALO (10 * 18)    // pixels of the halo tile
+template <int MT, int WP, int WC>
+__global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch a, int tiles_x, int tiles_y,
+                                                                int chunks_per_split) {
+    static_assert(MT * WP == 8 && WP * WC == 4, "tile is 8 rows, 4 waves");
+    constexpr int NT = 2, CO_WG = WC * NT * 16;
+    __shared__ __attribute__((aligned(16))) _Float16 s_in[2][2][C3_HALO * C3_PXS];   // [buf][hi|lo]  57.6 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int wp = wave % WP, wc = wave / WP;
+    const int n_co_blk = a.CoutPad / CO_WG;
+    const int blk_co = blockIdx.x % n_co_blk;
+    int tile = blockIdx.x / n_co_blk;
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty = tile % tiles_y, n = tile / tiles_y;
+    const int x0 = tx * 16, y0 = ty * 8;
+    const int KU32 = a.KU >> 1;
+    const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wpk16);
+    const int jt0 = blk_co * (CO_WG / 16) + wc * NT;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero4();
+
+    // staging role: thread t handles halo slots t, t+256, ... ; slot = pixel * 8 + channel quad
+    constexpr int NSLOT = C3_HALO * 8;              // 1440 float4 per chunk
+    constexpr int NPRE = (NSLOT + 255) / 256;       // 6
+    f32x4 pre[NPRE];
+    auto fetch = [&](const ConvSrc& S, int c) {
+        const int ni = (S.bmod ? n % S.bmod : n) / S.bdiv;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int slot = threadIdx.x + 256 * i;
+            const int pix = slot >> 3, q4 = slot & 7;
+            const int hy = pix / 18, hx = pix - hy * 18;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            const bool ok = slot < NSLOT && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const long off = ((long)(ni * a.H + (ok ? y : 0)) * a.W + (ok ? x : 0)) * S.C + 32 * c + 4 * q4;
+            const f32x4 v = ld4(S.p + off);           // always a valid address; masked below
+            pre[i] = ok ? v : zero4();
+        }
+    };
+    auto park = [&](int buf) {
+        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int slot = threadIdx.x + 256 * i;
+            if (slot < NSLOT) {
+                const int pix = slot >> 3, q4 = slot & 7;
+                half4_t hi, lo;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const _Float16 h = (_Float16)pre[i][t];
+                    hi[t] = h;
+                    lo[t] = (_Float16)(pre[i][t] - (float)h);
+                }
+                *reinterpret_cast<half4_t*>(&s_in[buf][0][pix * C3_PXS + 4 * q4]) = hi;
+                *reinterpret_cast<half4_t*>(&s_in[buf][1][pix * C3_PXS + 4 * q4]) = lo;
+            }
+        }
+    };
+
+    // flat chunk sequence over the sources
+    const int cu0 = a.src[0].C >> 5, cu1 = a.nsrc > 1 ? a.src[1].C >> 5 : 0;
+    // split-K: blockIdx.y owns chunks [ch_lo, ch_hi) and writes raw partial sums (deep layers have few pixels)
+    const int ch_lo = blockIdx.y * chunks_per_split;
+    const int nchunk = min(cu0 + cu1, ch_lo + chunks_per_split);
+    fetch(a.src[ch_lo < cu0 ? 0 : 1], ch_lo < cu0 ? ch_lo : ch_lo - cu0);
+    park(ch_lo & 1);
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = ch_lo; ch < nchunk; ++ch) {
+        const int s = ch < cu0 ? 0 : 1, c = s ? ch - cu0 : ch, cu = s ? cu1 : cu0;
+        const int ubase = s ? 9 * cu0 : 0;
+        const _Float16* wp0 = wimg + ((size_t)jt0 * KU32 + ubase + c) * 1024 + lane * 8;   // + tap*cu*1024, + nt*KU32*1024
+        // weight fragments of tap 0 are requested BEFORE the halo prefetch (vmcnt retires in order)
+        chalf8 wh[NT], wl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const _Float16* f = wp0 + (size_t)nt * KU32 * 1024;
+            wh[nt] = *reinterpret_cast<const chalf8*>(f);
+            wl[nt] = *reinterpret_cast<const chalf8*>(f + 512);
+        }
+        if (ch + 1 < nchunk) {
+            const int s1 = ch + 1 < cu0 ? 0 : 1;
+            fetch(a.src[s1], s1 ? ch + 1 - cu0 : ch + 1);
+        }
+        const _Float16* sh = s_in[ch & 1][0];
+        const _Float16* sl = s_in[ch & 1][1];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;   // halo-relative: output (r, m) reads halo (r + dy, m + dx)
+            chalf8 nwh[NT], nwl[NT];
+            if (tap < 8) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const _Float16* f = wp0 + ((size_t)nt * KU32 + (size_t)(tap + 1) * cu) * 1024;
+                    nwh[nt] = *reinterpret_cast<const chalf8*>(f);
+                    nwl[nt] = *reinterpret_cast<const chalf8*>(f + 512);
+                }
+            }
+            chalf8 bh[MT], bl[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int pix = (MT * wp + mt + dy) * 18 + m + dx;
+                bh[mt] = *reinterpret_cast<const chalf8*>(sh + pix * C3_PXS + 8 * g);
+                bl[mt] = *reinterpret_cast<const chalf8*>(sl + pix * C3_PXS + 8 * g);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bl[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+            }
+            if (tap < 8) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    wh[nt] = nwh[nt];
+                    wl[nt] = nwl[nt];
+                }
+            }
+        }
+        if (ch + 1 < nchunk) park((ch + 1) & 1);
+        __syncthreads();
+    }
+    int pn[MT], py[MT], px[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        pn[mt] = n;
+        py[mt] = y0 + MT * wp + mt;
+        px[mt] = x0 + m;
+        pv[mt] = py[mt] < a.H && px[mt] < a.W;
+    }
+    if (gridDim.y > 1) {   // partial[split][pixel][CoutPad]
+        float* part = a.splitk_ws + (size_t)blockIdx.y * ((size_t)a.N * a.H * a.W * a.CoutPad);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            if (pv[mt]) {
+                float* o = part + ((size_t)(n * a.H + py[mt]) * a.W + px[mt]) * a.CoutPad + 4 * g;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) st4(o + (jt0 + nt) * 16, acc[mt][nt]);
+            }
+        return;
+    }
+    conv_epilogue<MT, NT>(a, acc, pn, py, px, pv, jt0, g);
+}
+
+// sums the split-K partials of 4 consecutive output channels of one pixel and applies the conv epilogue
+__global__ void conv_splitk_finish_kernel(const ConvLaunch a, int nsplit) {
+    const long P = (long)a.N * a.H * a.W;
+    const int cq = a.CoutPad >> 2;
+    const long total = P * cq;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long p = idx / cq;
+        const int co = (int)(idx - p * cq) * 4;
+        f32x4 s = zero4();
+        for (int k = 0; k < nsplit; ++k) s += ld4(a.splitk_ws + ((size_t)k * P + p) * a.CoutPad + co);
+        f32x4 acc[1][1] = {{s}};
+        const int n = (int)(p / ((long)a.H * a.W));
+        const int r = (int)(p - (long)n * a.H * a.W);
+        const int pn[1] = {n}, py[1] = {r / a.W}, px[1] = {r % a.W};
+        const bool pv[1] = {true};
+        conv_epilogue<1, 1>(a, acc, pn, py, px, pv, co >> 4, (co >> 2) & 3);
+    }
+}
+
+static bool conv3x3_lds_eligible(const ConvLaunch& a) {
+    if (a.ks != 3 || a.stride > 1 || (a.Hin && a.Hin != a.H) || (a.Win && a.Win != a.W)) return false;
+    if (!a.wpk16 || a.KU % 2 || a.W < 16 || a.H < 8 || a.CoutPad % 32) return false;
+    for (int s = 0; s < a.nsrc; ++s)
+        if (a.src[s].C % 32 || a.src[s].sbcast) return false;
+    static const int on = [] {
+        const char* e = getenv("S3D_CONV_LDS");
+        return e ? atoi(e) : 1;
+    }();
+    return on != 0;
+}
+static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
+    const long tiles = (long)tiles_x * tiles_y * a.N;
+    const int co_wg = a.CoutPad % 64 == 0 ? 64 : 32;
+    const long nblk = tiles * (a.CoutPad / co_wg);
+    S3D_CHECK_ARG(nblk < (1L << 31), "conv grid out of range (%ld)", nblk);
+    int nchunk = 0;
+    for (int s = 0; s < a.nsrc; ++s) nchunk += a.src[s].C >> 5;
+    // split-K when the pixel x channel tiling cannot fill the chip (deep encoder layers at batch 1)
+    int splits = 1;
+    const size_t out_floats = (size_t)a.N * a.H * a.W * a.CoutPad;
+    if (a.splitk_ws && a.out_mode == S3D_OUT_NHWC) {
+        while (nblk * splits < 512 && splits * 2 <= nchunk && (size_t)(splits * 2) * out_floats <= a.splitk_floats)
+            splits *= 2;
+    }
+    const int cps = (nchunk + splits - 1) / splits;
+    splits = (nchunk + cps - 1) / cps;
+    dim3 grid((unsigned)nblk, (unsigned)splits);
+    if (co_wg == 64)
+        hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<4, 2, 2>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
+    else
+        hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<2, 4, 1>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
+    S3D_LAUNCH_CHECK();
+    if (splits > 1) {
+        const long total = (long)(out_floats >> 2);
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(blocks), dim3(256), 0, stream, a, splits);
+        S3D_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 template <int MT, int NT, int WM, int WN>
 static int launch_cfg(const ConvLaunch& a, hipStream_t stream) {
     constexpr int PIX_WG = WM * MT * 16, CO_WG = WN * NT * 16;
@@ -288,6 +520,7 @@ int launch_conv(const ConvLaunch& a, hipStream_t stream) {
     S3D_CHECK_ARG(a.CoutPad % 16 == 0 && a.CoutPad > 0, "conv: CoutPad %d", a.CoutPad);
     for (int s = 0; s < a.nsrc; ++s)
         S3D_CHECK_ARG(a.src[s].C % 16 == 0 && a.src[s].bdiv >= 1, "conv: bad source %d", s);
+    if (conv3x3_lds_eligible(a)) return launch_conv3x3_lds(a, stream);
     const long P = (long)a.N * a.H * a.W;
     // Tile menu: (pixels x couts) per workgroup of 4 waves.  Prefer the largest tile that still
     // yields >= ~2 workgroups per CU; small late-encoder maps fall through to the small tiles.
