@@ -252,14 +252,28 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int nchun
 // ---------------------------------------------------------------------------------------------
 #define FWR_XLD 136   // halfs per row of the row-major R tile (128 + 8 pad)
 template <int COLSUM>
-__global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArgs a, int steps_per_split) {
+__global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArgs a, int steps_per_split, int nsplit) {
     __shared__ __attribute__((aligned(16))) _Float16 s_d[2][128 * WL_LD];    // D^T hi|lo       20 KiB
     __shared__ __attribute__((aligned(16))) _Float16 s_z[2][128 * WL_LD];    // Z^T hi|lo       20 KiB
     __shared__ __attribute__((aligned(16))) _Float16 s_r[2][32 * FWR_XLD];   // R row-major     17 KiB
     __shared__ unsigned s_m[128];                                            // [row][g] mask dwords of this block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
-    const int hb = blockIdx.x;
+    // 1-D grid of 16 hidden blocks x nsplit row ranges.  Workgroups are dealt to the 8 XCDs round-robin; remap so
+    // that the 16 hidden blocks of one row range run on ONE XCD back to back: they read the same D / R rows, which
+    // then come from that XCD's L2 once instead of from the fabric 16 times (21 GB -> 1.3 GB per launch).
+    int hb, split;
+    {
+        const int L = blockIdx.x, nb = S3D_FFN / 128;
+        if (nsplit % 8 == 0) {
+            const int xcd = L & 7, k = L >> 3;
+            hb = k % nb;
+            split = (k / nb) * 8 + xcd;
+        } else {
+            hb = L % nb;
+            split = L / nb;
+        }
+    }
     const int ch = tid & 127, rg = tid >> 7;      // gather role: channel, row group
     const int rrow = tid >> 3, rcq = tid & 7;     // row-major role: row, channel quad
     const int wn = wave & 1, wc = wave >> 1;
@@ -311,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
             pm = a.mask[mr * 64 + (tid & 3) * 16 + hb];
         }
     };
-    const long p_begin = (long)blockIdx.y * steps_per_split * 32;
+    const long p_begin = (long)split * steps_per_split * 32;
     gload(p_begin);
     for (int it = 0; it < steps_per_split; ++it) {
         const long pb = p_begin + (long)it * 32;
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
         __syncthreads();
     }
     // partial[split][q][hidden]
-    float* part = a.partial + (size_t)blockIdx.y * 128 * S3D_FFN;
+    float* part = a.partial + (size_t)split * 128 * S3D_FFN;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
                 part[(size_t)q * S3D_FFN + hid] = acc[i][j][reg];
             }
     if (COLSUM) {
-        float* cp = a.partial + (size_t)gridDim.y * 128 * S3D_FFN + (size_t)blockIdx.y * S3D_FFN;
+        float* cp = a.partial + (size_t)nsplit * 128 * S3D_FFN + (size_t)split * S3D_FFN;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             float v = csum[e];
@@ -482,11 +496,11 @@ int launch_ffn_wgrad_rec(const FfnWgradArgs& a, hipStream_t stream) {
     }
     const int spw = (int)((total_steps + splits - 1) / splits);
     splits = (total_steps + spw - 1) / spw;
-    dim3 grid(S3D_FFN / 128, (unsigned)splits);
+    dim3 grid((unsigned)((S3D_FFN / 128) * splits));
     if (a.bias_out)
-        hipLaunchKernelGGL((ffn_wgrad_rec_kernel<1>), grid, dim3(256), 0, stream, a, spw);
+        hipLaunchKernelGGL((ffn_wgrad_rec_kernel<1>), grid, dim3(256), 0, stream, a, spw, (int)splits);
     else
-        hipLaunchKernelGGL((ffn_wgrad_rec_kernel<0>), grid, dim3(256), 0, stream, a, spw);
+        hipLaunchKernelGGL((ffn_wgrad_rec_kernel<0>), grid, dim3(256), 0, stream, a, spw, (int)splits);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(ffn_wgrad_rec_reduce_kernel, dim3(1024), dim3(256), 0, stream, a.partial, (int)splits, a.out,
                        a.transpose_out, a.accumulate);
