@@ -13,14 +13,19 @@ struct DropCfg {
     int site;
 };
 
+// 32-bit mixing only (three multiply / xor-shift rounds of the murmur3 finaliser on the folded counter): the
+// FFN forward draws 2 176 masks per token row, 64-bit multiplies there cost a millisecond per layer.
 __host__ __device__ inline unsigned s3d_hash32(unsigned long long seed, int site, unsigned long long idx) {
-    unsigned long long x = idx * 0x9E3779B97F4A7C15ull + seed + (unsigned long long)(site + 1) * 0xD1B54A32D192ED03ull;
-    x ^= x >> 32;
-    x *= 0xD6E8FEB86659FD93ull;
-    x ^= x >> 32;
-    x *= 0xD6E8FEB86659FD93ull;
-    x ^= x >> 32;
-    return (unsigned)x;
+    unsigned x = (unsigned)idx ^ ((unsigned)(idx >> 32) * 0x9E3779B1u) ^ (unsigned)seed ^
+                 ((unsigned)(seed >> 32) * 0x85EBCA77u) ^ ((unsigned)(site + 1) * 0xC2B2AE3Du);
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    x *= 0x9E3779B1u;
+    x ^= x >> 15;
+    return x;
 }
 __host__ __device__ inline float s3d_drop(const DropCfg& d, unsigned long long idx) {
     return s3d_hash32(d.seed, d.site, idx) >= d.thresh ? d.scale : 0.f;
