@@ -6,7 +6,7 @@
 // so the result is fp32-class (measured against the fp32 path in tests) at 3 MFMAs of 16 cycles per
 // 16x16x32 block instead of 8 MFMAs of 32 cycles — 5.3x fewer matrix-pipe cycles than the f32 kernel.
 //
-// Structure is that of ffn_layer_kernel (decode.hip): 256 rows per workgroup, activations live in
+// Structure is that of ffn_layer_kernel (decode.hip): 128 rows per 4-wave workgroup, activations live in
 // registers as B fragments (now f16 hi/lo pairs), W1/W2 stream through LDS in 32-hidden-unit chunks,
 // the hidden tile never leaves registers.  For K=32 MFMAs a lane (m = l&15, g = l>>4) owns the 8
 // consecutive channels {32u + 8g .. +7}; the output-channel permutation of W2's rows is chosen so that
