@@ -215,6 +215,38 @@ int s3d_gt_decode_grid_fwd(const void* head_packed, const S3dGtLatent* latent, c
                            size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Latent-diffusion denoising U-Net primitives — gen_slices/ldm/modules/diffusionmodules/openaimodel.py
+ * (BASELINE configs[4]).  The reference builds UNetModel from nn.Conv2d / GroupNorm32 / SiLU /
+ * QKVAttentionLegacy / F.interpolate / avg_pool2d; the host mirror (slice3d_amd/ldm_unet.py) builds the same
+ * module tree over these entry points.  All tensors channels-last fp32; C padded to a multiple of 16 where a
+ * convolution reads it.
+ * ------------------------------------------------------------------------------------------- */
+/* nn.Conv2d(cin0+cin1, cout, ks, padding=ks/2) on cat([x0, x1], channel) (openaimodel.py:772 th.cat + conv), also
+ * nn.Conv1d(k=1) over tokens (qkv / proj_out, :291,:299) and the ResBlock skip 1x1 (:240). */
+size_t s3d_conv_packed_bytes(int cout, int cin0, int cin1, int ks);
+int s3d_conv_pack(const float* w, const float* bias, int cout, int cin0, int cin1, int ks, void* packed,
+                  size_t packed_bytes, void* stream);
+int s3d_conv_fwd(const void* packed, const float* x0, const float* x1, const float* residual, float* out, int N,
+                 int H, int W, int cout, int cin0, int cin1, int ks, int prec, void* workspace,
+                 size_t workspace_bytes, void* stream);
+/* GroupNorm32 (util.py normalization) [+ FiLM: y*(1+scale)+shift, film = (N, 2C), openaimodel.py:268-270] [+ SiLU].
+ * stats: (N, groups, 2) scratch. */
+int s3d_group_norm_fwd(const float* x, const float* gamma, const float* beta, const float* film, float* y,
+                       float* stats, int N, int HW, int C, int groups, float eps, int silu, void* stream);
+/* QKVAttentionLegacy.forward (openaimodel.py:362-377): qkv (N, T, heads*3*ch) -> out (N, T, heads*ch) */
+int s3d_qkv_attention_fwd(const float* qkv, float* out, int N, int T, int heads, int ch, void* stream);
+/* Upsample / Downsample with use_conv=False (openaimodel.py:108-158): up != 0: nearest 2x; else 2x2 average pool */
+int s3d_resample2x_fwd(const float* x, float* y, int N, int H, int W, int C, int up, void* stream);
+/* linear(SiLU?(x)): time_embed (:506-510) and ResBlock.emb_layers (:222-228); x (N,K), w (M,K) */
+int s3d_small_linear_fwd(const float* x, const float* w, const float* b, float* out, int N, int K, int M,
+                         int silu_in, void* stream);
+/* timestep_embedding (util.py:151-170) */
+int s3d_timestep_embedding_fwd(const float* t, float* out, int N, int dim, float max_period, void* stream);
+/* out = a + b (c_fmaps injection, openaimodel.py:735-746) */
+int s3d_add_fwd(const float* a, const float* b, float* out, long n, void* stream);
+int s3d_nchw_to_nhwc_pad(const float* in, float* out, int n, int c, int h, int w, int cpad, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Training step — replaces train_step (reg_slices/train.py:41-53): train-mode forward (batch-statistic
  * BatchNorm with the running-stat update, unet_parts.py:17,20), the three losses of cal_loss_pred
  * (train.py:29-39) + cal_acc (train.py:21-27), backward of everything, and Adam (train.py:136).

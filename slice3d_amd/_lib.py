@@ -104,6 +104,16 @@ SYMBOLS = {
     "s3d_gt_decode_points_fwd": (_i, [_vp, C.POINTER(S3dGtLatent), _vp, _vp, _vp, _i, _vp, _i, _l, _i, _i,
                                       _vp, _sz, _vp]),
     "s3d_gt_decode_grid_fwd": (_i, [_vp, C.POINTER(S3dGtLatent), _vp, _i, _f, _vp, _i, _i, _vp, _sz, _vp]),
+    "s3d_conv_packed_bytes": (_sz, [_i, _i, _i, _i]),
+    "s3d_conv_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "s3d_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "s3d_group_norm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "s3d_qkv_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "s3d_resample2x_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "s3d_small_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "s3d_timestep_embedding_fwd": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "s3d_add_fwd": (_i, [_vp, _vp, _vp, _l, _vp]),
+    "s3d_nchw_to_nhwc_pad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "s3d_vgg_packed_bytes": (_sz, []),
     "s3d_vgg_pack": (_i, [C.POINTER(S3dVggParams), _vp, _sz, _vp]),
     "s3d_vgg_workspace_bytes": (_sz, [_i, _i]),

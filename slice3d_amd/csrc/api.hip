@@ -9,6 +9,7 @@
 #include "conv.h"
 #include "decode.h"
 #include "train.h"
+#include "ldm_ops.h"
 
 static thread_local char g_err[512] = "";
 
@@ -834,4 +835,5 @@ extern "C" int s3d_nhwc_to_nchw(const float* in, float* out, int n, int c, int h
 }
 
 #include "api_gt.inc"
+#include "api_ldm.inc"
 #include "api_train.inc"

@@ -1,0 +1,312 @@
+// ldm_ops.hip — primitives of the latent-diffusion denoising U-Net (gen_slices/ldm/modules/diffusionmodules/
+// openaimodel.py: ResBlock :160-275, AttentionBlock :278-331, QKVAttentionLegacy :353-381, Upsample/Downsample
+// :90-158, timestep_embedding util.py) on channels-last fp32 tensors.  Convolutions and the 1x1 qkv / proj
+// "conv1d"s run on the conv engine (conv.hip); this file adds GroupNorm(32)+SiLU(+FiLM), the spatial
+// self-attention, nearest-2x upsampling, 2x2 average pooling, the small timestep-embedding linears.
+#include "ldm_ops.h"
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm(32, C): statistics per (image, group) over HW x (C/32) values, two passes (mean, then variance
+// around it) in fp32 — what torch's native_group_norm computes in float32.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int HW, int C, int groups,
+                                                       float eps, float* __restrict__ stats) {
+    __shared__ float red[4];
+    const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
+    const int cpg = C / groups;
+    const float* base = x + (long)n * HW * C + gidx * cpg;
+    const long total = (long)HW * cpg;
+    auto block_sum = [&](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    float s = 0.f;
+    for (long i = threadIdx.x; i < total; i += 256) s += base[(i / cpg) * C + i % cpg];
+    const float mean = block_sum(s) / (float)total;
+    float v = 0.f;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const float d = base[(i / cpg) * C + i % cpg] - mean;
+        v += d * d;
+    }
+    const float var = block_sum(v) / (float)total;
+    if (threadIdx.x == 0) {
+        stats[2 * blockIdx.x] = mean;
+        stats[2 * blockIdx.x + 1] = 1.f / sqrtf(var + eps);
+    }
+}
+
+// y = gn(x) * gamma + beta ; optional FiLM (ResBlock use_scale_shift_norm): y = y * (1 + scale[n,c]) + shift[n,c]
+// with film = [N][2C] (scale | shift) ; optional SiLU.
+__global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ film, float* __restrict__ y, int N, int HW, int C, int groups,
+                                int silu) {
+    const int c4n = C >> 2, cpg = C / groups;
+    const long total = (long)N * HW * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long p = idx / c4n;
+        const int n = (int)(p / HW);
+        const f32x4 v = ld4(x + p * C + c);
+        const f32x4 ga = ld4(gamma + c), be = ld4(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = (c + i) / cpg;
+            const float m = stats[2 * (n * groups + g)], r = stats[2 * (n * groups + g) + 1];
+            float t = (v[i] - m) * r * ga[i] + be[i];
+            if (film) t = t * (1.f + film[(long)n * 2 * C + c + i]) + film[(long)n * 2 * C + C + c + i];
+            if (silu) t = t / (1.f + expf(-t));
+            o[i] = t;
+        }
+        st4(y + p * C + c, o);
+    }
+}
+
+int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
+                      int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream) {
+    S3D_CHECK_ARG(C % groups == 0 && C % 4 == 0 && N >= 1 && HW >= 1, "group_norm: C=%d groups=%d", C, groups);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups), dim3(256), 0, stream, x, HW, C, groups, eps, stats);
+    S3D_LAUNCH_CHECK();
+    const long total = (long)N * HW * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, stream, x, stats, gamma, beta, film, y, N, HW, C,
+                       groups, silu);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// QKVAttentionLegacy (openaimodel.py:353-381) on the token-major output of the qkv 1x1 conv:
+//   qkv [N][T][heads][3][ch]  ->  out [N][T][heads][ch],  softmax((q s)(k s)^T) v,  s = ch^-1/4, fp32.
+// One workgroup = 64 queries of one (image, head); wave = 16 queries.  Keys / values stream through LDS in
+// blocks of 64 with an online softmax.  S^T = K Q^T and O^T = V^T P^T run on the fp32 16x16x4 MFMA: the S^T
+// registers (lane (query, g): keys 4g+i) are directly the B operand of the second product.
+// ---------------------------------------------------------------------------------------------
+#define QA_KB 64
+template <int CH>
+__global__ __launch_bounds__(256) void qkv_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            int T, int heads) {
+    constexpr int LD = CH + 4;               // padded row: 16 query/key lanes hit 16 distinct bank quads
+    constexpr int DT = (CH + 15) / 16;       // 16-wide tiles of the head dimension (zero padded)
+    constexpr int KS = CH / 4;               // fp32 MFMA k-steps of the q.k contraction
+    __shared__ float s_k[QA_KB * LD], s_v[QA_KB * (DT * 16 + 4)];
+    constexpr int LDV = DT * 16 + 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int qblocks = (T + 63) / 64;
+    const int qb = blockIdx.x % qblocks;
+    const int hh = (blockIdx.x / qblocks) % heads, n = blockIdx.x / (qblocks * heads);
+    const int C3 = heads * 3 * CH;
+    const float* base = qkv + (long)n * T * C3 + hh * 3 * CH;
+    const float scale = 1.f / sqrtf(sqrtf((float)CH));
+    const int q = qb * 64 + wave * 16 + m;
+    const int qc = q < T ? q : T - 1;
+    float qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = base[(long)qc * C3 + 4 * s + g] * scale;
+    f32x4 acc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) acc[d] = zero4();
+    float mx = -1e30f, den = 0.f;
+
+    for (int k0 = 0; k0 < T; k0 += QA_KB) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < QA_KB * (CH / 4); i += 256) {
+            const int key = i / (CH / 4), c4 = (i % (CH / 4)) * 4;
+            const int kc = k0 + key < T ? k0 + key : T - 1;
+            const float* row = base + (long)kc * C3;
+            const f32x4 kv = ld4(row + CH + c4) * scale, vv = ld4(row + 2 * CH + c4);
+            float* dk = s_k + key * LD + c4;
+            float* dv = s_v + key * LDV + c4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                dk[t] = kv[t];
+                dv[t] = vv[t];
+            }
+        }
+        if (CH % 16)   // zero the padded head dims of V
+            for (int i = threadIdx.x; i < QA_KB * (DT * 16 - CH); i += 256)
+                s_v[(i / (DT * 16 - CH)) * LDV + CH + i % (DT * 16 - CH)] = 0.f;
+        __syncthreads();
+        // S^T[key][query]: lane (query m, g) gets keys kt*16 + 4g + i
+        f32x4 sv[4];
+        float bmax = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 s = zero4();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(s_k[(kt * 16 + m) * LD + 4 * ks + g], qf[ks], s, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (k0 + kt * 16 + 4 * g + i >= T) s[i] = -1e30f;
+                bmax = fmaxf(bmax, s[i]);
+            }
+            sv[kt] = s;
+        }
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+        const float mnew = fmaxf(mx, bmax);
+        const float corr = expf(mx - mnew);
+        float bsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p = sv[kt][i] > -1e29f ? expf(sv[kt][i] - mnew) : 0.f;
+                sv[kt][i] = p;
+                bsum += p;
+            }
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        den = den * corr + bsum;
+        mx = mnew;
+        // O^T[d][query] = corr * O^T + sum_key V[key][d] P[query][key]
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            f32x4 o = acc[d] * corr;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(s_v[(kt * 16 + 4 * g + i) * LDV + d * 16 + m], sv[kt][i], o, 0,
+                                                            0, 0);
+            acc[d] = o;
+        }
+    }
+    if (q < T) {
+        const float inv = 1.f / den;
+        float* o = out + ((long)n * T + q) * (heads * CH) + hh * CH;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+            if (d * 16 + 4 * g + 3 < CH) st4(o + d * 16 + 4 * g, acc[d] * inv);
+    }
+}
+
+int launch_qkv_attention(const float* qkv, float* out, int N, int T, int heads, int ch, hipStream_t stream) {
+    S3D_CHECK_ARG(N >= 1 && T >= 1 && heads >= 1, "qkv_attention: bad dims");
+    const int blocks = N * heads * ((T + 63) / 64);
+#define QA_CASE(c)                                                                                          \
+    if (ch == c) {                                                                                          \
+        hipLaunchKernelGGL((qkv_attention_kernel<c>), dim3(blocks), dim3(256), 0, stream, qkv, out, T, heads); \
+        S3D_LAUNCH_CHECK();                                                                                 \
+        return 0;                                                                                           \
+    }
+    QA_CASE(8) QA_CASE(16) QA_CASE(24) QA_CASE(32) QA_CASE(48) QA_CASE(64) QA_CASE(96)
+#undef QA_CASE
+    s3d_set_error("qkv_attention: head width %d not built (8,16,24,32,48,64,96)", ch);
+    return S3D_E_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------
+// resampling (openaimodel.py:90-158, use_conv = False): nearest 2x up / 2x2 average pool, channels-last
+// ---------------------------------------------------------------------------------------------
+__global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+    const int c4n = C >> 2;
+    const long total = (long)N * 4 * H * W * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        long p = idx / c4n;
+        const int ox = (int)(p % (2 * W));
+        p /= 2 * W;
+        const int oy = (int)(p % (2 * H)), n = (int)(p / (2 * H));
+        st4(y + (((long)n * 2 * H + oy) * 2 * W + ox) * C + c, ld4(x + (((long)n * H + oy / 2) * W + ox / 2) * C + c));
+    }
+}
+__global__ void avgpool2x_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+    const int c4n = C >> 2, Ho = H / 2, Wo = W / 2;
+    const long total = (long)N * Ho * Wo * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        long p = idx / c4n;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho), n = (int)(p / Ho);
+        const float* b = x + (((long)n * H + 2 * oy) * W + 2 * ox) * C + c;
+        st4(y + (((long)n * Ho + oy) * Wo + ox) * C + c,
+            ((ld4(b) + ld4(b + C)) + (ld4(b + (long)W * C) + ld4(b + (long)W * C + C))) * 0.25f);
+    }
+}
+int launch_resample2x(const float* x, float* y, int N, int H, int W, int C, int up, hipStream_t stream) {
+    S3D_CHECK_ARG(C % 4 == 0 && N >= 1 && H >= 1 && W >= 1 && (up || (H % 2 == 0 && W % 2 == 0)), "resample2x: bad dims");
+    const long total = up ? (long)N * 4 * H * W * (C / 4) : (long)N * (H / 2) * (W / 2) * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (up)
+        hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks), dim3(256), 0, stream, x, y, N, H, W, C);
+    else
+        hipLaunchKernelGGL(avgpool2x_kernel, dim3(blocks), dim3(256), 0, stream, x, y, N, H, W, C);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense layers on the timestep embedding: out[n][m] = b[m] + sum_k w[m][k] f(x[n][k]),  f = SiLU or id.
+// one wave per output element
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ out, int N,
+                                                           int K, int M, int silu_in) {
+    const int lane = threadIdx.x & 63;
+    const long total = (long)N * M;
+    for (long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6); o < total; o += (long)gridDim.x * 4) {
+        const int n = (int)(o / M), mo = (int)(o % M);
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            float v = x[(long)n * K + k];
+            if (silu_in) v = v / (1.f + expf(-v));
+            s += w[(long)mo * K + k] * v;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (lane == 0) out[o] = s + (b ? b[mo] : 0.f);
+    }
+}
+int launch_small_linear(const float* x, const float* w, const float* b, float* out, int N, int K, int M, int silu_in,
+                        hipStream_t stream) {
+    S3D_CHECK_ARG(N >= 1 && K >= 1 && M >= 1, "small_linear: bad dims");
+    const long total = (long)N * M;
+    const int blocks = (int)((total + 3) / 4 < 4096 ? (total + 3) / 4 : 4096);
+    hipLaunchKernelGGL(small_linear_kernel, dim3(blocks), dim3(256), 0, stream, x, w, b, out, N, K, M, silu_in);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// timestep_embedding (util.py:151-170): [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(max_period) i / half)
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int N, int dim,
+                                          float max_period) {
+    const int half = dim / 2;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N * half; idx += gridDim.x * blockDim.x) {
+        const int n = idx / half, i = idx % half;
+        const float freq = expf(-logf(max_period) * (float)i / (float)half);
+        const float a = t[n] * freq;
+        out[(long)n * dim + i] = cosf(a);
+        out[(long)n * dim + half + i] = sinf(a);
+        if ((dim & 1) && i == 0) out[(long)n * dim + dim - 1] = 0.f;
+    }
+}
+int launch_timestep_embedding(const float* t, float* out, int N, int dim, float max_period, hipStream_t stream) {
+    S3D_CHECK_ARG(N >= 1 && dim >= 2, "timestep_embedding: bad dims");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((N * (dim / 2) + 255) / 256), dim3(256), 0, stream, t, out, N, dim,
+                       max_period);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// out = a + b (c_fmaps injection openaimodel.py:731-746, elementwise glue)
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        st4(out + 4 * i, ld4(a + 4 * i) + ld4(b + 4 * i));
+}
+int launch_add(const float* a, const float* b, float* out, long n, hipStream_t stream) {
+    S3D_CHECK_ARG(n % 4 == 0 && n > 0, "add: n %ld must be a positive multiple of 4", n);
+    const long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(add_kernel, dim3(blocks), dim3(256), 0, stream, a, b, out, n4);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,302 @@
+"""UNetModel — MI355X-native counterpart of the latent-diffusion denoising U-Net
+(gen_slices/ldm/modules/diffusionmodules/openaimodel.py:413-757, configured by
+configs/latent-diffusion/objaverse-ldm-kl-8.yaml:22-34; BASELINE configs[4]).
+
+Inference only.  Same constructor arguments for the options that configuration uses, the same module tree and
+therefore the same state_dict keys as the reference (time_embed.*, input_blocks.N.M.{in_layers,emb_layers,
+out_layers,skip_connection,norm,qkv,proj_out}.*, middle_block.*, output_blocks.*, out.*), and the same
+forward(x, timesteps, c_fmaps=...) contract (NCHW in / NCHW out).  Every tensor op is an entry point of
+libslice3d_hip.so ("Latent-diffusion denoising U-Net primitives" in include/slice3d_hip.h): activations live
+channels-last, 3x3 convolutions run the LDS-staged split-precision kernel, the ResBlock residual add and the
+AttentionBlock residual are conv epilogues.  There is no
+CPU fallback.
+
+Not built (the configuration does not use them): class conditioning, SpatialTransformer / cross-attention,
+use_new_attention_order, conv_resample down/up-sampling, fp16 torso, dims != 2.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _gn(ch):
+    return nn.GroupNorm(32, ch)
+
+
+class ResBlock(nn.Module):
+    """openaimodel.py:160-275 (use_scale_shift_norm / up / down variants)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_scale_shift_norm=False, up=False,
+                 down=False):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.use_scale_shift_norm, self.up, self.down = use_scale_shift_norm, up, down
+        self.in_layers = nn.Sequential(_gn(channels), nn.SiLU(), nn.Conv2d(channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, 2 * self.out_channels
+                                                             if use_scale_shift_norm else self.out_channels))
+        self.out_layers = nn.Sequential(_gn(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1))
+        self.skip_connection = (nn.Identity() if self.out_channels == channels
+                                else nn.Conv2d(channels, self.out_channels, 1))
+
+
+class AttentionBlock(nn.Module):
+    """openaimodel.py:278-331 with QKVAttentionLegacy."""
+
+    def __init__(self, channels, num_heads):
+        super().__init__()
+        self.channels, self.num_heads = channels, num_heads
+        self.norm = _gn(channels)
+        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.proj_out = nn.Conv1d(channels, channels, 1)
+
+
+class UNetModel(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), num_heads=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 backend="hip", prec="f16x3"):
+        super().__init__()
+        if not resblock_updown:
+            raise NotImplementedError("conv_resample down/up-sampling is not built (the Slice3D configuration uses "
+                                      "resblock_updown=True)")
+        if num_heads < 1:
+            raise ValueError("num_heads must be set")
+        self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
+        self.out_channels, self.num_heads, self.prec, self.backend = out_channels, num_heads, prec, backend
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+        self.input_blocks = nn.ModuleList([nn.Sequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        chans, ch, ds = [model_channels], model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, ted, dropout, mult * model_channels, use_scale_shift_norm)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(AttentionBlock(ch, num_heads))
+                self.input_blocks.append(nn.Sequential(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(nn.Sequential(ResBlock(ch, ted, dropout, ch, use_scale_shift_norm, down=True)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = nn.Sequential(ResBlock(ch, ted, dropout, None, use_scale_shift_norm),
+                                          AttentionBlock(ch, num_heads),
+                                          ResBlock(ch, ted, dropout, None, use_scale_shift_norm))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [ResBlock(ch + ich, ted, dropout, model_channels * mult, use_scale_shift_norm)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(AttentionBlock(ch, num_heads))
+                if level and i == num_res_blocks:
+                    layers.append(ResBlock(ch, ted, dropout, ch, use_scale_shift_norm, up=True))
+                    ds //= 2
+                self.output_blocks.append(nn.Sequential(*layers))
+        self.out = nn.Sequential(_gn(ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
+        self._lib = _lib.load() if backend == "hip" else None
+        self._packed = {}
+        self._packed_key = None
+        self._ws = None
+
+    # ------------------------------------------------------------------------------------------
+    def _require_lib(self):
+        if self._lib is None:
+            raise _lib.S3dError("UNetModel(backend=%r) cannot compute: the HIP library is required; there is no CPU "
+                                "fallback in the product path" % self.backend)
+        return self._lib
+
+    def _dev(self):
+        return self.time_embed[0].weight.device
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self._dev()).cuda_stream)
+
+    def _precv(self):
+        return _lib.PREC_F16X3 if self.prec == "f16x3" else _lib.PREC_F32
+
+    def _params_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    @staticmethod
+    def _pad16(c):
+        return (c + 15) // 16 * 16
+
+    def _pack_conv(self, conv, split=None):
+        """packed weight image of a Conv2d / Conv1d(k=1); split = (cin0, cin1) for a two-source convolution."""
+        lib = self._lib
+        w = conv.weight
+        cout, cin = w.shape[0], w.shape[1]
+        ks = w.shape[2] if w.dim() == 4 else 1
+        cin0, cin1 = split if split else (cin, 0)
+        nb = lib.s3d_conv_packed_bytes(cout, cin0, cin1, ks)
+        buf = torch.empty(nb, dtype=torch.uint8, device=w.device)
+        _lib.check(lib.s3d_conv_pack(w.data_ptr(), conv.bias.data_ptr() if conv.bias is not None else None, cout, cin0,
+                                     cin1, ks, buf.data_ptr(), nb, self._stream()), "s3d_conv_pack")
+        return (buf, cout, cin0, cin1, ks)
+
+    def repack(self):
+        self._require_lib()
+        if self._dev().type != "cuda":
+            raise _lib.S3dError("move the model to the GPU (model.cuda())")
+        self._packed = {}
+        for mod in self.modules():
+            if isinstance(mod, ResBlock):
+                self._packed[id(mod.in_layers[2])] = self._pack_conv(mod.in_layers[2])
+                self._packed[id(mod.out_layers[3])] = self._pack_conv(mod.out_layers[3])
+                if isinstance(mod.skip_connection, nn.Conv2d):
+                    self._packed[id(mod.skip_connection)] = self._pack_conv(mod.skip_connection)
+            elif isinstance(mod, AttentionBlock):
+                self._packed[id(mod.qkv)] = self._pack_conv(mod.qkv)
+                self._packed[id(mod.proj_out)] = self._pack_conv(mod.proj_out)
+        self._packed[id(self.input_blocks[0][0])] = self._pack_conv(self.input_blocks[0][0])
+        self._packed[id(self.out[2])] = self._pack_conv(self.out[2])
+        self._packed_key = self._params_key()
+
+    # ------------------------------------------------------------------------------------------
+    # primitive wrappers (channels-last tensors)
+    # ------------------------------------------------------------------------------------------
+    def _conv(self, conv, x0, x1=None, residual=None):
+        lib = self._lib
+        buf, cout, cin0, cin1, ks = self._packed[id(conv)]
+        n, h, w, _ = x0.shape
+        out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x0.device)
+        if self._ws is None:
+            self._ws = torch.empty(8 << 20, dtype=torch.float32, device=x0.device)     # split-K scratch
+        _lib.check(lib.s3d_conv_fwd(buf.data_ptr(), x0.data_ptr(), x1.data_ptr() if x1 is not None else None,
+                                    residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w, cout,
+                                    cin0, cin1, ks, self._precv(), self._ws.data_ptr(), self._ws.numel() * 4,
+                                    self._stream()), "s3d_conv_fwd")
+        return out
+
+    def _group_norm(self, gn, x, film=None, silu=True):
+        lib = self._lib
+        n, h, w, c = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((n, gn.num_groups, 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.s3d_group_norm_fwd(x.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(),
+                                          film.data_ptr() if film is not None else None, y.data_ptr(), stats.data_ptr(),
+                                          n, h * w, c, gn.num_groups, C.c_float(gn.eps), 1 if silu else 0,
+                                          self._stream()), "s3d_group_norm_fwd")
+        return y
+
+    def _resample(self, x, up):
+        lib = self._lib
+        n, h, w, c = x.shape
+        y = torch.empty((n, h * 2, w * 2, c) if up else (n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+        _lib.check(lib.s3d_resample2x_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, 1 if up else 0, self._stream()),
+                   "s3d_resample2x_fwd")
+        return y
+
+    def _linear(self, lin, x, silu_in):
+        lib = self._lib
+        n, k = x.shape
+        m = lin.weight.shape[0]
+        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        _lib.check(lib.s3d_small_linear_fwd(x.data_ptr(), lin.weight.data_ptr(), lin.bias.data_ptr(), out.data_ptr(), n,
+                                            k, m, 1 if silu_in else 0, self._stream()), "s3d_small_linear_fwd")
+        return out
+
+    def _add(self, a, b):
+        lib = self._lib
+        out = torch.empty_like(a)
+        _lib.check(lib.s3d_add_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), self._stream()), "s3d_add_fwd")
+        return out
+
+    def _to_nhwc(self, x, cpad=None):
+        lib = self._lib
+        x = x.to(device=self._dev(), dtype=torch.float32).contiguous()
+        n, c, h, w = x.shape
+        cpad = cpad or c
+        out = torch.empty((n, h, w, cpad), dtype=torch.float32, device=x.device)
+        _lib.check(lib.s3d_nchw_to_nhwc_pad(x.data_ptr(), out.data_ptr(), n, c, h, w, cpad, self._stream()),
+                   "s3d_nchw_to_nhwc_pad")
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # blocks
+    # ------------------------------------------------------------------------------------------
+    def _res_block(self, blk, x, emb, skip=None):
+        """ResBlock._forward (openaimodel.py:253-275); x (and skip: the block input is cat([x, skip]))."""
+        if skip is not None:
+            # th.cat([h, hs.pop()], dim=1) (openaimodel.py:750): GroupNorm groups straddle the two sources, so the
+            # concatenation is materialised (a copy, no arithmetic)
+            xin = torch.cat([x, skip], dim=-1)
+        else:
+            xin = x
+        h = self._group_norm(blk.in_layers[0], xin, silu=True)
+        xs = xin
+        if blk.up or blk.down:
+            h = self._resample(h, blk.up)
+            xs = self._resample(xin, blk.up)
+        h = self._conv(blk.in_layers[2], h)
+        film = self._linear(blk.emb_layers[1], emb, silu_in=True)          # (N, 2*Cout) = scale | shift
+        if not blk.use_scale_shift_norm:
+            raise NotImplementedError("ResBlock without use_scale_shift_norm is not built")
+        h = self._group_norm(blk.out_layers[0], h, film=film, silu=True)
+        if isinstance(blk.skip_connection, nn.Conv2d):
+            res = self._conv(blk.skip_connection, xs)
+        else:
+            res = xs
+        return self._conv(blk.out_layers[3], h, residual=res)
+
+    def _attention_block(self, blk, x):
+        """AttentionBlock._forward (openaimodel.py:309-315)."""
+        lib = self._lib
+        n, h, w, c = x.shape
+        hn = self._group_norm(blk.norm, x, silu=False)
+        qkv = self._conv(blk.qkv, hn)                                        # (N, H, W, 3C), heads x (q|k|v) x ch
+        att = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+        _lib.check(lib.s3d_qkv_attention_fwd(qkv.data_ptr(), att.data_ptr(), n, h * w, blk.num_heads,
+                                             c // blk.num_heads, self._stream()), "s3d_qkv_attention_fwd")
+        return self._conv(blk.proj_out, att, residual=x)
+
+    def _run(self, seq, h, emb, skip=None):
+        for mod in seq:
+            if isinstance(mod, ResBlock):
+                h = self._res_block(mod, h, emb, skip)
+                skip = None
+            elif isinstance(mod, AttentionBlock):
+                h = self._attention_block(mod, h)
+            else:   # the stem convolution
+                h = self._conv(mod, h)
+        return h
+
+    def forward(self, x, timesteps=None, context=None, y=None, c_fmaps=None, **kwargs):
+        """openaimodel.py:710-757: x (N, in_channels, H, W), timesteps (N,), c_fmaps {'f1'..'f5'} NCHW feature maps
+        added after input blocks 0, 4, 7, 10, 12 -> (N, out_channels, H, W)."""
+        lib = self._require_lib()
+        if self.training:
+            raise RuntimeError("UNetModel computes the eval-mode forward; call model.eval()")
+        if context is not None or y is not None:
+            raise NotImplementedError("cross-attention context / class labels are not built")
+        if self._packed_key is None or self._packed_key != self._params_key():
+            self.repack()
+        dev = self._dev()
+        n = x.shape[0]
+        t = timesteps.to(device=dev, dtype=torch.float32).contiguous()
+        t_emb = torch.empty((n, self.model_channels), dtype=torch.float32, device=dev)
+        _lib.check(lib.s3d_timestep_embedding_fwd(t.data_ptr(), t_emb.data_ptr(), n, self.model_channels,
+                                                  C.c_float(10000.0), self._stream()), "s3d_timestep_embedding_fwd")
+        emb = self._linear(self.time_embed[2], self._linear(self.time_embed[0], t_emb, silu_in=False), silu_in=True)
+        inject = {0: "f1", 4: "f2", 7: "f3", 10: "f4", 12: "f5"}
+        h = self._to_nhwc(x, self._pad16(self.in_channels))
+        hs = []
+        for m_id, module in enumerate(self.input_blocks):
+            h = self._run(module, h, emb)
+            if c_fmaps is not None and m_id in inject:
+                h = self._add(h, self._to_nhwc(c_fmaps[inject[m_id]]))
+            hs.append(h)
+        h = self._run(self.middle_block, h, emb)
+        for module in self.output_blocks:
+            h = self._run(module, h, emb, skip=hs.pop())
+        hn = self._group_norm(self.out[0], h, silu=True)
+        o = self._conv(self.out[2], hn)                                       # (N, H, W, out_channels)
+        nn_, hh, ww, cc = o.shape
+        out = torch.empty((nn_, cc, hh, ww), dtype=torch.float32, device=dev)
+        _lib.check(lib.s3d_nhwc_to_nchw(o.data_ptr(), out.data_ptr(), nn_, cc, hh, ww, self._stream()), "s3d_nhwc_to_nchw")
+        return out

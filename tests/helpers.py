@@ -43,3 +43,31 @@ def seeded_sd_from_shapes(shapes, seed=0, dtype=torch.float32):
         t = torch.from_numpy(a)
         sd[k] = t.to(dtype) if t.is_floating_point() else t
     return sd
+
+
+def ldm_fmap_shapes(cfg):
+    """(channels, side) of h after input blocks 0, 4, 7, 10, 12 of the LDM UNetModel (openaimodel.py:735-746)."""
+    mc, side = cfg["model_channels"], cfg["image_size"]
+    out, ch, idx = {"f1": (mc, side)}, mc, 0
+    names = {4: "f2", 7: "f3", 10: "f4", 12: "f5"}
+    for level, mult in enumerate(cfg["channel_mult"]):
+        for _ in range(cfg["num_res_blocks"]):
+            idx += 1
+            ch = mult * mc
+            if idx in names:
+                out[names[idx]] = (ch, side)
+        if level != len(cfg["channel_mult"]) - 1:
+            idx += 1
+            side //= 2
+            if idx in names:
+                out[names[idx]] = (ch, side)
+    return out
+
+
+def ldm_inputs(cfg, batch, seed):
+    """Deterministic (CPU generator) inputs of one denoising step: x, timesteps, c_fmaps."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, cfg["in_channels"], cfg["image_size"], cfg["image_size"], generator=g)
+    t = torch.randint(0, 1000, (batch,), generator=g)
+    cf = {k: torch.randn(batch, c, s, s, generator=g) * 0.5 for k, (c, s) in ldm_fmap_shapes(cfg).items()}
+    return x, t, cf
