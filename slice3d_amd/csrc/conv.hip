@@ -445,7 +445,9 @@ __global__ void conv_splitk_finish_kernel(const ConvLaunch a, int nsplit) {
 
 static bool conv3x3_lds_eligible(const ConvLaunch& a) {
     if (a.ks != 3 || a.stride > 1 || (a.Hin && a.Hin != a.H) || (a.Win && a.Win != a.W)) return false;
-    if (!a.wpk16 || a.KU % 2 || a.W < 16 || a.H < 8 || a.CoutPad % 32) return false;
+    if (!a.wpk16 || a.KU % 2 || a.CoutPad % 32) return false;
+    // maps smaller than the 8 x 16 tile waste lanes; they are worth it only when split-K supplies the parallelism
+    if ((a.W < 16 || a.H < 8) && !(a.splitk_ws && a.out_mode == S3D_OUT_NHWC)) return false;
     for (int s = 0; s < a.nsrc; ++s)
         if (a.src[s].C % 32 || a.src[s].sbcast) return false;
     static const int on = [] {

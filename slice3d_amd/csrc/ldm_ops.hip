@@ -6,16 +6,20 @@
 #include "ldm_ops.h"
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm(32, C): statistics per (image, group) over HW x (C/32) values, two passes (mean, then variance
-// around it) in fp32 — what torch's native_group_norm computes in float32.
+// GroupNorm(32, C): statistics per (image, group) over HW x (C/32) values in fp32 (as torch's native_group_norm).
 // ---------------------------------------------------------------------------------------------
+// Stage 1: block (image, group, slice) -> (mean, M2) of its slice of the HW pixels (two passes over the slice, which
+// stays in L2).  Stage 2: one thread per (image, group) merges the slices with Chan's parallel-variance formula.
+#define GN_SLICES 16
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int HW, int C, int groups,
-                                                       float eps, float* __restrict__ stats) {
+                                                       float* __restrict__ part) {
     __shared__ float red[4];
-    const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
+    const int sl = blockIdx.x % GN_SLICES;
+    const int gidx = (blockIdx.x / GN_SLICES) % groups, n = blockIdx.x / (GN_SLICES * groups);
     const int cpg = C / groups;
-    const float* base = x + (long)n * HW * C + gidx * cpg;
-    const long total = (long)HW * cpg;
+    const int p0 = (int)((long)HW * sl / GN_SLICES), p1 = (int)((long)HW * (sl + 1) / GN_SLICES);
+    const float* base = x + ((long)n * HW + p0) * C + gidx * cpg;
+    const long total = (long)(p1 - p0) * cpg;
     auto block_sum = [&](float v) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -26,17 +30,34 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     };
     float s = 0.f;
     for (long i = threadIdx.x; i < total; i += 256) s += base[(i / cpg) * C + i % cpg];
-    const float mean = block_sum(s) / (float)total;
+    const float mean = total > 0 ? block_sum(s) / (float)total : 0.f;
     float v = 0.f;
     for (long i = threadIdx.x; i < total; i += 256) {
         const float d = base[(i / cpg) * C + i % cpg] - mean;
         v += d * d;
     }
-    const float var = block_sum(v) / (float)total;
+    const float m2 = block_sum(v);
     if (threadIdx.x == 0) {
-        stats[2 * blockIdx.x] = mean;
-        stats[2 * blockIdx.x + 1] = 1.f / sqrtf(var + eps);
+        part[3 * blockIdx.x] = (float)total;
+        part[3 * blockIdx.x + 1] = mean;
+        part[3 * blockIdx.x + 2] = m2;
     }
+}
+__global__ void gn_finalize_kernel(const float* __restrict__ part, int ngroups_total, float eps, float* __restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ngroups_total) return;
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int s = 0; s < GN_SLICES; ++s) {
+        const float nb = part[3 * (i * GN_SLICES + s)], mb = part[3 * (i * GN_SLICES + s) + 1],
+                    qb = part[3 * (i * GN_SLICES + s) + 2];
+        if (nb == 0.f) continue;
+        const float tot = cnt + nb, d = mb - mean;
+        mean += d * nb / tot;
+        m2 += qb + d * d * cnt * nb / tot;
+        cnt = tot;
+    }
+    stats[2 * i] = mean;
+    stats[2 * i + 1] = 1.f / sqrtf(m2 / cnt + eps);
 }
 
 // y = gn(x) * gamma + beta ; optional FiLM (ResBlock use_scale_shift_norm): y = y * (1 + scale[n,c]) + shift[n,c]
@@ -70,7 +91,10 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
                       int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream) {
     S3D_CHECK_ARG(C % groups == 0 && C % 4 == 0 && N >= 1 && HW >= 1, "group_norm: C=%d groups=%d", C, groups);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups), dim3(256), 0, stream, x, HW, C, groups, eps, stats);
+    float* part = stats + 2 * (size_t)N * groups;   // scratch behind the (N, groups, 2) result: 3 * GN_SLICES floats / group
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, x, HW, C, groups, part);
+    S3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * groups + 63) / 64), dim3(64), 0, stream, part, N * groups, eps, stats);
     S3D_LAUNCH_CHECK();
     const long total = (long)N * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

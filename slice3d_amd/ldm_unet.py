@@ -177,7 +177,7 @@ class UNetModel(nn.Module):
         lib = self._lib
         n, h, w, c = x.shape
         y = torch.empty_like(x)
-        stats = torch.empty((n, gn.num_groups, 2), dtype=torch.float32, device=x.device)
+        stats = torch.empty((n, gn.num_groups, 50), dtype=torch.float32, device=x.device)
         _lib.check(lib.s3d_group_norm_fwd(x.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(),
                                           film.data_ptr() if film is not None else None, y.data_ptr(), stats.data_ptr(),
                                           n, h * w, c, gn.num_groups, C.c_float(gn.eps), 1 if silu else 0,

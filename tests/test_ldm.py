@@ -76,7 +76,7 @@ def test_ldm_primitives_match_torch():
     want = F.silu(want).permute(0, 2, 3, 1).contiguous()
     xc = x.permute(0, 2, 3, 1).contiguous().cuda()
     y = torch.empty_like(xc)
-    stats = torch.empty(n, 32, 2, device="cuda")
+    stats = torch.empty(n, 32, 50, device="cuda")
     gw, gb, fc = gn.weight.detach().cuda(), gn.bias.detach().cuda(), film.cuda()   # keep the device copies alive
     _lib.check(lib.s3d_group_norm_fwd(xc.data_ptr(), gw.data_ptr(), gb.data_ptr(), fc.data_ptr(), y.data_ptr(),
                                       stats.data_ptr(), n, h * w, c, 32, C.c_float(1e-5), 1, None), "gn")

@@ -1,0 +1,23 @@
+"""Times one denoising step of the Slice3D latent-diffusion U-Net configuration (BASELINE configs[4])."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from helpers import ldm_inputs
+from test_ldm import LDM_FULL
+from slice3d_amd.ldm_unet import UNetModel
+from slice3d_amd.weights import load_seeded
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+m = load_seeded(UNetModel(**LDM_FULL), 0).cuda().eval()
+x, t, cf = ldm_inputs(LDM_FULL, B, 1)
+x, t, cf = x.cuda(), t.cuda(), {k: v.cuda() for k, v in cf.items()}
+for _ in range(3):
+    y = m(x, t, c_fmaps=cf)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 10
+for _ in range(n):
+    y = m(x, t, c_fmaps=cf)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / n * 1e3
+print("LDM denoise step B=%d: %.2f ms  (%.1f TFLOP/s algorithmic at 222 GFLOP/step/sample)" % (B, ms, 0.222 * B / ms * 1e3))
