@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--n-slices", type=int, default=12)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--prec", default="f16x3", choices=["f32", "f16x3"], help="arithmetic mode of the decoder GEMMs")
+    ap.add_argument("--ldm-steps", type=int, default=5, help="timed LDM denoising steps (BASELINE configs[4]; 0 = skip)")
     ap.add_argument("--train-steps", type=int, default=3, help="timed training steps for train_samples_per_s (0 = skip)")
     args = ap.parse_args()
 
@@ -163,6 +164,32 @@ def main():
                        "note": "algorithmic bytes: output write + grid read + pyramid once; time includes the query sort"}
         del code, feats
 
+    # ---- BASELINE configs[4]: one denoising step of the gen_slices latent-diffusion U-Net (295 M parameters,
+    #      64x64x4 latent mosaic + 4 conditioning channels, 21 attention blocks), batch 1 per GPU ----
+    ldm = None
+    if args.ldm_steps > 0 and rank == 0:
+        from slice3d_amd.ldm_unet import UNetModel
+        cfg = dict(image_size=64, in_channels=8, out_channels=4, model_channels=192, attention_resolutions=[1, 2, 4, 8],
+                   num_res_blocks=2, channel_mult=[1, 2, 2, 4, 4], num_heads=8, use_scale_shift_norm=True,
+                   resblock_updown=True)
+        um = load_seeded(UNetModel(prec=args.prec, **cfg), 0).cuda().eval()
+        g = torch.Generator().manual_seed(0)
+        lx = torch.randn(1, 8, 64, 64, generator=g).cuda()
+        lt = torch.tensor([500]).cuda()
+        lc = {k: (torch.randn(1, c, r, r, generator=g) * 0.5).cuda()
+              for k, (c, r) in (("f1", (192, 64)), ("f2", (384, 32)), ("f3", (384, 16)), ("f4", (768, 8)), ("f5", (768, 4)))}
+        for _ in range(2):
+            um(lx, lt, c_fmaps=lc)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.ldm_steps):
+            um(lx, lt, c_fmaps=lc)
+        torch.cuda.synchronize()
+        lms = (time.perf_counter() - t1) / args.ldm_steps * 1e3
+        ldm = {"workload": "gen_slices LDM UNetModel denoise step, objaverse-ldm-kl-8.yaml, batch 1 (222 GFLOP)",
+               "ms_per_step": lms, "tflops_algorithmic": 0.222 / lms * 1e3, "dtype": args.prec}
+        del um, lx, lc
+
     # ---- secondary metric: training samples/s (train.py:41-53 train_step, B = 1 object per GPU) ----
     train_ms = None
     if args.train_steps > 0:
@@ -236,6 +263,7 @@ def main():
                  "frac": UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"] / peak,
                  "note": "algorithmic FLOPs 241.97 GFLOP/object at 256^2 (SURVEY 8d) / whole unet_encode stage time"},
             ],
+            "ldm_denoise_step": ldm,
             "stage_ms_per_step": stage_ms,
             "decode_tflops_fmin": args.n_qry * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,
             "train_samples_per_s": (world / (train_ms * 1e-3)) if train_ms else None,

@@ -8,8 +8,8 @@
 // ---------------------------------------------------------------------------------------------
 // GroupNorm(32, C): statistics per (image, group) over HW x (C/32) values in fp32 (as torch's native_group_norm).
 // ---------------------------------------------------------------------------------------------
-// Stage 1: block (image, group, slice) -> (mean, M2) of its slice of the HW pixels (two passes over the slice, which
-// stays in L2).  Stage 2: one thread per (image, group) merges the slices with Chan's parallel-variance formula.
+// Stage 1: block (image, group, slice) -> (count, mean, M2) of its slice of the HW pixels (two passes over the slice,
+// which stays in L2).  Stage 2 (inside the apply kernel): the slices are merged with Chan's parallel-variance formula.
 #define GN_SLICES 16
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int HW, int C, int groups,
                                                        float* __restrict__ part) {
@@ -43,29 +43,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         part[3 * blockIdx.x + 2] = m2;
     }
 }
-__global__ void gn_finalize_kernel(const float* __restrict__ part, int ngroups_total, float eps, float* __restrict__ stats) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ngroups_total) return;
-    float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    for (int s = 0; s < GN_SLICES; ++s) {
-        const float nb = part[3 * (i * GN_SLICES + s)], mb = part[3 * (i * GN_SLICES + s) + 1],
-                    qb = part[3 * (i * GN_SLICES + s) + 2];
-        if (nb == 0.f) continue;
-        const float tot = cnt + nb, d = mb - mean;
-        mean += d * nb / tot;
-        m2 += qb + d * d * cnt * nb / tot;
-        cnt = tot;
-    }
-    stats[2 * i] = mean;
-    stats[2 * i + 1] = 1.f / sqrtf(m2 / cnt + eps);
-}
-
 // y = gn(x) * gamma + beta ; optional FiLM (ResBlock use_scale_shift_norm): y = y * (1 + scale[n,c]) + shift[n,c]
 // with film = [N][2C] (scale | shift) ; optional SiLU.
-__global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ film, float* __restrict__ y, int N, int HW, int C, int groups,
-                                int silu) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ film, float* __restrict__ y, int N,
+                                                       int HW, int C, int groups, float eps, int silu) {
+    // every block first merges the slice moments of all (image, group) pairs (Chan's parallel-variance formula)
+    extern __shared__ float s_stats[];   // [N*groups][2] = mean, rstd
+    for (int i = threadIdx.x; i < N * groups; i += 256) {
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+        for (int s = 0; s < GN_SLICES; ++s) {
+            const float nb = part[3 * (i * GN_SLICES + s)], mb = part[3 * (i * GN_SLICES + s) + 1],
+                        qb = part[3 * (i * GN_SLICES + s) + 2];
+            if (nb == 0.f) continue;
+            const float tot = cnt + nb, d = mb - mean;
+            mean += d * nb / tot;
+            m2 += qb + d * d * cnt * nb / tot;
+            cnt = tot;
+        }
+        s_stats[2 * i] = mean;
+        s_stats[2 * i + 1] = 1.f / sqrtf(m2 / cnt + eps);
+    }
+    __syncthreads();
     const int c4n = C >> 2, cpg = C / groups;
     const long total = (long)N * HW * c4n;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -78,7 +78,7 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int g = (c + i) / cpg;
-            const float m = stats[2 * (n * groups + g)], r = stats[2 * (n * groups + g) + 1];
+            const float m = s_stats[2 * (n * groups + g)], r = s_stats[2 * (n * groups + g) + 1];
             float t = (v[i] - m) * r * ga[i] + be[i];
             if (film) t = t * (1.f + film[(long)n * 2 * C + c + i]) + film[(long)n * 2 * C + C + c + i];
             if (silu) t = t / (1.f + expf(-t));
@@ -91,15 +91,13 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
                       int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream) {
     S3D_CHECK_ARG(C % groups == 0 && C % 4 == 0 && N >= 1 && HW >= 1, "group_norm: C=%d groups=%d", C, groups);
-    float* part = stats + 2 * (size_t)N * groups;   // scratch behind the (N, groups, 2) result: 3 * GN_SLICES floats / group
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, x, HW, C, groups, part);
-    S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * groups + 63) / 64), dim3(64), 0, stream, part, N * groups, eps, stats);
+    S3D_CHECK_ARG((size_t)N * groups * 2 * sizeof(float) <= 48 * 1024, "group_norm: N*groups %d too large", N * groups);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, x, HW, C, groups, stats);
     S3D_LAUNCH_CHECK();
     const long total = (long)N * HW * (C / 4);
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, stream, x, stats, gamma, beta, film, y, N, HW, C,
-                       groups, silu);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), (size_t)N * groups * 2 * sizeof(float), stream, x, stats,
+                       gamma, beta, film, y, N, HW, C, groups, eps, silu);
     S3D_LAUNCH_CHECK();
     return 0;
 }
