@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--img-size", type=int, default=256)
     ap.add_argument("--n-qry", type=int, default=100000)
     ap.add_argument("--n-slices", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=4, help="objects per GPU per step (BASELINE C2: B = 1..4)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--prec", default="f16x3", choices=["f32", "f16x3"], help="arithmetic mode of the decoder GEMMs")
     ap.add_argument("--ldm-steps", type=int, default=5, help="timed LDM denoising steps (BASELINE configs[4]; 0 = skip)")
@@ -107,7 +108,7 @@ def main():
     load_seeded(model, 0)
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model.cuda().eval()
-    fd = make_feed_dict(1, args.img_size, args.n_qry, args.n_slices, seed=1234 + rank, with_slices=False,
+    fd = make_feed_dict(args.batch, args.img_size, args.n_qry, args.n_slices, seed=1234 + rank, with_slices=False,
                         device="cuda")
     lib = _lib.load()
 
@@ -144,9 +145,10 @@ def main():
     # ---- secondary rooflines (north_star): stand-alone feature-sample op (HBM bound) ----
     sample_roof = None
     if rank == 0:
-        code = model.encode(fd, build_latent=False)
-        g = model.project_coord(fd["qry_norot"] * torch.tensor([1.0, -1.0, -1.0], device="cuda"),   # mode='test' flip
-                                fd["trans_mat_wo_rot_tp"])
+        fd1 = {k: v[:1].contiguous() for k, v in fd.items()}      # one object: the (12, Q, 992) tensor is 4.8 GB
+        code = model.encode(fd1, build_latent=False)
+        g = model.project_coord(fd1["qry_norot"] * torch.tensor([1.0, -1.0, -1.0], device="cuda"),   # mode='test' flip
+                                fd1["trans_mat_wo_rot_tp"])
         model.sample_pyramid(code.pyramid, g)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -198,7 +200,7 @@ def main():
         load_seeded(tmodel, 0)
         tmodel.cuda()
         trainer = HipTrainer(tmodel, dropout=0.1, seed=rank, prec=args.prec)   # dropout: the reference's default
-        tfd = make_feed_dict(1, args.img_size, args.n_qry, args.n_slices, seed=4321 + rank, device="cuda")
+        tfd = make_feed_dict(args.batch, args.img_size, args.n_qry, args.n_slices, seed=4321 + rank, device="cuda")
         trainer.train_step(tfd)                      # warm-up (allocates the ~25 GB activation workspace)
         barrier()
         t1 = time.perf_counter()
@@ -214,18 +216,20 @@ def main():
         del trainer, tmodel
 
     if rank == 0:
-        q_total = args.n_qry * world * args.steps
+        q_total = args.n_qry * args.batch * world * args.steps
         n_tok = args.n_slices + 1
         ffn_launches = max(counts["ffn_layer"], 1)
         ffn_ms = stage_ms["ffn_layer"] * args.steps / ffn_launches
-        ffn_flops = n_tok * args.n_qry * FFN_FLOP_PER_ROW          # algorithmic FLOPs of one launch
+        # algorithmic FLOPs of the average launch (a step's 2 full FFN layers are split into <= 262 144-query passes)
+        ffn_flops = 2.0 * n_tok * args.n_qry * args.batch * FFN_FLOP_PER_ROW * args.steps / ffn_launches
         achieved = ffn_flops / (ffn_ms * 1e-3) / 1e12
         peak = F32_MFMA_PEAK_TFLOPS if args.prec == "f32" else F16_MFMA_PEAK_TFLOPS
         traffic = None   # HBM bytes/launch of the dominant kernel from the committed PMC pass of this command
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             wl = pmc["workload"]
-            if (wl["img_size"], wl["n_slices"], wl["n_qry"]) == (args.img_size, args.n_slices, args.n_qry):
+            if (wl["img_size"], wl["n_slices"], wl["n_qry"], wl.get("batch", 1)) == (args.img_size, args.n_slices,
+                                                                                      args.n_qry, args.batch):
                 kname = "ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_kernel<false>"
                 traffic = pmc["kernels"][args.prec][kname]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
@@ -237,13 +241,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "reg_slices regression inference, %d^2 x %d slices, %d query points/object, "
-                                   "1 object per GPU per step (BASELINE configs[1]); arithmetic: %s"
-                                   % (args.img_size, args.n_slices, args.n_qry,
+                                   "%d objects per GPU per step (BASELINE configs[1], C2: B = 1..4); arithmetic: %s"
+                                   % (args.img_size, args.n_slices, args.n_qry, args.batch,
                                       "exact fp32 MFMA" if args.prec == "f32" else
                                       "fp32 operands split into f16 hi+lo, 3 f16 MFMAs per product, fp32 accumulate "
                                       "(fp32-class accuracy, passes the 1e-4 parity gate)"),
                        "img_size": args.img_size, "n_slices": args.n_slices, "n_qry": args.n_qry,
-                       "objects_per_step": world, "parallelism": "objects x%d (no collective)" % world},
+                       "objects_per_step": world * args.batch, "parallelism": "objects x%d (no collective)" % world},
             "roofline": {"kernel": ("ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_kernel<false>")
                                    + " (decoder FFN 128->2048->128 + residual + LN2)",
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -258,23 +262,24 @@ def main():
             "secondary_rooflines": [
                 sample_roof,
                 {"kernel": "U-Net conv stack (conv_igemm_f16x3_kernel family, 33 launches)", "bound": "mfma",
-                 "achieved": UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"],
+                 "achieved": args.batch * UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"],
                  "peak": peak, "unit": "TFLOP/s",
-                 "frac": UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"] / peak,
+                 "frac": args.batch * UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"] / peak,
                  "note": "algorithmic FLOPs 241.97 GFLOP/object at 256^2 (SURVEY 8d) / whole unet_encode stage time"},
             ],
             "ldm_denoise_step": ldm,
             "stage_ms_per_step": stage_ms,
-            "decode_tflops_fmin": args.n_qry * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,
-            "train_samples_per_s": (world / (train_ms * 1e-3)) if train_ms else None,
+            "decode_tflops_fmin": args.n_qry * args.batch * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,
+            "train_samples_per_s": (world * args.batch / (train_ms * 1e-3)) if train_ms else None,
             "train_ms_per_step": train_ms,
-            "train_config": "train_step (fwd + 3 losses + bwd + grad all-reduce + Adam), B=1 object/GPU, %d^2 x %d slices, "
+            "train_config": "train_step (fwd + 3 losses + bwd + grad all-reduce + Adam), B=%d objects/GPU, %d^2 x %d slices, "
                             "Q=%d, dropout 0.1, batch-statistic BatchNorm; forward/dgrad GEMMs and linear-layer weight gradients in --prec, "
                             "3x3-conv weight gradients fp32 MFMA"
-                            % (args.img_size, args.n_slices, args.n_qry),
+                            % (args.batch, args.img_size, args.n_slices, args.n_qry),
         }
         if world == 1 and args.cpu_sample > 0:
-            base, err = cpu_baseline(sd_cpu, fd, args.n_slices, min(args.cpu_sample, args.n_qry), out)
+            base, err = cpu_baseline(sd_cpu, {k: v[:1] for k, v in fd.items()}, args.n_slices,
+                                     min(args.cpu_sample, args.n_qry), out[:1])
             res["cpu_baseline"] = base
             res["parity_vs_oracle"] = {"max_abs_err": err, "n": min(args.cpu_sample, args.n_qry), "tol": 1e-4}
         print(json.dumps(res))

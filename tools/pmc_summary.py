@@ -44,7 +44,7 @@ def main():
     with open(out_md, "w") as o:
         o.write("# rocprofv3 PMC passes (HBM traffic), --prec %s\n\n" % prec)
         o.write("`rocprofv3 --pmc FETCH_SIZE --output-format csv` and `rocprofv3 --pmc WRITE_SIZE --output-format csv` "
-                "(separate passes) of\n`python bench.py --steps 3 --warmup 1 --cpu-sample 0 --train-steps 0`.  "
+                "(separate passes) of\n`python bench.py --steps 3 --warmup 1 --cpu-sample 0 --train-steps 0 --ldm-steps 0`.  "
                 "Counter unit KiB; corrected bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n(gfx950 FETCH_SIZE halving per "
                 "MI355X_MICROARCH.md; an upper bound for narrow loads).\n\n")
         o.write("| kernel | launches | FETCH_SIZE avg KiB | WRITE_SIZE avg KiB | corrected HBM bytes / launch |\n|---|---|---|---|---|\n")
@@ -54,7 +54,8 @@ def main():
         try:
             J = json.load(open(jpath))
         except OSError:
-            J = {"workload": {"img_size": 256, "n_slices": 12, "n_qry": 100000}, "source": {}, "kernels": {}}
+            J = {"workload": {"img_size": 256, "n_slices": 12, "n_qry": 100000, "batch": 4}, "source": {}, "kernels": {}}
+        J["workload"]["batch"] = 4      # bench.py default: 4 objects per step
         J["source"][prec] = out_md
         J["kernels"][prec] = {short(k): {"fetch_kib": fa, "write_kib": wa, "hbm_bytes_per_launch": b}
                               for k, n, fa, wa, b in rows[:24]}
