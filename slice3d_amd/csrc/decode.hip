@@ -804,6 +804,7 @@ __global__ void sample_pyramid_pts_kernel(const SamplePyrArgs a) {
         a.pts[i] = make_float4(gp[0], gp[1], __int_as_float(q), 0.f);
     }
 }
+#define SP_ROWS 4   // rows per pass: 4 point records and 16 tap loads in flight per thread (8 measured slower)
 __global__ __launch_bounds__(256) void sample_pyramid_kernel(const SamplePyrArgs a) {
     const long rows = (long)a.batch * a.n_slices * a.n_qry;
     // a workgroup handles whole rows: 248 quads per row, 256 threads -> thread t < 248 active
@@ -818,21 +819,21 @@ __global__ __launch_bounds__(256) void sample_pyramid_kernel(const SamplePyrArgs
     const int C = 512 >> l, W = (a.size / 16) << l;
     const float* plane = a.level[l];
     // row order: (image, point in visiting order): consecutive rows = neighbouring points of ONE image, their
-    // taps meet in L1 / L2.  4 rows per pass: the 4 point records and the 16 tap loads are each one batch.
-    for (long r0 = (long)blockIdx.x * 4; r0 < rows; r0 += (long)gridDim.x * 4) {
-        long img[4];
-        float4 pt[4];
+    // taps meet in L1 / L2.  SP_ROWS rows per pass: the point records and the tap loads are each one batch.
+    for (long r0 = (long)blockIdx.x * SP_ROWS; r0 < rows; r0 += (long)gridDim.x * SP_ROWS) {
+        long img[SP_ROWS];
+        float4 pt[SP_ROWS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SP_ROWS; ++u) {
             const long r = r0 + u < rows ? r0 + u : rows - 1;
             img[u] = r / a.n_qry;
             pt[u] = a.pts[(img[u] / a.n_slices) * a.n_qry + (r - img[u] * a.n_qry)];
         }
         __builtin_amdgcn_sched_barrier(0);
-        f32x4 t[4][4];
-        float w[4][4];
+        f32x4 t[SP_ROWS][4];
+        float w[SP_ROWS][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SP_ROWS; ++u) {
             const Tap4 tp = make_taps(pt[u].x, pt[u].y, W, W);
             const float* base = plane + img[u] * (long)W * W * C + c0;
 #pragma unroll
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(256) void sample_pyramid_kernel(const SamplePyrArgs
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < SP_ROWS; ++u)
             if (r0 + u < rows)
                 __builtin_nontemporal_store((t[u][0] * w[u][0] + t[u][1] * w[u][1]) + (t[u][2] * w[u][2] + t[u][3] * w[u][3]),
                                             reinterpret_cast<f32x4*>(a.out + (img[u] * a.n_qry + __float_as_int(pt[u].z)) * 992 + 4 * cq));
@@ -861,7 +862,7 @@ int launch_sample_pyramid(const float* const* level, const float* grid, const in
     hipLaunchKernelGGL(sample_pyramid_pts_kernel, dim3((unsigned)((np + 255) / 256 < 4096 ? (np + 255) / 256 : 4096)),
                        dim3(256), 0, stream, a);
     S3D_LAUNCH_CHECK();
-    const long blocks = (rows + 3) / 4 < 32768 ? (rows + 3) / 4 : 32768;
+    const long blocks = (rows + SP_ROWS - 1) / SP_ROWS < 32768 ? (rows + SP_ROWS - 1) / SP_ROWS : 32768;
     hipLaunchKernelGGL(sample_pyramid_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     S3D_LAUNCH_CHECK();
     return 0;
