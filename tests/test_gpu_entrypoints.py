@@ -41,3 +41,12 @@ def test_train_then_reconstruct_on_disk_dataset(tmp_path):
               ["--name_model", "gtslice", "--name_ckpt", "none.ckpt", "--mode", "test", "--mc_res0", "8",
                "--mc_up_steps", "0", "--name_exp", "toy_gt"], str(work))
     assert len(glob.glob(str(work / "experiments" / "toy_gt" / "results" / "custom" / "*.obj"))) == 2, out
+
+
+def test_reconstruct_slices_writes_the_twelve_slice_images(tmp_path):
+    work = tmp_path / "work"
+    work.mkdir()
+    run([os.path.join(ROOT, "reg_slices", "reconstruct_slices.py"), "--name_dataset", "synthetic", "--synthetic_len", "2",
+         "--img_size", "32", "--name_exp", "sl", "--name_ckpt", "none.ckpt", "--mode", "test"], str(work))
+    names = sorted(os.path.basename(p) for p in glob.glob(str(work / "experiments" / "sl" / "img_slices" / "synthetic_0001" / "*.png")))
+    assert names == sorted(["%s_%d.png" % (a, i) for a in "XYZ" for i in range(1, 5)])
