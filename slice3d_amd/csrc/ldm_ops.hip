@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void qkv_attention_kernel(const float* __restr
     constexpr int LD = CH + 4;               // padded row: 16 query/key lanes hit 16 distinct bank quads
     constexpr int DT = (CH + 15) / 16;       // 16-wide tiles of the head dimension (zero padded)
     constexpr int KS = CH / 4;               // fp32 MFMA k-steps of the q.k contraction
-    __shared__ float s_k[QA_KB * LD], s_v[QA_KB * (DT * 16 + 4)];
     constexpr int LDV = DT * 16 + 4;
+    constexpr int NLD = (QA_KB * (CH / 4) + 255) / 256;   // float4 (K, V) pairs a thread stages per key block
+    __shared__ float s_k[2][QA_KB * LD], s_v[2][QA_KB * LDV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int qblocks = (T + 63) / 64;
@@ -136,25 +137,48 @@ __global__ __launch_bounds__(256) void qkv_attention_kernel(const float* __restr
     for (int d = 0; d < DT; ++d) acc[d] = zero4();
     float mx = -1e30f, den = 0.f;
 
-    for (int k0 = 0; k0 < T; k0 += QA_KB) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < QA_KB * (CH / 4); i += 256) {
-            const int key = i / (CH / 4), c4 = (i % (CH / 4)) * 4;
-            const int kc = k0 + key < T ? k0 + key : T - 1;
-            const float* row = base + (long)kc * C3;
-            const f32x4 kv = ld4(row + CH + c4) * scale, vv = ld4(row + 2 * CH + c4);
-            float* dk = s_k + key * LD + c4;
-            float* dv = s_v + key * LDV + c4;
+    // key/value blocks are double buffered: the next block's global loads are in flight under this block's MFMAs
+    f32x4 pk[NLD], pv[NLD];
+    auto fetch = [&](int k0) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                dk[t] = kv[t];
-                dv[t] = vv[t];
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int key = idx / (CH / 4), c4 = (idx % (CH / 4)) * 4;
+            const int kc = (idx < QA_KB * (CH / 4) && k0 + key < T) ? k0 + key : T - 1;
+            const float* row = base + (long)kc * C3;
+            pk[i] = ld4(row + CH + c4);
+            pv[i] = ld4(row + 2 * CH + c4);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            if (idx < QA_KB * (CH / 4)) {
+                const int key = idx / (CH / 4), c4 = (idx % (CH / 4)) * 4;
+                float* dk = s_k[buf] + key * LD + c4;
+                float* dv = s_v[buf] + key * LDV + c4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    dk[t] = pk[i][t] * scale;
+                    dv[t] = pv[i][t];
+                }
             }
         }
-        if (CH % 16)   // zero the padded head dims of V
-            for (int i = threadIdx.x; i < QA_KB * (DT * 16 - CH); i += 256)
-                s_v[(i / (DT * 16 - CH)) * LDV + CH + i % (DT * 16 - CH)] = 0.f;
-        __syncthreads();
+    };
+    if (CH % 16)   // zero the padded head dims of V once (both buffers)
+        for (int i = threadIdx.x; i < 2 * QA_KB * (DT * 16 - CH); i += 256) {
+            const int buf = i / (QA_KB * (DT * 16 - CH)), r = i % (QA_KB * (DT * 16 - CH));
+            s_v[buf][(r / (DT * 16 - CH)) * LDV + CH + r % (DT * 16 - CH)] = 0.f;
+        }
+    fetch(0);
+    park(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < T; k0 += QA_KB, buf ^= 1) {
+        if (k0 + QA_KB < T) fetch(k0 + QA_KB);
+        const float* sk = s_k[buf];
+        const float* sv_ = s_v[buf];
         // S^T[key][query]: lane (query m, g) gets keys kt*16 + 4g + i
         f32x4 sv[4];
         float bmax = -1e30f;
@@ -163,7 +187,7 @@ __global__ __launch_bounds__(256) void qkv_attention_kernel(const float* __restr
             f32x4 s = zero4();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(s_k[(kt * 16 + m) * LD + 4 * ks + g], qf[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(sk[(kt * 16 + m) * LD + 4 * ks + g], qf[ks], s, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (k0 + kt * 16 + 4 * g + i >= T) s[i] = -1e30f;
@@ -196,10 +220,12 @@ __global__ __launch_bounds__(256) void qkv_attention_kernel(const float* __restr
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(s_v[(kt * 16 + 4 * g + i) * LDV + d * 16 + m], sv[kt][i], o, 0,
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(sv_[(kt * 16 + 4 * g + i) * LDV + d * 16 + m], sv[kt][i], o, 0,
                                                             0, 0);
             acc[d] = o;
         }
+        if (k0 + QA_KB < T) park(buf ^ 1);
+        __syncthreads();
     }
     if (q < T) {
         const float inv = 1.f / den;

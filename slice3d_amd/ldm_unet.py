@@ -155,6 +155,15 @@ class UNetModel(nn.Module):
                 self._packed[id(mod.proj_out)] = self._pack_conv(mod.proj_out)
         self._packed[id(self.input_blocks[0][0])] = self._pack_conv(self.input_blocks[0][0])
         self._packed[id(self.out[2])] = self._pack_conv(self.out[2])
+        # all ResBlock.emb_layers read the same timestep embedding: one stacked GEMV instead of one launch per block
+        res = [m for m in self.modules() if isinstance(m, ResBlock)]
+        self._film_w = torch.cat([m.emb_layers[1].weight for m in res], 0).contiguous()
+        self._film_b = torch.cat([m.emb_layers[1].bias for m in res], 0).contiguous()
+        self._film_off, off = {}, 0
+        for m in res:
+            rows = m.emb_layers[1].weight.shape[0]
+            self._film_off[id(m)] = (off, rows)
+            off += rows
         self._packed_key = self._params_key()
 
     # ------------------------------------------------------------------------------------------
@@ -234,7 +243,8 @@ class UNetModel(nn.Module):
             h = self._resample(h, blk.up)
             xs = self._resample(xin, blk.up)
         h = self._conv(blk.in_layers[2], h)
-        film = self._linear(blk.emb_layers[1], emb, silu_in=True)          # (N, 2*Cout) = scale | shift
+        off, rows = self._film_off[id(blk)]
+        film = self._film_all[:, off:off + rows].contiguous()               # (N, 2*Cout) = scale | shift
         if not blk.use_scale_shift_norm:
             raise NotImplementedError("ResBlock without use_scale_shift_norm is not built")
         h = self._group_norm(blk.out_layers[0], h, film=film, silu=True)
@@ -283,6 +293,12 @@ class UNetModel(nn.Module):
         _lib.check(lib.s3d_timestep_embedding_fwd(t.data_ptr(), t_emb.data_ptr(), n, self.model_channels,
                                                   C.c_float(10000.0), self._stream()), "s3d_timestep_embedding_fwd")
         emb = self._linear(self.time_embed[2], self._linear(self.time_embed[0], t_emb, silu_in=False), silu_in=True)
+        # emb_layers of every ResBlock (SiLU + Linear on the same emb, openaimodel.py:222-228,262) in one launch
+        m_all = self._film_w.shape[0]
+        self._film_all = torch.empty((n, m_all), dtype=torch.float32, device=dev)
+        _lib.check(lib.s3d_small_linear_fwd(emb.data_ptr(), self._film_w.data_ptr(), self._film_b.data_ptr(),
+                                            self._film_all.data_ptr(), n, emb.shape[1], m_all, 1, self._stream()),
+                   "s3d_small_linear_fwd")
         inject = {0: "f1", 4: "f2", 7: "f3", 10: "f4", 12: "f5"}
         h = self._to_nhwc(x, self._pad16(self.in_channels))
         hs = []
