@@ -49,7 +49,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvLaunch& a, f32x4 (&acc)[
                     }
                     if (a.residual) v += ld4(a.residual + oi);
                     if (a.out_accumulate) v += ld4(a.out + oi);
-                    st4(a.out + oi, v);
+                    // streaming store: activations are far larger than L2, keeping them out of it measured faster
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + oi));
                 }
             } else if (a.out_mode == S3D_OUT_CONVT) {
                 const int ct = a.cout_store;  // multiple of 16: a lane's 4 channels share a quadrant

@@ -21,3 +21,22 @@ for _ in range(n):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 print("LDM denoise step B=%d: %.2f ms  (%.1f TFLOP/s algorithmic at 222 GFLOP/step/sample)" % (B, ms, 0.222 * B / ms * 1e3))
+
+# the same step captured once into a HIP graph (static shapes, ~370 launches) and replayed
+g = torch.cuda.CUDAGraph()
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    for _ in range(2):
+        y = m(x, t, c_fmaps=cf)
+torch.cuda.current_stream().wait_stream(s)
+with torch.cuda.graph(g):
+    yg = m(x, t, c_fmaps=cf)
+g.replay(); torch.cuda.synchronize()
+print("graph output matches eager:", float((yg - y).abs().max()))
+t0 = time.perf_counter()
+for _ in range(n):
+    g.replay()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / n * 1e3
+print("LDM denoise step B=%d, HIP-graph replay: %.2f ms" % (B, ms))
