@@ -272,6 +272,20 @@ int s3d_train_fwd_bwd(const S3dUNetParams* unet, const S3dHeadParams* head, cons
                       const S3dTrainBatch* batch, int batch_size, int size, long n_qry, int n_slices,
                       float dropout_p, unsigned long long seed, int prec, float* losses_out, float* sdf_pred_out,
                       float* slices_rec_out, void* workspace, size_t workspace_bytes, void* stream);
+/* Slices3DGTModel training step — reg_slices/train_gt.py:38-52 (train_step: zero_grad, model(batch), L1 on the
+ * sdf, backward) without opt.step (s3d_adam_step).  Train-mode forward of model_gt.py:59-111: batch-statistics
+ * BatchNorm in the VGG16-BN encoder over the B*n_slices slice images (running statistics updated in place through
+ * enc->conv[i].bn[2..3], including conv[12]'s, whose output the model never uses), dropout p in the transformer.
+ * batch->img is ignored (model_gt.py:75-76 concatenates it and drops the result).  Gradients are written to the
+ * tensors of enc_grad / head_grad (same shapes as the parameters; conv[12].bn, the classifier and the unused
+ * att_layer / fc_global never receive one, as in the reference).  losses_out[0] = L1(sdf_pred, sdf),
+ * losses_out[1] = sign accuracy (train_gt.py:21-26).  sdf_pred_out (B,Q) optional. */
+size_t s3d_gt_train_workspace_bytes(int batch, int size, long n_qry, int n_slices);
+int s3d_gt_train_fwd_bwd(const S3dVgg16BnParams* enc, const S3dGtHeadParams* head,
+                         const S3dVgg16BnParams* enc_grad, const S3dGtHeadParams* head_grad,
+                         const S3dTrainBatch* batch, int batch_size, int size, long n_qry, int n_slices,
+                         float dropout_p, unsigned long long seed, int prec, float* losses_out, float* sdf_pred_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* The dropout mask the kernels use: out[i] = keep(seed, site, idx0+i) ? 1/(1-p) : 0.  site = 4*layer +
  * {0 attention probabilities [(row*4 + head)*16 + key], 1 attention-block output [row*128 + c],
  *  2 FFN hidden [row*2048 + unit], 3 FFN output [row*128 + c]}; rows index the token tensor

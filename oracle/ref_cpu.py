@@ -381,9 +381,10 @@ _GT_BLOCK = {"down1": "conv1_2", "down2": "conv2_2", "down3": "conv3_3", "down4"
 GT_LEVEL_CHANNELS = (64, 128, 256, 512, 512)   # conv1_2 ... conv5_3, sum = 1472
 
 
-def gt_encoder(sd, x, pfx="img_encoder."):
+def gt_encoder(sd, x, pfx="img_encoder.", train=None):
     """VGG16BNFeats.forward (vgg16bn_feats.py:42-57): the five RAW conv outputs conv1_2..conv5_3 — the slices
-    [:4] [4:11] [11:21] [21:31] [31:41] end on a conv, the BN/ReLU/pool that follow open the next slice."""
+    [:4] [4:11] [11:21] [21:31] [31:41] end on a conv, the BN/ReLU/pool that follow open the next slice.
+    train: a TrainState -> batch-statistics BatchNorm (running-stat updates collected in train.new_stats)."""
     taps = []
     h = x
     for ci in _VGG16_CONV_IDX:
@@ -392,15 +393,21 @@ def gt_encoder(sd, x, pfx="img_encoder."):
         if ci in _VGG16_TAPS:
             taps.append(h)
         if ci == 40:
-            break   # conv_last (BN-ReLU-pool) only feeds feat_global, which forward() never uses
-        h = torch.relu(_bn_eval(h, sd, f"{pfx}{_GT_BLOCK[_VGG16_BN_OWNER[ci]]}.{ci + 1}"))
+            # conv_last (BN-ReLU-pool) only feeds feat_global, which forward() never uses; in train mode its
+            # BatchNorm still sees the batch, so its running statistics move
+            if train is not None:
+                with torch.no_grad():
+                    _bn(h, sd, f"{pfx}conv_last.41", train)
+            break
+        h = torch.relu(_bn(h, sd, f"{pfx}{_GT_BLOCK[_VGG16_BN_OWNER[ci]]}.{ci + 1}", train))
         if ci in _VGG16_POOL_AFTER_BN_OF:
             h = F.max_pool2d(h, 2, 2)
     return taps
 
 
-def gt_decode_points(sd, feats, qry_rot, trans_mat, n_slices, chunk=2048):
-    """model_gt.py:77-106 for a set of (already rotated / flipped) queries."""
+def gt_decode_points(sd, feats, qry_rot, trans_mat, n_slices, chunk=2048, dropout=0.0, masks=None):
+    """model_gt.py:77-106 for a set of (already rotated / flipped) queries.  dropout / masks: train-mode
+    transformer (see transformer_layer); masks index all queries, so they need chunk >= Q."""
     outs = []
     b = qry_rot.shape[0]
     for s in range(0, qry_rot.shape[1], chunk):
@@ -418,7 +425,7 @@ def gt_decode_points(sd, feats, qry_rot, trans_mat, n_slices, chunk=2048):
             loc = torch.relu(loc @ sd[f"fc_local.{i}.weight"].t() + sd[f"fc_local.{i}.bias"])
         x = torch.cat([h.reshape(b * q, 1, D_MODEL), loc.reshape(b * q, n_slices, D_MODEL)], 1)
         for i in range(3):
-            x = transformer_layer(sd, x, f"att_decoder.layers.{i}")
+            x = transformer_layer(sd, x, f"att_decoder.layers.{i}", dropout, masks[i] if masks is not None else None)
         tok0 = x[:, 0, :].view(b, q, D_MODEL)
         outs.append((tok0 @ sd["fc_out.0.weight"].t() + sd["fc_out.0.bias"]).squeeze(-1))
     return torch.cat(outs, 1)
@@ -431,3 +438,20 @@ def gt_forward(sd, feed_dict, mode="train", n_slices=12):
     feats = gt_encoder(sd, sl.reshape(b * n_slices, 3, hh, ww))
     qry_rot = rotate_queries(feed_dict, mode)
     return gt_decode_points(sd, feats, qry_rot, feed_dict["trans_mat_wo_rot_tp"], n_slices), feats
+
+
+def gt_forward_train(sd, feed_dict, n_slices=12, dropout=0.0, masks=None):
+    """Slices3DGTModel.forward in TRAIN mode (model_gt.py:59-111: batch-stat BN over the B*n_slices slice images,
+    transformer dropout) + the loss / accuracy of train_gt.py:21-36, differentiable w.r.t. the tensors of `sd`
+    that require grad.  Returns (loss, acc, sdf_pred, TrainState)."""
+    ts = TrainState(dropout)
+    sl = feed_dict["img_slices"]
+    b, _, hh, ww = sl.shape
+    feats = gt_encoder(sd, sl.reshape(b * n_slices, 3, hh, ww), train=ts)
+    qry_rot = torch.bmm(feed_dict["qry_norot"], feed_dict["obj_rot_mat"])
+    q = qry_rot.shape[1]
+    sdf = gt_decode_points(sd, feats, qry_rot, feed_dict["trans_mat_wo_rot_tp"], n_slices, chunk=q,
+                           dropout=dropout, masks=masks)
+    loss = F.l1_loss(sdf, feed_dict["sdf"])
+    acc = (((sdf >= 0) == (feed_dict["sdf"] >= 0)).float().sum(dim=-1) / q).mean()
+    return loss, acc, sdf, ts

@@ -122,6 +122,10 @@ SYMBOLS = {
     "s3d_train_fwd_bwd": (_i, [C.POINTER(S3dUNetParams), C.POINTER(S3dHeadParams), C.POINTER(S3dVggParams),
                                C.POINTER(S3dUNetParams), C.POINTER(S3dHeadParams), C.POINTER(S3dTrainBatch),
                                _i, _i, _l, _i, _f, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "s3d_gt_train_workspace_bytes": (_sz, [_i, _i, _l, _i]),
+    "s3d_gt_train_fwd_bwd": (_i, [C.POINTER(S3dVgg16BnParams), C.POINTER(S3dGtHeadParams),
+                                  C.POINTER(S3dVgg16BnParams), C.POINTER(S3dGtHeadParams), C.POINTER(S3dTrainBatch),
+                                  _i, _i, _l, _i, _f, C.c_ulonglong, _i, _vp, _vp, _vp, _sz, _vp]),
     "s3d_dropout_mask": (_i, [C.c_ulonglong, _i, C.c_ulonglong, _l, _f, _vp, _vp]),
     "s3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _i, _vp]),
     "s3d_prof_enable": (_i, [_i]),

@@ -837,3 +837,4 @@ extern "C" int s3d_nhwc_to_nchw(const float* in, float* out, int n, int c, int h
 #include "api_gt.inc"
 #include "api_ldm.inc"
 #include "api_train.inc"
+#include "api_train_gt.inc"

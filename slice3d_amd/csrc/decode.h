@@ -82,6 +82,7 @@ struct SampleGtArgs {
     float box;
     float* X;               // out [g_count][T][16][128]; token-0 rows are zero-filled
     const int* perm;
+    float* raw_out;         // optional (training): sampled conv1_2 features [g_count][T][16][64], token-0 rows zero
 };
 int launch_sample_tokens_gt(const SampleGtArgs& a, hipStream_t stream);
 struct GtPointArgs {
@@ -93,6 +94,7 @@ struct GtPointArgs {
     float box;
     float* X;
     const int* perm;
+    float *h1_out, *h2_out;  // optional (training): hidden activations per query row, [rows][32] and [rows][64]
 };
 int launch_gt_point_tokens(const GtPointArgs& a, hipStream_t stream);
 int launch_sample_pyramid(const float* const* level, const float* grid, const int* perm, float* pts, float* out,

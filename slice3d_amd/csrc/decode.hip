@@ -930,6 +930,7 @@ __global__ __launch_bounds__(256) void sample_tokens_gt_kernel(const SampleGtArg
         project(a.trans + b * 12, x, y, z, gx, gy);
         for (int t = wave; t < T; t += 4) {
             f32x4 acc[8];
+            f32x4 braw[4] = {zero4(), zero4(), zero4(), zero4()};
             if (t == 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = zero4();
@@ -960,7 +961,6 @@ __global__ __launch_bounds__(256) void sample_tokens_gt_kernel(const SampleGtArg
                         }
                     }
                 }
-                f32x4 braw[4];
                 {
                     const Tap4 tp = make_taps(gx, gy, S, S);
                     const float* base = a.fine + img * (long)S * S * 64 + 4 * g;
@@ -987,6 +987,11 @@ __global__ __launch_bounds__(256) void sample_tokens_gt_kernel(const SampleGtArg
             float* o = a.X + ((gi * T + t) * S3D_GROUP + m) * 128 + 4 * g;
 #pragma unroll
             for (int j = 0; j < 8; ++j) st4(o + 16 * j, acc[j]);
+            if (a.raw_out) {
+                float* ro = a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 64 + 4 * g;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) st4(ro + 16 * u, braw[u]);
+            }
         }
     }
 }
@@ -1049,6 +1054,11 @@ __global__ __launch_bounds__(256) void gt_point_tokens_kernel(const GtPointArgs 
             out[i] = fmaxf(s, 0.f);
         }
         if (ok) st4(a.X + ((gi * T) * S3D_GROUP + m) * 128 + 4 * l, out);
+        if (ok && a.h1_out) {
+            a.h1_out[r * 32 + l] = s_h1[sub][l];
+            a.h2_out[r * 64 + l] = s_h2[sub][l];
+            a.h2_out[r * 64 + 32 + l] = s_h2[sub][32 + l];
+        }
         __syncthreads();
     }
 }

@@ -112,6 +112,8 @@ struct SampleBwdArgs {
     long n_qry, groups_per_batch, groups;
     const int* perm;         // optional: token rows are in sorted order, perm[b*Q + slot] = query (s3d_query_sort)
     const int* bin_ends;     // with perm: [B][65536] end offset of every Morton bin (launch_query_sort's ws)
+    int gt;                  // Slices3DGTModel levels: dproj[0..2] + dfine[0] are the four folded 128-ch maps
+                             // (S/16 ... S/2), dfine[1] the raw 64-ch conv1_2 map, ws34_t the [4][8] image of Wraw^T
 };
 int launch_sample_bwd(const SampleBwdArgs& a, hipStream_t stream);
 int launch_tok0_copy(float* full, float* compact, long groups, int T, int dir, int width, hipStream_t stream);

@@ -200,9 +200,23 @@ __device__ __forceinline__ void atomic_add4(float* p, const f32x4 v) {
     unsafeAtomicAdd(p + 3, v[3]);
 }
 
+// GT = 0: Slices3DRegModel levels (3 folded 128-ch maps, raw 64-ch and 32-ch maps through Ws34^T, NU = 6 tiles)
+// GT = 1: Slices3DGTModel levels (4 folded 128-ch maps, the raw 64-ch conv1_2 map through Wraw^T, NU = 4 tiles);
+//         the five gradient maps are dproj[0..2], dfine[0] (128 ch), dfine[1] (64 ch)
+template <int GT>
+struct SbLevels {
+    static constexpr int NU = GT ? 4 : 6;
+    __host__ __device__ static constexpr int C(int l) { return GT ? (l < 4 ? 128 : 64) : (l < 3 ? 128 : (l == 3 ? 64 : 32)); }
+    __host__ __device__ static constexpr bool folded(int l) { return GT ? l < 4 : l < 3; }
+    __host__ __device__ static constexpr int draw0(int l) { return GT ? 0 : (l == 3 ? 0 : 4); }   // first draw tile of a raw level
+};
+
+template <int GT>
 __global__ __launch_bounds__(256) void sample_bwd_kernel(const SampleBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_wt[6 * 8 * 256];  // Ws34^T fragment image [6][8], 48 KiB
-    for (int i = threadIdx.x; i < 6 * 8 * 64; i += 256) st4(s_wt + 4 * i, ld4(a.ws34_t + 4 * i));
+    using LV = SbLevels<GT>;
+    constexpr int NU = LV::NU;
+    __shared__ __attribute__((aligned(16))) float s_wt[NU * 8 * 256];  // W_raw^T fragment image [NU][8]
+    for (int i = threadIdx.x; i < NU * 8 * 64; i += 256) st4(s_wt + 4 * i, ld4(a.ws34_t + 4 * i));
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -236,10 +250,10 @@ __global__ __launch_bounds__(256) void sample_bwd_kernel(const SampleBwdArgs a) 
             f32x4 dt[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) dt[j] = qv ? ld4(dp + 16 * j) : zero4();
-            // d raw34 = Ws34^T dtok  (6 output tiles of 16 channels, K = 128)
-            f32x4 draw[6];
+            // d raw = W_raw^T dtok  (NU output tiles of 16 channels, K = 128)
+            f32x4 draw[NU];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 f32x4 c = zero4();
 #pragma unroll
                 for (int j = 0; j < 8; ++j) c = mfma4(ld4(s_wt + ((u * 8 + j) * 64 + lane) * 4), dt[j], c);
@@ -247,39 +261,18 @@ __global__ __launch_bounds__(256) void sample_bwd_kernel(const SampleBwdArgs a) 
             }
             if (!qv) continue;
 #pragma unroll
-            for (int l = 0; l < 3; ++l) {
+            for (int l = 0; l < 5; ++l) {
+                const int C = LV::C(l), nv = C / 16;
                 const int W = S >> (4 - l);
                 const Tap4b tp = make_taps_b(gx, gy, W, W);
-                float* base = a.dproj[l] + img * (long)W * W * 128 + 4 * g;
+                float* base = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + img * (long)W * W * C + 4 * g;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (tp.w[k] == 0.f) continue;
-                    float* o = base + (long)tp.off[k] * 128;
+                    float* o = base + (long)tp.off[k] * C;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) atomic_add4(o + 16 * j, dt[j] * tp.w[k]);
-                }
-            }
-            {
-                const int W = S >> 1;
-                const Tap4b tp = make_taps_b(gx, gy, W, W);
-                float* base = a.dfine[0] + img * (long)W * W * 64 + 4 * g;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (tp.w[k] == 0.f) continue;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) atomic_add4(base + (long)tp.off[k] * 64 + 16 * u, draw[u] * tp.w[k]);
-                }
-            }
-            {
-                const int W = S;
-                const Tap4b tp = make_taps_b(gx, gy, W, W);
-                float* base = a.dfine[1] + img * (long)W * W * 32 + 4 * g;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (tp.w[k] == 0.f) continue;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        atomic_add4(base + (long)tp.off[k] * 32 + 16 * u, draw[4 + u] * tp.w[k]);
+                    for (int j = 0; j < nv; ++j)
+                        atomic_add4(o + 16 * j, (LV::folded(l) ? dt[j] : draw[LV::draw0(l) + j]) * tp.w[k]);
                 }
             }
         }
@@ -329,17 +322,20 @@ __device__ __forceinline__ TapL make_taps_l(float gx, float gy, int W, int ox, i
     return t;
 }
 
+template <int GT>
 __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdArgs a, const SbtGeom G) {
+    using LV = SbLevels<GT>;
+    constexpr int NU = LV::NU;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_wt = smem;                 // Ws34^T fragment image [6][8], 48 KiB
-    float* s_acc = smem + 6 * 8 * 256;  // per-level footprint accumulators
+    float* s_wt = smem;                  // W_raw^T fragment image [NU][8]
+    float* s_acc = smem + NU * 8 * 256;  // per-level footprint accumulators
     const int tile = blockIdx.x & 255;
     const int ts = (blockIdx.x >> 8) % a.n_slices;
     const int b = (blockIdx.x >> 8) / a.n_slices;
     const int* ends = a.bin_ends + (long)b * 65536;
     const long qs_lo = tile ? ends[256 * tile - 1] : 0, qs_hi = ends[256 * tile + 255];
     if (qs_lo >= qs_hi) return;
-    for (int i = threadIdx.x; i < 6 * 8 * 64; i += 512) st4(s_wt + 4 * i, ld4(a.ws34_t + 4 * i));
+    for (int i = threadIdx.x; i < NU * 8 * 64; i += 512) st4(s_wt + 4 * i, ld4(a.ws34_t + 4 * i));
     for (int i = threadIdx.x; i < G.total / 4; i += 512) st4(s_acc + 4 * i, zero4());
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -381,9 +377,9 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
         f32x4 dt[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) dt[j] = qv ? ld4(dp + 16 * j) : zero4();
-        f32x4 draw[6];
+        f32x4 draw[NU];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
+        for (int u = 0; u < NU; ++u) {
             f32x4 c = zero4();
 #pragma unroll
             for (int j = 0; j < 8; ++j) c = mfma4(ld4(s_wt + ((u * 8 + j) * 64 + lane) * 4), dt[j], c);
@@ -391,8 +387,8 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
         }
 #pragma unroll
         for (int l = 0; l < 5; ++l) {
-            const int C = l < 3 ? 128 : (l == 3 ? 64 : 32);
-            const int nv = l < 3 ? 8 : (l == 3 ? 4 : 2);
+            const int C = LV::C(l);
+            const int nv = C / 16;
             const TapL tp = make_taps_l(gx, gy, G.W[l], ox[l], oy[l], G.fw[l]);
             float* gbase = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + img * (long)G.W[l] * G.W[l] * C + 4 * g;
             float* lbase = s_acc + G.off[l] + 4 * g;
@@ -420,7 +416,7 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
                     float* o = lbase + tp.lofs[k] * C;
 #pragma unroll
                     for (int j = 0; j < nv; ++j) {
-                        f32x4 v = (l < 3 ? dt[j] : draw[(l == 3 ? 0 : 4) + j]) * tp.w[k];
+                        f32x4 v = (LV::folded(l) ? dt[j] : draw[LV::draw0(l) + j]) * tp.w[k];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             float x = v[i];
@@ -441,12 +437,12 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
                         float* o = lbase + tp.lofs[k] * C;
 #pragma unroll
                         for (int j = 0; j < nv; ++j)
-                            atomic_add4(o + 16 * j, (l < 3 ? dt[j] : draw[(l == 3 ? 0 : 4) + j]) * tp.w[k]);
+                            atomic_add4(o + 16 * j, (LV::folded(l) ? dt[j] : draw[LV::draw0(l) + j]) * tp.w[k]);
                     } else {   // rounding put the tap one pixel outside the footprint: global atomic
                         float* o = gbase + (long)tp.gofs[k] * C;
 #pragma unroll
                         for (int j = 0; j < nv; ++j)
-                            atomic_add4(o + 16 * j, (l < 3 ? dt[j] : draw[(l == 3 ? 0 : 4) + j]) * tp.w[k]);
+                            atomic_add4(o + 16 * j, (LV::folded(l) ? dt[j] : draw[LV::draw0(l) + j]) * tp.w[k]);
                     }
                 }
             }
@@ -469,38 +465,44 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
     }
 }
 
-int launch_sample_bwd(const SampleBwdArgs& a, hipStream_t stream) {
-    if (a.groups <= 0) return 0;
+template <int GT>
+static int launch_sample_bwd_t(const SampleBwdArgs& a, hipStream_t stream) {
+    using LV = SbLevels<GT>;
     if (a.perm && a.bin_ends) {
         SbtGeom G;
         int off = 0;
         for (int l = 0; l < 5; ++l) {
             G.W[l] = a.size >> (4 - l);
-            G.C[l] = l < 3 ? 128 : (l == 3 ? 64 : 32);
+            G.C[l] = LV::C(l);
             G.fw[l] = (16 * (G.W[l] - 1) + 254) / 255 + 2;
             G.off[l] = off;
             off += G.fw[l] * G.fw[l] * G.C[l];
         }
         G.total = off;
-        const size_t lds = (size_t)(6 * 8 * 256 + off) * sizeof(float);
+        const size_t lds = (size_t)(LV::NU * 8 * 256 + off) * sizeof(float);
         if (lds <= 160 * 1024) {
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)sample_bwd_tiled_kernel,
+                (void)hipFuncSetAttribute((const void*)sample_bwd_tiled_kernel<GT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_set = true;
             }
             const long batch = a.groups / a.groups_per_batch;
-            hipLaunchKernelGGL(sample_bwd_tiled_kernel, dim3((unsigned)(batch * a.n_slices * 256)), dim3(512), lds,
+            hipLaunchKernelGGL(sample_bwd_tiled_kernel<GT>, dim3((unsigned)(batch * a.n_slices * 256)), dim3(512), lds,
                                stream, a, G);
             S3D_LAUNCH_CHECK();
             return 0;
         }
     }
     const long blocks = a.groups < 4096 ? a.groups : 4096;
-    hipLaunchKernelGGL(sample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(sample_bwd_kernel<GT>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     S3D_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_sample_bwd(const SampleBwdArgs& a, hipStream_t stream) {
+    if (a.groups <= 0) return 0;
+    return a.gt ? launch_sample_bwd_t<1>(a, stream) : launch_sample_bwd_t<0>(a, stream);
 }
 
 // ---- copy the first `cdst` columns of a [rows][csrc] matrix into a dense [rows][cdst] matrix

@@ -24,14 +24,12 @@ class HipTrainer:
         self.group = process_group
         self.step = 0
         self.seed, self._calls, self.last_seed = seed, 0, 0
-        dev = model.fc_p.weight.device
+        dev = model.fc_out[0].weight.device
         if dev.type != "cuda":
             raise _lib.S3dError("move the model to the GPU before building a HipTrainer")
-        # trainable tensors = everything the forward touches (reference: 14 tensors never get a grad —
-        # the dead att_layer.* twin and down5_.41.* — and vggptlossfunc.* is frozen)
         self.names, self.params = [], []
         for k, p in model.named_parameters():
-            if k.startswith("att_layer.") or k.startswith("vggptlossfunc.") or ".down5_." in k:
+            if not self._trainable(k):
                 continue
             self.names.append(k)
             self.params.append(p)
@@ -46,6 +44,12 @@ class HipTrainer:
             off += p.numel()
         self._losses = torch.zeros(4, dtype=torch.float32, device=dev)
         self._ws = None
+
+    @staticmethod
+    def _trainable(k):
+        """Trainable tensors = everything the forward touches (reference: 14 tensors never get a grad — the dead
+        att_layer.* twin and down5_.41.* — and vggptlossfunc.* is frozen)."""
+        return not (k.startswith("att_layer.") or k.startswith("vggptlossfunc.") or ".down5_." in k)
 
     # -- struct builders ------------------------------------------------------------------------
     def _gptr(self, t):
@@ -83,12 +87,8 @@ class HipTrainer:
         up.n_slices = self.model.n_slices
         return up
 
-    def _head_struct(self, grad):
+    def _fill_layers(self, hp, pick):
         m = self.model
-        pick = (lambda t: self._gptr(t)) if grad else (lambda t: t.data_ptr())
-        hp = _lib.S3dHeadParams()
-        hp.fc_p_w, hp.fc_p_b = pick(m.fc_p.weight), pick(m.fc_p.bias)
-        hp.fc_s_w, hp.fc_s_b = pick(m.fc_s.weight), pick(m.fc_s.bias)
         for i, layer in enumerate(m.att_decoder.layers):
             lp = hp.layer[i]
             lp.in_proj_w, lp.in_proj_b = pick(layer.self_attn.in_proj_weight), pick(layer.self_attn.in_proj_bias)
@@ -98,6 +98,14 @@ class HipTrainer:
             lp.norm1_w, lp.norm1_b = pick(layer.norm1.weight), pick(layer.norm1.bias)
             lp.norm2_w, lp.norm2_b = pick(layer.norm2.weight), pick(layer.norm2.bias)
         hp.fc_out_w, hp.fc_out_b = pick(m.fc_out[0].weight), pick(m.fc_out[0].bias)
+
+    def _head_struct(self, grad):
+        m = self.model
+        pick = (lambda t: self._gptr(t)) if grad else (lambda t: t.data_ptr())
+        hp = _lib.S3dHeadParams()
+        hp.fc_p_w, hp.fc_p_b = pick(m.fc_p.weight), pick(m.fc_p.bias)
+        hp.fc_s_w, hp.fc_s_b = pick(m.fc_s.weight), pick(m.fc_s.bias)
+        self._fill_layers(hp, pick)
         return hp
 
     def _vgg_struct(self):
@@ -198,3 +206,81 @@ class HipTrainer:
         self.adam_step()
         lp, li, lv, acc = losses.tolist()    # the reference's 4 .item() syncs, as one
         return lp, li, lv, acc
+
+
+class HipGtTrainer(HipTrainer):
+    """Training step of Slices3DGTModel — host side of reg_slices/train_gt.py:38-52 (train_step) and :115 (Adam):
+    s3d_gt_train_fwd_bwd + s3d_adam_step.  `train_step(batch)` returns (loss_pred, acc)."""
+
+    @staticmethod
+    def _trainable(k):
+        # never reached by the forward's gradient (model_gt.py:77 drops feat_global; fc_global and the att_layer
+        # twin are dead): torch.optim.Adam skips them because their .grad stays None
+        dead = ("att_layer.", "fc_global.", "img_encoder.classifier.", "img_encoder.conv_last.")
+        return not k.startswith(dead)
+
+    def _enc_struct(self, grad):
+        from .models_gt import _GT_SLICES
+        e = self.model.img_encoder
+        vp = _lib.S3dVgg16BnParams()
+        for i, (idx, _, _) in enumerate(_VGG16_CFG):
+            conv = getattr(getattr(e, _slice_of(idx, _GT_SLICES)), str(idx))
+            bn = getattr(getattr(e, _slice_of(idx + 1, _GT_SLICES)), str(idx + 1))
+            if i < 12:
+                vp.conv[i] = self._conv(conv, bn, grad)
+            else:   # conv5_3's BatchNorm (conv_last.41): running statistics move, weight / bias get no gradient
+                vp.conv[i] = self._conv(conv, None, grad)
+                if not grad:
+                    vp.conv[i].bn[2], vp.conv[i].bn[3] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        return vp
+
+    def _gt_head_struct(self, grad):
+        m = self.model
+        pick = (lambda t: self._gptr(t)) if grad else (lambda t: t.data_ptr())
+        hp = _lib.S3dGtHeadParams()
+        for k, idx in enumerate((0, 2, 4)):
+            hp.pts_w[k], hp.pts_b[k] = pick(m.pts_feat_extractor[idx].weight), pick(m.pts_feat_extractor[idx].bias)
+        for k, idx in enumerate((0, 2)):
+            hp.local_w[k], hp.local_b[k] = pick(m.fc_local[idx].weight), pick(m.fc_local[idx].bias)
+        self._fill_layers(hp, pick)
+        return hp
+
+    def forward_backward(self, batch, want_outputs=False):
+        """Train-mode forward + L1 loss + backward; fills param.grad.  Returns the device tensor
+        [loss_pred, acc, 0, 0] (and sdf_pred if asked)."""
+        m, lib = self.model, self.lib
+        dev = self.grad_flat.device
+        f = lambda k: batch[k].to(device=dev, dtype=torch.float32).contiguous()
+        sl, qry, rot, tm, sdf = (f(k) for k in ("img_slices", "qry_norot", "obj_rot_mat", "trans_mat_wo_rot_tp",
+                                                  "sdf"))
+        b, c, s, _ = sl.shape
+        q, ns = qry.shape[1], m.n_slices
+        if c != 3 * ns:
+            raise ValueError("img_slices has %d channels, expected 3*n_slices = %d" % (c, 3 * ns))
+        tb = _lib.S3dTrainBatch()
+        tb.img_slices, tb.qry = sl.data_ptr(), qry.data_ptr()
+        tb.rot, tb.trans, tb.sdf = rot.data_ptr(), tm.data_ptr(), sdf.data_ptr()
+        nb = lib.s3d_gt_train_workspace_bytes(b, s, q, ns)
+        if self._ws is None or self._ws.numel() < nb:
+            self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        sdf_pred = torch.empty((b, q), dtype=torch.float32, device=dev) if want_outputs else None
+        e, h = self._enc_struct(False), self._gt_head_struct(False)
+        de, dh = self._enc_struct(True), self._gt_head_struct(True)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.s3d_gt_train_fwd_bwd(C.byref(e), C.byref(h), C.byref(de), C.byref(dh), C.byref(tb),
+                                            b, s, q, ns, float(self.dropout), self._next_seed(), self.prec,
+                                            self._losses.data_ptr(),
+                                            sdf_pred.data_ptr() if want_outputs else None,
+                                            self._ws.data_ptr(), self._ws.numel(), stream), "s3d_gt_train_fwd_bwd")
+        m._packed_key = None   # BN running statistics changed in place: eval-mode packs are stale
+        if want_outputs:
+            return self._losses, sdf_pred
+        return self._losses
+
+    def train_step(self, batch):
+        """train_gt.py:38-52 — returns python floats (loss_pred, acc)."""
+        losses = self.forward_backward(batch)
+        self.all_reduce_grads()
+        self.adam_step()
+        lp, acc = losses[:2].tolist()
+        return lp, acc

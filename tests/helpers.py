@@ -71,3 +71,23 @@ def ldm_inputs(cfg, batch, seed):
     t = torch.randint(0, 1000, (batch,), generator=g)
     cf = {k: torch.randn(batch, c, s, s, generator=g) * 0.5 for k, (c, s) in ldm_fmap_shapes(cfg).items()}
     return x, t, cf
+
+
+def check_grads_against_golden(z, grads, skip=(), tol=2e-2):
+    """z: a *_train_* golden (gn:/gi:/gv: entries written by make_golden*.py from the real reference's .grad);
+    grads: name -> flat numpy gradient.  Per tensor: the L2 norm within tol and the 32 sampled entries within
+    tol * max|g|.  Tensors in `skip` (exactly-zero gradients, rounding noise on both sides) only need to be tiny.
+    Returns the worst sampled error / max|g|."""
+    worst = 0.0
+    for k in z["grad_names"]:
+        k = str(k)
+        g = grads[k]
+        norm, gmax = z["gn:" + k]
+        if k in skip:
+            assert np.abs(g).max() < 1e-4, k
+            continue
+        assert abs(np.linalg.norm(g) - norm) < tol * norm, (k, np.linalg.norm(g), norm)
+        err = np.abs(g[z["gi:" + k]] - z["gv:" + k]).max() / gmax
+        worst = max(worst, err)
+        assert err < tol, (k, err)
+    return worst

@@ -122,3 +122,29 @@ def test_oracle_matches_live_reference():
         assert (ref["sdf_pred"] - out["sdf_pred"]).abs().max() < ORACLE_TIGHT
         assert (ref["slices_rec"] - out["slices_rec"]).abs().max() < 2e-5
         assert abs(float(ref["vgg_loss"] - out["vgg_loss"])) < 1e-6
+
+
+def test_train_oracle_matches_reference_golden():
+    """forward_train (batch-stat BN, the three losses, autograd gradients, running-stat updates) against one
+    train-mode forward/backward of the real reference (g5, tests/golden/make_golden.py train_case)."""
+    from helpers import check_grads_against_golden
+    z = np.load(os.path.join(GOLDEN, "g5_train_s32_n12_q128_b2.npz"))
+    b, s, q, ns, _ = [int(v) for v in z["meta"]]
+    fd = {k: torch.from_numpy(z[k]) for k in
+          ("img_input", "img_slices", "qry_norot", "sdf", "obj_rot_mat", "trans_mat_wo_rot_tp")}
+    sd = seeded_sd_from_shapes(_shapes(ns))
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and not k.startswith("vggptlossfunc"):
+            v.requires_grad_(True)
+    loss, parts, out, ts = ref_cpu.forward_train(sd, fd, ns, 0.0)
+    loss.backward()
+    assert np.abs(out["sdf_pred"].detach().numpy() - z["sdf_pred"]).max() < ORACLE_TOL
+    for i in range(3):
+        assert abs(float(parts[i].detach()) - z["losses"][i]) < 2e-5 * abs(z["losses"][i]) + 1e-7
+    pre_bn = {"slices_generator.%s.bias" % k for k in
+              ("down1.0", "down2.7", "down3.14", "down3.17", "down4.24", "down4.27", "down5.34", "down5.37")}
+    names = [str(k) for k in z["grad_names"]]
+    check_grads_against_golden(z, {k: sd[k].grad.reshape(-1).numpy() for k in names}, skip=pre_bn)
+    for key in z.files:
+        if key.startswith("bn:") and ".down5_." not in key:
+            assert np.abs(ts.new_stats[key[3:]].numpy() - z[key]).max() < 1e-5, key
