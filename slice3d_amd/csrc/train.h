@@ -79,8 +79,24 @@ int launch_slice_sum(const float* in, float* out, int batch, int ns, long per_im
 int launch_tanh_bwd(const float* y_nchw, const float* dy_nchw, float* dz_nhwc, int n, int c, int h, int w, int cpad,
                     hipStream_t stream);   // dz[n,y,x,c] = dy*(1-y^2), NCHW -> NHWC(cpad), zero padded
 // L1 loss: loss_acc[0] += scale*sum|a-b|; grad[i] (+)= scale*sign(a-b)
+// grad_mul: extra factor on the gradient only (the backward scale of the split-precision training path)
 int launch_l1_fwd_bwd(const float* a, const float* b, long n, float scale, float* grad, int accumulate_grad,
-                      float* partial, float* loss_acc, hipStream_t stream);
+                      float* partial, float* loss_acc, hipStream_t stream, float grad_mul = 1.f);
+// in-place multiply of up to S3D_SCALE_TABLE_MAX tensors by one factor (one launch)
+#define S3D_SCALE_TABLE_MAX 224
+struct ScaleTable {
+    float* p[S3D_SCALE_TABLE_MAX];
+    long n[S3D_SCALE_TABLE_MAX];
+    int count;
+    void add(const float* q, long k) {
+        if (q && k > 0 && count < S3D_SCALE_TABLE_MAX) {
+            p[count] = const_cast<float*>(q);
+            n[count] = k;
+            ++count;
+        }
+    }
+};
+int launch_scale_table(const ScaleTable& t, float s, hipStream_t stream);
 int launch_relu_mask_bwd(const float* y, float* dy, long n, hipStream_t stream);              // dy *= (y > 0)
 int launch_pool_bwd(const float* y, const float* dyp, float* dy, int n, int h, int w, int c, hipStream_t stream);
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,

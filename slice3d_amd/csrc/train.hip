@@ -1023,7 +1023,7 @@ int launch_tanh_bwd(const float* y, const float* dy, float* dz, int n, int c, in
 #define L1B 1024
 __global__ __launch_bounds__(256) void l1_fb_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
                                                     float scale, float* __restrict__ grad, int acc_grad,
-                                                    float* __restrict__ partial) {
+                                                    float* __restrict__ partial) {   // scale: of the gradient
     __shared__ float red[4];
     float s = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -1052,13 +1052,26 @@ __global__ __launch_bounds__(256) void scalar_final_kernel(const float* __restri
     if (threadIdx.x == 0) acc[0] += scale * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 int launch_l1_fwd_bwd(const float* a, const float* b, long n, float scale, float* grad, int accumulate_grad,
-                      float* partial, float* loss_acc, hipStream_t stream) {
+                      float* partial, float* loss_acc, hipStream_t stream, float grad_mul) {
     if (n <= 0) return 0;
     const int blocks = (int)((n + 255) / 256 < L1B ? (n + 255) / 256 : L1B);
-    hipLaunchKernelGGL(l1_fb_kernel, dim3(blocks), dim3(256), 0, stream, a, b, n, scale, grad, accumulate_grad,
-                       partial);
+    hipLaunchKernelGGL(l1_fb_kernel, dim3(blocks), dim3(256), 0, stream, a, b, n, scale * grad_mul, grad,
+                       accumulate_grad, partial);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, scale, loss_acc);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// in-place x *= s on a table of tensors (blockIdx.y = table entry)
+__global__ __launch_bounds__(256) void scale_table_kernel(const ScaleTable t, int first, float s) {
+    float* p = t.p[first + blockIdx.y];
+    const long n = t.n[first + blockIdx.y];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] *= s;
+}
+int launch_scale_table(const ScaleTable& t, float s, hipStream_t stream) {
+    if (t.count <= 0 || s == 1.f) return 0;
+    hipLaunchKernelGGL(scale_table_kernel, dim3(64, (unsigned)t.count), dim3(256), 0, stream, t, 0, s);
     S3D_LAUNCH_CHECK();
     return 0;
 }

@@ -50,3 +50,24 @@ def test_reconstruct_slices_writes_the_twelve_slice_images(tmp_path):
          "--img_size", "32", "--name_exp", "sl", "--name_ckpt", "none.ckpt", "--mode", "test"], str(work))
     names = sorted(os.path.basename(p) for p in glob.glob(str(work / "experiments" / "sl" / "img_slices" / "synthetic_0001" / "*.png")))
     assert names == sorted(["%s_%d.png" % (a, i) for a in "XYZ" for i in range(1, 5)])
+
+
+def test_train_gt_then_reconstruct_from_given_slices(tmp_path):
+    """reg_slices/train_gt.py for one epoch on the toy dataset, then reconstruct.py --name_model gtslice from the
+    checkpoint it wrote (the generation pipeline's second stage, README 'GT-slices -> 3D')."""
+    from slice3d_amd.datasets import write_toy_dataset
+    data = tmp_path / "data"
+    write_toy_dataset(str(data), "custom", n_views=6, size=40, n_pts=600, seed=4)
+    work = tmp_path / "work"
+    work.mkdir()
+    common = ["--dir_data", str(data), "--name_dataset", "custom", "--img_size", "32", "--n_qry", "256", "--n_views", "6",
+              "--n_wk", "0", "--name_exp", "toy_gt"]
+    out = run([os.path.join(ROOT, "reg_slices", "train_gt.py")] + common +
+              ["--n_bs", "2", "--n_epochs", "1", "--freq_ckpt", "1", "--freq_log", "1", "--mode", "train"], str(work))
+    assert "[train]" in out and "[val]" in out
+    ckpts = glob.glob(str(work / "experiments" / "toy_gt" / "ckpt" / "*.ckpt"))
+    assert len(ckpts) == 1 and len(os.path.basename(ckpts[0]).split("_")) == 4   # {epoch}_{iter}_{loss}_{acc}.ckpt
+    out = run([os.path.join(ROOT, "reg_slices", "reconstruct.py")] + common +
+              ["--name_model", "gtslice", "--name_ckpt", os.path.basename(ckpts[0]), "--mode", "test", "--mc_res0", "8",
+               "--mc_up_steps", "0"], str(work))
+    assert len(glob.glob(str(work / "experiments" / "toy_gt" / "results" / "custom" / "*.obj"))) == 2, out

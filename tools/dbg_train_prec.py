@@ -7,7 +7,8 @@ from slice3d_amd.synth import make_feed_dict
 from slice3d_amd.trainer import HipTrainer
 from slice3d_amd.weights import load_seeded
 q = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-fd = {k: v.cuda() for k, v in make_feed_dict(1, 64, q, 12, seed=77).items()}
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+fd = {k: v.cuda() for k, v in make_feed_dict(1, size, q, 12, seed=77).items()}
 res = {}
 for prec in ("f32", "f16x3", "f32b"):
     m = load_seeded(Slices3DRegModel(n_slices=12, mode="train"), 0).cuda()
