@@ -537,6 +537,228 @@ int launch_pack_ffn_rec_f16x3(const float* w, int sh, int sk, float* out, hipStr
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-precision weight gradient of a 3x3 convolution (stride 1, padding 1):
+//   dW[n][ky][kx][c] = sum over pixels p of dY[p][n] * X[p + (ky-1, kx-1)][c]
+// Workgroup = 64 (n) x 64 (c) x all 9 taps, 4 waves of 32 x 32 x 9 (36 accumulator tiles each); the contraction
+// runs over 4-row x 8-column pixel tiles, one v_mfma_f32_16x16x32_f16 K per tile (k-slot g <-> tile row, the
+// lane's 8 halfs <-> the 8 columns).  Per tile the workgroup stages, as f16 hi/lo and channel-major,
+//   dY^T [n][4 rows][8 cols]                 and
+//   X^T  [c][6 halo rows][col -1 | 8 cols | col 8]   (interior 16-byte aligned at half 8, neighbours at 7 and 16)
+// once, and all nine taps read from it: the row shift picks another halo row, the column shift is made in
+// registers from the aligned word and its two neighbour dwords (v_alignbyte).  dY / X are read once per tile
+// instead of once per tap; next tile's global loads are in flight during the MFMAs.
+// ---------------------------------------------------------------------------------------------
+#define W3_DLD 40     // halfs per n row of the dY^T tile (4 x 8 + 8 pad: 80 B, odd multiple of 16)
+#define W3_XROW 24    // halfs per halo row
+#define W3_XLD 152    // halfs per channel of the X^T tile (6 x 24 + 8 pad: 304 B, odd multiple of 16)
+typedef int w3_int4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wl_half8 w3_frag(int d0, int d1, int d2, int d3) {
+    w3_int4 v = {d0, d1, d2, d3};
+    return __builtin_bit_cast(wl_half8, v);
+}
+__global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradArgs a, int n_cblk, long n_tiles,
+                                                                   int tiles_per_split, int Ktot) {
+    __shared__ __attribute__((aligned(16))) _Float16 s_d[2][64 * W3_DLD];   // dY^T hi|lo, 10 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 s_x[2][64 * W3_XLD];   // X^T  hi|lo, 38 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int ch = tid & 63, slot = tid >> 6;   // staging role: channel, dY tile row / X halo rows slot, slot + 4
+    const int cb = blockIdx.x % n_cblk, nb = blockIdx.x / n_cblk;
+    const int n0 = nb * 64, c0 = cb * 64;
+    const int wn = wave & 1, wc = wave >> 1;
+    const int H = a.H, W = a.W;
+    const int tiles_x = W >> 3, tpi = tiles_x * (H >> 2);
+    const float* dyp = a.dy + a.dy_coff + n0 + ch;
+    const float* xp = a.x.p + a.x_coff + c0 + ch;
+    const long dstride = a.dy_cstride, xstride = a.x.C;
+
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = zero4();
+
+    // raw prefetch registers (unconditional clamped loads; validity becomes a 0/1 factor at conversion time)
+    float pd[8], px[2][10];
+    unsigned vm = 0;   // bit 0 tile valid, 1/2 halo row u inside the image, 3 left column valid, 4 right column valid
+    const long t_begin = (long)blockIdx.y * tiles_per_split;
+    long t_end = t_begin + tiles_per_split;
+    if (t_end > n_tiles) t_end = n_tiles;
+    auto gload = [&](long t) {
+        const bool tv = t < t_end;
+        const long tc = tv ? t : t_end - 1;
+        const int img = (int)(tc / tpi);
+        const int r = (int)(tc - (long)img * tpi);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int ni = (a.x.bmod ? img % a.x.bmod : img) / a.x.bdiv;
+        {
+            const float* p = dyp + ((long)(img * H + ty * 4 + slot) * W + tx * 8) * dstride;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pd[j] = p[j * dstride];
+        }
+        const bool xl = tx > 0, xr = tx + 1 < tiles_x;
+        vm = (tv ? 1u : 0u) | (xl ? 8u : 0u) | (xr ? 16u : 0u);
+        if (slot < 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int y = ty * 4 - 1 + slot + 4 * u;
+                const bool yok = y >= 0 && y < H;
+                vm |= yok ? (2u << u) : 0u;
+                const int yc = min(max(y, 0), H - 1);
+                const float* p = xp + (long)(ni * H + yc) * W * xstride;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const int x = min(max(tx * 8 - 1 + j, 0), W - 1);
+                    px[u][j] = p[x * xstride];
+                }
+            }
+        } else {
+            const int y = ty * 4 - 1 + slot;     // halo rows 2, 3 are always inside the image
+            vm |= 2u;
+            const float* p = xp + (long)(ni * H + y) * W * xstride;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int x = min(max(tx * 8 - 1 + j, 0), W - 1);
+                px[0][j] = p[x * xstride];
+            }
+        }
+    };
+    if (t_begin < t_end) gload(t_begin);
+    for (long t = t_begin; t < t_end; ++t) {
+        // ---- stage the tile ----
+        {
+            const float tvf = (vm & 1u) ? 1.f : 0.f;
+            wl_half8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = pd[j] * tvf;
+                const _Float16 h = (_Float16)v;
+                hi[j] = h;
+                lo[j] = (_Float16)(v - (float)h);
+            }
+            *reinterpret_cast<wl_half8*>(&s_d[0][ch * W3_DLD + 8 * slot]) = hi;
+            *reinterpret_cast<wl_half8*>(&s_d[1][ch * W3_DLD + 8 * slot]) = lo;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && slot >= 2) break;
+                const float rf = (vm & (2u << u)) ? tvf : 0.f;
+                const float lf = (vm & 8u) ? rf : 0.f, rtf = (vm & 16u) ? rf : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = px[u][j + 1] * rf;
+                    const _Float16 h = (_Float16)v;
+                    hi[j] = h;
+                    lo[j] = (_Float16)(v - (float)h);
+                }
+                const int o = ch * W3_XLD + (slot + 4 * u) * W3_XROW;
+                *reinterpret_cast<wl_half8*>(&s_x[0][o + 8]) = hi;
+                *reinterpret_cast<wl_half8*>(&s_x[1][o + 8]) = lo;
+                const float vl = px[u][0] * lf, vr = px[u][9] * rtf;
+                const _Float16 hl = (_Float16)vl, hr = (_Float16)vr;
+                s_x[0][o + 7] = hl;
+                s_x[1][o + 7] = (_Float16)(vl - (float)hl);
+                s_x[0][o + 16] = hr;
+                s_x[1][o + 16] = (_Float16)(vr - (float)hr);
+            }
+        }
+        __syncthreads();
+        if (t + 1 < t_end) gload(t + 1);
+        // ---- 9 taps x (2 x 2) tiles ----
+        wl_half8 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = (32 * wn + 16 * i + m) * W3_DLD + 8 * g;
+            ah[i] = *reinterpret_cast<const wl_half8*>(&s_d[0][o]);
+            al[i] = *reinterpret_cast<const wl_half8*>(&s_d[1][o]);
+        }
+#pragma unroll
+        for (int dyi = 0; dyi < 3; ++dyi) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = (32 * wc + 16 * j + m) * W3_XLD + (g + dyi) * W3_XROW;
+                wl_half8 bh[3], bl[3];
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    const w3_int4 I = *reinterpret_cast<const w3_int4*>(&s_x[hl][o + 8]);
+                    const int Pw = *reinterpret_cast<const int*>(&s_x[hl][o + 6]);
+                    const int Nw = *reinterpret_cast<const int*>(&s_x[hl][o + 16]);
+                    const int s01 = __builtin_amdgcn_alignbyte(I[1], I[0], 2);
+                    const int s12 = __builtin_amdgcn_alignbyte(I[2], I[1], 2);
+                    const int s23 = __builtin_amdgcn_alignbyte(I[3], I[2], 2);
+                    const wl_half8 f0 = w3_frag(__builtin_amdgcn_alignbyte(I[0], Pw, 2), s01, s12, s23);
+                    const wl_half8 f1 = __builtin_bit_cast(wl_half8, I);
+                    const wl_half8 f2 = w3_frag(s01, s12, s23, __builtin_amdgcn_alignbyte(Nw, I[3], 2));
+                    if (hl == 0) {
+                        bh[0] = f0; bh[1] = f1; bh[2] = f2;
+                    } else {
+                        bl[0] = f0; bl[1] = f1; bl[2] = f2;
+                    }
+                }
+#pragma unroll
+                for (int dxi = 0; dxi < 3; ++dxi)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        f32x4 c = acc[dyi * 3 + dxi][i][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[dxi], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[dxi], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[dxi], c, 0, 0, 0);
+                        acc[dyi * 3 + dxi][i][j] = c;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    // D[row = 4g+reg <-> n][col = m <-> c]  ->  partial[split][n][tap*Cx + c]
+    float* part = a.partial + (size_t)blockIdx.y * a.N * Ktot;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int n = n0 + 32 * wn + 16 * i + 4 * g + reg;
+                    const int c = c0 + 32 * wc + 16 * j + m;
+                    part[(size_t)n * Ktot + tap * a.Cx + c] = acc[tap][i][j][reg];
+                }
+}
+
+static bool wgrad_conv3_eligible(const WgradArgs& a) {
+    static const bool off = getenv("S3D_WGRAD3_F32") != nullptr;
+    return !off && a.prec == S3D_PREC_F16X3 && a.ks == 3 && a.stride <= 1 && !a.x.sbcast && a.x.bdiv >= 1 &&
+           (a.Hin == 0 || a.Hin == a.H) && (a.Win == 0 || a.Win == a.W) && a.N % 64 == 0 && a.Cx % 64 == 0 &&
+           a.H % 4 == 0 && a.W % 8 == 0 && a.out_kind == S3D_PACK_CONV;
+}
+
+static int launch_wgrad_conv3_f16x3(const WgradArgs& a, hipStream_t stream) {
+    const int n_nblk = a.N / 64, n_cblk = a.Cx / 64, Ktot = 9 * a.Cx;
+    const long n_tiles = (long)a.Nimg * (a.H / 4) * (a.W / 8);
+    const long blocks = (long)n_nblk * n_cblk;
+    long splits = (2048 + blocks - 1) / blocks;                // aim at >= 2048 workgroups
+    const long max_by_tiles = (n_tiles + 7) / 8;               // >= 8 tiles per workgroup
+    if (splits > max_by_tiles) splits = max_by_tiles;
+    const long cap = (long)(a.partial_floats / ((size_t)a.N * Ktot));
+    if (splits > cap) splits = cap;
+    if (splits < 1) {
+        s3d_set_error("wgrad: partial workspace too small for %d x %d x 9", a.N, a.Cx);
+        return S3D_E_WORKSPACE;
+    }
+    const int tps = (int)((n_tiles + splits - 1) / splits);
+    splits = (n_tiles + tps - 1) / tps;
+    hipLaunchKernelGGL(wgrad_conv3_f16x3_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(256), 0, stream, a,
+                       n_cblk, n_tiles, tps, Ktot);
+    S3D_LAUNCH_CHECK();
+    const long total = (long)a.N * Ktot;
+    const int rb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, a, (int)splits, Ktot);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
 static bool wgrad_lin_eligible(const WgradArgs& a, long P) {
     return a.prec == S3D_PREC_F16X3 && a.ks == 1 && a.stride <= 1 && !a.x.sbcast && !a.x.bmod && a.x.bdiv == 1 &&
            (a.Hin == 0 || a.Hin == a.H) && (a.Win == 0 || a.Win == a.W) && a.N >= 64 && a.Cx >= 64 && P >= 1024;
@@ -598,6 +820,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
                   "wgrad: channel strides/offsets must be multiples of 4");
     const long P = (long)a.Nimg * a.H * a.W;
     if (wgrad_lin_eligible(a, P)) return launch_wgrad_lin_f16x3(a, P, stream);
+    if (wgrad_conv3_eligible(a)) return launch_wgrad_conv3_f16x3(a, stream);
     const int taps = a.ks * a.ks;
     int TN, TK, n_nblk, n_cblk, sy, spw;
     wgrad_plan(P, a.N, a.Cx, taps, TN, TK, n_nblk, n_cblk, sy, spw);
