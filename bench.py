@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--prec", default="f16x3", choices=["f32", "f16x3"], help="arithmetic mode of the decoder GEMMs")
     ap.add_argument("--ldm-steps", type=int, default=5, help="timed LDM denoising steps (BASELINE configs[4]; 0 = skip)")
     ap.add_argument("--train-steps", type=int, default=3, help="timed training steps for train_samples_per_s (0 = skip)")
+    ap.add_argument("--gt-train-steps", type=int, default=5, help="timed Slices3DGTModel training steps (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,6 +216,27 @@ def main():
         train_ms = tdt / args.train_steps * 1e3
         del trainer, tmodel
 
+    # ---- secondary metric: Slices3DGTModel training (train_gt.py:38-52) at the reference's default options
+    #      (options.py: n_bs 16, img_size 128, n_qry 256), rank 0 only ----
+    gt_train = None
+    if args.gt_train_steps > 0 and rank == 0:
+        from slice3d_amd.models_gt import Slices3DGTModel
+        from slice3d_amd.trainer import HipGtTrainer
+        gm = load_seeded(Slices3DGTModel(img_size=128, n_slices=args.n_slices, mode="train"), 0).cuda()
+        gtr = HipGtTrainer(gm, dropout=0.1, seed=0, prec=args.prec)
+        gfd = make_feed_dict(16, 128, 256, args.n_slices, seed=99, device="cuda")
+        gtr.train_step(gfd)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.gt_train_steps):
+            gtr.train_step(gfd)
+        torch.cuda.synchronize()
+        gms = (time.perf_counter() - t1) / args.gt_train_steps * 1e3
+        gt_train = {"workload": "Slices3DGTModel train_step (fwd + L1 + bwd + Adam), 16 objects x %d slices at 128^2, "
+                                "256 queries each, dropout 0.1 (reg_slices/options.py defaults)" % args.n_slices,
+                    "ms_per_step": gms, "samples_per_s": 16 / gms * 1e3, "dtype": args.prec}
+        del gtr, gm, gfd
+
     if rank == 0:
         q_total = args.n_qry * args.batch * world * args.steps
         n_tok = args.n_slices + 1
@@ -268,13 +290,14 @@ def main():
                  "note": "algorithmic FLOPs 241.97 GFLOP/object at 256^2 (SURVEY 8d) / whole unet_encode stage time"},
             ],
             "ldm_denoise_step": ldm,
+            "gt_train_step": gt_train,
             "stage_ms_per_step": stage_ms,
             "decode_tflops_fmin": args.n_qry * args.batch * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,
             "train_samples_per_s": (world * args.batch / (train_ms * 1e-3)) if train_ms else None,
             "train_ms_per_step": train_ms,
             "train_config": "train_step (fwd + 3 losses + bwd + grad all-reduce + Adam), B=%d objects/GPU, %d^2 x %d slices, "
-                            "Q=%d, dropout 0.1, batch-statistic BatchNorm; forward/dgrad GEMMs and linear-layer weight gradients in --prec, "
-                            "3x3-conv weight gradients fp32 MFMA"
+                            "Q=%d, dropout 0.1, batch-statistic BatchNorm; forward / data-gradient / weight-gradient GEMMs in --prec "
+                            "(power-of-two backward scale), narrow and strided conv weight gradients fp32 MFMA"
                             % (args.batch, args.img_size, args.n_slices, args.n_qry),
         }
         if world == 1 and args.cpu_sample > 0:

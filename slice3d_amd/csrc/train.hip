@@ -557,33 +557,51 @@ __device__ __forceinline__ wl_half8 w3_frag(int d0, int d1, int d2, int d3) {
     w3_int4 v = {d0, d1, d2, d3};
     return __builtin_bit_cast(wl_half8, v);
 }
+// WNT x WCT accumulator tile pairs per wave per tap, WVN x WVC waves: block = 16*WNT*WVN (n) x 16*WCT*WVC (c).
+// <2,2,2,2>: 64 x 64 (channel counts that are multiples of 64); <1,1,4,1>: 64 x 16 (the 3 -> 16 padded first layer,
+// which is bound by reading dY: the per-tap kernel read it nine times).
+template <int WNT, int WCT, int WVN, int WVC>
 __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradArgs a, int n_cblk, long n_tiles,
                                                                    int tiles_per_split, int Ktot) {
-    __shared__ __attribute__((aligned(16))) _Float16 s_d[2][64 * W3_DLD];   // dY^T hi|lo, 10 KiB
-    __shared__ __attribute__((aligned(16))) _Float16 s_x[2][64 * W3_XLD];   // X^T  hi|lo, 38 KiB
+    constexpr int NB = 16 * WNT * WVN, CB = 16 * WCT * WVC;
+    static_assert(WVN * WVC == 4 && NB == 64, "4 waves, 64 dY channels per block");
+    constexpr int XU = CB * 6;                        // (channel, halo row) staging units
+    constexpr int XK = (XU + 255) / 256;              // units per thread
+    __shared__ __attribute__((aligned(16))) _Float16 s_d[2][NB * W3_DLD];   // dY^T hi|lo
+    __shared__ __attribute__((aligned(16))) _Float16 s_x[2][CB * W3_XLD];   // X^T  hi|lo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
-    const int ch = tid & 63, slot = tid >> 6;   // staging role: channel, dY tile row / X halo rows slot, slot + 4
+    const int ch = tid & 63, slot = tid >> 6;   // dY staging role: channel, tile row
     const int cb = blockIdx.x % n_cblk, nb = blockIdx.x / n_cblk;
-    const int n0 = nb * 64, c0 = cb * 64;
-    const int wn = wave & 1, wc = wave >> 1;
+    const int n0 = nb * NB, c0 = cb * CB;
+    const int wn = wave % WVN, wc = wave / WVN;
     const int H = a.H, W = a.W;
     const int tiles_x = W >> 3, tpi = tiles_x * (H >> 2);
     const float* dyp = a.dy + a.dy_coff + n0 + ch;
-    const float* xp = a.x.p + a.x_coff + c0 + ch;
     const long dstride = a.dy_cstride, xstride = a.x.C;
+    // X staging role k: unit u = tid + 256 k -> (channel, halo row); threads past the last unit shadow unit 0
+    int xc[XK], xr[XK];
+    bool xact[XK];
+#pragma unroll
+    for (int k = 0; k < XK; ++k) {
+        const int u = tid + 256 * k;
+        xact[k] = u < XU;
+        xc[k] = xact[k] ? u % CB : 0;
+        xr[k] = xact[k] ? u / CB : 0;
+    }
+    const float* xp = a.x.p + a.x_coff + c0;
 
-    f32x4 acc[9][2][2];
+    f32x4 acc[9][WNT][WCT];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WNT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[t][i][j] = zero4();
+            for (int j = 0; j < WCT; ++j) acc[t][i][j] = zero4();
 
     // raw prefetch registers (unconditional clamped loads; validity becomes a 0/1 factor at conversion time)
-    float pd[8], px[2][10];
-    unsigned vm = 0;   // bit 0 tile valid, 1/2 halo row u inside the image, 3 left column valid, 4 right column valid
+    float pd[8], px[XK][10];
+    unsigned vm = 0;   // bit 0 tile valid, 1 + k halo row of unit k inside the image, 3 left column valid, 4 right column valid
     const long t_begin = (long)blockIdx.y * tiles_per_split;
     long t_end = t_begin + tiles_per_split;
     if (t_end > n_tiles) t_end = n_tiles;
@@ -599,30 +617,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradAr
 #pragma unroll
             for (int j = 0; j < 8; ++j) pd[j] = p[j * dstride];
         }
-        const bool xl = tx > 0, xr = tx + 1 < tiles_x;
-        vm = (tv ? 1u : 0u) | (xl ? 8u : 0u) | (xr ? 16u : 0u);
-        if (slot < 2) {
+        const bool xl = tx > 0, xrt = tx + 1 < tiles_x;
+        vm = (tv ? 1u : 0u) | (xl ? 8u : 0u) | (xrt ? 16u : 0u);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int y = ty * 4 - 1 + slot + 4 * u;
-                const bool yok = y >= 0 && y < H;
-                vm |= yok ? (2u << u) : 0u;
-                const int yc = min(max(y, 0), H - 1);
-                const float* p = xp + (long)(ni * H + yc) * W * xstride;
-#pragma unroll
-                for (int j = 0; j < 10; ++j) {
-                    const int x = min(max(tx * 8 - 1 + j, 0), W - 1);
-                    px[u][j] = p[x * xstride];
-                }
-            }
-        } else {
-            const int y = ty * 4 - 1 + slot;     // halo rows 2, 3 are always inside the image
-            vm |= 2u;
-            const float* p = xp + (long)(ni * H + y) * W * xstride;
+        for (int k = 0; k < XK; ++k) {
+            const int y = ty * 4 - 1 + xr[k];
+            const bool yok = y >= 0 && y < H;
+            vm |= yok ? (2u << k) : 0u;
+            const int yc = min(max(y, 0), H - 1);
+            const float* p = xp + xc[k] + (long)(ni * H + yc) * W * xstride;
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
                 const int x = min(max(tx * 8 - 1 + j, 0), W - 1);
-                px[0][j] = p[x * xstride];
+                px[k][j] = p[x * xstride];
             }
         }
     };
@@ -642,43 +649,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradAr
             *reinterpret_cast<wl_half8*>(&s_d[0][ch * W3_DLD + 8 * slot]) = hi;
             *reinterpret_cast<wl_half8*>(&s_d[1][ch * W3_DLD + 8 * slot]) = lo;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (u == 1 && slot >= 2) break;
-                const float rf = (vm & (2u << u)) ? tvf : 0.f;
+            for (int k = 0; k < XK; ++k) {
+                const float rf = (vm & (2u << k)) ? tvf : 0.f;
                 const float lf = (vm & 8u) ? rf : 0.f, rtf = (vm & 16u) ? rf : 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float v = px[u][j + 1] * rf;
+                    const float v = px[k][j + 1] * rf;
                     const _Float16 h = (_Float16)v;
                     hi[j] = h;
                     lo[j] = (_Float16)(v - (float)h);
                 }
-                const int o = ch * W3_XLD + (slot + 4 * u) * W3_XROW;
-                *reinterpret_cast<wl_half8*>(&s_x[0][o + 8]) = hi;
-                *reinterpret_cast<wl_half8*>(&s_x[1][o + 8]) = lo;
-                const float vl = px[u][0] * lf, vr = px[u][9] * rtf;
+                const float vl = px[k][0] * lf, vr = px[k][9] * rtf;
                 const _Float16 hl = (_Float16)vl, hr = (_Float16)vr;
-                s_x[0][o + 7] = hl;
-                s_x[1][o + 7] = (_Float16)(vl - (float)hl);
-                s_x[0][o + 16] = hr;
-                s_x[1][o + 16] = (_Float16)(vr - (float)hr);
+                if (xact[k]) {
+                    const int o = xc[k] * W3_XLD + xr[k] * W3_XROW;
+                    *reinterpret_cast<wl_half8*>(&s_x[0][o + 8]) = hi;
+                    *reinterpret_cast<wl_half8*>(&s_x[1][o + 8]) = lo;
+                    s_x[0][o + 7] = hl;
+                    s_x[1][o + 7] = (_Float16)(vl - (float)hl);
+                    s_x[0][o + 16] = hr;
+                    s_x[1][o + 16] = (_Float16)(vr - (float)hr);
+                }
             }
         }
         __syncthreads();
         if (t + 1 < t_end) gload(t + 1);
-        // ---- 9 taps x (2 x 2) tiles ----
-        wl_half8 ah[2], al[2];
+        // ---- 9 taps x (WNT x WCT) tiles ----
+        wl_half8 ah[WNT], al[WNT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int o = (32 * wn + 16 * i + m) * W3_DLD + 8 * g;
+        for (int i = 0; i < WNT; ++i) {
+            const int o = (16 * (wn * WNT + i) + m) * W3_DLD + 8 * g;
             ah[i] = *reinterpret_cast<const wl_half8*>(&s_d[0][o]);
             al[i] = *reinterpret_cast<const wl_half8*>(&s_d[1][o]);
         }
 #pragma unroll
         for (int dyi = 0; dyi < 3; ++dyi) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int o = (32 * wc + 16 * j + m) * W3_XLD + (g + dyi) * W3_XROW;
+            for (int j = 0; j < WCT; ++j) {
+                const int o = (16 * (wc * WCT + j) + m) * W3_XLD + (g + dyi) * W3_XROW;
                 wl_half8 bh[3], bl[3];
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl) {
@@ -700,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradAr
 #pragma unroll
                 for (int dxi = 0; dxi < 3; ++dxi)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
+                    for (int i = 0; i < WNT; ++i) {
                         f32x4 c = acc[dyi * 3 + dxi][i][j];
                         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[dxi], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[dxi], c, 0, 0, 0);
@@ -716,13 +724,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradAr
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WNT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < WCT; ++j)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const int n = n0 + 32 * wn + 16 * i + 4 * g + reg;
-                    const int c = c0 + 32 * wc + 16 * j + m;
+                    const int n = n0 + 16 * (wn * WNT + i) + 4 * g + reg;
+                    const int c = c0 + 16 * (wc * WCT + j) + m;
                     part[(size_t)n * Ktot + tap * a.Cx + c] = acc[tap][i][j][reg];
                 }
 }
@@ -730,12 +738,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradAr
 static bool wgrad_conv3_eligible(const WgradArgs& a) {
     static const bool off = getenv("S3D_WGRAD3_F32") != nullptr;
     return !off && a.prec == S3D_PREC_F16X3 && a.ks == 3 && a.stride <= 1 && !a.x.sbcast && a.x.bdiv >= 1 &&
-           (a.Hin == 0 || a.Hin == a.H) && (a.Win == 0 || a.Win == a.W) && a.N % 64 == 0 && a.Cx % 64 == 0 &&
-           a.H % 4 == 0 && a.W % 8 == 0 && a.out_kind == S3D_PACK_CONV;
+           (a.Hin == 0 || a.Hin == a.H) && (a.Win == 0 || a.Win == a.W) && a.N % 64 == 0 &&
+           (a.Cx % 64 == 0 || a.Cx == 16) && a.H % 4 == 0 && a.W % 8 == 0 && a.out_kind == S3D_PACK_CONV;
 }
 
 static int launch_wgrad_conv3_f16x3(const WgradArgs& a, hipStream_t stream) {
-    const int n_nblk = a.N / 64, n_cblk = a.Cx / 64, Ktot = 9 * a.Cx;
+    const bool narrow = a.Cx == 16;
+    const int n_nblk = a.N / 64, n_cblk = narrow ? 1 : a.Cx / 64, Ktot = 9 * a.Cx;
     const long n_tiles = (long)a.Nimg * (a.H / 4) * (a.W / 8);
     const long blocks = (long)n_nblk * n_cblk;
     long splits = (2048 + blocks - 1) / blocks;                // aim at >= 2048 workgroups
@@ -749,8 +758,13 @@ static int launch_wgrad_conv3_f16x3(const WgradArgs& a, hipStream_t stream) {
     }
     const int tps = (int)((n_tiles + splits - 1) / splits);
     splits = (n_tiles + tps - 1) / tps;
-    hipLaunchKernelGGL(wgrad_conv3_f16x3_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(256), 0, stream, a,
-                       n_cblk, n_tiles, tps, Ktot);
+    const dim3 grid((unsigned)blocks, (unsigned)splits);
+    if (narrow)
+        hipLaunchKernelGGL((wgrad_conv3_f16x3_kernel<1, 1, 4, 1>), grid, dim3(256), 0, stream, a, n_cblk, n_tiles, tps,
+                           Ktot);
+    else
+        hipLaunchKernelGGL((wgrad_conv3_f16x3_kernel<2, 2, 2, 2>), grid, dim3(256), 0, stream, a, n_cblk, n_tiles, tps,
+                           Ktot);
     S3D_LAUNCH_CHECK();
     const long total = (long)a.N * Ktot;
     const int rb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
