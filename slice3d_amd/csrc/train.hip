@@ -132,7 +132,8 @@ __global__ void wgrad_reduce_kernel(const WgradArgs a, int nsplit, int Ktot) {
 // reads).  Next step's global loads are issued before the MFMAs of the current one.
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 wl_half8 __attribute__((ext_vector_type(8)));
-#define WL_LD 40
+#define WL_LD 40     // (a 96-byte stride makes the b128 fragment reads conflict-free but the stores slower: measured no gain)
+#define WZ_LD 40
 __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a, int n_cblk, long P,
                                                               int steps_per_split) {
     __shared__ __attribute__((aligned(16))) _Float16 s_t[2][2][128 * WL_LD];   // [dy|x][hi|lo], 40 KiB
@@ -254,7 +255,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int nchun
 template <int COLSUM>
 __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArgs a, int steps_per_split, int nsplit) {
     __shared__ __attribute__((aligned(16))) _Float16 s_d[2][128 * WL_LD];    // D^T hi|lo       20 KiB
-    __shared__ __attribute__((aligned(16))) _Float16 s_z[2][128 * WL_LD];    // Z^T hi|lo       20 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 s_z[2][128 * WZ_LD];    // Z^T hi|lo       20 KiB
     __shared__ __attribute__((aligned(16))) _Float16 s_r[2][32 * FWR_XLD];   // R row-major     17 KiB
     __shared__ unsigned s_m[128];                                            // [row][g] mask dwords of this block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
                     hi[i] = h;
                     lo[i] = (_Float16)(v - (float)h);
                 }
-                const int o = ((2 * wave + e) * 16 + m) * WL_LD + rt * 16 + 4 * g;
+                const int o = ((2 * wave + e) * 16 + m) * WZ_LD + rt * 16 + 4 * g;
                 *reinterpret_cast<half4_t*>(&s_z[0][o]) = hi;
                 *reinterpret_cast<half4_t*>(&s_z[1][o]) = lo;
             }
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int o = (64 * wc + 16 * j + m) * WL_LD + 8 * g;
+            const int o = (64 * wc + 16 * j + m) * WZ_LD + 8 * g;
             bh[j] = *reinterpret_cast<const wl_half8*>(&s_z[0][o]);
             bl[j] = *reinterpret_cast<const wl_half8*>(&s_z[1][o]);
         }
@@ -549,9 +550,9 @@ int launch_pack_ffn_rec_f16x3(const float* w, int sh, int sk, float* out, hipStr
 // registers from the aligned word and its two neighbour dwords (v_alignbyte).  dY / X are read once per tile
 // instead of once per tap; next tile's global loads are in flight during the MFMAs.
 // ---------------------------------------------------------------------------------------------
-#define W3_DLD 40     // halfs per n row of the dY^T tile (4 x 8 + 8 pad: 80 B, odd multiple of 16)
+#define W3_DLD 48     // halfs per n row of the dY^T tile (4 x 8 + 16 pad: 96 B = 32 mod 64, conflict-free b128 reads)
 #define W3_XROW 24    // halfs per halo row
-#define W3_XLD 152    // halfs per channel of the X^T tile (6 x 24 + 8 pad: 304 B, odd multiple of 16)
+#define W3_XLD 144    // halfs per channel of the X^T tile (6 x 24: 288 B = 32 mod 64)
 typedef int w3_int4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ wl_half8 w3_frag(int d0, int d1, int d2, int d3) {
     w3_int4 v = {d0, d1, d2, d3};
