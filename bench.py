@@ -193,6 +193,27 @@ def main():
                "ms_per_step": lms, "tflops_algorithmic": 0.222 / lms * 1e3, "dtype": args.prec}
         del um, lx, lc
 
+    # ---- secondary metric: Slices3DGTModel training (train_gt.py:38-52) at the reference's default options
+    #      (options.py: n_bs 16, img_size 128, n_qry 256), rank 0 only (the other ranks wait at the next leg's barrier) ----
+    gt_train = None
+    if args.gt_train_steps > 0 and rank == 0:
+        from slice3d_amd.models_gt import Slices3DGTModel
+        from slice3d_amd.trainer import HipGtTrainer
+        gm = load_seeded(Slices3DGTModel(img_size=128, n_slices=args.n_slices, mode="train"), 0).cuda()
+        gtr = HipGtTrainer(gm, dropout=0.1, seed=0, prec=args.prec)
+        gfd = make_feed_dict(16, 128, 256, args.n_slices, seed=99, device="cuda")
+        gtr.train_step(gfd)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.gt_train_steps):
+            gtr.train_step(gfd)
+        torch.cuda.synchronize()
+        gms = (time.perf_counter() - t1) / args.gt_train_steps * 1e3
+        gt_train = {"workload": "Slices3DGTModel train_step (fwd + L1 + bwd + Adam), 16 objects x %d slices at 128^2, "
+                                "256 queries each, dropout 0.1 (reg_slices/options.py defaults)" % args.n_slices,
+                    "ms_per_step": gms, "samples_per_s": 16 / gms * 1e3, "dtype": args.prec}
+        del gtr, gm, gfd
+
     # ---- secondary metric: training samples/s (train.py:41-53 train_step, B = 1 object per GPU) ----
     train_ms = None
     if args.train_steps > 0:
@@ -215,27 +236,6 @@ def main():
             tdt = float(t.item())
         train_ms = tdt / args.train_steps * 1e3
         del trainer, tmodel
-
-    # ---- secondary metric: Slices3DGTModel training (train_gt.py:38-52) at the reference's default options
-    #      (options.py: n_bs 16, img_size 128, n_qry 256), rank 0 only ----
-    gt_train = None
-    if args.gt_train_steps > 0 and rank == 0:
-        from slice3d_amd.models_gt import Slices3DGTModel
-        from slice3d_amd.trainer import HipGtTrainer
-        gm = load_seeded(Slices3DGTModel(img_size=128, n_slices=args.n_slices, mode="train"), 0).cuda()
-        gtr = HipGtTrainer(gm, dropout=0.1, seed=0, prec=args.prec)
-        gfd = make_feed_dict(16, 128, 256, args.n_slices, seed=99, device="cuda")
-        gtr.train_step(gfd)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.gt_train_steps):
-            gtr.train_step(gfd)
-        torch.cuda.synchronize()
-        gms = (time.perf_counter() - t1) / args.gt_train_steps * 1e3
-        gt_train = {"workload": "Slices3DGTModel train_step (fwd + L1 + bwd + Adam), 16 objects x %d slices at 128^2, "
-                                "256 queries each, dropout 0.1 (reg_slices/options.py defaults)" % args.n_slices,
-                    "ms_per_step": gms, "samples_per_s": 16 / gms * 1e3, "dtype": args.prec}
-        del gtr, gm, gfd
 
     if rank == 0:
         q_total = args.n_qry * args.batch * world * args.steps
