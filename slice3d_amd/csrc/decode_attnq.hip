@@ -12,8 +12,7 @@
 //   O^T = V^T P^T fp32 MFMA: A = the V registers, B = the P registers; result lane (token, g) holds dims 4g+i
 //   out_proj      f16x3 MFMA: O^T registers are its B operand (k-slot 8g+t <-> dim 16(t>>2) + 4g + (t&3), folded
 //                 into the packed W_o columns), accumulated over heads
-// No Q/K/V/O ever touches LDS; LDS holds only the in_proj fragments of the current and the next head (LDS-DMA ring,
-// one barrier per head instead of three barriers + three exchanges).  13 of 16 tile rows are useful (19 % padding);
+// No Q/K/V/O ever touches LDS; LDS holds only weight fragments (LDS-DMA ring of half-head slots, see the kernel).  13 of 16 tile rows are useful (19 % padding);
 // the token-0-pruned last layer keeps the token-major kernel (decode_f16.hip), where pruning skips whole tiles.
 #include "decode.h"
 
@@ -21,7 +20,6 @@ typedef _Float16 half8q __attribute__((ext_vector_type(8)));
 
 #define AQ_WIN_HALFS (24 * 1024)   // per head: 24 fragment pairs (q0,q1,k0,k1,v0,v1) x 4 k-steps, hi|lo = 48 KiB
 #define AQ_WO_HALFS (8 * 1024)     // per head: 8 fragment pairs = 16 KiB
-#define AQ_STEP_HALFS (AQ_WIN_HALFS + AQ_WO_HALFS)   // one ring slot: 64 KiB
 
 __device__ __forceinline__ half8q ldq8(const _Float16* p) { return *reinterpret_cast<const half8q*>(p); }
 __device__ __forceinline__ void splitq8(const float (&x)[8], half8q& hi, half8q& lo) {
@@ -49,32 +47,44 @@ __device__ __forceinline__ float colmax16(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups, int T, const _Float16* wimg,
-                                                           const LayerPtrs w) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // 2 x 64 KiB ring: in_proj | out_proj fragments of a head
+// ---------------------------------------------------------------------------------------------
+// Four waves per workgroup, TWO workgroups per CU; a workgroup owns half a group (8 queries).  Its LDS ring holds two
+// HALF-head slots of 32 KiB — slot A: the q,k in_proj fragments, slot B: the v in_proj + out_proj fragments — filled
+// by LDS-DMA one half-step ahead (one barrier per half-step).  (An eight-wave, one-workgroup-per-CU version with
+// whole-head slots ran its two waves per SIMD in lockstep and was 2 % slower.)
+// ---------------------------------------------------------------------------------------------
+#define AQ2_SLOT_HALFS (16 * 1024)   // 16 fragment pairs = 32 KiB
+__global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long groups, int T, const _Float16* wimg,
+                                                               const LayerPtrs w) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // 2 x 32 KiB
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
     const float scale = 0.17677669529663687f;   // 1/sqrt(32)
     const _Float16* g_in = wimg;
     const _Float16* g_out = wimg + 4 * AQ_WIN_HALFS;
-    auto dma_head = [&](int h, int buf) {
-        const _Float16* gs = g_in + (size_t)h * AQ_WIN_HALFS;
-        const _Float16* go = g_out + (size_t)h * AQ_WO_HALFS;
-        for (int i = wave; i < 64; i += 8) {
-            const _Float16* src = i < 48 ? gs + i * 512 : go + (i - 48) * 512;
+    // half-step hs = 2*h (A) or 2*h + 1 (B) of a head: 32 chunks of 1 KiB
+    auto dma_half = [&](int hsm, int buf) {
+        const int h = hsm >> 1;
+        const _Float16* sa = g_in + (size_t)h * AQ_WIN_HALFS;              // q,k fragments: pairs 0..15
+        const _Float16* sv = sa + 16 * 1024;                                // v fragments: pairs 16..23
+        const _Float16* so = g_out + (size_t)h * AQ_WO_HALFS;               // out_proj fragments: 8 pairs
+        for (int i = wave; i < 32; i += 4) {
+            const _Float16* src = (hsm & 1) ? (i < 16 ? sv + i * 512 : so + (i - 16) * 512) : sa + i * 512;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
-                                             (__attribute__((address_space(3))) void*)(s_win + buf * AQ_STEP_HALFS + i * 512),
+                                             (__attribute__((address_space(3))) void*)(s_win + buf * AQ2_SLOT_HALFS + i * 512),
                                              16, 0, 0);
         }
     };
-    // (group, head) steps form one sequence; the fragments of step s+1 are requested at the start of step s
-    long step = 0;
-    if ((long)blockIdx.x < groups) dma_head(0, 0);
+    const long items = 2 * groups;   // (group, half of its 16 queries)
+    long hs = 0;                     // running half-step count: slot = hs & 1
+    if ((long)blockIdx.x < items) dma_half(0, 0);
     const bool row_ok = m < T;
-    const int mt = row_ok ? m : T - 1;   // padding rows read a valid token, their results are never stored
+    const int mt = row_ok ? m : T - 1;
 
-    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    for (long item = blockIdx.x; item < items; item += gridDim.x) {
+        const long grp = item >> 1;
+        const int q0 = 8 * (int)(item & 1) + 2 * wave;   // the wave's two queries inside the group
         float* Xg = X + grp * T * S3D_GROUP * 128;
         f32x4 acc_o[2][8];
 #pragma unroll
@@ -82,9 +92,9 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc_o[r][j] = zero4();
 #pragma unroll 1
-        for (int h = 0; h < 4; ++h, ++step) {
-            __syncthreads();   // fragments of this step have landed (vmcnt drained); the other buffer is free
-            // biases first: vmcnt retires in order, a load issued after the DMA request would wait for all of it
+        for (int h = 0; h < 4; ++h) {
+            // =============== half-step A: Q^T, K^T ===============
+            __syncthreads();   // slot A of this head has landed; the other slot is free
             f32x4 bq[2], bk[2];
             float bv[2];
 #pragma unroll
@@ -93,12 +103,10 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
                 bk[j] = ld4(w.inb + 128 + 32 * h + 16 * j + 4 * g);
                 bv[j] = w.inb[256 + 32 * h + 16 * j + m];
             }
-            // the activation fragments are re-read per head (L2) rather than held across heads: 64 registers that
-            // the fragment pipeline below needs; like the biases they are requested ahead of the DMA
             half8q xh[2][4], xl[2][4];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const float* p = Xg + (mt * S3D_GROUP + 2 * wave + r) * 128 + 8 * g;
+                const float* p = Xg + (mt * S3D_GROUP + q0 + r) * 128 + 8 * g;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
@@ -106,12 +114,7 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
                     splitq8(v, xh[r][u], xl[r][u]);
                 }
             }
-            {
-                const bool more_h = h < 3, more_g = grp + gridDim.x < groups;
-                if (more_h || more_g) dma_head(more_h ? h + 1 : 0, (int)((step + 1) & 1));
-            }
-            const _Float16* sw = s_win + (step & 1) * AQ_STEP_HALFS;
-            // ---- Q^T, K^T (swapped) and V (plain) of both query tiles: 6 x 4 fragment pairs ----
+            dma_half(2 * h + 1, (int)((hs + 1) & 1));   // slot B of this head
             f32x4 qd[2][2], kd[2][2], vd[2][2];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -121,46 +124,75 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
                     kd[r][j] = zero4();
                     vd[r][j] = zero4();
                 }
-            // software pipeline over the 8 fragment batches (q,k of k-step u | v of k-step u): the LDS reads of
-            // the next batch are issued before the MFMAs of the current one (sched_barrier pins that order)
-            half8q ah[4], al[4], bh2[2], bl2[2];
-            auto load_qk = [&](int u) {
+            {
+                const _Float16* sw = s_win + (hs & 1) * AQ2_SLOT_HALFS;
+                // q and k fragments alternate: the LDS reads of one kind travel under the MFMAs of the other
+                half8q aq[2], aql[2], ak[2], akl[2];
+                auto load_q = [&](int u) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    ah[f] = ldq8(sw + (f * 4 + u) * 1024 + lane * 8);
-                    al[f] = ldq8(sw + (f * 4 + u) * 1024 + 512 + lane * 8);
-                }
-            };
-            auto load_v = [&](int u) {
-#pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    bh2[f] = ldq8(sw + ((4 + f) * 4 + u) * 1024 + lane * 8);
-                    bl2[f] = ldq8(sw + ((4 + f) * 4 + u) * 1024 + 512 + lane * 8);
-                }
-            };
-            load_qk(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                load_v(u);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        qd[r][j] = mfma3q(ah[j], al[j], xh[r][u], xl[r][u], qd[r][j]);
-                        kd[r][j] = mfma3q(ah[2 + j], al[2 + j], xh[r][u], xl[r][u], kd[r][j]);
+                    for (int f = 0; f < 2; ++f) {
+                        aq[f] = ldq8(sw + (f * 4 + u) * 1024 + lane * 8);
+                        aql[f] = ldq8(sw + (f * 4 + u) * 1024 + 512 + lane * 8);
                     }
-                __builtin_amdgcn_sched_barrier(0);
-                if (u < 3) load_qk(u + 1);
-                __builtin_amdgcn_sched_barrier(0);
+                };
+                auto load_k = [&](int u) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int f = 0; f < 2; ++f) {
+                        ak[f] = ldq8(sw + ((2 + f) * 4 + u) * 1024 + lane * 8);
+                        akl[f] = ldq8(sw + ((2 + f) * 4 + u) * 1024 + 512 + lane * 8);
+                    }
+                };
+                load_q(0);
+                load_k(0);
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) vd[r][j] = mfma3q(xh[r][u], xl[r][u], bh2[j], bl2[j], vd[r][j]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < 4; ++u) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) qd[r][j] = mfma3q(aq[j], aql[j], xh[r][u], xl[r][u], qd[r][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u < 3) load_q(u + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) kd[r][j] = mfma3q(ak[j], akl[j], xh[r][u], xl[r][u], kd[r][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u < 3) load_k(u + 1);
+                }
             }
-            // first half of the out_proj fragments travels under the attention math
-            const _Float16* gw = sw + AQ_WIN_HALFS;
+            ++hs;
+            // =============== half-step B: V, attention, out_proj ===============
+            __syncthreads();   // slot B has landed; slot A is free
+            {
+                const bool more_h = h < 3, more_i = item + gridDim.x < items;
+                if (more_h || more_i) dma_half(more_h ? 2 * (h + 1) : 0, (int)((hs + 1) & 1));
+            }
+            const _Float16* sw = s_win + (hs & 1) * AQ2_SLOT_HALFS;
+            {
+                half8q bh2[2][2], bl2[2][2];
+                auto load_v = [&](int u, int bsel) {
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        bh2[bsel][f] = ldq8(sw + (f * 4 + u) * 1024 + lane * 8);
+                        bl2[bsel][f] = ldq8(sw + (f * 4 + u) * 1024 + 512 + lane * 8);
+                    }
+                };
+                load_v(0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u < 3) load_v(u + 1, (u + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+                            vd[r][j] = mfma3q(xh[r][u], xl[r][u], bh2[u & 1][j], bl2[u & 1][j], vd[r][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const _Float16* gw = sw + 8 * 1024;
             half8q wh[4], wl[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -168,7 +200,6 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
                 wl[jj] = ldq8(gw + jj * 1024 + 512 + lane * 8);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // biases: q,k rows 16j + 4g + i of the head; v column 16j + m
             half8q oh[2], ol[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -179,7 +210,6 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
 #pragma unroll
                     for (int i = 0; i < 4; ++i) vd[r][j][i] += bv[j];
                 }
-                // S^T[tk][tq] = sum_dims K[tk] Q[tq]: lane (tq = m, g) gets keys tk = 4g + i
                 f32x4 s = zero4();
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -201,7 +231,6 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
                     den += e[i];
                 }
                 const float inv = 1.f / colsum16(den);
-                // O^T[d][tq] = sum_tk V[tk][d] P[tq][tk]: A = V registers (lane (d, g): tokens 4g+i), B = P registers
                 f32x4 od[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -214,7 +243,6 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
                 const float ov[8] = {od[0][0], od[0][1], od[0][2], od[0][3], od[1][0], od[1][1], od[1][2], od[1][3]};
                 splitq8(ov, oh[r], ol[r]);
             }
-            // ---- out_proj partial sums of this head ----
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
@@ -230,8 +258,9 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int r = 0; r < 2; ++r) acc_o[r][4 + jj] = mfma3q(wh[jj], wl[jj], oh[r], ol[r], acc_o[r][4 + jj]);
+            ++hs;
         }
-        // ---- residual + LayerNorm1 (columns 32*(j>>1) + 8g + 4*(j&1) + i), store ----
+        // ---- residual + LayerNorm1, store ----
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             f32x4 y[8];
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
             for (int j = 0; j < 8; ++j) {
                 const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
                 const f32x4 bo = ld4(w.outb + col);
-                const f32x4 xr = ld4(Xg + (mt * S3D_GROUP + 2 * wave + r) * 128 + col);
+                const f32x4 xr = ld4(Xg + (mt * S3D_GROUP + q0 + r) * 128 + col);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     y[j][i] = acc_o[r][j][i] + bo[i] + xr[i];
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
                     v += dd * dd;
                 }
             const float rstd = 1.f / sqrtf(colsum16(v) * (1.f / 128.f) + 1e-5f);
-            float* o = Xg + (mt * S3D_GROUP + 2 * wave + r) * 128;
+            float* o = Xg + (mt * S3D_GROUP + q0 + r) * 128;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
@@ -274,14 +303,14 @@ __global__ __launch_bounds__(512) void attn_layer_q_kernel(float* X, long groups
 int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream) {
     if (groups <= 0) return 0;
     S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr, "attn_q: T %d", T);
-    const size_t lds = (size_t)2 * AQ_STEP_HALFS * 2;   // 128 KiB
+    const size_t lds = (size_t)2 * AQ2_SLOT_HALFS * 2;   // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const long blocks = groups < 2048 ? groups : 2048;
-    hipLaunchKernelGGL(attn_layer_q_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, X, groups, T,
+    const long blocks = 2 * groups < 4096 ? 2 * groups : 4096;
+    hipLaunchKernelGGL(attn_layer_q_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T,
                        reinterpret_cast<const _Float16*>(w.aq16), w);
     S3D_LAUNCH_CHECK();
     return 0;
