@@ -550,6 +550,9 @@ HeadLayout head_layout() {
     }
     H.fco_w = take(128);
     H.fco_b = take(4);
+    H.last.wm = take(512 * 128); H.last.wm16 = take(512 * 128); H.last.bm = take(512);
+    H.last.wn = take(128 * 512); H.last.wn16 = take(128 * 512); H.last.bn = take(128);
+    H.last.dense = take(512 * 128);
     H.total = off;
     return H;
 }
@@ -583,6 +586,16 @@ static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLa
         TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wf16, st));
         TRY(launch_pack_attn_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].af16, st));
         TRY(launch_pack_attn_q_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].aq16, st));
+    }
+    {   // absorbed token-0 attention of the last layer (launch_attn_last_mix)
+        const S3dLayerParams& p = layers[S3D_N_LAYERS - 1];
+        float* dense = b + H.last.dense;
+        TRY(launch_absorb_last(p.in_proj_w, p.in_proj_b, p.out_proj_w, p.out_proj_b, dense, b + H.last.bm, 0, st));
+        TRY(pack_linear(dense, b + H.last.wm, 512, 512, 128, 128, 0, st));
+        TRY(pack_linear(dense, b + H.last.wm16, 512, 512, 128, 128, 0, st, 1));
+        TRY(launch_absorb_last(p.in_proj_w, p.in_proj_b, p.out_proj_w, p.out_proj_b, dense, b + H.last.bn, 1, st));
+        TRY(pack_linear(dense, b + H.last.wn, 128, 128, 512, 512, 0, st));
+        TRY(pack_linear(dense, b + H.last.wn16, 128, 128, 512, 512, 0, st, 1));
     }
     return 0;
 }
@@ -642,8 +655,10 @@ extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, 
 #define S3D_CHUNK_GROUPS 16384  // 262144 queries per pass: X = 16384*13*16*128*4 B = 1.74 GB
 
 struct DecodeWs {
-    size_t X, X0, perm, sortws, total;
+    size_t X, X0, perm, sortws, last, total;
 };
+// scratch of the absorbed last-layer attention per query row: x0 | u (128 each), qt | xbar (512 each)
+#define S3D_LAST_ROW_FLOATS (2 * 128 + 2 * 512)
 #define S3D_SORT_MIN_QUERIES 4096   // below this the sort costs more than the locality buys
 static DecodeWs decode_ws(int batch, long n_qry, int ns) {
     const long gpb = (n_qry + S3D_GROUP - 1) / S3D_GROUP;
@@ -654,7 +669,8 @@ static DecodeWs decode_ws(int batch, long n_qry, int ns) {
     W.X0 = (size_t)g * (ns + 1) * S3D_GROUP * 128;
     W.perm = W.X0 + (size_t)g * S3D_GROUP * 128;
     W.sortws = W.perm + (size_t)batch * n_qry;
-    W.total = W.sortws + query_sort_ws_ints(batch, n_qry);
+    W.last = (W.sortws + query_sort_ws_ints(batch, n_qry) + 63) / 64 * 64;
+    W.total = W.last + (size_t)g * S3D_GROUP * S3D_LAST_ROW_FLOATS;
     return W;
 }
 
@@ -679,6 +695,45 @@ static bool attn_query_major() {   // S3D_ATTN_Q=0 selects the token-major kerne
         return e ? atoi(e) : 1;
     }();
     return on != 0;
+}
+
+static bool attn_last_absorbed() {   // S3D_ATTN_LAST=0 selects the token-major pruned kernel (A/B timing)
+    static const int on = [] {
+        const char* e = getenv("S3D_ATTN_LAST");
+        return e ? atoi(e) : 1;
+    }();
+    return on != 0;
+}
+
+// rows x k  ->  rows x n  linear map on the conv engine (1x1 convolution over a row "image")
+static int rows_linear(const float* b, size_t w32, size_t w16, int n, int k, const float* bias, const float* x,
+                       long nrows, float* out, const float* residual, int prec, hipStream_t st) {
+    ConvLaunch c = {};
+    c.N = 1; c.H = 1; c.W = (int)nrows; c.ks = 1;
+    c.CoutPad = n; c.wpk = b + w32; c.KU = k / 16;
+    c.wpk16 = prec == S3D_PREC_F16X3 ? (const void*)(b + w16) : nullptr;
+    c.shift = bias; c.act = S3D_ACT_NONE;
+    c.out_mode = S3D_OUT_NHWC; c.cout_store = n; c.out_cstride = n;
+    c.nsrc = 1;
+    c.src[0] = plain_src(x, k);
+    c.out = out; c.residual = residual;
+    return launch_conv(c, st);
+}
+
+// X [gc][T][16][128] (input of the last layer) -> X0 [gc*16][128] = LN1(x0 + out_proj(attention of token 0)),
+// see launch_attn_last_mix.  scratch: gc*16*S3D_LAST_ROW_FLOATS floats.
+static int attn_last_layer(const float* b, const HeadLayout& H, const LayerPtrs& lp, const float* X, float* X0, long gc,
+                           int T, float* scratch, int prec, hipStream_t st) {
+    const long rows0 = gc * S3D_GROUP;
+    float* x0 = scratch;
+    float* u = x0 + rows0 * 128;
+    float* qt = u + rows0 * 128;
+    float* xbar = qt + rows0 * 512;
+    TRY(launch_tok0_copy(const_cast<float*>(X), x0, gc, T, 0, 128, st));
+    TRY(rows_linear(b, H.last.wm, H.last.wm16, 512, 128, b + H.last.bm, x0, rows0, qt, nullptr, prec, st));
+    TRY(launch_attn_last_mix(X, qt, xbar, gc, T, st));
+    TRY(rows_linear(b, H.last.wn, H.last.wn16, 128, 512, b + H.last.bn, xbar, rows0, u, x0, prec, st));
+    return launch_ln_fwd(u, lp.ln1g, lp.ln1b, X0, rows0, st);
 }
 
 static int decode_impl(const void* head_packed, const S3dLatent* lat, const float* qry, const float* rot,
@@ -727,7 +782,9 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
             const bool last = l == S3D_N_LAYERS - 1;
             {
                 ProfScope prof_(S3D_PROF_ATTN, st);
-                if (prec == S3D_PREC_F16X3 && !last && attn_query_major())
+                if (last && attn_last_absorbed())
+                    TRY(attn_last_layer(b, H, lp, X, X0, gc, T, (float*)workspace + W.last, prec, st));
+                else if (prec == S3D_PREC_F16X3 && !last && attn_query_major())
                     TRY(launch_attn_layer_q(X, gc, T, lp, st));
                 else if (prec == S3D_PREC_F16X3)
                     TRY(launch_attn_layer_f16x3(X, last ? X0 : nullptr, gc, T, lp, st));

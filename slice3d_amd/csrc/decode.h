@@ -21,6 +21,11 @@ struct HeadLayout {
         size_t af16;                         // f16 hi/lo fragment pairs of in_proj (96) and out_proj (32)
     } L[S3D_N_LAYERS];
     size_t fco_w, fco_b;
+    // token-0-only attention of the LAST layer in absorbed form (launch_attn_last_mix): fragment images (fp32 | f16
+    // hi/lo) of M = [Wk_h^T Wq_h]_h (512x128) and N = [Wo_h Wv_h]_h (128x512), their bias vectors, dense scratch
+    struct {
+        size_t wm, wm16, bm, wn, wn16, bn, dense;
+    } last;
     size_t total;
 };
 HeadLayout head_layout();
@@ -120,6 +125,20 @@ int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, uns
                                  const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
                                  hipStream_t stream);
 int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream);
+// Last layer, token 0 only (models.py:83 consumes nothing else), with the projections absorbed.  Per head h, with
+// q = Wq_h x0 + bq_h:   score_h[t] = q . (Wk_h x_t + bk_h) = (M_h x0 + m_h) . x_t + const   (const cancels in the softmax)
+//                       M_h = Wk_h^T Wq_h (128x128),  m_h = Wk_h^T bq_h
+// and, since the probabilities sum to 1:   out_proj(concat_h(Wv_h xbar_h + bv_h)) = sum_h N_h xbar_h + n
+//                       xbar_h = sum_t p_h[t] x_t,  N_h = Wo[:, head h] Wv_h (128x128),  n = Wo bv + bo
+// so the 13 tokens are never projected: per query two dense (128 <-> 512) GEMMs + 2 x 4 x 13 x 128 MACs here.
+//   qt   [rows0][512]: per head the 128-vector M_h x0 + m_h
+//   xbar [rows0][512]: per head sum_t softmax_t(qt_h . x_t / sqrt(32)) x_t
+int launch_attn_last_mix(const float* X, const float* qt, float* xbar, long groups, int T, hipStream_t stream);
+// the absorbed matrices from in_proj_weight (384,128), in_proj_bias (384), out_proj.weight (128,128), out_proj.bias:
+//   kind 0: out [512][128] = M (row h*128 + c), bias_out [512] = m
+//   kind 1: out [128][512] = N (column h*128 + c), bias_out [128] = n
+int launch_absorb_last(const float* in_w, const float* in_b, const float* out_w, const float* out_b, float* out,
+                       float* bias_out, int kind, hipStream_t stream);
 int launch_pack_attn_q_f16x3(const float* win, const float* wout, float* out, hipStream_t stream);
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,

@@ -574,6 +574,112 @@ int launch_ffn_layer_train(const float* Xin, float* Yout, float* Uout, long rows
 }
 
 // ---------------------------------------------------------------------------------------------
+// Token-0 attention of the last layer, absorbed form (see decode.h).  16 lanes per query (8 channels each), 4 queries
+// per wave, one 256-thread workgroup per group of 16 queries.  The 13 token rows of the query stay in registers
+// (104 floats per lane) for both passes (scores, then the probability-weighted sum); per head the 16-lane dot
+// products are all-reduced with four DPP steps (quad xor 1, quad xor 2, half mirror, row mirror).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_allsum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
+}
+__global__ __launch_bounds__(256) void attn_last_mix_kernel(const float* __restrict__ X, const float* __restrict__ qt,
+                                                            float* __restrict__ xbar, long groups, int T) {
+    const int mq = threadIdx.x >> 4, c0 = (threadIdx.x & 15) * 8;   // query of the group, first channel of the lane
+    const float scale = 0.17677669529663687f;                       // 1/sqrt(32)
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const float* xg = X + (grp * T * S3D_GROUP + mq) * 128 + c0;
+        f32x4 xa[S3D_N_TOKENS_MAX], xb[S3D_N_TOKENS_MAX];
+#pragma unroll
+        for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+            const int tc = t < T ? t : T - 1;
+            xa[t] = ld4(xg + (long)tc * S3D_GROUP * 128);
+            xb[t] = ld4(xg + (long)tc * S3D_GROUP * 128 + 4);
+        }
+        const long row = grp * S3D_GROUP + mq;
+#pragma unroll 1
+        for (int h = 0; h < 4; ++h) {
+            const f32x4 qa = ld4(qt + row * 512 + h * 128 + c0), qb = ld4(qt + row * 512 + h * 128 + c0 + 4);
+            float sc[S3D_N_TOKENS_MAX];
+            float mx = -1e30f;
+#pragma unroll
+            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+                float d = qa[0] * xa[t][0] + qa[1] * xa[t][1] + qa[2] * xa[t][2] + qa[3] * xa[t][3] +
+                          qb[0] * xb[t][0] + qb[1] * xb[t][1] + qb[2] * xb[t][2] + qb[3] * xb[t][3];
+                d = row16_allsum(d) * scale;
+                sc[t] = t < T ? d : -1e30f;
+                mx = fmaxf(mx, sc[t]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+                sc[t] = t < T ? expf(sc[t] - mx) : 0.f;
+                den += sc[t];
+            }
+            const float inv = 1.f / den;
+            f32x4 oa = zero4(), ob = zero4();
+#pragma unroll
+            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+                const float pt = sc[t] * inv;
+                oa += xa[t] * pt;
+                ob += xb[t] * pt;
+            }
+            st4(xbar + row * 512 + h * 128 + c0, oa);
+            st4(xbar + row * 512 + h * 128 + c0 + 4, ob);
+        }
+    }
+}
+int launch_attn_last_mix(const float* X, const float* qt, float* xbar, long groups, int T, hipStream_t stream) {
+    if (groups <= 0) return 0;
+    S3D_CHECK_ARG(T >= 1 && T <= S3D_N_TOKENS_MAX, "attn_last_mix: T %d", T);
+    const long blocks = groups < 8192 ? groups : 8192;
+    hipLaunchKernelGGL(attn_last_mix_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, qt, xbar, groups, T);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// pack-time products of the absorbed form (double accumulation, rounded once to fp32)
+__global__ void absorb_last_kernel(const float* __restrict__ in_w, const float* __restrict__ in_b,
+                                   const float* __restrict__ out_w, const float* __restrict__ out_b,
+                                   float* __restrict__ out, float* __restrict__ bias_out, int kind) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // 65536 matrix elements
+    if (idx >= 512 * 128) return;
+    const float* Wq = in_w;
+    const float* Wk = in_w + 128 * 128;
+    const float* Wv = in_w + 256 * 128;
+    if (kind == 0) {   // M[h*128 + c][k] = sum_d Wk[32h+d][c] Wq[32h+d][k]
+        const int r = idx >> 7, k = idx & 127, h = r >> 7, c = r & 127;
+        double s = 0.0;
+        for (int d = 0; d < 32; ++d) s += (double)Wk[(32 * h + d) * 128 + c] * (double)Wq[(32 * h + d) * 128 + k];
+        out[idx] = (float)s;
+        if (k == 0) {
+            double v = 0.0;
+            for (int d = 0; d < 32; ++d) v += (double)Wk[(32 * h + d) * 128 + c] * (double)in_b[32 * h + d];
+            bias_out[r] = (float)v;
+        }
+    } else {           // N[n][h*128 + c] = sum_d Wo[n][32h+d] Wv[32h+d][c]
+        const int n = idx >> 9, kk = idx & 511, h = kk >> 7, c = kk & 127;
+        double s = 0.0;
+        for (int d = 0; d < 32; ++d) s += (double)out_w[n * 128 + 32 * h + d] * (double)Wv[(32 * h + d) * 128 + c];
+        out[idx] = (float)s;
+        if (kk == 0) {
+            double v = (double)out_b[n];
+            for (int d = 0; d < 128; ++d) v += (double)out_w[n * 128 + d] * (double)in_b[256 + d];
+            bias_out[n] = (float)v;
+        }
+    }
+}
+int launch_absorb_last(const float* in_w, const float* in_b, const float* out_w, const float* out_b, float* out,
+                       float* bias_out, int kind, hipStream_t stream) {
+    hipLaunchKernelGGL(absorb_last_kernel, dim3(256), dim3(256), 0, stream, in_w, in_b, out_w, out_b, out, bias_out, kind);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // image-space locality sort of the queries (counting sort, 65536 Morton bins of the projected pixel)
 // ---------------------------------------------------------------------------------------------
 #define QS_BINS 65536
