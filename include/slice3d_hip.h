@@ -233,8 +233,9 @@ int s3d_conv_fwd(const void* packed, const float* x0, const float* x1, const flo
  * stats: N*groups*50 floats of scratch (mean / rstd per group, then the per-slice partial moments). */
 int s3d_group_norm_fwd(const float* x, const float* gamma, const float* beta, const float* film, float* y,
                        float* stats, int N, int HW, int C, int groups, float eps, int silu, void* stream);
-/* QKVAttentionLegacy.forward (openaimodel.py:362-377): qkv (N, T, heads*3*ch) -> out (N, T, heads*ch) */
-int s3d_qkv_attention_fwd(const float* qkv, float* out, int N, int T, int heads, int ch, void* stream);
+/* QKVAttentionLegacy.forward (openaimodel.py:362-377): qkv (N, T, heads*3*ch) -> out (N, T, heads*ch);
+ * prec: S3D_PREC_F32 = fp32 MFMA, S3D_PREC_F16X3 = split-precision f16 MFMA (fp32-class accuracy) */
+int s3d_qkv_attention_fwd(const float* qkv, float* out, int N, int T, int heads, int ch, int prec, void* stream);
 /* Upsample / Downsample with use_conv=False (openaimodel.py:108-158): up != 0: nearest 2x; else 2x2 average pool */
 int s3d_resample2x_fwd(const float* x, float* y, int N, int H, int W, int C, int up, void* stream);
 /* linear(SiLU?(x)): time_embed (:506-510) and ResBlock.emb_layers (:222-228); x (N,K), w (M,K) */

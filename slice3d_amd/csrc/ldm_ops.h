@@ -4,7 +4,7 @@
 
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
                       int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream);
-int launch_qkv_attention(const float* qkv, float* out, int N, int T, int heads, int ch, hipStream_t stream);
+int launch_qkv_attention(const float* qkv, float* out, int N, int T, int heads, int ch, int prec, hipStream_t stream);
 int launch_resample2x(const float* x, float* y, int N, int H, int W, int C, int up, hipStream_t stream);
 int launch_small_linear(const float* x, const float* w, const float* b, float* out, int N, int K, int M, int silu_in,
                         hipStream_t stream);

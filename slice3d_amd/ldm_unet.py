@@ -262,7 +262,7 @@ class UNetModel(nn.Module):
         qkv = self._conv(blk.qkv, hn)                                        # (N, H, W, 3C), heads x (q|k|v) x ch
         att = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
         _lib.check(lib.s3d_qkv_attention_fwd(qkv.data_ptr(), att.data_ptr(), n, h * w, blk.num_heads,
-                                             c // blk.num_heads, self._stream()), "s3d_qkv_attention_fwd")
+                                             c // blk.num_heads, self._precv(), self._stream()), "s3d_qkv_attention_fwd")
         return self._conv(blk.proj_out, att, residual=x)
 
     def _run(self, seq, h, emb, skip=None):

@@ -91,8 +91,20 @@ def test_ldm_primitives_match_torch():
     want = torch.einsum("bts,bcs->bct", wgt, v).reshape(n, -1, T).permute(0, 2, 1).contiguous()
     qc = qkv.permute(0, 2, 1).contiguous().cuda()
     out = torch.empty(n, T, heads * ch, device="cuda")
-    _lib.check(lib.s3d_qkv_attention_fwd(qc.data_ptr(), out.data_ptr(), n, T, heads, ch, None), "attn")
-    assert (out.cpu() - want).abs().max() < 2e-5
+    for prec in (_lib.PREC_F32, _lib.PREC_F16X3):   # (the split-precision attention kernel is opt-in: same kernel here)
+        out.zero_()
+        _lib.check(lib.s3d_qkv_attention_fwd(qc.data_ptr(), out.data_ptr(), n, T, heads, ch, prec, None), "attn")
+        assert (out.cpu() - want).abs().max() < 2e-5, (prec, float((out.cpu() - want).abs().max()))
+    for ch2, T2 in ((48, 100), (96, 40), (8, 300)):   # the other head widths of the full configuration
+        qkv2 = torch.randn(1, 2 * 3 * ch2, T2, generator=g)
+        q2, k2, v2 = qkv2.reshape(2, ch2 * 3, T2).split(ch2, dim=1)
+        sc2 = 1 / math.sqrt(math.sqrt(ch2))
+        w2 = torch.softmax(torch.einsum("bct,bcs->bts", q2 * sc2, k2 * sc2), dim=-1)
+        want2 = torch.einsum("bts,bcs->bct", w2, v2).reshape(1, -1, T2).permute(0, 2, 1).contiguous()
+        qc2 = qkv2.permute(0, 2, 1).contiguous().cuda()
+        out2 = torch.empty(1, T2, 2 * ch2, device="cuda")
+        _lib.check(lib.s3d_qkv_attention_fwd(qc2.data_ptr(), out2.data_ptr(), 1, T2, 2, ch2, _lib.PREC_F16X3, None), "attn")
+        assert (out2.cpu() - want2).abs().max() < 2e-5, (ch2, float((out2.cpu() - want2).abs().max()))
     up = torch.empty(n, 2 * h, 2 * w, c, device="cuda")
     _lib.check(lib.s3d_resample2x_fwd(xc.data_ptr(), up.data_ptr(), n, h, w, c, 1, None), "up")
     assert torch.equal(up.cpu(), F.interpolate(x, scale_factor=2, mode="nearest").permute(0, 2, 3, 1))
