@@ -287,6 +287,12 @@ int s3d_gt_train_fwd_bwd(const S3dVgg16BnParams* enc, const S3dGtHeadParams* hea
                          const S3dTrainBatch* batch, int batch_size, int size, long n_qry, int n_slices,
                          float dropout_p, unsigned long long seed, int prec, float* losses_out, float* sdf_pred_out,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same Adam update for n_tensors parameters in one call (one kernel launch per 128 tensors).  params, offsets,
+ * sizes: HOST arrays; tensor i takes its gradient from grad_flat[offsets[i] .. + sizes[i]) and keeps its moments at the
+ * same range of exp_avg_flat / exp_avg_sq_flat (all three flat arrays on the device). */
+int s3d_adam_step_multi(float* const* params, const long* offsets, const long* sizes, int n_tensors,
+                        const float* grad_flat, float* exp_avg_flat, float* exp_avg_sq_flat, float lr, float beta1,
+                        float beta2, float eps, int step, void* stream);
 /* The dropout mask the kernels use: out[i] = keep(seed, site, idx0+i) ? 1/(1-p) : 0.  site = 4*layer +
  * {0 attention probabilities [(row*4 + head)*16 + key], 1 attention-block output [row*128 + c],
  *  2 FFN hidden [row*2048 + unit], 3 FFN output [row*128 + c]}; rows index the token tensor

@@ -128,6 +128,7 @@ SYMBOLS = {
                                   _i, _i, _l, _i, _f, C.c_ulonglong, _i, _vp, _vp, _vp, _sz, _vp]),
     "s3d_dropout_mask": (_i, [C.c_ulonglong, _i, C.c_ulonglong, _l, _f, _vp, _vp]),
     "s3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _i, _vp]),
+    "s3d_adam_step_multi": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp]),
     "s3d_prof_enable": (_i, [_i]),
     "s3d_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "s3d_project_coord_fwd": (_i, [_vp, _vp, _vp, _i, _l, _vp]),

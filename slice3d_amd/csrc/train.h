@@ -101,6 +101,16 @@ int launch_relu_mask_bwd(const float* y, float* dy, long n, hipStream_t stream);
 int launch_pool_bwd(const float* y, const float* dyp, float* dy, int n, int h, int w, int c, hipStream_t stream);
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                 float bc1, float bc2, hipStream_t stream);
+// one launch for up to S3D_ADAM_TABLE_MAX tensors: parameter i is updated from g / m / v [off[i], off[i] + n[i])
+#define S3D_ADAM_TABLE_MAX 128
+struct AdamTable {
+    float* p[S3D_ADAM_TABLE_MAX];
+    long off[S3D_ADAM_TABLE_MAX];
+    long n[S3D_ADAM_TABLE_MAX];
+    int count;
+};
+int launch_adam_table(const AdamTable& t, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
+                      float bc1, float bc2, hipStream_t stream);
 
 // ---- decoder backward pieces ----
 // LayerNorm backward over rows of 128: du = LN'(u; gamma) dy ; dgamma/dbeta (+)= column sums

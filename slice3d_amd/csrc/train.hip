@@ -1388,6 +1388,31 @@ int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, 
     return 0;
 }
 
+// the same update for a table of tensors whose gradient / moment buffers are slices of three flat arrays
+__global__ __launch_bounds__(256) void adam_table_kernel(const AdamTable t, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, float lr, float b1,
+                                                         float b2, float eps, float bc1, float bc2) {
+    float* __restrict__ p = t.p[blockIdx.y];
+    const long off = t.off[blockIdx.y], n = t.n[blockIdx.y];
+    const float step = lr / bc1, rbc2 = 1.f / sqrtf(bc2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[off + i];
+        const float mi = b1 * m[off + i] + (1.f - b1) * gi;
+        const float vi = b2 * v[off + i] + (1.f - b2) * gi * gi;
+        m[off + i] = mi;
+        v[off + i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) * rbc2 + eps);
+    }
+}
+int launch_adam_table(const AdamTable& t, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
+                      float bc1, float bc2, hipStream_t stream) {
+    if (t.count <= 0) return 0;
+    hipLaunchKernelGGL(adam_table_kernel, dim3(64, (unsigned)t.count), dim3(256), 0, stream, t, g, m, v, lr, b1, b2, eps,
+                       bc1, bc2);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // a <- dropout(relu(a)), dh <- dh * mask * (a > 0); element i of the block is hidden unit (row0*2048 + i)
 __global__ void relu_bwd_inplace_kernel(float* __restrict__ a, float* __restrict__ dh, long n, long row0,
                                         const DropCfg drop) {

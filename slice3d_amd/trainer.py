@@ -166,12 +166,13 @@ class HipTrainer:
     def adam_step(self):
         self.step += 1
         stream = C.c_void_p(torch.cuda.current_stream(self.grad_flat.device).cuda_stream)
-        for k, p in zip(self.names, self.params):
-            off, n = self.offsets[k], p.numel()
-            _lib.check(self.lib.s3d_adam_step(p.data_ptr(), self.grad_flat[off:].data_ptr(),
-                                              self.exp_avg[off:].data_ptr(), self.exp_avg_sq[off:].data_ptr(), n,
-                                              self.lr, self.betas[0], self.betas[1], self.eps, self.step, stream),
-                       "s3d_adam_step")
+        n = len(self.params)
+        ptrs = (C.c_void_p * n)(*[p.data_ptr() for p in self.params])
+        offs = (C.c_long * n)(*[self.offsets[k] for k in self.names])
+        sizes = (C.c_long * n)(*[p.numel() for p in self.params])
+        _lib.check(self.lib.s3d_adam_step_multi(ptrs, offs, sizes, n, self.grad_flat.data_ptr(), self.exp_avg.data_ptr(),
+                                                self.exp_avg_sq.data_ptr(), self.lr, self.betas[0], self.betas[1],
+                                                self.eps, self.step, stream), "s3d_adam_step_multi")
         self.model._packed_key = None
 
     def state_dict(self):
