@@ -296,7 +296,8 @@ int s3d_adam_step_multi(float* const* params, const long* offsets, const long* s
 /* The dropout mask the kernels use: out[i] = keep(seed, site, idx0+i) ? 1/(1-p) : 0.  site = 4*layer +
  * {0 attention probabilities [(row*4 + head)*16 + key], 1 attention-block output [row*128 + c],
  *  2 FFN hidden [row*2048 + unit], 3 FFN output [row*128 + c]}; rows index the token tensor
- * [group][token][16 queries] (the last layer's FFN sites index its compact token-0 rows). */
+ * [group][token][16 queries]; all four sites of the LAST layer index its compact token-0 rows [group][16 queries]
+ * (only token 0 of that layer is computed). */
 int s3d_dropout_mask(unsigned long long seed, int site, unsigned long long idx0, long n, float p, float* out,
                      void* stream);
 /* torch.optim.Adam defaults semantics (no weight decay, no amsgrad); step counts from 1. */

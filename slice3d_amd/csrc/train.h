@@ -155,5 +155,10 @@ int launch_qry_rot_rows(const float* qry, const float* rot, int flip_yz, long n_
                         const int* perm,
                         float* out, hipStream_t stream);
 int launch_copy_cols(const float* src, float* dst, int rows, int csrc, int cdst, hipStream_t stream);
+// token-0 attention core of the last layer (training): see train2.hip
+int launch_attn_core0_fwd(const float* q0, const float* kv, float* o0, long groups, int T, const DropCfg& drop,
+                          hipStream_t stream);
+int launch_attn_core0_bwd(const float* q0, const float* kv, const float* d_o0, float* dq0, float* dkv, long groups, int T,
+                          const DropCfg& drop, hipStream_t stream);
 int launch_emb_grad(const float* dF0, const float* w, float* demds, int B, int ns, int npix, hipStream_t stream);
 #define CS_CHUNKS_MAX 512

@@ -120,15 +120,19 @@ def _hip_dropout_masks(b, q, ns, p, seed):
         # row of (batch bb, query q, token t) in the token tensor
         row = torch.stack([torch.stack([((bb * gpb + qi // 16) * T + t) * 16 + qi % 16 for t in range(T)], 1)
                            for bb in range(b)]).reshape(b * q, T)                       # (R, T)
-        m_att = gen(0, rows * 4 * 16).view(rows, 4, 16)[row][:, :, :, :T].permute(0, 2, 1, 3)   # (R, 4, Tq, Tk)
-        m_o = gen(1, rows * 128).view(rows, 128)[row]                                             # (R, T, 128)
         if l < 2:
+            m_att = gen(0, rows * 4 * 16).view(rows, 4, 16)[row][:, :, :, :T].permute(0, 2, 1, 3)   # (R, 4, Tq, Tk)
+            m_o = gen(1, rows * 128).view(rows, 128)[row]                                             # (R, T, 128)
             m_h = gen(2, rows * 2048).view(rows, 2048)[row]
             m_f = gen(3, rows * 128).view(rows, 128)[row]
-        else:   # the last layer's FFN runs on the compact token-0 rows; other tokens are never consumed
+        else:   # only token 0 of the last layer is consumed: all four of its sites index the compact token-0 rows
             row0 = torch.cat([(bb * gpb + qi // 16) * 16 + qi % 16 for bb in range(b)])
+            m_att = torch.ones(b * q, 4, T, T)
+            m_o = torch.ones(b * q, T, 128)
             m_h = torch.ones(b * q, T, 2048)
             m_f = torch.ones(b * q, T, 128)
+            m_att[:, :, 0, :] = gen(0, rows0 * 4 * 16).view(rows0, 4, 16)[row0][:, :, :T]
+            m_o[:, 0] = gen(1, rows0 * 128).view(rows0, 128)[row0]
             m_h[:, 0] = gen(2, rows0 * 2048).view(rows0, 2048)[row0]
             m_f[:, 0] = gen(3, rows0 * 128).view(rows0, 128)[row0]
         masks.append({"att": m_att, "o": m_o, "h": m_h, "f": m_f})
