@@ -88,9 +88,81 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
 }
 
+// One-launch variant for the maps of this U-Net (<= 64 x 64): a 1024-thread workgroup owns one (image, group), keeps
+// its HW x C/32 values in registers (EPT per thread), reduces mean and centred second moment through LDS and writes
+// the normalised values - statistics, apply, FiLM and SiLU in one pass over the data instead of two launches
+// (the denoising step has 92 GroupNorms, most of them a few microseconds of launch latency each).
+template <int EPT>
+__global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ film,
+                                                        float* __restrict__ y, int HW, int C, int groups, float eps,
+                                                        int silu) {
+    __shared__ float red[16];
+    const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
+    const int cpg = C / groups;
+    const long total = (long)HW * cpg;
+    const float* base = x + (long)n * HW * C + gidx * cpg;
+    float* obase = y + (long)n * HW * C + gidx * cpg;
+    auto block_sum = [&](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        return t;
+    };
+    float v[EPT];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const long i = threadIdx.x + 1024L * k;
+        v[k] = i < total ? base[(i / cpg) * C + i % cpg] : 0.f;
+        s += v[k];
+    }
+    const float mean = block_sum(s) / (float)total;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const long i = threadIdx.x + 1024L * k;
+        const float d = i < total ? v[k] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.f / sqrtf(block_sum(q) / (float)total + eps);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const long i = threadIdx.x + 1024L * k;
+        if (i < total) {
+            const int c = gidx * cpg + (int)(i % cpg);
+            float t = (v[k] - mean) * rstd * gamma[c] + beta[c];
+            if (film) t = t * (1.f + film[(long)n * 2 * C + c]) + film[(long)n * 2 * C + C + c];
+            if (silu) t = t / (1.f + expf(-t));
+            obase[(i / cpg) * C + i % cpg] = t;
+        }
+    }
+}
+
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
                       int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream) {
     S3D_CHECK_ARG(C % groups == 0 && C % 4 == 0 && N >= 1 && HW >= 1, "group_norm: C=%d groups=%d", C, groups);
+    {
+        static const bool two_pass = getenv("S3D_GN_TWO_PASS") != nullptr;
+        const long per_thread = ((long)HW * (C / groups) + 1023) / 1024;
+        if (!two_pass && per_thread <= 24) {   // 1024 threads leave 128 registers per lane: larger slabs would spill
+            const dim3 grid((unsigned)(N * groups));
+#define GN_CASE(e)                                                                                                     \
+    if (per_thread <= e) {                                                                                             \
+        hipLaunchKernelGGL((gn_fused_kernel<e>), grid, dim3(1024), 0, stream, x, gamma, beta, film, y, HW, C, groups, eps, \
+                           silu);                                                                                      \
+        S3D_LAUNCH_CHECK();                                                                                            \
+        return 0;                                                                                                      \
+    }
+            GN_CASE(2) GN_CASE(8) GN_CASE(24)
+#undef GN_CASE
+        }
+    }
     S3D_CHECK_ARG((size_t)N * groups * 2 * sizeof(float) <= 48 * 1024, "group_norm: N*groups %d too large", N * groups);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, x, HW, C, groups, stats);
     S3D_LAUNCH_CHECK();
