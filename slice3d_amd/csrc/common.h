@@ -75,3 +75,12 @@ void s3d_set_error(const char* fmt, ...);
     } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Workgroup barrier that publishes LDS-DMA (global_load_lds) data: a wave must see ITS OWN requests land before it
+// arrives, because the other waves read those bytes right after the barrier.  __syncthreads() alone does not wait
+// on vmcnt (the compiler only guards a wave's own later LDS reads), which left a window in which a wave could read
+// a chunk another wave's DMA had not delivered yet (seen as rare garbage rows once nothing else delayed the reads).
+__device__ __forceinline__ void dma_publish_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}

@@ -12,7 +12,8 @@
 //   O^T = V^T P^T fp32 MFMA: A = the V registers, B = the P registers; result lane (token, g) holds dims 4g+i
 //   out_proj      f16x3 MFMA: O^T registers are its B operand (k-slot 8g+t <-> dim 16(t>>2) + 4g + (t&3), folded
 //                 into the packed W_o columns), accumulated over heads
-// No Q/K/V/O ever touches LDS; LDS holds only weight fragments (LDS-DMA ring of half-head slots, see the kernel).  13 of 16 tile rows are useful (19 % padding);
+// No Q/K/V/O ever touches LDS; LDS holds weight fragments (LDS-DMA ring of quarter-head slots) and the high halves of
+// the rows (see the kernel).  13 of 16 tile rows are useful (19 % padding);
 // the token-0-pruned last layer keeps the token-major kernel (decode_f16.hip), where pruning skips whole tiles.
 #include "decode.h"
 
@@ -48,158 +49,127 @@ __device__ __forceinline__ float colmax16(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Four waves per workgroup, TWO workgroups per CU; a workgroup owns half a group (8 queries).  Its LDS ring holds two
-// HALF-head slots of 32 KiB — slot A: the q,k in_proj fragments, slot B: the v in_proj + out_proj fragments — filled
-// by LDS-DMA one half-step ahead (one barrier per half-step).  (An eight-wave, one-workgroup-per-CU version with
-// whole-head slots ran its two waves per SIMD in lockstep and was 2 % slower.)
+// Four waves per workgroup, TWO workgroups per CU (one computes while the other sits at a barrier); a workgroup owns
+// half a group (8 queries), a wave two of them.  The rows of the wave's two queries are loaded and split ONCE per
+// item: the low halves stay in registers, the high halves in a wave-private 8 KiB LDS region, so the four heads do
+// not re-read (and re-split) them from L2.  The weight ring holds QUARTER-head slots of 16 KiB (q | k | v | out_proj
+// fragments) filled by LDS-DMA one phase ahead, four barriers per head; LDS = 2 x 16 KiB ring + 4 x 8 KiB rows.
+// (Earlier versions: eight waves / whole-head slots / rows re-read per head: 1.16 ms per layer; four waves / half-head
+// slots: 1.13 ms; this one 0.94 ms.)
 // ---------------------------------------------------------------------------------------------
-#define AQ2_SLOT_HALFS (16 * 1024)   // 16 fragment pairs = 32 KiB
+#define AQ3_SLOT_HALFS (8 * 1024)    // 8 fragment pairs = 16 KiB
+#define AQ3_XROW_HALFS (4 * 1024)    // per wave: 2 tiles x 4 k-steps x 64 lanes x 8 halfs
 __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long groups, int T, const _Float16* wimg,
                                                                const LayerPtrs w) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // 2 x 32 KiB
+    extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // ring 2 x 16 KiB, then the rows 4 x 8 KiB
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
     const float scale = 0.17677669529663687f;   // 1/sqrt(32)
     const _Float16* g_in = wimg;
     const _Float16* g_out = wimg + 4 * AQ_WIN_HALFS;
-    // half-step hs = 2*h (A) or 2*h + 1 (B) of a head: 32 chunks of 1 KiB
-    auto dma_half = [&](int hsm, int buf) {
-        const int h = hsm >> 1;
-        const _Float16* sa = g_in + (size_t)h * AQ_WIN_HALFS;              // q,k fragments: pairs 0..15
-        const _Float16* sv = sa + 16 * 1024;                                // v fragments: pairs 16..23
-        const _Float16* so = g_out + (size_t)h * AQ_WO_HALFS;               // out_proj fragments: 8 pairs
-        for (int i = wave; i < 32; i += 4) {
-            const _Float16* src = (hsm & 1) ? (i < 16 ? sv + i * 512 : so + (i - 16) * 512) : sa + i * 512;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
-                                             (__attribute__((address_space(3))) void*)(s_win + buf * AQ2_SLOT_HALFS + i * 512),
+    _Float16* s_x = s_win + 2 * AQ3_SLOT_HALFS + wave * AQ3_XROW_HALFS;
+    // phase ph = 4*h + {0 q, 1 k, 2 v, 3 out_proj}: 16 chunks of 1 KiB
+    auto dma_phase = [&](int ph, int buf) {
+        const int h = ph >> 2, part = ph & 3;
+        const _Float16* src0 = part < 3 ? g_in + (size_t)h * AQ_WIN_HALFS + part * AQ3_SLOT_HALFS
+                                        : g_out + (size_t)h * AQ_WO_HALFS;
+        for (int i = wave; i < 16; i += 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + i * 512 + lane * 8),
+                                             (__attribute__((address_space(3))) void*)(s_win + buf * AQ3_SLOT_HALFS + i * 512),
                                              16, 0, 0);
-        }
     };
-    const long items = 2 * groups;   // (group, half of its 16 queries)
-    long hs = 0;                     // running half-step count: slot = hs & 1
-    if ((long)blockIdx.x < items) dma_half(0, 0);
+    const long items = 2 * groups;
+    long ps = 0;   // running phase count: slot = ps & 1
+    if ((long)blockIdx.x < items) dma_phase(0, 0);
     const bool row_ok = m < T;
     const int mt = row_ok ? m : T - 1;
 
     for (long item = blockIdx.x; item < items; item += gridDim.x) {
         const long grp = item >> 1;
-        const int q0 = 8 * (int)(item & 1) + 2 * wave;   // the wave's two queries inside the group
+        const int q0 = 8 * (int)(item & 1) + 2 * wave;
         float* Xg = X + grp * T * S3D_GROUP * 128;
         f32x4 acc_o[2][8];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc_o[r][j] = zero4();
+        // rows of the item: low halves in registers for the whole item, high halves parked in LDS
+        half8q xl[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float* p = Xg + (mt * S3D_GROUP + q0 + r) * 128 + 8 * g;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
+                const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                half8q hi;
+                splitq8(v, hi, xl[r][u]);
+                *reinterpret_cast<half8q*>(s_x + ((r * 4 + u) * 64 + lane) * 8) = hi;
+            }
+        }
+        auto xh_at = [&](int r, int u) { return ldq8(s_x + ((r * 4 + u) * 64 + lane) * 8); };
 #pragma unroll 1
         for (int h = 0; h < 4; ++h) {
-            // =============== half-step A: Q^T, K^T ===============
-            __syncthreads();   // slot A of this head has landed; the other slot is free
+            f32x4 qd[2][2], kd[2][2], vd[2][2];
             f32x4 bq[2], bk[2];
             float bv[2];
+            // =============== phases q, k, v: one swapped (q, k) or plain (v) GEMM each ===============
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bq[j] = ld4(w.inb + 32 * h + 16 * j + 4 * g);
-                bk[j] = ld4(w.inb + 128 + 32 * h + 16 * j + 4 * g);
-                bv[j] = w.inb[256 + 32 * h + 16 * j + m];
-            }
-            half8q xh[2][4], xl[2][4];
+            for (int part = 0; part < 3; ++part) {
+                dma_publish_barrier();   // this phase's fragments have landed; the other slot is free
+                if (part == 0) {   // the head's biases: requested three phases before the attention core needs them
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float* p = Xg + (mt * S3D_GROUP + q0 + r) * 128 + 8 * g;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
-                    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                    splitq8(v, xh[r][u], xl[r][u]);
+                    for (int j = 0; j < 2; ++j) {
+                        bq[j] = ld4(w.inb + 32 * h + 16 * j + 4 * g);
+                        bk[j] = ld4(w.inb + 128 + 32 * h + 16 * j + 4 * g);
+                        bv[j] = w.inb[256 + 32 * h + 16 * j + m];
+                    }
                 }
-            }
-            dma_half(2 * h + 1, (int)((hs + 1) & 1));   // slot B of this head
-            f32x4 qd[2][2], kd[2][2], vd[2][2];
+                dma_phase(4 * h + part + 1, (int)((ps + 1) & 1));
+                const _Float16* sw = s_win + (ps & 1) * AQ3_SLOT_HALFS;
+                f32x4 d[2][2];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    qd[r][j] = zero4();
-                    kd[r][j] = zero4();
-                    vd[r][j] = zero4();
-                }
-            {
-                const _Float16* sw = s_win + (hs & 1) * AQ2_SLOT_HALFS;
-                // q and k fragments alternate: the LDS reads of one kind travel under the MFMAs of the other
-                half8q aq[2], aql[2], ak[2], akl[2];
-                auto load_q = [&](int u) {
+                    for (int j = 0; j < 2; ++j) d[r][j] = zero4();
+                half8q fh[2][2], fl[2][2];
+                auto load_f = [&](int u, int b) {
 #pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        aq[f] = ldq8(sw + (f * 4 + u) * 1024 + lane * 8);
-                        aql[f] = ldq8(sw + (f * 4 + u) * 1024 + 512 + lane * 8);
+                    for (int j = 0; j < 2; ++j) {
+                        fh[b][j] = ldq8(sw + (j * 4 + u) * 1024 + lane * 8);
+                        fl[b][j] = ldq8(sw + (j * 4 + u) * 1024 + 512 + lane * 8);
                     }
                 };
-                auto load_k = [&](int u) {
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        ak[f] = ldq8(sw + ((2 + f) * 4 + u) * 1024 + lane * 8);
-                        akl[f] = ldq8(sw + ((2 + f) * 4 + u) * 1024 + 512 + lane * 8);
-                    }
-                };
-                load_q(0);
-                load_k(0);
+                load_f(0, 0);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
+                    const half8q x0 = xh_at(0, u), x1 = xh_at(1, u);
+                    if (u < 3) load_f(u + 1, (u + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) qd[r][j] = mfma3q(aq[j], aql[j], xh[r][u], xl[r][u], qd[r][j]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (u < 3) load_q(u + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) kd[r][j] = mfma3q(ak[j], akl[j], xh[r][u], xl[r][u], kd[r][j]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (u < 3) load_k(u + 1);
-                }
-            }
-            ++hs;
-            // =============== half-step B: V, attention, out_proj ===============
-            __syncthreads();   // slot B has landed; slot A is free
-            {
-                const bool more_h = h < 3, more_i = item + gridDim.x < items;
-                if (more_h || more_i) dma_half(more_h ? 2 * (h + 1) : 0, (int)((hs + 1) & 1));
-            }
-            const _Float16* sw = s_win + (hs & 1) * AQ2_SLOT_HALFS;
-            {
-                half8q bh2[2][2], bl2[2][2];
-                auto load_v = [&](int u, int bsel) {
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        bh2[bsel][f] = ldq8(sw + (f * 4 + u) * 1024 + lane * 8);
-                        bl2[bsel][f] = ldq8(sw + (f * 4 + u) * 1024 + 512 + lane * 8);
+                    for (int j = 0; j < 2; ++j) {
+                        if (part < 2) {   // D^T = W X^T
+                            d[0][j] = mfma3q(fh[u & 1][j], fl[u & 1][j], x0, xl[0][u], d[0][j]);
+                            d[1][j] = mfma3q(fh[u & 1][j], fl[u & 1][j], x1, xl[1][u], d[1][j]);
+                        } else {          // D = X W^T
+                            d[0][j] = mfma3q(x0, xl[0][u], fh[u & 1][j], fl[u & 1][j], d[0][j]);
+                            d[1][j] = mfma3q(x1, xl[1][u], fh[u & 1][j], fl[u & 1][j], d[1][j]);
+                        }
                     }
-                };
-                load_v(0, 0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (u < 3) load_v(u + 1, (u + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r)
-                            vd[r][j] = mfma3q(xh[r][u], xl[r][u], bh2[u & 1][j], bl2[u & 1][j], vd[r][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-            const _Float16* gw = sw + 8 * 1024;
-            half8q wh[4], wl[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                wh[jj] = ldq8(gw + jj * 1024 + lane * 8);
-                wl[jj] = ldq8(gw + jj * 1024 + 512 + lane * 8);
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (part == 0) qd[r][j] = d[r][j];
+                        if (part == 1) kd[r][j] = d[r][j];
+                        if (part == 2) vd[r][j] = d[r][j];
+                    }
+                ++ps;
             }
-            __builtin_amdgcn_sched_barrier(0);
+            // =============== attention core, then phase out_proj ===============
             half8q oh[2], ol[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -243,22 +213,29 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 const float ov[8] = {od[0][0], od[0][1], od[0][2], od[0][3], od[1][0], od[1][1], od[1][2], od[1][3]};
                 splitq8(ov, oh[r], ol[r]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int r = 0; r < 2; ++r) acc_o[r][jj] = mfma3q(wh[jj], wl[jj], oh[r], ol[r], acc_o[r][jj]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                wh[jj] = ldq8(gw + (4 + jj) * 1024 + lane * 8);
-                wl[jj] = ldq8(gw + (4 + jj) * 1024 + 512 + lane * 8);
+            dma_publish_barrier();   // out_proj fragments have landed; the v slot is free
+            {
+                const bool more_h = h < 3, more_i = item + gridDim.x < items;
+                if (more_h || more_i) dma_phase(more_h ? 4 * (h + 1) : 0, (int)((ps + 1) & 1));
             }
+            {
+                const _Float16* gw = s_win + (ps & 1) * AQ3_SLOT_HALFS;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+                for (int half = 0; half < 2; ++half) {
+                    half8q wh[4], wl[4];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) acc_o[r][4 + jj] = mfma3q(wh[jj], wl[jj], oh[r], ol[r], acc_o[r][4 + jj]);
-            ++hs;
+                    for (int jj = 0; jj < 4; ++jj) {
+                        wh[jj] = ldq8(gw + (4 * half + jj) * 1024 + lane * 8);
+                        wl[jj] = ldq8(gw + (4 * half + jj) * 1024 + 512 + lane * 8);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+                            acc_o[r][4 * half + jj] = mfma3q(wh[jj], wl[jj], oh[r], ol[r], acc_o[r][4 * half + jj]);
+                }
+            }
+            ++ps;
         }
         // ---- residual + LayerNorm1, store ----
 #pragma unroll
@@ -303,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
 int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream) {
     if (groups <= 0) return 0;
     S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr, "attn_q: T %d", T);
-    const size_t lds = (size_t)2 * AQ2_SLOT_HALFS * 2;   // 64 KiB
+    const size_t lds = (size_t)(2 * AQ3_SLOT_HALFS + 4 * AQ3_XROW_HALFS) * 2;   // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_kernel(const f
     }
     // stage chunk 0 (LDS-DMA); chunk c+1 is requested at the top of iteration c into the other buffer
     dma_chunk32k(wimg, s_w[0], wave, lane, F16_WAVES);
-    __syncthreads();
+    dma_publish_barrier();
 
     unsigned mword[F16_R] = {};
     // lin1 bias of the NEXT chunk is fetched one iteration ahead and BEFORE the weight prefetch: vmcnt retires
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_kernel(const f
                 for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], hh[r], acc[r][j], 0, 0, 0);
             }
         }
-        __syncthreads();   // chunk c+1 has landed (the barrier drains vmcnt); everyone is done with buffer c & 1
+        dma_publish_barrier();   // chunk c+1 has landed; everyone is done with buffer c & 1
     }
 
     if (MODE == 3) return;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_bwd_dx_f16x3_kernel(const 
         for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
     }
     dma_chunk32k(timg, s_w[0], wave, lane, F16_WAVES);
-    __syncthreads();
+    dma_publish_barrier();
 
     unsigned mw[F16_R] = {};
 #pragma unroll 1
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_bwd_dx_f16x3_kernel(const 
                 for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], dh_[r], acc[r][j], 0, 0, 0);
             }
         }
-        __syncthreads();   // chunk c+1 has landed (the barrier drains vmcnt); everyone is done with buffer c & 1
+        dma_publish_barrier();   // chunk c+1 has landed; everyone is done with buffer c & 1
     }
     // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
 #pragma unroll
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
         for (int ti = 0; ti < A16_MAXT; ++ti)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc_o[ti][j] = zero4();
-        __syncthreads();
+        dma_publish_barrier();   // head 0 weights have landed
 
 #pragma unroll 1
         for (int h = 0; h < 4; ++h) {
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* 
                     acc_o[ti][j] = mfma3(ldh8(f), ldh8(f + 512), oh, ol, acc_o[ti][j]);
                 }
             }
-            __syncthreads();   // Q/K/V buffers free for the next head; W_in_{h+1} has landed
+            dma_publish_barrier();   // Q/K/V buffers free for the next head; W_in_{h+1} has landed
         }
         // ---- residual + LayerNorm1 (columns 32*(j>>1) + 8g + 4*(j&1) + i), store ----
 #pragma unroll
