@@ -60,3 +60,15 @@ def test_gt_dense_grid_equals_point_decode():
     sdf = m.decode_sdf(pts, code, trans_mat_wo_rot_tp=fd["trans_mat_wo_rot_tp"], mode="test")
     assert logits.shape == (nx, nx, nx)
     assert (logits.reshape(-1) + sdf.reshape(-1)).abs().max() < 2e-5
+
+
+def test_gt_decode_is_bit_reproducible_run_to_run():
+    """Regression test of a race in the LDS-DMA weight rings (a wave could read a chunk another wave's DMA had not
+    delivered yet): it showed as rare wrong rows on this shape — every workgroup of the attention kernel handles a
+    single item, so nothing delays its first fragment reads.  Twenty decodes must agree bit for bit."""
+    from slice3d_amd.synth import make_feed_dict
+    fd = {k: v.cuda() for k, v in make_feed_dict(2, 48, 4500, 5, seed=5400).items()}
+    m = make_model(5, "f16x3", "test")
+    first = m(fd)["sdf_pred"].clone()
+    for _ in range(19):
+        assert torch.equal(m(fd)["sdf_pred"], first)
