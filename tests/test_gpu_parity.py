@@ -183,6 +183,19 @@ def test_sorted_and_unsorted_decodes_agree_across_chunks():
         assert torch.equal(full[:, s:s + 3000], part), s
 
 
+def test_decode_is_bit_reproducible_run_to_run():
+    """The decode has no atomics and no order-dependent reductions: repeated runs must agree bit for bit (this also
+    guards the LDS-DMA weight rings, whose publishing barrier once let a wave read a chunk before it had landed)."""
+    from slice3d_amd.synth import make_feed_dict
+    model = get_model(12, "test")
+    for b, s, q in ((1, 256, 100000), (2, 64, 4500)):
+        fd = to_gpu(make_feed_dict(b, s, q, 12, seed=77, with_slices=False))
+        code = model.encode(fd)
+        first = model.decode_sdf(fd["qry_norot"], code).clone()
+        for _ in range(8):
+            assert torch.equal(model.decode_sdf(fd["qry_norot"], code), first)
+
+
 def test_batch_items_are_independent():
     from slice3d_amd.synth import make_feed_dict
     model = get_model(12, "train")
