@@ -36,3 +36,15 @@ for heads, ch, T in ((8, 24, 4096), (2, 96, 40)):
     # which keys matter: relate error to the largest |v| and the attention weight mass
     qi = int(tq.argmax())
     print("  worst query", qi, "its max softmax weight", float(wgt[:, qi].max()), "max |score|", float((torch.einsum('bct,bcs->bts', q*sc, k*sc))[:, qi].abs().max()))
+
+# is the split-precision kernel deterministic run to run?
+os.environ["S3D_LDM_ATTN_F16X3"] = "1"
+heads, ch, T = 8, 24, 4096
+qkv = torch.randn(1, heads * 3 * ch, T, generator=g)
+qc = qkv.permute(0, 2, 1).contiguous().cuda()
+outs = []
+for _ in range(6):
+    out = torch.empty(1, T, heads * ch, device="cuda")
+    _lib.check(lib.s3d_qkv_attention_fwd(qc.data_ptr(), out.data_ptr(), 1, T, heads, ch, 1, None), "attn")
+    outs.append(out.cpu())
+print("run-to-run max differences:", [float((o - outs[0]).abs().max()) for o in outs[1:]])
