@@ -507,7 +507,7 @@ int launch_ffn_wgrad_rec(const FfnWgradArgs& a, hipStream_t stream) {
                        a.transpose_out, a.accumulate);
     S3D_LAUNCH_CHECK();
     if (a.bias_out) {
-        hipLaunchKernelGGL(colsum_final_kernel, dim3(S3D_FFN / 64), dim3(256), 0, stream,
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(S3D_FFN / 64), dim3(1024), 0, stream,
                            a.partial + (size_t)splits * 128 * S3D_FFN, (int)splits, S3D_FFN, 1.f, a.bias_out,
                            a.accumulate);
         S3D_LAUNCH_CHECK();
@@ -859,18 +859,31 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     return 0;
 }
 
+__device__ __forceinline__ f32x4 bn_relu4(const f32x4 z, const f32x4 mu, const f32x4 rs, const f32x4 ga,
+                                          const f32x4 be) {
+    f32x4 y = (z - mu) * rs * ga + be;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = fmaxf(y[i], 0.f);
+    return y;
+}
+
 // =============================================================================================
 // column reductions (deterministic two-stage).  mode 0: sum x ; 1: sum (x-m[c])^2 ;
 // 2: two sums at once: sum g and sum g*(z-m[c])*r[c]   (BN backward; g in `in`, z in `in2`)
+// 3: as 2 with g = relu'(bn(z)) * dy recomputed from the BN parameters (dy in `in`): no g tensor in memory
+// 4: two sums at once about a pilot value: sum (x-k[c]) and sum (x-k[c])^2 with k = row 0 of `in` (one-pass
+//    BatchNorm statistics: the shift keeps the E[d^2] - E[d]^2 cancellation at the size of (mean-k)^2 / var)
 // =============================================================================================
 #define CS_CHUNKS CS_CHUNKS_MAX
 template <int MODE>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, const float* __restrict__ in2,
                                                      long P, int cstride, int coff, int C,
                                                      const float* __restrict__ m, const float* __restrict__ r,
-                                                     float* __restrict__ partial, long rows_per_chunk) {
+                                                     float* __restrict__ partial, long rows_per_chunk,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta) {
     // thread = (row lane rl, column quad cq): narrow matrices (C = 64..128) still use all 256 threads
-    __shared__ f32x4 red[256], red2[MODE == 2 ? 256 : 1];
+    __shared__ f32x4 red[256], red2[MODE >= 2 ? 256 : 1];
     const int c4n = C >> 2;
     const int tpr = c4n < 256 ? c4n : 256;
     const int rl_n = 256 / tpr;
@@ -884,8 +897,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
         const int c = (cq < c4n ? cq : 0) * 4;
         f32x4 s = zero4(), s2 = zero4();
         f32x4 mv = zero4(), rv = zero4();
-        if (MODE >= 1) mv = ld4(m + c);
-        if (MODE == 2) rv = ld4(r + c);
+        f32x4 gav = zero4(), bev = zero4();
+        if (MODE >= 1 && MODE <= 3) mv = ld4(m + c);
+        if (MODE == 2 || MODE == 3) rv = ld4(r + c);
+        if (MODE == 4) mv = ld4(in + coff + c);
+        if (MODE == 3) {
+            gav = ld4(gamma + c);
+            bev = ld4(beta + c);
+        }
+        auto masked = [&](f32x4 d, const f32x4 zz) {   // MODE 3: dy -> g
+            const f32x4 y = bn_relu4(zz, mv, rv, gav, bev);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = y[i] > 0.f ? d[i] : 0.f;
+            return d;
+        };
         if (active) {
             const float* src = in + coff + c;
             if (MODE == 0) {   // 8 independent row streams: 8 loads in flight per thread
@@ -904,14 +929,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
                 for (; p < r1; p += rl_n) t[0] += ld4(src + p * cstride);
                 s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
             } else {
-                const float* src2 = MODE == 2 ? in2 + coff + c : src;
+                const float* src2 = (MODE == 2 || MODE == 3) ? in2 + coff + c : src;
                 long p = r0 + rl;
                 for (; p + 3L * rl_n < r1; p += 4L * rl_n) {
                     f32x4 v[4], z[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         v[k] = ld4(src + (p + (long)k * rl_n) * cstride);
-                        if (MODE == 2) z[k] = ld4(src2 + (p + (long)k * rl_n) * cstride);
+                        if (MODE == 2 || MODE == 3) z[k] = ld4(src2 + (p + (long)k * rl_n) * cstride);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -919,19 +944,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
                         if (MODE == 1) {
                             const f32x4 d = v[k] - mv;
                             s += d * d;
+                        } else if (MODE == 4) {
+                            const f32x4 d = v[k] - mv;
+                            s += d;
+                            s2 += d * d;
                         } else {
+                            if (MODE == 3) v[k] = masked(v[k], z[k]);
                             s += v[k];
                             s2 += v[k] * ((z[k] - mv) * rv);
                         }
                     }
                 }
                 for (; p < r1; p += rl_n) {
-                    const f32x4 v = ld4(src + p * cstride);
+                    f32x4 v = ld4(src + p * cstride);
                     if (MODE == 1) {
                         const f32x4 d = v - mv;
                         s += d * d;
+                    } else if (MODE == 4) {
+                        const f32x4 d = v - mv;
+                        s += d;
+                        s2 += d * d;
                     } else {
                         const f32x4 z = ld4(src2 + p * cstride);
+                        if (MODE == 3) v = masked(v, z);
                         s += v;
                         s2 += v * ((z - mv) * rv);
                     }
@@ -939,43 +974,49 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
             }
         }
         red[threadIdx.x] = s;
-        if (MODE == 2) red2[threadIdx.x] = s2;
+        if (MODE >= 2) red2[threadIdx.x] = s2;
         __syncthreads();
         if (rl == 0 && cq < c4n) {
             for (int k = 1; k < rl_n; ++k) {
                 s += red[k * tpr + ct];
-                if (MODE == 2) s2 += red2[k * tpr + ct];
+                if (MODE >= 2) s2 += red2[k * tpr + ct];
             }
             st4(partial + ((size_t)blockIdx.x * C + c), s);
-            if (MODE == 2) st4(partial + ((size_t)(gridDim.x + blockIdx.x) * C + c), s2);
+            if (MODE >= 2) st4(partial + ((size_t)(gridDim.x + blockIdx.x) * C + c), s2);
         }
         __syncthreads();
     }
 }
 
-// final: out[c] (+)= scale * sum over chunks.  Block = 64 columns x 4 chunk slices (coalesced 256-byte
-// rows, 4-way split of the chunk loop, LDS combine): deterministic.
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nchunks, int C,
-                                                           float scale, float* __restrict__ out, int accumulate) {
-    __shared__ float red[4][64];
+// final: out[c] (+)= scale * sum over chunks.  Block = 64 columns x 16 chunk slices (coalesced 256-byte
+// rows, 16-way split of the chunk loop with 8 loads in flight per thread, LDS combine): deterministic.
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, int nchunks, int C,
+                                                            float scale, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
     if (c < C) {
         int k = sl;
-        for (; k + 12 < nchunks; k += 16) {
-            s0 += partial[(size_t)k * C + c];
-            s1 += partial[(size_t)(k + 4) * C + c];
-            s2 += partial[(size_t)(k + 8) * C + c];
-            s3 += partial[(size_t)(k + 12) * C + c];
+        for (; k + 7 * 16 < nchunks; k += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(k + 16 * j) * C + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += v[j];
         }
-        for (; k < nchunks; k += 4) s0 += partial[(size_t)k * C + c];
+        for (; k < nchunks; k += 16) s[0] += partial[(size_t)k * C + c];
     }
-    red[sl][cl] = (s0 + s1) + (s2 + s3);
+    red[sl][cl] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     if (sl == 0 && c < C) {
-        const float s = scale * ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
-        out[c] = accumulate ? out[c] + s : s;
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][cl];
+        t *= scale;
+        out[c] = accumulate ? out[c] + t : t;
     }
 }
 
@@ -993,9 +1034,9 @@ int launch_colsum(const float* in, long P, int cstride, int coff, int C, float* 
     long rpc;
     const int n = colsum_chunks(P, rpc);
     hipLaunchKernelGGL((colsum_kernel<0>), dim3(n), dim3(256), 0, stream, in, nullptr, P, cstride, coff, C, nullptr,
-                       nullptr, partial, rpc);
+                       nullptr, partial, rpc, nullptr, nullptr);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, partial, n, C, 1.f, out,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial, n, C, 1.f, out,
                        accumulate);
     S3D_LAUNCH_CHECK();
     return 0;
@@ -1018,34 +1059,60 @@ __global__ void bn_finalize_kernel(const float* __restrict__ var_sum, long P, in
     }
 }
 
+// one-pass variant: m1 = E[x - k] (in `mean`), m2 = E[(x - k)^2] (in `rstd`), k = row 0 of z
+__global__ void bn_finalize_shift_kernel(const float* __restrict__ krow, long P, int C, float* __restrict__ mean,
+                                         float* __restrict__ rstd, float* __restrict__ running_mean,
+                                         float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float m1 = mean[c], m2 = rstd[c];
+    const float mu = krow[c] + m1;
+    const float var = fmaxf(m2 - m1 * m1, 0.f);
+    mean[c] = mu;
+    rstd[c] = 1.f / sqrtf(var + 1e-5f);
+    if (running_mean) {
+        running_mean[c] = 0.9f * running_mean[c] + 0.1f * mu;
+        const float unb = P > 1 ? var * (float)P / (float)(P - 1) : var;
+        running_var[c] = 0.9f * running_var[c] + 0.1f * unb;
+    }
+}
+
 int launch_bn_stats(const float* z, long P, int C, float* mean, float* rstd, float* running_mean,
                     float* running_var, float* partial, hipStream_t stream) {
     S3D_CHECK_ARG(C % 4 == 0 && P > 0, "bn_stats: bad dims");
     long rpc;
     const int n = colsum_chunks(P, rpc);
+    static const bool two_pass = getenv("S3D_BN_TWO_PASS") != nullptr;
+    if (!two_pass) {
+        hipLaunchKernelGGL((colsum_kernel<4>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, nullptr,
+                           nullptr, partial, rpc, nullptr, nullptr);
+        S3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial, n, C,
+                           1.f / (float)P, mean, 0);
+        S3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial + (size_t)n * C,
+                           n, C, 1.f / (float)P, rstd, 0);
+        S3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_finalize_shift_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, z, P, C, mean, rstd,
+                           running_mean, running_var);
+        S3D_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL((colsum_kernel<0>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, nullptr, nullptr,
-                       partial, rpc);
+                       partial, rpc, nullptr, nullptr);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, partial, n, C,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial, n, C,
                        1.f / (float)P, mean, 0);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL((colsum_kernel<1>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, mean, nullptr,
-                       partial, rpc);
+                       partial, rpc, nullptr, nullptr);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, partial, n, C, 1.f, rstd, 0);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial, n, C, 1.f, rstd, 0);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, rstd, P, C, rstd, mean,
                        running_mean, running_var);
     S3D_LAUNCH_CHECK();
     return 0;
-}
-
-__device__ __forceinline__ f32x4 bn_relu4(const f32x4 z, const f32x4 mu, const f32x4 rs, const f32x4 ga,
-                                          const f32x4 be) {
-    f32x4 y = (z - mu) * rs * ga + be;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = fmaxf(y[i], 0.f);
-    return y;
 }
 
 template <bool POOL>
@@ -1146,10 +1213,13 @@ __global__ void bn_bwd_g_kernel(const float* __restrict__ z, const float* __rest
     }
 }
 
+// MASK: g is recomputed as relu'(bn(z)) * dy (dy may alias g_dz); otherwise g_dz holds g on entry
+template <bool MASK>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* dy,
                                     const float* __restrict__ dbeta, const float* __restrict__ dgamma,
-                                    float* __restrict__ g_dz, long P, int c) {
+                                    float* g_dz, long P, int c) {
     const int c4 = c >> 2;
     const long total = P * c4;
     const float invP = 1.f / (float)P;
@@ -1158,8 +1228,17 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __
         const int cc = (int)(idx % c4) * 4;
         const f32x4 mu = ld4(mean + cc), rs = ld4(rstd + cc), ga = ld4(gamma + cc);
         const f32x4 sb = ld4(dbeta + cc), sg = ld4(dgamma + cc);
-        const f32x4 xh = (ld4(z + idx * 4) - mu) * rs;
-        const f32x4 g = ld4(g_dz + idx * 4);
+        const f32x4 zz = ld4(z + idx * 4);
+        const f32x4 xh = (zz - mu) * rs;
+        f32x4 g;
+        if (MASK) {
+            g = ld4(dy + idx * 4);
+            const f32x4 y = bn_relu4(zz, mu, rs, ga, ld4(beta + cc));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+        } else {
+            g = ld4(g_dz + idx * 4);
+        }
         st4(g_dz + idx * 4, ga * rs * (g - sb * invP - xh * (sg * invP)));
     }
 }
@@ -1171,28 +1250,33 @@ int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const fl
     const long P = (long)n * h * w;
     const long tot_g = (long)n * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (c / 4);
     const int bg = (int)((tot_g + 255) / 256 < 8192 ? (tot_g + 255) / 256 : 8192);
-    if (pool)
-        hipLaunchKernelGGL((bn_bwd_g_kernel<true>), dim3(bg), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy, dz,
-                           n, h, w, c);
-    else
-        hipLaunchKernelGGL((bn_bwd_g_kernel<false>), dim3(bg), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy,
-                           dz, n, h, w, c);
-    S3D_LAUNCH_CHECK();
     long rpc;
     const int nch = colsum_chunks(P, rpc);
-    hipLaunchKernelGGL((colsum_kernel<2>), dim3(nch), dim3(256), 0, stream, dz, z, P, c, 0, c, mean, rstd, partial,
-                       rpc);
+    if (pool) {   // the pooled gradient is routed to the window maxima first: g lives in dz
+        hipLaunchKernelGGL((bn_bwd_g_kernel<true>), dim3(bg), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy, dz,
+                           n, h, w, c);
+        S3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL((colsum_kernel<2>), dim3(nch), dim3(256), 0, stream, dz, z, P, c, 0, c, mean, rstd,
+                           partial, rpc, nullptr, nullptr);
+    } else {      // g = relu mask * dy is recomputed in both passes instead of stored
+        hipLaunchKernelGGL((colsum_kernel<3>), dim3(nch), dim3(256), 0, stream, dy, z, P, c, 0, c, mean, rstd,
+                           partial, rpc, gamma, beta);
+    }
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 63) / 64), dim3(256), 0, stream, partial, nch, c, 1.f, dbeta,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 63) / 64), dim3(1024), 0, stream, partial, nch, c, 1.f, dbeta,
                        0);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 63) / 64), dim3(256), 0, stream, partial + (size_t)nch * c,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 63) / 64), dim3(1024), 0, stream, partial + (size_t)nch * c,
                        nch, c, 1.f, dgamma, 0);
     S3D_LAUNCH_CHECK();
     const long tot = P * (c / 4);
     const int ba = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, dbeta, dgamma, dz, P,
-                       c);
+    if (pool)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, beta,
+                           dy, dbeta, dgamma, dz, P, c);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy,
+                           dbeta, dgamma, dz, P, c);
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1524,7 +1608,7 @@ int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, u, gamma, dy, du, rows, partial);
     S3D_LAUNCH_CHECK();
     // partial rows are [block][256] = dgamma(128) | dbeta(128)
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(4), dim3(256), 0, stream, partial, nb, 256, 1.f, partial + (size_t)nb * 256, 0);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(4), dim3(1024), 0, stream, partial, nb, 256, 1.f, partial + (size_t)nb * 256, 0);
     S3D_LAUNCH_CHECK();
     float* fin = partial + (size_t)nb * 256;
     if (accumulate) {
