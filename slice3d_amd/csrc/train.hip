@@ -748,7 +748,11 @@ static int launch_wgrad_conv3_f16x3(const WgradArgs& a, hipStream_t stream) {
     const int n_nblk = a.N / 64, n_cblk = narrow ? 1 : a.Cx / 64, Ktot = 9 * a.Cx;
     const long n_tiles = (long)a.Nimg * (a.H / 4) * (a.W / 8);
     const long blocks = (long)n_nblk * n_cblk;
-    long splits = (2048 + blocks - 1) / blocks;                // aim at >= 2048 workgroups
+    static const long want_wgs = [] {
+        const char* e = getenv("S3D_WGRAD3_WGS");
+        return e ? atol(e) : 1024L;
+    }();
+    long splits = (want_wgs + blocks - 1) / blocks;            // aim at >= 1024 workgroups (4 per CU): more only grows the partial-sum reduction
     const long max_by_tiles = (n_tiles + 7) / 8;               // >= 8 tiles per workgroup
     if (splits > max_by_tiles) splits = max_by_tiles;
     const long cap = (long)(a.partial_floats / ((size_t)a.N * Ktot));
@@ -812,7 +816,7 @@ static void wgrad_plan(long P, int N, int Cx, int taps, int& TN, int& TK, int& n
     n_cblk = (Cx + 16 * TK - 1) / (16 * TK);
     const long total_steps = (P + 3) / 4;
     const long tiles = (long)n_nblk * n_cblk * taps;
-    long sy = (2048 + tiles - 1) / tiles;                       // aim at >= 2048 workgroups
+    long sy = (2048 + tiles - 1) / tiles;                       // aim at >= 1024 workgroups (4 per CU): more only grows the partial-sum reduction
     const long max_by_steps = (total_steps + 4 * 16 - 1) / (4 * 16);  // >= 16 MFMA steps per wave
     if (sy > max_by_steps) sy = max_by_steps;
     const long cap = (64L << 20) / ((long)N * Cx * taps * 4);   // partial buffer <= 64 Mi floats
@@ -1219,7 +1223,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* dy,
                                     const float* __restrict__ dbeta, const float* __restrict__ dgamma,
-                                    float* g_dz, long P, int c) {
+                                    float* g_dz, const float* __restrict__ add, long P, int c) {
     const int c4 = c >> 2;
     const long total = P * c4;
     const float invP = 1.f / (float)P;
@@ -1239,13 +1243,15 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __
         } else {
             g = ld4(g_dz + idx * 4);
         }
-        st4(g_dz + idx * 4, ga * rs * (g - sb * invP - xh * (sg * invP)));
+        f32x4 o = ga * rs * (g - sb * invP - xh * (sg * invP));
+        if (add) o += ld4(add + idx * 4);
+        st4(g_dz + idx * 4, o);
     }
 }
 
 int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   const float* dy, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c, int pool,
-                  float* partial, hipStream_t stream) {
+                  float* partial, hipStream_t stream, const float* add) {
     S3D_CHECK_ARG(c % 4 == 0, "bn_bwd: C %% 4");
     const long P = (long)n * h * w;
     const long tot_g = (long)n * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (c / 4);
@@ -1273,10 +1279,77 @@ int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const fl
     const int ba = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
     if (pool)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, beta,
-                           dy, dbeta, dgamma, dz, P, c);
+                           dy, dbeta, dgamma, dz, add, P, c);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy,
-                           dbeta, dgamma, dz, P, c);
+                           dbeta, dgamma, dz, add, P, c);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
+// first encoder conv: 3x3, C_in <= 4 straight from the NCHW image, 64 output channels, exact fp32 FMA.  The layer
+// is a 0.1 GFLOP/image trickle behind an 805 MB output write: the implicit-GEMM tile (K padded to 16 channels)
+// spent 0.84 ms on it, this kernel is bound by the write.  Thread = 4 pixels of a row x 4 output channels.
+// =============================================================================================
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restrict__ img,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int n, int H, int W) {
+    __shared__ f32x4 s_w[9 * CIN][16];   // [tap * CIN + ci][channel quad]
+    for (int idx = threadIdx.x; idx < 9 * CIN * 64; idx += 256) {
+        const int co = idx & 63, k = idx >> 6, tap = k / CIN, ci = k - tap * CIN;
+        ((float*)s_w)[k * 64 + co] = w[(co * CIN + ci) * 9 + tap];
+    }
+    __syncthreads();
+    const int cq = threadIdx.x & 15, wq = W >> 2;
+    const f32x4 b4 = bias ? ld4(bias + cq * 4) : zero4();
+    const long groups = (long)n * H * wq;
+    for (long grp = (long)blockIdx.x * 16 + (threadIdx.x >> 4); grp < groups; grp += (long)gridDim.x * 16) {
+        const int x0 = (int)(grp % wq) * 4;
+        const long r = grp / wq;
+        const int y = (int)(r % H);
+        const long ni = r / H;
+        f32x4 acc[4] = {b4, b4, b4, b4};
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + dy - 1;
+                float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (yy >= 0 && yy < H) {
+                    const float* row = img + ((ni * CIN + ci) * H + yy) * W;
+                    const f32x4 mid = ld4(row + x0);
+                    v[0] = x0 > 0 ? row[x0 - 1] : 0.f;
+                    v[1] = mid[0]; v[2] = mid[1]; v[3] = mid[2]; v[4] = mid[3];
+                    v[5] = x0 + 4 < W ? row[x0 + 4] : 0.f;
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const f32x4 wv = s_w[(dy * 3 + dx) * CIN + ci][cq];
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) acc[px] += wv * v[px + dx];
+                }
+            }
+        }
+        float* o = out + ((ni * H + y) * W + x0) * 64 + cq * 4;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) st4(o + px * 64, acc[px]);
+    }
+}
+
+int launch_conv3x3_first(const float* img_nchw, int cin, const float* w_oihw, const float* bias, float* out_nhwc,
+                         int n, int h, int w, hipStream_t stream) {
+    S3D_CHECK_ARG((cin == 1 || cin == 3) && w % 4 == 0, "conv3x3_first: C_in %d, W %d", cin, w);
+    const long groups = (long)n * h * (w / 4);
+    const int blocks = (int)((groups + 15) / 16 < 16384 ? (groups + 15) / 16 : 16384);
+    if (cin == 1)
+        hipLaunchKernelGGL((conv3x3_first_kernel<1>), dim3(blocks), dim3(256), 0, stream, img_nchw, w_oihw, bias,
+                           out_nhwc, n, h, w);
+    else
+        hipLaunchKernelGGL((conv3x3_first_kernel<3>), dim3(blocks), dim3(256), 0, stream, img_nchw, w_oihw, bias,
+                           out_nhwc, n, h, w);
     S3D_LAUNCH_CHECK();
     return 0;
 }
