@@ -1166,53 +1166,123 @@ int launch_bn_apply(const float* z, const float* mean, const float* rstd, const 
     return 0;
 }
 
-// g = dL/d(bn output) on the z grid: relu mask (+ max-pool routing to the first maximum of the window)
-template <bool POOL>
-__global__ void bn_bwd_g_kernel(const float* __restrict__ z, const float* __restrict__ mean,
-                                const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const float* __restrict__ dy,
-                                float* __restrict__ g, int n, int h, int w, int c) {
-    const int c4 = c >> 2;
-    const int ho = POOL ? h >> 1 : h, wo = POOL ? w >> 1 : w;
+// BN -> ReLU -> 2x2 max-pool backward without a stored g: the pooled gradient belongs to the first maximum of its
+// window (if that maximum is positive).  Both passes walk the POOLED grid, read the window's four z values and
+// redo the forward's comparison.
+struct PoolPick {
+    f32x4 g[4];   // gradient routed to each of the four window positions
+};
+__device__ __forceinline__ PoolPick pool_route(const f32x4 (&zz)[4], const f32x4 d, const f32x4 mu, const f32x4 rs,
+                                               const f32x4 ga, const f32x4 be) {
+    f32x4 v[4], best;
+    int arg[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        v[t] = bn_relu4(zz[t], mu, rs, ga, be);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t == 0 || v[t][i] > best[i]) {
+                best[i] = v[t][i];
+                arg[i] = t;
+            }
+    }
+    PoolPick o;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.g[t][i] = (arg[i] == t && best[i] > 0.f) ? d[i] : 0.f;
+    return o;
+}
+
+// partial[chunk][c] = sum g, partial[nchunks + chunk][c] = sum g * xhat  over the chunk's pooled pixels
+__global__ __launch_bounds__(256) void bn_bwd_pool_sums_kernel(const float* __restrict__ z,
+                                                               const float* __restrict__ dy, int n, int h, int w,
+                                                               int C, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               float* __restrict__ partial, long rows_per_chunk) {
+    __shared__ f32x4 red[256], red2[256];
+    const int c4n = C >> 2;
+    const int tpr = c4n < 256 ? c4n : 256;
+    const int rl_n = 256 / tpr;
+    const int rl = threadIdx.x / tpr, ct = threadIdx.x - rl * tpr;
+    const int ho = h >> 1, wo = w >> 1;
+    const long Pp = (long)n * ho * wo;
+    const long r0 = (long)blockIdx.x * rows_per_chunk;
+    long r1 = r0 + rows_per_chunk;
+    if (r1 > Pp) r1 = Pp;
+    for (int cq0 = 0; cq0 < c4n; cq0 += tpr) {
+        const int cq = cq0 + ct;
+        const bool active = rl < rl_n && cq < c4n;
+        const int c = (cq < c4n ? cq : 0) * 4;
+        const f32x4 mu = ld4(mean + c), rs = ld4(rstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+        f32x4 s = zero4(), s2 = zero4();
+        if (active) {
+            for (long p = r0 + rl; p < r1; p += rl_n) {
+                const int x = (int)(p % wo);
+                const long r = p / wo;
+                const int yy = (int)(r % ho);
+                const long ni = r / ho;
+                const float* zb = z + ((ni * h + 2 * yy) * w + 2 * x) * C + c;
+                f32x4 zz[4];
+                zz[0] = ld4(zb);
+                zz[1] = ld4(zb + C);
+                zz[2] = ld4(zb + (long)w * C);
+                zz[3] = ld4(zb + (long)w * C + C);
+                const PoolPick pk = pool_route(zz, ld4(dy + p * C + c), mu, rs, ga, be);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    s += pk.g[t];
+                    s2 += pk.g[t] * ((zz[t] - mu) * rs);
+                }
+            }
+        }
+        red[threadIdx.x] = s;
+        red2[threadIdx.x] = s2;
+        __syncthreads();
+        if (rl == 0 && cq < c4n) {
+            for (int k = 1; k < rl_n; ++k) {
+                s += red[k * tpr + ct];
+                s2 += red2[k * tpr + ct];
+            }
+            st4(partial + ((size_t)blockIdx.x * C + c), s);
+            st4(partial + ((size_t)(gridDim.x + blockIdx.x) * C + c), s2);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_bwd_pool_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, const float* __restrict__ dy,
+                                         const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                         float* __restrict__ dz, const float* __restrict__ add, int n, int h, int w,
+                                         int c) {
+    const int c4 = c >> 2, ho = h >> 1, wo = w >> 1;
     const long total = (long)n * ho * wo * c4;
+    const float invP = 1.f / (float)((long)n * h * w);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const int cc = (int)(idx % c4) * 4;
+        long r = idx / c4;
+        const int x = (int)(r % wo);
+        r /= wo;
+        const int yy = (int)(r % ho);
+        const long ni = r / ho;
         const f32x4 mu = ld4(mean + cc), rs = ld4(rstd + cc), ga = ld4(gamma + cc), be = ld4(beta + cc);
-        const f32x4 d = ld4(dy + idx * 4);
-        if (!POOL) {
-            const f32x4 y = bn_relu4(ld4(z + idx * 4), mu, rs, ga, be);
-            f32x4 o;
+        const f32x4 sb = ld4(dbeta + cc) * invP, sg = ld4(dgamma + cc) * invP;
+        const long base = ((ni * h + 2 * yy) * w + 2 * x) * c + cc;
+        const long off[4] = {0, c, (long)w * c, (long)w * c + c};
+        f32x4 zz[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = y[i] > 0.f ? d[i] : 0.f;
-            st4(g + idx * 4, o);
-        } else {
-            long r = idx / c4;
-            const int x = (int)(r % wo);
-            r /= wo;
-            const int yy = (int)(r % ho);
-            const int ni = (int)(r / ho);
-            f32x4 v[4];
-            int arg[4] = {0, 0, 0, 0};
-            f32x4 best;
+        for (int t = 0; t < 4; ++t) zz[t] = ld4(z + base + off[t]);
+        const PoolPick pk = pool_route(zz, ld4(dy + idx * 4), mu, rs, ga, be);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                v[t] = bn_relu4(ld4(z + ((long)(ni * h + 2 * yy + (t >> 1)) * w + 2 * x + (t & 1)) * c + cc), mu, rs,
-                                ga, be);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (t == 0 || v[t][i] > best[i]) {
-                        best[i] = v[t][i];
-                        arg[i] = t;
-                    }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                f32x4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (arg[i] == t && best[i] > 0.f) ? d[i] : 0.f;
-                st4(g + ((long)(ni * h + 2 * yy + (t >> 1)) * w + 2 * x + (t & 1)) * c + cc, o);
-            }
+        for (int t = 0; t < 4; ++t) {
+            f32x4 o = ga * rs * (pk.g[t] - sb - (zz[t] - mu) * rs * sg);
+            if (add) o += ld4(add + base + off[t]);
+            st4(dz + base + off[t], o);
         }
     }
 }
@@ -1253,21 +1323,32 @@ int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const fl
                   const float* dy, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c, int pool,
                   float* partial, hipStream_t stream, const float* add) {
     S3D_CHECK_ARG(c % 4 == 0, "bn_bwd: C %% 4");
+    S3D_CHECK_ARG(!pool || (h % 2 == 0 && w % 2 == 0), "bn_bwd: pooled map %d x %d must be even", h, w);
     const long P = (long)n * h * w;
-    const long tot_g = (long)n * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (c / 4);
-    const int bg = (int)((tot_g + 255) / 256 < 8192 ? (tot_g + 255) / 256 : 8192);
     long rpc;
-    const int nch = colsum_chunks(P, rpc);
-    if (pool) {   // the pooled gradient is routed to the window maxima first: g lives in dz
-        hipLaunchKernelGGL((bn_bwd_g_kernel<true>), dim3(bg), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy, dz,
-                           n, h, w, c);
+    if (pool) {   // both passes walk the pooled grid and redo the window comparison
+        const long Pp = (long)n * (h / 2) * (w / 2);
+        const int nch = colsum_chunks(Pp, rpc);
+        hipLaunchKernelGGL(bn_bwd_pool_sums_kernel, dim3(nch), dim3(256), 0, stream, z, dy, n, h, w, c, mean, rstd,
+                           gamma, beta, partial, rpc);
         S3D_LAUNCH_CHECK();
-        hipLaunchKernelGGL((colsum_kernel<2>), dim3(nch), dim3(256), 0, stream, dz, z, P, c, 0, c, mean, rstd,
-                           partial, rpc, nullptr, nullptr);
-    } else {      // g = relu mask * dy is recomputed in both passes instead of stored
-        hipLaunchKernelGGL((colsum_kernel<3>), dim3(nch), dim3(256), 0, stream, dy, z, P, c, 0, c, mean, rstd,
-                           partial, rpc, gamma, beta);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 63) / 64), dim3(1024), 0, stream, partial, nch, c, 1.f,
+                           dbeta, 0);
+        S3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 63) / 64), dim3(1024), 0, stream,
+                           partial + (size_t)nch * c, nch, c, 1.f, dgamma, 0);
+        S3D_LAUNCH_CHECK();
+        const long tot = Pp * (c / 4);
+        const int ba = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+        hipLaunchKernelGGL(bn_bwd_pool_apply_kernel, dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy,
+                           dbeta, dgamma, dz, add, n, h, w, c);
+        S3D_LAUNCH_CHECK();
+        return 0;
     }
+    // g = relu mask * dy is recomputed in both passes instead of stored
+    const int nch = colsum_chunks(P, rpc);
+    hipLaunchKernelGGL((colsum_kernel<3>), dim3(nch), dim3(256), 0, stream, dy, z, P, c, 0, c, mean, rstd, partial,
+                       rpc, gamma, beta);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 63) / 64), dim3(1024), 0, stream, partial, nch, c, 1.f, dbeta,
                        0);
@@ -1277,12 +1358,8 @@ int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const fl
     S3D_LAUNCH_CHECK();
     const long tot = P * (c / 4);
     const int ba = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
-    if (pool)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, beta,
-                           dy, dbeta, dgamma, dz, add, P, c);
-    else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy,
-                           dbeta, dgamma, dz, add, P, c);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy,
+                       dbeta, dgamma, dz, add, P, c);
     S3D_LAUNCH_CHECK();
     return 0;
 }
