@@ -588,6 +588,7 @@ static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLa
         TRY(launch_pack_attn_q_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].aq16, st));
     }
     {   // absorbed token-0 attention of the last layer (launch_attn_last_mix)
+        PackBatchSuspend now;   // `dense` is reused: these packs must run between the two absorb launches
         const S3dLayerParams& p = layers[S3D_N_LAYERS - 1];
         float* dense = b + H.last.dense;
         TRY(launch_absorb_last(p.in_proj_w, p.in_proj_b, p.out_proj_w, p.out_proj_b, dense, b + H.last.bm, 0, st));

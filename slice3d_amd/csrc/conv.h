@@ -72,6 +72,27 @@ struct PackArgs {
     int chunk_ku;  // LINEAR only: if > 0 the image is stored [k-chunk group][row tile][chunk_ku] (FFN W2 staging order)
 };
 int launch_pack(const PackArgs& a, hipStream_t stream);
+// While a scope is alive on this thread launch_pack() only queues; flush() issues the queued packs as table launches
+// (48 per launch) and ends the queueing.  Nothing that READS a packed image may be launched between the first queued pack and flush().
+class PackBatchScope {
+public:
+    PackBatchScope();
+    ~PackBatchScope();
+    int flush(hipStream_t stream);
+    PackBatchScope(const PackBatchScope&) = delete;
+    PackBatchScope& operator=(const PackBatchScope&) = delete;
+private:
+    void* prev_;
+    void* q_;
+};
+// launch_pack() launches immediately while this is alive (for packs whose SOURCE is a scratch buffer that is reused)
+class PackBatchSuspend {
+public:
+    PackBatchSuspend();
+    ~PackBatchSuspend();
+private:
+    void* saved_;
+};
 // scale/shift for conv epilogues.  bn may be all-NULL (scale = 1, shift = bias or 0).
 // rep > 1 tiles the vector (ConvT: 4 quadrants share the bias).
 int launch_fold_bn(const float* bias, const float* const bn[4], float* scale, float* shift, int c_valid,

@@ -13,6 +13,7 @@
 // MFMA per (MT|NT)-fold reuse, so the operand streams fit the L1/L2 path at this precision.
 #include <stdlib.h>
 #include "conv.h"
+#include <vector>
 
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvLaunch& a, f32x4 (&acc)[MT][NT], const int (&pn)[MT],
@@ -551,7 +552,7 @@ int launch_conv(const ConvLaunch& a, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 // packers
 // ---------------------------------------------------------------------------------------------
-__global__ void pack_frag_kernel(const PackArgs a) {
+__device__ __forceinline__ void pack_frag_body(const PackArgs& a) {
     const long total = (long)(a.n_pad / 16) * a.ku_seg * 256;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
@@ -609,8 +610,51 @@ __global__ void pack_frag_kernel(const PackArgs a) {
     }
 }
 
+__global__ void pack_frag_kernel(const PackArgs a) { pack_frag_body(a); }
+
+// many packs in one launch (a training step repacks every weight matrix: 145 - 273 of them); blockIdx.y = entry
+#define PACK_TABLE_MAX 48
+struct PackTable {
+    PackArgs e[PACK_TABLE_MAX];
+};
+__global__ void pack_frag_table_kernel(const PackTable t) { pack_frag_body(t.e[blockIdx.y]); }
+
+static thread_local std::vector<PackArgs>* t_pack_batch = nullptr;
+PackBatchScope::PackBatchScope() : prev_(t_pack_batch), q_(new std::vector<PackArgs>()) {
+    t_pack_batch = (std::vector<PackArgs>*)q_;
+}
+PackBatchScope::~PackBatchScope() {
+    if (t_pack_batch == (std::vector<PackArgs>*)q_) t_pack_batch = (std::vector<PackArgs>*)prev_;
+    delete (std::vector<PackArgs>*)q_;
+}
+PackBatchSuspend::PackBatchSuspend() : saved_(t_pack_batch) { t_pack_batch = nullptr; }
+PackBatchSuspend::~PackBatchSuspend() { t_pack_batch = (std::vector<PackArgs>*)saved_; }
+int PackBatchScope::flush(hipStream_t stream) {
+    std::vector<PackArgs>& q = *(std::vector<PackArgs>*)q_;
+    for (size_t i0 = 0; i0 < q.size(); i0 += PACK_TABLE_MAX) {
+        PackTable t;
+        const int cnt = (int)(q.size() - i0 < PACK_TABLE_MAX ? q.size() - i0 : PACK_TABLE_MAX);
+        long mx = 0;
+        for (int i = 0; i < cnt; ++i) {
+            t.e[i] = q[i0 + i];
+            const long total = (long)(t.e[i].n_pad / 16) * t.e[i].ku_seg * 256;
+            if (total > mx) mx = total;
+        }
+        const int bx = (int)((mx + 255) / 256 < 1024 ? (mx + 255) / 256 : 1024);
+        hipLaunchKernelGGL(pack_frag_table_kernel, dim3(bx, cnt), dim3(256), 0, stream, t);
+        S3D_LAUNCH_CHECK();
+    }
+    q.clear();
+    t_pack_batch = (std::vector<PackArgs>*)prev_;   // later packs launch directly again
+    return 0;
+}
+
 int launch_pack(const PackArgs& a, hipStream_t stream) {
     S3D_CHECK_ARG(a.n_pad % 16 == 0 && a.ku_seg > 0, "pack: bad dims");
+    if (t_pack_batch) {   // inside a PackBatchScope: queued until its flush()
+        t_pack_batch->push_back(a);
+        return 0;
+    }
     const long total = (long)(a.n_pad / 16) * a.ku_seg * 256;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, stream, a);
