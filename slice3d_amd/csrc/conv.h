@@ -37,6 +37,7 @@ struct ConvLaunch {
     int out_cstride;     // channel stride of the NHWC output tensor
     const float* residual;  // NHWC mode only: v += residual[same index] (after activation)
     int out_accumulate;  // NHWC mode only: out += v
+    int xcd_remap;       // set by launch_conv: XCD-aware block -> (pixel tile, cout tile) mapping
     const float* gate;   // NHWC mode only: v = gate[same index] > 0 ? v * gate_scale : 0  (ReLU/dropout backward)
     float gate_scale;
     unsigned long long drop_base;  // element index of this launch's out[0] in the dropout counter space

@@ -71,6 +71,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvLaunch& a, f32x4 (&acc)[
     }
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin by linear block id.  The cout tiles of one pixel tile read the same
+// input: mapped to consecutive block ids they land on different XCDs and every L2 fetches that input again (up to
+// CoutPad / CO_WG times).  Remapped, XCD x owns the pixel tiles x, x+8, ... and runs all cout tiles of a pixel tile
+// back to back, so the input comes from HBM once.
+__device__ __forceinline__ void conv_block_tile(const ConvLaunch& a, int n_co_blk, int& blk_co, long& blk_px) {
+    const long L = blockIdx.x;
+    if (!a.xcd_remap || n_co_blk == 1) {
+        blk_co = (int)(L % n_co_blk);
+        blk_px = L / n_co_blk;
+        return;
+    }
+    const long n_px = gridDim.x / n_co_blk, full = n_px & ~7L, lim = full * n_co_blk;
+    if (L < lim) {
+        const long k = L >> 3;
+        blk_co = (int)(k % n_co_blk);
+        blk_px = (k / n_co_blk) * 8 + (L & 7);
+    } else {
+        const long r = L - lim;
+        blk_co = (int)(r % n_co_blk);
+        blk_px = full + r / n_co_blk;
+    }
+}
+
 template <int MT, int NT, int WM, int WN, int KS>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvLaunch a) {
     const int lane = threadIdx.x & 63;
@@ -81,8 +104,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvLaunc
     constexpr int CO_WG = WN * NT * 16;
     const long P = (long)a.N * a.H * a.W;
     const int n_co_blk = a.CoutPad / CO_WG;
-    const int blk_co = blockIdx.x % n_co_blk;
-    const long blk_px = blockIdx.x / n_co_blk;
+    int blk_co;
+    long blk_px;
+    conv_block_tile(a, n_co_blk, blk_co, blk_px);
     const int HW = a.H * a.W;
     const int stride = a.stride > 1 ? a.stride : 1;
     const int Hin = a.Hin ? a.Hin : a.H, Win = a.Win ? a.Win : a.W;
@@ -162,8 +186,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     constexpr int CO_WG = WN * NT * 16;
     const long P = (long)a.N * a.H * a.W;
     const int n_co_blk = a.CoutPad / CO_WG;
-    const int blk_co = blockIdx.x % n_co_blk;
-    const long blk_px = blockIdx.x / n_co_blk;
+    int blk_co;
+    long blk_px;
+    conv_block_tile(a, n_co_blk, blk_co, blk_px);
     const int HW = a.H * a.W;
     const int stride = a.stride > 1 ? a.stride : 1;
     const int Hin = a.Hin ? a.Hin : a.H, Win = a.Win ? a.Win : a.W;
@@ -280,8 +305,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
     const int m = lane & 15, g = lane >> 4;
     const int wp = wave % WP, wc = wave / WP;
     const int n_co_blk = a.CoutPad / CO_WG;
-    const int blk_co = blockIdx.x % n_co_blk;
-    int tile = blockIdx.x / n_co_blk;
+    int blk_co;
+    long blk_tile;
+    conv_block_tile(a, n_co_blk, blk_co, blk_tile);
+    int tile = (int)blk_tile;
     const int tx = tile % tiles_x;
     tile /= tiles_x;
     const int ty = tile % tiles_y, n = tile / tiles_y;
@@ -519,7 +546,13 @@ static int launch_cfg(const ConvLaunch& a, hipStream_t stream) {
     return 0;
 }
 
-int launch_conv(const ConvLaunch& a, hipStream_t stream) {
+int launch_conv(const ConvLaunch& a_in, hipStream_t stream) {
+    static const int xcd_on = [] {
+        const char* e = getenv("S3D_CONV_XCD");
+        return e ? atoi(e) : 1;
+    }();
+    ConvLaunch a = a_in;
+    a.xcd_remap = xcd_on;
     S3D_CHECK_ARG(a.ks >= 1 && a.ks <= 3, "conv: ks must be 1, 2 or 3");
     S3D_CHECK_ARG(a.CoutPad % 16 == 0 && a.CoutPad > 0, "conv: CoutPad %d", a.CoutPad);
     for (int s = 0; s < a.nsrc; ++s)
