@@ -871,11 +871,26 @@ __device__ __forceinline__ f32x4 bn_relu4(const f32x4 z, const f32x4 mu, const f
     return y;
 }
 
+// Pilot value of the one-pass BatchNorm statistics: the mean of 16 rows at Fibonacci-hashed positions (not a single
+// row: row 0 is an image corner, whose zero-padded conv output can sit many sigmas from the channel mean).  Every
+// workgroup and the finalize kernel add the same rows in the same order, so they all hold the same bits.
+#define BN_PILOT_ROWS 16
+__device__ __forceinline__ long bn_pilot_row(int j, long P) {
+    const unsigned long long h = (unsigned)(j * 2654435769u + 1327217885u);
+    return (long)((h * (unsigned long long)P) >> 32);
+}
+__device__ __forceinline__ f32x4 bn_pilot4(const float* __restrict__ col, long P, int cstride) {
+    f32x4 k = zero4();
+#pragma unroll 4
+    for (int j = 0; j < BN_PILOT_ROWS; ++j) k += ld4(col + bn_pilot_row(j, P) * cstride);
+    return k * (1.f / BN_PILOT_ROWS);
+}
+
 // =============================================================================================
 // column reductions (deterministic two-stage).  mode 0: sum x ; 1: sum (x-m[c])^2 ;
 // 2: two sums at once: sum g and sum g*(z-m[c])*r[c]   (BN backward; g in `in`, z in `in2`)
 // 3: as 2 with g = relu'(bn(z)) * dy recomputed from the BN parameters (dy in `in`): no g tensor in memory
-// 4: two sums at once about a pilot value: sum (x-k[c]) and sum (x-k[c])^2 with k = row 0 of `in` (one-pass
+// 4: two sums at once about a pilot value: sum (x-k[c]) and sum (x-k[c])^2 with k = bn_pilot4 of `in` (one-pass
 //    BatchNorm statistics: the shift keeps the E[d^2] - E[d]^2 cancellation at the size of (mean-k)^2 / var)
 // =============================================================================================
 #define CS_CHUNKS CS_CHUNKS_MAX
@@ -904,7 +919,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
         f32x4 gav = zero4(), bev = zero4();
         if (MODE >= 1 && MODE <= 3) mv = ld4(m + c);
         if (MODE == 2 || MODE == 3) rv = ld4(r + c);
-        if (MODE == 4) mv = ld4(in + coff + c);
+        if (MODE == 4) mv = bn_pilot4(in + coff + c, P, cstride);
         if (MODE == 3) {
             gav = ld4(gamma + c);
             bev = ld4(beta + c);
@@ -1063,14 +1078,17 @@ __global__ void bn_finalize_kernel(const float* __restrict__ var_sum, long P, in
     }
 }
 
-// one-pass variant: m1 = E[x - k] (in `mean`), m2 = E[(x - k)^2] (in `rstd`), k = row 0 of z
-__global__ void bn_finalize_shift_kernel(const float* __restrict__ krow, long P, int C, float* __restrict__ mean,
+// one-pass variant: m1 = E[x - k] (in `mean`), m2 = E[(x - k)^2] (in `rstd`), k = the pilot value of colsum mode 4
+__global__ void bn_finalize_shift_kernel(const float* __restrict__ z, long P, int C, float* __restrict__ mean,
                                          float* __restrict__ rstd, float* __restrict__ running_mean,
                                          float* __restrict__ running_var) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    float k = 0.f;
+    for (int j = 0; j < BN_PILOT_ROWS; ++j) k += z[bn_pilot_row(j, P) * C + c];
+    k *= 1.f / BN_PILOT_ROWS;
     const float m1 = mean[c], m2 = rstd[c];
-    const float mu = krow[c] + m1;
+    const float mu = k + m1;
     const float var = fmaxf(m2 - m1 * m1, 0.f);
     mean[c] = mu;
     rstd[c] = 1.f / sqrtf(var + 1e-5f);
