@@ -371,8 +371,10 @@ __global__ __launch_bounds__(256) void qkv_attention_f16x3_kernel(const float* _
     for (int d = 0; d < DT; ++d) acc[d] = zero4();
     float mx = -1e30f, den = 0.f;
 
-    f32x4 pk[NLD], pv[NLD];
-    auto fetch = [&](int k0) {
+    // two register stages: block j+2 is requested before block j is computed, so a whole iteration (not just the
+    // MFMA part of one) hides the L2 latency of the 64-key block loads
+    f32x4 pkA[NLD], pvA[NLD], pkB[NLD], pvB[NLD];
+    auto fetch = [&](f32x4 (&pk)[NLD], f32x4 (&pv)[NLD], int k0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = threadIdx.x + 256 * i;
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256) void qkv_attention_f16x3_kernel(const float* _
             pv[i] = ld4(row + 2 * CH + c4);
         }
     };
-    auto park = [&]() {
+    auto park = [&](const f32x4 (&pk)[NLD], const f32x4 (&pv)[NLD]) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = threadIdx.x + 256 * i;
@@ -411,12 +413,7 @@ __global__ __launch_bounds__(256) void qkv_attention_f16x3_kernel(const float* _
             }
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < T; k0 += QA_KB) {
-        __syncthreads();   // every wave is done with the previous block
-        park();
-        __syncthreads();
-        if (k0 + QA_KB < T) fetch(k0 + QA_KB);   // in flight under this block's MFMAs
+    auto compute = [&](int k0) {
         // S^T[key][query]: lane (query m, g) gets keys kt*16 + 4g + i
         f32x4 sv[4];
         float bmax = -1e30f;
@@ -470,6 +467,22 @@ __global__ __launch_bounds__(256) void qkv_attention_f16x3_kernel(const float* _
                              ph[kk], pl[kk], o);
             }
             acc[d] = acc[d] * corr + o;
+        }
+    };
+    fetch(pkA, pvA, 0);
+    if (QA_KB < T) fetch(pkB, pvB, QA_KB);
+    for (int k0 = 0; k0 < T; k0 += 2 * QA_KB) {
+        __syncthreads();   // every wave is done with the previous block
+        park(pkA, pvA);
+        __syncthreads();
+        if (k0 + 2 * QA_KB < T) fetch(pkA, pvA, k0 + 2 * QA_KB);
+        compute(k0);
+        if (k0 + QA_KB < T) {
+            __syncthreads();
+            park(pkB, pvB);
+            __syncthreads();
+            if (k0 + 3 * QA_KB < T) fetch(pkB, pvB, k0 + 3 * QA_KB);
+            compute(k0 + QA_KB);
         }
     }
     if (q < T) {
