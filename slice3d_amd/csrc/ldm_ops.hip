@@ -182,16 +182,22 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
 // registers (lane (query, g): keys 4g+i) are directly the B operand of the second product.
 // ---------------------------------------------------------------------------------------------
 #define QA_KB 64
-template <int CH>
-__global__ __launch_bounds__(256) void qkv_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                            int T, int heads) {
+// KW = 2: eight waves; waves 4..7 take the odd key blocks of the same 64 queries (own LDS buffers, staged by
+// themselves) and the two partial softmax states are merged through LDS at the end.  Used when the grid is too
+// small to give every SIMD more than two waves (batch 1: 512 workgroups).
+template <int CH, int KW>
+__global__ __launch_bounds__(256 * KW) void qkv_attention_kernel(const float* __restrict__ qkv,
+                                                                 float* __restrict__ out, int T, int heads) {
     constexpr int LD = CH + 4;               // padded row: 16 query/key lanes hit 16 distinct bank quads
     constexpr int DT = (CH + 15) / 16;       // 16-wide tiles of the head dimension (zero padded)
     constexpr int KS = CH / 4;               // fp32 MFMA k-steps of the q.k contraction
     constexpr int LDV = DT * 16 + 4;
     constexpr int NLD = (QA_KB * (CH / 4) + 255) / 256;   // float4 (K, V) pairs a thread stages per key block
-    __shared__ float s_k[2][QA_KB * LD], s_v[2][QA_KB * LDV];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float s_kk[KW][2][QA_KB * LD], s_vv[KW][2][QA_KB * LDV];
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, kh = threadIdx.x >> 8;
+    const int tid = threadIdx.x & 255;   // index within the key half
+    float(*s_k)[QA_KB * LD] = s_kk[kh];
+    float(*s_v)[QA_KB * LDV] = s_vv[kh];
     const int m = lane & 15, g = lane >> 4;
     const int qblocks = (T + 63) / 64;
     const int qb = blockIdx.x % qblocks;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256) void qkv_attention_kernel(const float* __restr
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = tid + 256 * i;
             const int key = idx / (CH / 4), c4 = (idx % (CH / 4)) * 4;
             const int kc = (idx < QA_KB * (CH / 4) && k0 + key < T) ? k0 + key : T - 1;
             const float* row = base + (long)kc * C3;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256) void qkv_attention_kernel(const float* __restr
     auto park = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = tid + 256 * i;
             if (idx < QA_KB * (CH / 4)) {
                 const int key = idx / (CH / 4), c4 = (idx % (CH / 4)) * 4;
                 float* dk = s_k[buf] + key * LD + c4;
@@ -239,16 +245,19 @@ __global__ __launch_bounds__(256) void qkv_attention_kernel(const float* __restr
         }
     };
     if (CH % 16)   // zero the padded head dims of V once (both buffers)
-        for (int i = threadIdx.x; i < 2 * QA_KB * (DT * 16 - CH); i += 256) {
+        for (int i = tid; i < 2 * QA_KB * (DT * 16 - CH); i += 256) {
             const int buf = i / (QA_KB * (DT * 16 - CH)), r = i % (QA_KB * (DT * 16 - CH));
             s_v[buf][(r / (DT * 16 - CH)) * LDV + CH + r % (DT * 16 - CH)] = 0.f;
         }
-    fetch(0);
+    // this half's blocks: kh, kh + KW, ...; both halves run the same trip count (blocks past T are fully masked)
+    const int nit = ((T + QA_KB - 1) / QA_KB + KW - 1) / KW;
+    fetch(kh * QA_KB);
     park(0);
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < T; k0 += QA_KB, buf ^= 1) {
-        if (k0 + QA_KB < T) fetch(k0 + QA_KB);
+    for (int it = 0; it < nit; ++it, buf ^= 1) {
+        const int k0 = (it * KW + kh) * QA_KB;
+        if (it + 1 < nit) fetch(k0 + KW * QA_KB);
         const float* sk = s_k[buf];
         const float* sv_ = s_v[buf];
         // S^T[key][query]: lane (query m, g) gets keys kt*16 + 4g + i
@@ -296,8 +305,29 @@ __global__ __launch_bounds__(256) void qkv_attention_kernel(const float* __restr
                                                             0, 0);
             acc[d] = o;
         }
-        if (k0 + QA_KB < T) park(buf ^ 1);
+        if (it + 1 < nit) park(buf ^ 1);
         __syncthreads();
+    }
+    if constexpr (KW > 1) {   // merge the two key halves' (max, denominator, accumulator) states; s_vv[1] is free now
+        float* mrg = &s_vv[1][0][0] + (wave * 64 + lane) * (4 * DT + 2);
+        if (kh == 1) {
+            mrg[0] = mx;
+            mrg[1] = den;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mrg[2 + 4 * d + i] = acc[d][i];
+        }
+        __syncthreads();
+        if (kh == 1) return;
+        const float m1 = mrg[0], d1 = mrg[1];
+        const float mm = fmaxf(mx, m1);
+        const float w0 = expf(mx - mm), w1 = expf(m1 - mm);
+        den = den * w0 + d1 * w1;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[d][i] = acc[d][i] * w0 + mrg[2 + 4 * d + i] * w1;
     }
     if (q < T) {
         const float inv = 1.f / den;
@@ -511,11 +541,17 @@ int launch_qkv_attention(const float* qkv, float* out, int N, int T, int heads, 
         QA16_CASE(8) QA16_CASE(16) QA16_CASE(24) QA16_CASE(32) QA16_CASE(48) QA16_CASE(64) QA16_CASE(96)
 #undef QA16_CASE
     }
-#define QA_CASE(c)                                                                                          \
-    if (ch == c) {                                                                                          \
-        hipLaunchKernelGGL((qkv_attention_kernel<c>), dim3(blocks), dim3(256), 0, stream, qkv, out, T, heads); \
-        S3D_LAUNCH_CHECK();                                                                                 \
-        return 0;                                                                                           \
+    // batch-1 grids (512 workgroups on 256 CUs) run the eight-wave key-split form; its LDS fits up to 48 channels
+    const bool split = blocks <= 1024 && ch <= 48 && T > QA_KB;
+#define QA_CASE(c)                                                                                                 \
+    if (ch == c) {                                                                                                 \
+        if (split && c <= 48)                                                                                      \
+            hipLaunchKernelGGL((qkv_attention_kernel<c, (c <= 48 ? 2 : 1)>), dim3(blocks), dim3(c <= 48 ? 512 : 256), 0, \
+                               stream, qkv, out, T, heads);                                                        \
+        else                                                                                                       \
+            hipLaunchKernelGGL((qkv_attention_kernel<c, 1>), dim3(blocks), dim3(256), 0, stream, qkv, out, T, heads); \
+        S3D_LAUNCH_CHECK();                                                                                        \
+        return 0;                                                                                                  \
     }
     QA_CASE(8) QA_CASE(16) QA_CASE(24) QA_CASE(32) QA_CASE(48) QA_CASE(64) QA_CASE(96)
 #undef QA_CASE
