@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <unordered_map>
 #include <vector>
 
@@ -36,18 +37,33 @@ struct Mise {
     double thr;
     std::vector<MiseVoxel> vox;
     std::vector<MisePoint> pts;
-    std::unordered_map<int64_t, int64_t> index;   // linearised (x,y,z) at full resolution -> pts index
+    // (x,y,z) at full resolution -> pts index: a dense (res+1)^3 table when that is small enough, else a hash map
+    std::vector<int32_t> dense;
+    std::unordered_map<int64_t, int64_t> index;
+    // Refinement state.  The reference recomputes, on every update(), for every leaf the OR of
+    //   f(p) = (value >= thr) | (value <= thr) << 1   over the known points p in the leaf's closed box
+    // and splits the leaves that hold both bits (mise.pyx:182-232): O(rounds x points).  The same flags are kept
+    // incrementally here: a newly known point is OR-ed into the <= 8 leaves around it, a new child starts from the known
+    // points inside its box, and a leaf becomes a split candidate the moment its flags reach 3.  Splits still happen in
+    // ascending voxel order among the leaves that existed when update() was called, so voxel / point numbering — and
+    // with it query() order — is the reference's.
+    std::vector<uint8_t> flags;
+    std::vector<int64_t> cand;       // leaves whose flags reached 3 since the last refine
+    bool need_full = false;          // a point was updated twice: rebuild the flags from scratch
+    size_t scan_from = 0;            // every point before this index is known
 
     int64_t key(int x, int y, int z) const {
         const int64_t r = res + 1;
         return (r * x + y) * r + z;
     }
     int64_t find_point(int x, int y, int z) const {
+        if (!dense.empty()) return dense[(size_t)key(x, y, z)];
         auto it = index.find(key(x, y, z));
         return it == index.end() ? -1 : it->second;
     }
     void add_point(int x, int y, int z) {
-        index[key(x, y, z)] = (int64_t)pts.size();
+        if (!dense.empty()) dense[(size_t)key(x, y, z)] = (int32_t)pts.size();
+        else index[key(x, y, z)] = (int64_t)pts.size();
         pts.push_back(MisePoint{x, y, z, 0.0, false});
     }
     // leaf voxel containing integer location (x,y,z), or -1 outside the grid (mise.pyx:283-348)
@@ -64,10 +80,24 @@ struct Mise {
         }
         return idx;
     }
+    uint8_t point_flag(const MisePoint& p) const { return (p.value >= thr ? 1 : 0) | (p.value <= thr ? 2 : 0); }
+    void touch(const MisePoint& p) {   // OR a known point into the leaves around it
+        const uint8_t f = point_flag(p);
+        for (int i = -1; i < 1; ++i)
+            for (int j = -1; j < 1; ++j)
+                for (int k = -1; k < 1; ++k) {
+                    const int64_t v = leaf_at(p.x + i, p.y + j, p.z + k);
+                    if (v < 0) continue;
+                    const uint8_t old = flags[v];
+                    flags[v] = old | f;
+                    if (old != 3 && flags[v] == 3 && vox[v].level != depth) cand.push_back(v);
+                }
+    }
     void split(int64_t idx) {
         const MiseVoxel v = vox[idx];
         const int lvl = v.level + 1, size = 1 << (depth - lvl);
         vox[idx].leaf = false;
+        const int64_t first = (int64_t)vox.size();
         for (int i = 0; i < 2; ++i)
             for (int j = 0; j < 2; ++j)
                 for (int k = 0; k < 2; ++k) {
@@ -75,6 +105,21 @@ struct Mise {
                     MiseVoxel c{v.x + i * size, v.y + j * size, v.z + k * size, lvl, true, {0, 0, 0, 0, 0, 0, 0, 0}};
                     vox.push_back(c);
                 }
+        // the children start from the known points already inside their boxes (parent corners, hanging points of finer
+        // neighbours); the points this split creates below are unknown and do not count
+        flags.resize(vox.size(), 0);
+        for (int64_t c = first; c < first + 8; ++c) {
+            const MiseVoxel& cv = vox[c];
+            uint8_t f = 0;
+            for (int i = 0; i <= size && f != 3; ++i)
+                for (int j = 0; j <= size && f != 3; ++j)
+                    for (int k = 0; k <= size; ++k) {
+                        const int64_t pi = find_point(cv.x + i, cv.y + j, cv.z + k);
+                        if (pi >= 0 && pts[pi].known) f |= point_flag(pts[pi]);
+                    }
+            flags[c] = f;
+            if (f == 3 && lvl != depth) cand.push_back(c);   // split on the NEXT update, as the reference would
+        }
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j)
                 for (int k = 0; k < 3; ++k) {
@@ -82,22 +127,30 @@ struct Mise {
                     if (find_point(x, y, z) < 0) add_point(x, y, z);
                 }
     }
-    // mise.pyx:182-232: a leaf is refined when known values >= and <= threshold both touch it
     void refine() {
-        std::vector<uint8_t> flags(vox.size(), 0);
-        for (const MisePoint& p : pts) {
-            if (!p.known) continue;
-            const uint8_t f = (p.value >= thr ? 1 : 0) | (p.value <= thr ? 2 : 0);
-            for (int i = -1; i < 1; ++i)
-                for (int j = -1; j < 1; ++j)
-                    for (int k = -1; k < 1; ++k) {
-                        const int64_t v = leaf_at(p.x + i, p.y + j, p.z + k);
-                        if (v >= 0) flags[v] |= f;
-                    }
+        if (need_full) {   // rebuild from scratch, the reference's way
+            flags.assign(vox.size(), 0);
+            cand.clear();
+            for (const MisePoint& p : pts)
+                if (p.known) {
+                    const uint8_t f = point_flag(p);
+                    for (int i = -1; i < 1; ++i)
+                        for (int j = -1; j < 1; ++j)
+                            for (int k = -1; k < 1; ++k) {
+                                const int64_t v = leaf_at(p.x + i, p.y + j, p.z + k);
+                                if (v >= 0) flags[v] |= f;
+                            }
+                }
+            for (size_t v = 0; v < vox.size(); ++v)
+                if (vox[v].leaf && vox[v].level != depth && flags[v] == 3) cand.push_back((int64_t)v);
+            need_full = false;
         }
-        const size_t n = vox.size();
-        for (size_t v = 0; v < n; ++v)
-            if (vox[v].leaf && vox[v].level != depth && flags[v] == 3) split((int64_t)v);
+        std::vector<int64_t> todo;
+        todo.swap(cand);   // split() refills cand with next round's candidates
+        std::sort(todo.begin(), todo.end());
+        todo.erase(std::unique(todo.begin(), todo.end()), todo.end());
+        for (const int64_t v : todo)
+            if (vox[v].leaf && vox[v].level != depth && flags[v] == 3) split(v);
     }
 };
 
@@ -106,6 +159,10 @@ void* s3d_mise_create(int resolution0, int depth, double threshold) {
     Mise* m = new Mise();
     m->res0 = resolution0; m->depth = depth; m->thr = threshold;
     m->vs0 = 1 << depth; m->res = resolution0 * m->vs0;
+    {
+        const int64_t r = (int64_t)m->res + 1;
+        if (r * r * r <= (int64_t)300 * 1000 * 1000) m->dense.assign((size_t)(r * r * r), -1);
+    }
     m->vox.reserve((size_t)resolution0 * resolution0 * resolution0);
     for (int i = 0; i < resolution0; ++i)
         for (int j = 0; j < resolution0; ++j)
@@ -114,30 +171,46 @@ void* s3d_mise_create(int resolution0, int depth, double threshold) {
     for (int i = 0; i <= resolution0; ++i)
         for (int j = 0; j <= resolution0; ++j)
             for (int k = 0; k <= resolution0; ++k) m->add_point(i * m->vs0, j * m->vs0, k * m->vs0);
+    m->flags.assign(m->vox.size(), 0);
     return m;
 }
 void s3d_mise_destroy(void* h) { delete (Mise*)h; }
 int s3d_mise_resolution(void* h) { return ((Mise*)h)->res; }
+static void mise_skip_known(Mise* m) {
+    while (m->scan_from < m->pts.size() && m->pts[m->scan_from].known) ++m->scan_from;
+}
 long s3d_mise_query_count(void* h) {
+    Mise* m = (Mise*)h;
+    mise_skip_known(m);
     long n = 0;
-    for (const MisePoint& p : ((Mise*)h)->pts) n += !p.known;
+    for (size_t i = m->scan_from; i < m->pts.size(); ++i) n += !m->pts[i].known;
     return n;
 }
 // out: (n,3) int64, unknown points in insertion order (mise.pyx:106-129)
 void s3d_mise_query(void* h, int64_t* out) {
-    for (const MisePoint& p : ((Mise*)h)->pts)
+    Mise* m = (Mise*)h;
+    mise_skip_known(m);
+    for (size_t i = m->scan_from; i < m->pts.size(); ++i) {
+        const MisePoint& p = m->pts[i];
         if (!p.known) {
             *out++ = p.x; *out++ = p.y; *out++ = p.z;
         }
+    }
 }
 // returns 0, or -1 if a point is not a grid point (the reference raises ValueError)
 int s3d_mise_update(void* h, const int64_t* points, const double* values, long n) {
     Mise* m = (Mise*)h;
+    const int64_t r = m->res;
     for (long i = 0; i < n; ++i) {
-        const int64_t idx = m->find_point((int)points[3 * i], (int)points[3 * i + 1], (int)points[3 * i + 2]);
+        const int64_t x = points[3 * i], y = points[3 * i + 1], z = points[3 * i + 2];
+        if (x < 0 || y < 0 || z < 0 || x > r || y > r || z > r) return -1;
+        const int64_t idx = m->find_point((int)x, (int)y, (int)z);
         if (idx < 0) return -1;
-        m->pts[idx].value = values[i];
-        m->pts[idx].known = true;
+        MisePoint& p = m->pts[idx];
+        if (p.known) m->need_full = true;   // re-valued point: its old flag bits may no longer hold
+        p.value = values[i];
+        p.known = true;
+        if (!m->need_full) m->touch(p);
     }
     m->refine();
     return 0;

@@ -82,6 +82,43 @@ def test_sphere_counts(mesh, gold):
     assert (counts == 2).all()
 
 
+@pytest.mark.parametrize("kind", ["noise", "sparse", "ties"])
+def test_mise_incremental_flags_equal_full_recompute(mesh, kind):
+    """The refinement flags are kept incrementally; re-valuing an already known point makes update() rebuild them the
+    reference's way (all known points -> all leaves, mise.pyx:182-232).  Both must give the same queries, in the same
+    order, through a cascade of rounds — also when the caller answers only part of a query."""
+    def field(pts, res, rng):
+        p = pts.astype(np.float64) / res - 0.5
+        if kind == "noise":
+            return rng.standard_normal(len(pts))
+        if kind == "sparse":      # isolated positives: hanging points keep flagging coarse neighbours, many rounds
+            return np.where(rng.random(len(pts)) < 0.02, 1.0, -1.0) * (0.1 + rng.random(len(pts)))
+        return np.round(np.sin(7 * p[:, 0]) * np.cos(5 * p[:, 1]) + p[:, 2], 1)    # many values exactly at threshold
+    for r0, depth in ((6, 3), (9, 2)):
+        a, b = mesh.MISE(r0, depth, 0.0), mesh.MISE(r0, depth, 0.0)
+        rng = np.random.default_rng(r0)
+        first = None
+        rounds = 0
+        while True:
+            qa, qb = a.query(), b.query()
+            assert np.array_equal(qa, qb)
+            if not len(qa):
+                break
+            vals = field(qa, a.resolution, rng)
+            keep = rng.random(len(qa)) < 0.8
+            keep[0] = True
+            pts, vals = qa[keep], vals[keep]
+            if first is None:
+                first = (pts[:1].copy(), vals[:1].copy())
+            a.update(pts, vals)
+            # b: the same update plus one old point with its old value again -> full rebuild path
+            b.update(np.concatenate([pts, first[0]]), np.concatenate([vals, first[1]]))
+            rounds += 1
+            assert rounds < 500
+        assert rounds > depth
+        assert np.array_equal(a.to_dense(), b.to_dense())
+
+
 def test_update_rejects_foreign_points(mesh):
     m = mesh.MISE(2, 1, 0.0)
     with pytest.raises(ValueError):
