@@ -301,6 +301,7 @@ struct TapL {
     int lofs[4];   // LDS pixel index inside the footprint, or -1 -> use gofs
     int gofs[4];   // global pixel index
     float w[4];
+    bool ok[4];    // tap lies inside the map (an outside tap has weight 0 and is never written)
 };
 __device__ __forceinline__ TapL make_taps_l(float gx, float gy, int W, int ox, int oy, int fw) {
     const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
@@ -314,6 +315,7 @@ __device__ __forceinline__ TapL make_taps_l(float gx, float gy, int W, int ox, i
     for (int k = 0; k < 4; ++k) {
         const int x = x0 + (k & 1), y = y0 + (k >> 1);
         const bool ok = x >= 0 && x < W && y >= 0 && y < W;
+        t.ok[k] = ok;
         t.w[k] = ok ? wx[k & 1] * wy[k >> 1] : 0.f;
         t.gofs[k] = ok ? y * W + x : 0;
         const int lx = x - ox, ly = y - oy;
@@ -396,8 +398,11 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
             // contiguous runs; sum w*d over each run with 4 predicated DPP shifts (Hillis-Steele restricted to
             // the run) and let the run's last lane issue ONE LDS add per value.  LDS float atomics cost ~3
             // cycles per lane, so the number of lanes that reach them is what matters.
-            const bool regular = tp.lofs[0] >= 0 && tp.lofs[1] == tp.lofs[0] + 1 && tp.lofs[2] == tp.lofs[0] + G.fw[l] &&
-                                 tp.lofs[3] == tp.lofs[2] + 1;
+            // A tap outside the map (queries clamped to the right / bottom border: x0 = W-1) carries weight 0 and is
+            // simply not written: whether taps 1..3 exist depends only on tap 0's pixel, i.e. it is uniform over a run.
+            const bool regular = tp.lofs[0] >= 0 && (!tp.ok[1] || tp.lofs[1] == tp.lofs[0] + 1) &&
+                                 (!tp.ok[2] || tp.lofs[2] == tp.lofs[0] + G.fw[l]) &&
+                                 (!tp.ok[3] || tp.lofs[3] == tp.lofs[0] + G.fw[l] + 1);
             const int key = regular ? tp.lofs[0] : -1 - m;
             const int key_prev = __builtin_amdgcn_update_dpp(-100, key, 0x111, 0xF, 0xF, false);   // row_shr:1
             const int key_next = __builtin_amdgcn_update_dpp(-100, key, 0x101, 0xF, 0xF, false);   // row_shl:1
@@ -413,7 +418,8 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
             if (regular) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float* o = lbase + tp.lofs[k] * C;
+                    float* o = lbase + (tp.ok[k] ? tp.lofs[k] : 0) * C;
+                    const bool wr = tail && tp.ok[k];
 #pragma unroll
                     for (int j = 0; j < nv; ++j) {
                         f32x4 v = (LV::folded(l) ? dt[j] : draw[LV::draw0(l) + j]) * tp.w[k];
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
                             x = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xF, false)), p8, x);
                             v[i] = x;
                         }
-                        if (tail) atomic_add4(o + 16 * j, v);
+                        if (wr) atomic_add4(o + 16 * j, v);
                     }
                 }
             } else if (qv) {   // a tap outside the map / footprint: per-tap handling
