@@ -559,8 +559,8 @@ __device__ __forceinline__ wl_half8 w3_frag(int d0, int d1, int d2, int d3) {
     return __builtin_bit_cast(wl_half8, v);
 }
 // WNT x WCT accumulator tile pairs per wave per tap, WVN x WVC waves: block = 16*WNT*WVN (n) x 16*WCT*WVC (c).
-// <2,2,2,2>: 64 x 64 (channel counts that are multiples of 64); <1,1,4,1>: 64 x 16 (the 3 -> 16 padded first layer,
-// which is bound by reading dY: the per-tap kernel read it nine times).
+// <2,2,2,2>: 64 x 64 (channel counts that are multiples of 64); <2,1,2,2>: 64 x 32; <1,1,4,1>: 64 x 16 (the 3 -> 16
+// padded first layer, which is bound by reading dY: the per-tap kernel read it nine times).  N = 32 uses half a block.
 template <int WNT, int WCT, int WVN, int WVC>
 __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradArgs a, int n_cblk, long n_tiles,
                                                                    int tiles_per_split, int Ktot) {
@@ -578,7 +578,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradAr
     const int wn = wave % WVN, wc = wave / WVN;
     const int H = a.H, W = a.W;
     const int tiles_x = W >> 3, tpi = tiles_x * (H >> 2);
-    const float* dyp = a.dy + a.dy_coff + n0 + ch;
+    const bool nvalid = n0 + ch < a.N;   // N = 32 layers run as a half-empty 64-row block
+    const float* dyp = a.dy + a.dy_coff + n0 + (nvalid ? ch : 0);
     const long dstride = a.dy_cstride, xstride = a.x.C;
     // X staging role k: unit u = tid + 256 k -> (channel, halo row); threads past the last unit shadow unit 0
     int xc[XK], xr[XK];
@@ -639,10 +640,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradAr
         // ---- stage the tile ----
         {
             const float tvf = (vm & 1u) ? 1.f : 0.f;
+            const float dvf = nvalid ? tvf : 0.f;
             wl_half8 hi, lo;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = pd[j] * tvf;
+                const float v = pd[j] * dvf;
                 const _Float16 h = (_Float16)v;
                 hi[j] = h;
                 lo[j] = (_Float16)(v - (float)h);
@@ -732,20 +734,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradAr
                 for (int reg = 0; reg < 4; ++reg) {
                     const int n = n0 + 16 * (wn * WNT + i) + 4 * g + reg;
                     const int c = c0 + 16 * (wc * WCT + j) + m;
-                    part[(size_t)n * Ktot + tap * a.Cx + c] = acc[tap][i][j][reg];
+                    if (n < a.N) part[(size_t)n * Ktot + tap * a.Cx + c] = acc[tap][i][j][reg];
                 }
 }
 
 static bool wgrad_conv3_eligible(const WgradArgs& a) {
     static const bool off = getenv("S3D_WGRAD3_F32") != nullptr;
     return !off && a.prec == S3D_PREC_F16X3 && a.ks == 3 && a.stride <= 1 && !a.x.sbcast && a.x.bdiv >= 1 &&
-           (a.Hin == 0 || a.Hin == a.H) && (a.Win == 0 || a.Win == a.W) && a.N % 64 == 0 &&
-           (a.Cx % 64 == 0 || a.Cx == 16) && a.H % 4 == 0 && a.W % 8 == 0 && a.out_kind == S3D_PACK_CONV;
+           (a.Hin == 0 || a.Hin == a.H) && (a.Win == 0 || a.Win == a.W) && (a.N % 64 == 0 || a.N == 32) &&
+           (a.Cx % 64 == 0 || a.Cx == 32 || a.Cx == 16) && a.H % 4 == 0 && a.W % 8 == 0 &&
+           a.out_kind == S3D_PACK_CONV;
 }
 
 static int launch_wgrad_conv3_f16x3(const WgradArgs& a, hipStream_t stream) {
-    const bool narrow = a.Cx == 16;
-    const int n_nblk = a.N / 64, n_cblk = narrow ? 1 : a.Cx / 64, Ktot = 9 * a.Cx;
+    const bool narrow = a.Cx == 16, half = a.Cx == 32;
+    const int n_nblk = (a.N + 63) / 64, n_cblk = narrow ? 1 : (half ? 1 : a.Cx / 64), Ktot = 9 * a.Cx;
     const long n_tiles = (long)a.Nimg * (a.H / 4) * (a.W / 8);
     const long blocks = (long)n_nblk * n_cblk;
     static const long want_wgs = [] {
@@ -766,6 +769,9 @@ static int launch_wgrad_conv3_f16x3(const WgradArgs& a, hipStream_t stream) {
     const dim3 grid((unsigned)blocks, (unsigned)splits);
     if (narrow)
         hipLaunchKernelGGL((wgrad_conv3_f16x3_kernel<1, 1, 4, 1>), grid, dim3(256), 0, stream, a, n_cblk, n_tiles, tps,
+                           Ktot);
+    else if (half)   // the U-Net's last stage: 32-channel inputs (and 32 outputs, a half-empty n block)
+        hipLaunchKernelGGL((wgrad_conv3_f16x3_kernel<2, 1, 2, 2>), grid, dim3(256), 0, stream, a, n_cblk, n_tiles, tps,
                            Ktot);
     else
         hipLaunchKernelGGL((wgrad_conv3_f16x3_kernel<2, 2, 2, 2>), grid, dim3(256), 0, stream, a, n_cblk, n_tiles, tps,
