@@ -479,8 +479,10 @@ __global__ __launch_bounds__(256) void ffn_layer_kernel(const float* X, float* Y
                 for (int r = 0; r < FFN_R; ++r) {
                     const unsigned long long base =
                         (unsigned long long)(row0 + r * 16 + m) * S3D_FFN + c * S3D_FFN_CHUNK + 16 * a + 4 * g;
+                    float mk4[4];
+                    s3d_drop4(dh, base, mk4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) hd[r][i] *= s3d_drop(dh, base + i);
+                    for (int i = 0; i < 4; ++i) hd[r][i] *= mk4[i];
                 }
             }
 #pragma unroll

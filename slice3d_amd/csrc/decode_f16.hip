@@ -141,8 +141,10 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_kernel(const f
                 for (int r = 0; r < F16_R; ++r) {
                     const unsigned long long base =
                         (unsigned long long)(ta.row_base + row0 + r * 16 + m) * S3D_FFN + c * S3D_FFN_CHUNK + 16 * a + 4 * g;
+                    float mk4[4];
+                    s3d_drop4(ta.dh, base, mk4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) hv[r][4 * a + i] *= s3d_drop(ta.dh, base + i);
+                    for (int i = 0; i < 4; ++i) hv[r][4 * a + i] *= mk4[i];
                 }
             }
         }
@@ -208,11 +210,13 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_kernel(const f
         for (int j = 0; j < 8; ++j) {
             const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
             const f32x4 b2 = ld4(w.b2 + col);
+            float mq4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (MODE == 2 && ta.dq.p > 0.f) s3d_drop4(ta.dq, (unsigned long long)row * 128 + col, mq4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int t = 4 * (j & 1) + i;
                 float f = acc[r][j][i] + b2[i];
-                if (MODE == 2 && ta.dq.p > 0.f) f *= s3d_drop(ta.dq, (unsigned long long)row * 128 + col + i);
+                if (MODE == 2) f *= mq4[i];
                 y[j][i] = f + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
                 s += y[j][i];
             }

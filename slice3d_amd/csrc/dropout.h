@@ -9,7 +9,7 @@ struct DropCfg {
     unsigned long long seed;
     float p;          // 0 = off
     float scale;      // 1/(1-p)
-    unsigned thresh;  // keep iff hash >= thresh
+    unsigned thresh;  // keep iff the element's 16-bit hash field >= thresh
     int site;
 };
 
@@ -27,13 +27,33 @@ __host__ __device__ inline unsigned s3d_hash32(unsigned long long seed, int site
     x ^= x >> 15;
     return x;
 }
+// One full hash serves FOUR consecutive elements (idx >> 2): two 16-bit fields of the hash word and two of a cheap
+// remix of it.  keep iff field >= thresh (thresh = round(p * 65536): p = 0.1 -> 6554 / 65536).  s3d_drop4 draws the four
+// masks of an aligned quad at once — the FFN forward's 2 048 hidden masks per row cost 512 hashes instead of 2 048.
+__host__ __device__ inline unsigned s3d_drop_remix(unsigned h) {
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 12;
+    return h;
+}
 __host__ __device__ inline float s3d_drop(const DropCfg& d, unsigned long long idx) {
-    return s3d_hash32(d.seed, d.site, idx) >= d.thresh ? d.scale : 0.f;
+    unsigned h = s3d_hash32(d.seed, d.site, idx >> 2);
+    if (idx & 2) h = s3d_drop_remix(h);
+    const unsigned f = (idx & 1) ? h >> 16 : h & 0xFFFFu;
+    return f >= d.thresh ? d.scale : 0.f;
+}
+// masks of elements base .. base+3, base % 4 == 0 (the same values s3d_drop gives one by one)
+__host__ __device__ inline void s3d_drop4(const DropCfg& d, unsigned long long base, float (&out)[4]) {
+    const unsigned h = s3d_hash32(d.seed, d.site, base >> 2), h2 = s3d_drop_remix(h);
+    out[0] = (h & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+    out[1] = (h >> 16) >= d.thresh ? d.scale : 0.f;
+    out[2] = (h2 & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+    out[3] = (h2 >> 16) >= d.thresh ? d.scale : 0.f;
 }
 static inline DropCfg make_drop(unsigned long long seed, float p, int site) {
     DropCfg d;
     d.seed = seed; d.p = p; d.site = site;
     d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    d.thresh = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;
+    d.thresh = p > 0.f ? (unsigned)((double)p * 65536.0 + 0.5) : 0u;
     return d;
 }
