@@ -59,7 +59,10 @@ def main():
     v, t = ref_marching_cubes(np.pad(dense, 1, "constant", constant_values=-1e6), 0.0)
     rec["sphere_counts"] = np.array([rounds, nq, dense.shape[0], v.shape[0], t.shape[0]], dtype=np.int64)
     # MISE traces: every round's query points and the final dense grid, small configs
-    for name, (r0, d, thr, seed) in {"t1": (1, 2, 0.0, 0), "t2": (4, 2, 0.1, 3), "t3": (6, 1, -0.05, 4)}.items():
+    # t4 / t5: isolated positives and pure noise — hanging points of refined neighbours keep flagging coarse leaves, so
+    # the refinement cascades over many rounds (the case an incremental update() must reproduce query for query)
+    for name, (r0, d, thr, seed) in {"t1": (1, 2, 0.0, 0), "t2": (4, 2, 0.1, 3), "t3": (6, 1, -0.05, 4),
+                                     "t4": (6, 3, 0.0, 5), "t5": (3, 3, 0.0, 6)}.items():
         rng = np.random.default_rng(seed)
         c, rad = rng.uniform(0.35, 0.65, 3), rng.uniform(0.2, 0.35)
         m = MISE(r0, d, thr)
@@ -69,6 +72,10 @@ def main():
             vals = rad - np.linalg.norm(pts / m.resolution - c, axis=-1)
             if name == "t1":
                 vals = pts[:, 0].astype(np.float64) / m.resolution - 0.45     # libmise/test.py style half-space
+            elif name == "t4":
+                vals = np.where(rng.random(len(pts)) < 0.02, 1.0, -1.0) * (0.1 + rng.random(len(pts)))
+            elif name == "t5":
+                vals = np.round(rng.standard_normal(len(pts)), 1)             # also exact-threshold hits
             rec["mise_%s_v%d" % (name, k)] = vals
             m.update(pts, vals)
             pts, k = m.query(), k + 1

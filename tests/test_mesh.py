@@ -34,7 +34,7 @@ def test_marching_cubes_bit_exact(mesh, gold, name):
     assert np.array_equal(v, gold["mc_%s_v" % name])          # bit-exact coordinates
 
 
-@pytest.mark.parametrize("name", ["t1", "t2", "t3"])
+@pytest.mark.parametrize("name", ["t1", "t2", "t3", "t4", "t5"])
 def test_mise_trace_matches_reference(mesh, gold, name):
     r0, d, thr, rounds = gold["mise_%s_cfg" % name]
     m = mesh.MISE(int(r0), int(d), float(thr))
