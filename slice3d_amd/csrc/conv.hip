@@ -283,6 +283,124 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row-linear layers (1x1 convolution of ONE plain source with K <= 128 input channels) on long row sets: the decoder's
+// attention-block projections, the pyramid level projections.  The implicit-GEMM kernel above walks (pixel tile, cout
+// tile) blocks and re-requests its few K chunks block by block (3.2 TB/s on 1.3 M rows); here a wave owns 48 rows,
+// requests ALL of their K channels at once (24 x 16 B per lane in flight), keeps them in registers as f16 hi/lo
+// fragments and walks the output channels 32 at a time — every input byte is requested once, weights come from L2.
+// No LDS, no barriers.  Same accumulation order as conv_igemm_f16x3_kernel, same epilogue.
+// ---------------------------------------------------------------------------------------------
+#define LR_MT 3
+__global__ __launch_bounds__(256, 2) void lin_rows_f16x3_kernel(const ConvLaunch a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const long P = (long)a.N * a.H * a.W;
+    const int HW = a.H * a.W;
+    const ConvSrc S = a.src[0];
+    const int KU32 = S.C >> 5;   // 1 .. 4
+    const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wpk16);
+    int pn[LR_MT], py[LR_MT], px[LR_MT];
+    bool pv[LR_MT];
+    f32x4 v0[LR_MT][4], v1[LR_MT][4];
+#pragma unroll
+    for (int mt = 0; mt < LR_MT; ++mt) {
+        const long p = ((long)blockIdx.x * 4 + wave) * (16 * LR_MT) + 16 * mt + m;
+        pv[mt] = p < P;
+        const long pc = pv[mt] ? p : 0;
+        pn[mt] = (int)(pc / HW);
+        const int r = (int)(pc - (long)pn[mt] * HW);
+        py[mt] = r / a.W;
+        px[mt] = r - py[mt] * a.W;
+        const float* row = S.p + pc * S.C + 8 * g;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = pv[mt] && u < KU32;
+            v0[mt][u] = ok ? ld4(row + 32 * u) : zero4();
+            v1[mt][u] = ok ? ld4(row + 32 * u + 4) : zero4();
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // every row request is out before the first conversion waits
+    // split in place: v0 becomes the hi fragment, v1 the lo fragment (same registers: 128 for the rows, not 256)
+#pragma unroll
+    for (int mt = 0; mt < LR_MT; ++mt)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            chalf8 h, l;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const _Float16 h0 = (_Float16)v0[mt][u][t], h1 = (_Float16)v1[mt][u][t];
+                h[t] = h0; h[4 + t] = h1;
+                l[t] = (_Float16)(v0[mt][u][t] - (float)h0);
+                l[4 + t] = (_Float16)(v1[mt][u][t] - (float)h1);
+            }
+            v0[mt][u] = __builtin_bit_cast(f32x4, h);
+            v1[mt][u] = __builtin_bit_cast(f32x4, l);
+        }
+#define LR_XH(mt, u) __builtin_bit_cast(chalf8, v0[mt][u])
+#define LR_XL(mt, u) __builtin_bit_cast(chalf8, v1[mt][u])
+    const int n_jt = a.CoutPad >> 4;
+#pragma unroll 1
+    for (int jt = 0; jt < n_jt; jt += 2) {
+        f32x4 acc[LR_MT][2];
+#pragma unroll
+        for (int mt = 0; mt < LR_MT; ++mt) acc[mt][0] = acc[mt][1] = zero4();
+        const _Float16* wp = wimg + (size_t)jt * KU32 * 1024 + lane * 8;
+        chalf8 wh[2][2], wl[2][2];   // [buffer][nt]: the next k-step's fragments are requested before this one's MFMAs
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            wh[0][nt] = *reinterpret_cast<const chalf8*>(wp + (size_t)nt * KU32 * 1024);
+            wl[0][nt] = *reinterpret_cast<const chalf8*>(wp + (size_t)nt * KU32 * 1024 + 512);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < KU32) {
+                if (u + 1 < KU32) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const _Float16* f = wp + ((size_t)nt * KU32 + u + 1) * 1024;
+                        wh[(u + 1) & 1][nt] = *reinterpret_cast<const chalf8*>(f);
+                        wl[(u + 1) & 1][nt] = *reinterpret_cast<const chalf8*>(f + 512);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                    for (int mt = 0; mt < LR_MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1][nt], LR_XL(mt, u), acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < LR_MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u & 1][nt], LR_XH(mt, u), acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < LR_MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1][nt], LR_XH(mt, u), acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        conv_epilogue<LR_MT, 2>(a, acc, pn, py, px, pv, jt, g);
+    }
+}
+
+static bool lin_rows_eligible(const ConvLaunch& a) {
+    static const int on = [] {
+        const char* e = getenv("S3D_LIN_ROWS");
+        return e ? atoi(e) : 1;
+    }();
+    if (!on || a.ks != 1 || a.nsrc != 1 || a.stride > 1 || !a.wpk16 || (a.KU & 1) || a.CoutPad % 32) return false;
+    if ((a.Hin && a.Hin != a.H) || (a.Win && a.Win != a.W)) return false;
+    const ConvSrc& S = a.src[0];
+    if (S.sbcast || S.bmod || S.bdiv != 1 || S.C % 32 || S.C > 128 || a.KU != S.C / 16) return false;
+    return (long)a.N * a.H * a.W >= 65536;   // short row sets stay on the tile menu (more, smaller workgroups)
+}
+static int launch_lin_rows(const ConvLaunch& a, hipStream_t stream) {
+    const long P = (long)a.N * a.H * a.W;
+    const long nblk = (P + 64 * LR_MT - 1) / (64 * LR_MT);
+    S3D_CHECK_ARG(nblk < (1L << 31), "conv grid out of range (%ld)", nblk);
+    hipLaunchKernelGGL(lin_rows_f16x3_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, a);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS-staged 3x3 convolution (stride 1, "same"), split precision.
 // A workgroup (4 waves) owns an 8-row x 16-column pixel tile of one image and CO_WG output channels.  Per
 // 32-channel K chunk the (8+2) x (16+2) input halo is fetched ONCE (coalesced 16 B/lane), split into f16 hi/lo
@@ -558,6 +676,7 @@ int launch_conv(const ConvLaunch& a_in, hipStream_t stream) {
     for (int s = 0; s < a.nsrc; ++s)
         S3D_CHECK_ARG(a.src[s].C % 16 == 0 && a.src[s].bdiv >= 1, "conv: bad source %d", s);
     if (conv3x3_lds_eligible(a)) return launch_conv3x3_lds(a, stream);
+    if (lin_rows_eligible(a)) return launch_lin_rows(a, stream);
     const long P = (long)a.N * a.H * a.W;
     // Tile menu: (pixels x couts) per workgroup of 4 waves.  Prefer the largest tile that still
     // yields >= ~2 workgroups per CU; small late-encoder maps fall through to the small tiles.
