@@ -111,3 +111,36 @@ def test_ldm_primitives_match_torch():
     dn = torch.empty(n, h // 2, w // 2, c, device="cuda")
     _lib.check(lib.s3d_resample2x_fwd(xc.data_ptr(), dn.data_ptr(), n, h, w, c, 0, None), "down")
     assert (dn.cpu() - F.avg_pool2d(x, 2).permute(0, 2, 3, 1)).abs().max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n,rows", [(128, 384, 70001), (96, 120, 65600), (32, 64, 131072), (64, 128, 66000)])
+def test_row_linear_path_matches_torch(k, n, rows):
+    """1x1 layers with K <= 128 on >= 65 536 rows take lin_rows_f16x3_kernel (rows kept in registers, all output tiles
+    walked by one wave) in split precision: ragged row tails, an output width below its padded width, bias and residual;
+    the f32 mode (tile menu) is the second opinion."""
+    import torch
+    from slice3d_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(k + n)
+    w = (torch.randn(n, k, 1, 1, generator=g) * 0.1).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    x = torch.randn(1, 1, rows, k, generator=g).cuda()
+    res = torch.randn(1, 1, rows, n, generator=g).cuda()
+    nb = lib.s3d_conv_packed_bytes(n, k, 0, 1)
+    buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.s3d_conv_pack(w.data_ptr(), b.data_ptr(), n, k, 0, 1, buf.data_ptr(), nb, None), "pack")
+    ws = torch.empty(1 << 20, dtype=torch.float32, device="cuda")
+    sel = torch.cat([torch.arange(0, 300), torch.arange(rows - 300, rows)])          # head and ragged tail
+    want = (torch.nn.functional.linear(x[0, 0, sel].double().cpu(), w[:, :, 0, 0].double().cpu(), b.double().cpu())
+            + res[0, 0, sel].double().cpu())
+    outs = []
+    for prec in (1, 0):
+        out = torch.full((1, 1, rows, n), float("nan"), device="cuda")
+        _lib.check(lib.s3d_conv_fwd(buf.data_ptr(), x.data_ptr(), None, res.data_ptr(), out.data_ptr(), 1, 1, rows, n, k,
+                                    0, 1, prec, ws.data_ptr(), ws.numel() * 4, None), "conv")
+        assert torch.isfinite(out).all()
+        err = float((out[0, 0, sel].double().cpu() - want).abs().max())
+        assert err < 2e-5, (prec, err)
+        outs.append(out)
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5
