@@ -147,6 +147,13 @@ int s3d_decode_points_fwd(const void* head_packed, const S3dLatent* latent, cons
 int s3d_decode_grid_fwd(const void* head_packed, const S3dLatent* latent, const float* trans,
                         int nx, float box, float* logits_out, int n_slices, int prec,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* A contiguous slab [q_begin, q_begin + q_count) of the same grid's linear index (x slowest, z fastest):
+ * logits_out[q_count].  This is the query-parallel split of reconstruct.py:135-146 over N processes
+ * (SURVEY.md 8(e)): every rank encodes the object itself and decodes 1/N of the grid; the host gathers.
+ * Workspace: s3d_decode_workspace_bytes(1, q_count, n_slices). */
+int s3d_decode_grid_slab_fwd(const void* head_packed, const S3dLatent* latent, const float* trans,
+                             int nx, float box, long q_begin, long q_count, float* logits_out,
+                             int n_slices, int prec, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * VGG19 perceptual loss — replaces VGGPerceptualLoss.forward / VGG19Feats.forward

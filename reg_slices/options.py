@@ -55,7 +55,12 @@ _REFERENCE_FLAGS = [
 
 _BUILD_FLAGS = [
     ("synthetic_len", dict(type=int, default=64, help="[build] samples per epoch of --name_dataset synthetic")),
-    ("dropout", dict(type=float, default=0.0, help="[build] transformer dropout in training (reference: 0.1)")),
+    ("dropout", dict(type=float, default=0.1, help="[build] transformer dropout in training (the reference trains with "
+                                                   "nn.TransformerEncoderLayer's default 0.1, models.py:18)")),
+    ("seed", dict(type=int, default=0, help="[build] base seed of the dropout streams (mixed with the rank)")),
+    ("synthetic_weights", dict(action=_BOOL, help="[build] reconstruct*.py: run on name-seeded random weights when "
+                                                  "no checkpoint is given (smoke tests only; meshes are meaningless)")),
+    ("sync_bn", dict(action=_BOOL, help="[build] data-parallel training: BatchNorm statistics over all ranks")),
 ]
 
 

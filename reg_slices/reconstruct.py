@@ -31,10 +31,13 @@ def main():
     path_ckpt = os.path.join("experiments", args.name_exp, "ckpt", args.name_ckpt)
     if os.path.isfile(path_ckpt):
         model.load_state_dict(torch.load(path_ckpt, map_location="cpu")["model"])     # strict, as the reference
-    else:
-        print("checkpoint %s not found: using name-seeded synthetic weights" % path_ckpt)
+    elif args.synthetic_weights:   # smoke tests without a trained checkpoint; never silently
+        print("checkpoint %s not found: --synthetic_weights -> name-seeded random weights" % path_ckpt)
         from slice3d_amd.weights import load_seeded
         load_seeded(model, 0)
+    else:   # the reference fails here too (reconstruct.py:343 torch.load)
+        raise FileNotFoundError("checkpoint %s not found (check --name_exp / --name_ckpt; --synthetic_weights runs on "
+                                "random weights for smoke tests)" % path_ckpt)
     model = model.cuda().eval()
     path_res = os.path.join("experiments", args.name_exp, "results", args.name_dataset)
     os.makedirs(path_res, exist_ok=True)

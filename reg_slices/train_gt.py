@@ -58,7 +58,7 @@ def train(args):
     if world > 1:   # identical initial weights on every rank
         for t in list(model.parameters()) + list(model.buffers()):
             torch.distributed.broadcast(t.data, 0)
-    trainer = HipGtTrainer(model, lr=args.lr, dropout=args.dropout)
+    trainer = HipGtTrainer(model, lr=args.lr, dropout=args.dropout, seed=args.seed * 65537 + rank)   # per-rank dropout streams
     epoch_latest, n_iter = 0, 0
     if args.resume:
         ckpts = glob.glob(os.path.join(dir_ckpt, "*"))
@@ -69,6 +69,8 @@ def train(args):
     n_epoch = epoch_latest
     for _ in range(epoch_latest, args.n_epochs):
         model.train()
+        if hasattr(train_loader.sampler, "set_epoch"):
+            train_loader.sampler.set_epoch(n_epoch)   # a fresh shuffle per epoch (DistributedSampler replays epoch 0 otherwise)
         for batch in train_loader:
             batch = {k: v.cuda() for k, v in batch.items()}
             loss_pred, acc = train_step(batch, trainer, args)

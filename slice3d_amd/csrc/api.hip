@@ -739,7 +739,8 @@ static int attn_last_layer(const float* b, const HeadLayout& H, const LayerPtrs&
 
 static int decode_impl(const void* head_packed, const S3dLatent* lat, const float* qry, const float* rot,
                        const float* trans, int flip_yz, int nx, float box, float sign, float* out, int batch,
-                       long n_qry, int ns, int prec, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                       long n_qry, int ns, int prec, void* workspace, size_t workspace_bytes, hipStream_t st,
+                       long q_offset = 0) {
     S3D_CHECK_ARG(head_packed && lat && trans && out && workspace, "decode: null argument");
     S3D_CHECK_ARG(batch >= 1 && n_qry >= 1, "decode: batch=%d n_qry=%ld", batch, n_qry);
     S3D_CHECK_ARG(ns >= 1 && ns <= 12, "decode: n_slices %d", ns);
@@ -773,7 +774,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
         sa.fcp_w = b + H.fcp_w; sa.fcp_b = b + H.fcp_b; sa.fcs_b = b + H.fcs_b; sa.ws34 = b + H.ws34;
         sa.qry = qry; sa.rot = rot; sa.trans = trans; sa.flip_yz = flip_yz;
         sa.n_qry = n_qry; sa.groups_per_batch = gpb; sa.g_begin = g0; sa.g_count = gc;
-        sa.nx = nx; sa.box = box; sa.X = X; sa.perm = perm;
+        sa.nx = nx; sa.box = box; sa.q_offset = q_offset; sa.X = X; sa.perm = perm;
         {
             ProfScope prof_(S3D_PROF_SAMPLE, st);
             TRY(launch_sample_tokens(sa, st));
@@ -821,6 +822,17 @@ extern "C" int s3d_decode_grid_fwd(const void* head_packed, const S3dLatent* lat
     // mode='test' prologue (reconstruct.py:336 builds the model with mode='test'); logits = -sdf
     return decode_impl(head_packed, latent, nullptr, nullptr, trans, 1, nx, box, -1.f, logits_out, 1, n, n_slices,
                        prec, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int s3d_decode_grid_slab_fwd(const void* head_packed, const S3dLatent* latent, const float* trans, int nx,
+                                        float box, long q_begin, long q_count, float* logits_out, int n_slices,
+                                        int prec, void* workspace, size_t workspace_bytes, void* stream) {
+    S3D_CHECK_ARG(nx >= 2 && nx <= 1024, "decode_grid_slab: nx %d", nx);
+    const long n = (long)nx * nx * nx;
+    S3D_CHECK_ARG(q_begin >= 0 && q_count >= 1 && q_begin + q_count <= n,
+                  "decode_grid_slab: [%ld, %ld) outside the %ld-point grid", q_begin, q_begin + q_count, n);
+    return decode_impl(head_packed, latent, nullptr, nullptr, trans, 1, nx, box, -1.f, logits_out, 1, q_count,
+                       n_slices, prec, workspace, workspace_bytes, (hipStream_t)stream, q_begin);
 }
 
 // =============================================================================================

@@ -53,6 +53,7 @@ struct SampleArgs {
     // grid mode (qry == NULL): coordinates box*linspace(-.5,.5,nx) generated from the query index
     int nx;
     float box;
+    long q_offset;       // grid mode: linear grid index of this call's query 0 (slab decode; 0 = whole grid)
     float* X;            // out [g_count][T][16][128]
     const int* perm;     // optional: slot -> query index within the batch item (locality sort), (B, Q) ints
     float* raw_out;      // optional (training): sampled level-3/4 features [g_count][T][16][96], token-0 rows zero

@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
             const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
             x = p[0]; y = p[1]; z = p[2];
         } else {  // dense grid: x slowest, z fastest (common.py:145-164)
-            const long nn = (long)a.nx * a.nx;
-            const int ixg = (int)(q / nn), iyg = (int)((q / a.nx) % a.nx), izg = (int)(q % a.nx);
+            const long nn = (long)a.nx * a.nx, ql = q + a.q_offset;
+            const int ixg = (int)(ql / nn), iyg = (int)((ql / a.nx) % a.nx), izg = (int)(ql % a.nx);
             x = a.box * linspace_at(-0.5f, 0.5f, a.nx, ixg);
             y = a.box * linspace_at(-0.5f, 0.5f, a.nx, iyg);
             z = a.box * linspace_at(-0.5f, 0.5f, a.nx, izg);

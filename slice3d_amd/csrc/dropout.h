@@ -13,11 +13,28 @@ struct DropCfg {
     int site;
 };
 
-// 32-bit mixing only (three multiply / xor-shift rounds of the murmur3 finaliser on the folded counter): the
-// FFN forward draws 2 176 masks per token row, 64-bit multiplies there cost a millisecond per layer.
+// Stream key of a (seed, site) pair: both words of the seed and the site go through full avalanche rounds BEFORE they
+// meet the element index, so the streams of different steps / sites / ranks are not XOR re-indexings of one table
+// (seed ^ idx alone would make stream(seed a)[i] == stream(seed b)[i ^ a ^ b]).  Uniform per launch: the compiler
+// hoists it out of the element loops (scalar ALU).
+__host__ __device__ inline unsigned s3d_mix32(unsigned x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline unsigned s3d_stream_key(unsigned long long seed, int site) {
+    unsigned k = s3d_mix32((unsigned)seed + 0x9E3779B9u);
+    k = s3d_mix32(k ^ (unsigned)(seed >> 32)) + (unsigned)(site + 1) * 0xC2B2AE3Du;
+    return s3d_mix32(k);
+}
+// 32-bit mixing only (three multiply / xor-shift rounds of the murmur3 finaliser on the keyed counter; the key is
+// ADDED, the high index word multiplied in): the FFN forward draws 2 176 masks per token row, 64-bit multiplies there
+// cost a millisecond per layer.
 __host__ __device__ inline unsigned s3d_hash32(unsigned long long seed, int site, unsigned long long idx) {
-    unsigned x = (unsigned)idx ^ ((unsigned)(idx >> 32) * 0x9E3779B1u) ^ (unsigned)seed ^
-                 ((unsigned)(seed >> 32) * 0x85EBCA77u) ^ ((unsigned)(site + 1) * 0xC2B2AE3Du);
+    unsigned x = ((unsigned)idx ^ ((unsigned)(idx >> 32) * 0x9E3779B1u)) + s3d_stream_key(seed, site);
     x ^= x >> 16;
     x *= 0x85EBCA6Bu;
     x ^= x >> 13;

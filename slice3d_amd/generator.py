@@ -5,7 +5,11 @@
     re-runs the U-Net and VGG19 for every 3000-point chunk, reconstruct.py:74-102);
   * upsampling_steps == 0 evaluates the dense grid with in-kernel coordinates (s3d_decode_grid_fwd), never
     building the (n^3,3) tensor of reconstruct.py:135-146;
-  * MISE / marching cubes come from slice3d_amd.mesh when that native library is built.
+  * MISE / marching cubes (SURVEY.md 8(f-1)) come from slice3d_amd.mesh when that native library is built;
+  * with torch.distributed initialised (one process per GPU, `process_group` argument or the default group) the
+    queries of ONE object are split over the ranks ("C4 query-parallel"): every rank runs the cheap
+    encoder itself and decodes a contiguous 1/N slab of the dense grid / of each MISE round, one all_gather of the
+    fp32 logits per grid / round; every rank returns the full value grid.
 """
 import math
 import time
@@ -18,8 +22,10 @@ class Generator3D(object):
     def __init__(self, model, points_batch_size=100000, threshold=0.5, refinement_step=0, device=None,
                  resolution0=64, upsampling_steps=2, chunk_size=3000, with_normals=False, padding=0.0,
                  sample=False, input_type=None, vol_info=None, vol_bound=None, simplify_nfaces=None,
-                 pred_type="occ"):
+                 pred_type="occ", process_group=None, shard_queries=True):
         self.model = model
+        self.process_group = process_group
+        self.shard_queries = shard_queries
         self.points_batch_size = points_batch_size
         self.refinement_step = refinement_step
         self.threshold = threshold
@@ -56,6 +62,22 @@ class Generator3D(object):
             ret.append(-sdf)
         return torch.cat(ret, -1).squeeze(0)
 
+    def _world(self):
+        import torch.distributed as dist
+        if self.shard_queries and dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+        return 1, 0
+
+    def decode_dense_grid(self, code, nx, box_size, trans):
+        """(nx,nx,nx) logits on this rank's device; sharded over the ranks of the process group when there is one."""
+        world, rank = self._world()
+        if world == 1:
+            return self.model.decode_grid(code, nx, box=box_size, trans_mat_wo_rot_tp=trans)
+        from .parallel import gather_slabs, shard_range
+        lo, hi = shard_range(nx ** 3, rank, world)
+        local = self.model.decode_grid(code, nx, box=box_size, trans_mat_wo_rot_tp=trans, q_range=(lo, hi))
+        return gather_slabs(local, nx ** 3, self.process_group).view(nx, nx, nx)
+
     def generate_value_grid(self, data, stats_dict=None):
         """The (n+1)^3 / n^3 grid of logits the reference hands to marching cubes (reconstruct.py:121-170)."""
         stats_dict = {} if stats_dict is None else stats_dict
@@ -64,8 +86,7 @@ class Generator3D(object):
         code = self.encode(data)
         if self.upsampling_steps == 0:
             nx = self.resolution0
-            value_grid = self.model.decode_grid(code, nx, box=box_size,
-                                                trans_mat_wo_rot_tp=data["trans_mat_wo_rot_tp"]).cpu().numpy()
+            value_grid = self.decode_dense_grid(code, nx, box_size, data["trans_mat_wo_rot_tp"]).cpu().numpy()
         else:
             from .mesh import MISE
             threshold = np.log(self.threshold) - np.log(1.0 - self.threshold)
@@ -77,7 +98,15 @@ class Generator3D(object):
                 d["qry_norot"] = torch.from_numpy(pointsf).unsqueeze(0).to(data["img_input"].device)
                 chunk = self.chunk_size
                 self.chunk_size = max(chunk, 1 << 18)      # chunking is for the reference's memory, not ours
-                values = self.eval_points(d, code).cpu().numpy().astype(np.float64)
+                world, _ = self._world()
+                if world > 1:      # one object's round of points split over the ranks, values gathered on all
+                    from .parallel import decode_points_sharded
+                    values = decode_points_sharded(
+                        lambda slab: self.eval_points(dict(d, qry_norot=slab), code).view(1, -1), d["qry_norot"],
+                        self.process_group).view(-1)
+                else:
+                    values = self.eval_points(d, code)
+                values = values.cpu().numpy().astype(np.float64)
                 self.chunk_size = chunk
                 mise.update(points, values)
                 points = mise.query()

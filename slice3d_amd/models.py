@@ -425,20 +425,41 @@ class Slices3DRegModel(nn.Module):
         sdf = self.decode_sdf(p, c, **kwargs)
         return SimpleNamespace(logits=-sdf, sdf=sdf)
 
-    def decode_grid(self, c, nx, box=1.0, trans_mat_wo_rot_tp=None):
-        """Dense nx^3 logits (-sdf) with in-kernel grid coordinates (reconstruct.py:135-146); batch 1."""
+    def decode_grid(self, c, nx, box=1.0, trans_mat_wo_rot_tp=None, q_range=None):
+        """Dense nx^3 logits (-sdf) with in-kernel grid coordinates (reconstruct.py:135-146); batch 1.
+        q_range=(lo, hi): only that contiguous slab of the grid's linear index (x slowest, z fastest), returned
+        flat — the per-rank piece of the query-parallel split (slice3d_amd.parallel).
+        The kernel runs the mode='test' prologue (the mode reconstruct.py:336 builds the model with); a model in
+        another mode must go through decode_sdf on explicit points, which applies obj_rot_mat."""
         lib = self._require_lib()
         self._require_eval()
+        if self.mode != "test":
+            raise ValueError("decode_grid evaluates the mode='test' prologue (y, z negated, no obj_rot_mat); this model "
+                             "has mode=%r — decode explicit grid points with decode_sdf instead" % self.mode)
         if c.batch != 1:
             raise ValueError("decode_grid expects a single encoded object")
         tm = self._f32(trans_mat_wo_rot_tp) if trans_mat_wo_rot_tp is not None else c.trans_mat_wo_rot_tp
-        out = torch.empty((nx, nx, nx), dtype=torch.float32, device=self._device())
-        nb = lib.s3d_decode_workspace_bytes(1, nx ** 3, self.n_slices)
-        ws = self._workspace("decode", nb)
-        _lib.check(lib.s3d_decode_grid_fwd(self._head_packed.data_ptr(), C.byref(c._latent_struct), tm.data_ptr(), nx,
-                                           float(box), out.data_ptr(), self.n_slices, self.prec, ws.data_ptr(),
-                                           ws.numel(), self._stream()), "s3d_decode_grid_fwd")
-        return out
+        if tm is None:
+            raise KeyError("trans_mat_wo_rot_tp")
+        n = nx ** 3
+        lo, hi = (0, n) if q_range is None else (int(q_range[0]), int(q_range[1]))
+        if not 0 <= lo <= hi <= n:
+            raise ValueError("q_range %r outside the %d-point grid" % (q_range, n))
+        out = torch.empty((hi - lo,), dtype=torch.float32, device=self._device())
+        if q_range is None:
+            nb = lib.s3d_decode_workspace_bytes(1, n, self.n_slices)
+            ws = self._workspace("decode", nb)
+            _lib.check(lib.s3d_decode_grid_fwd(self._head_packed.data_ptr(), C.byref(c._latent_struct), tm.data_ptr(), nx,
+                                               float(box), out.data_ptr(), self.n_slices, self.prec, ws.data_ptr(),
+                                               ws.numel(), self._stream()), "s3d_decode_grid_fwd")
+        elif hi > lo:
+            nb = lib.s3d_decode_workspace_bytes(1, hi - lo, self.n_slices)
+            ws = self._workspace("decode", nb)
+            _lib.check(lib.s3d_decode_grid_slab_fwd(self._head_packed.data_ptr(), C.byref(c._latent_struct),
+                                                    tm.data_ptr(), nx, float(box), lo, hi - lo, out.data_ptr(),
+                                                    self.n_slices, self.prec, ws.data_ptr(), ws.numel(),
+                                                    self._stream()), "s3d_decode_grid_slab_fwd")
+        return out.view(nx, nx, nx) if q_range is None else out
 
     # ------------------------------------------------------------------------------------------
     # reference forward (models.py:48-94)

@@ -67,7 +67,8 @@ class SyntheticSlice3DDataset(torch.utils.data.Dataset):
     (no batch dimension): deterministic in (split, index), sharded over ranks like a DistributedSampler."""
 
     def __init__(self, length, img_size, n_qry, n_slices=12, split="train", rank=0, world=1):
-        self.indices = list(range(rank, length, world))
+        per_rank = length // world if world > 1 else length   # equal shard lengths: every rank runs the same number of steps
+        self.indices = list(range(rank, length, world))[:max(per_rank, 1)]
         self.img_size, self.n_qry, self.n_slices = img_size, n_qry, n_slices
         self.base = {"train": 0, "val": 1 << 20, "test": 2 << 20}[split]
 

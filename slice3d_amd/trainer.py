@@ -176,29 +176,51 @@ class HipTrainer:
         self.model._packed_key = None
 
     def state_dict(self):
-        """Optimiser state in torch.optim.Adam's checkpoint layout ('opt' entry of train.py:174-176)."""
+        """Optimiser state in the checkpoint layout of the reference's `torch.optim.Adam(model.parameters())`
+        ('opt' entry, train.py:136,174-176): parameters are numbered by their position in model.parameters() — ALL of
+        them, frozen VGG19 and never-touched tensors included — and only the tensors that received a gradient carry a
+        state entry, exactly what torch writes.  `torch.optim.Adam(model.parameters()).load_state_dict()` accepts it."""
+        index = {id(p): i for i, p in enumerate(self.model.parameters())}
         state = {}
-        for i, (k, p) in enumerate(zip(self.names, self.params)):
+        for k, p in zip(self.names, self.params):
+            if self.step == 0:
+                break              # torch creates the state lazily at the first step
             off, n = self.offsets[k], p.numel()
-            state[i] = {"step": torch.tensor(float(self.step)),
-                        "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
-                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
-        return {"state": state, "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps,
-                                                  "weight_decay": 0, "amsgrad": False,
-                                                  "params": list(range(len(self.params)))}],
-                "param_names": list(self.names)}
+            state[index[id(p)]] = {"step": torch.tensor(float(self.step)),
+                                   "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
+                                   "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
+        group = dict(torch.optim.Adam([torch.zeros(1)]).state_dict()["param_groups"][0])   # this torch's key set
+        group.update(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=0, amsgrad=False,
+                     params=list(range(len(index))))
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """Accepts the 'opt' entry of a reference checkpoint (or of state_dict() above): state keyed by the index in
+        model.parameters().  Shapes are validated; a state entry for a tensor this trainer does not update is an error."""
         g = sd["param_groups"][0]
+        all_params = list(self.model.named_parameters())
+        if len(g["params"]) != len(all_params):
+            raise _lib.S3dError("optimizer state numbers %d parameters, the model has %d (a checkpoint of another model?)"
+                                % (len(g["params"]), len(all_params)))
         self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
-        for i, (k, p) in enumerate(zip(self.names, self.params)):
-            st = sd["state"].get(i)
-            if st is None:
-                continue
-            off, n = self.offsets[k], p.numel()
+        position = {idx: i for i, idx in enumerate(g["params"])}
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for idx, st in sd["state"].items():
+            name, p = all_params[position[int(idx)]]
+            if name not in self.offsets:
+                raise _lib.S3dError("optimizer state for %s, which this trainer never updates" % name)
+            if tuple(st["exp_avg"].shape) != tuple(p.shape) or tuple(st["exp_avg_sq"].shape) != tuple(p.shape):
+                raise _lib.S3dError("optimizer state of %s has shape %s, the parameter %s"
+                                    % (name, tuple(st["exp_avg"].shape), tuple(p.shape)))
+            off, n = self.offsets[name], p.numel()
             self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
-            self.step = int(st["step"])
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise _lib.S3dError("optimizer state holds different step counts %s (one global step is kept)" % sorted(steps))
+        self.step = steps.pop() if steps else 0
 
     def train_step(self, batch):
         """train.py:41-53 — returns python floats (loss_pred, loss_img, loss_img_vgg, acc)."""

@@ -39,15 +39,27 @@ def test_train_then_reconstruct_on_disk_dataset(tmp_path):
     # the given-slices model (no checkpoint: name-seeded weights) through the same generator
     out = run([os.path.join(ROOT, "reg_slices", "reconstruct.py")] + common +
               ["--name_model", "gtslice", "--name_ckpt", "none.ckpt", "--mode", "test", "--mc_res0", "8",
-               "--mc_up_steps", "0", "--name_exp", "toy_gt"], str(work))
+               "--mc_up_steps", "0", "--name_exp", "toy_gt", "--synthetic_weights"], str(work))
     assert len(glob.glob(str(work / "experiments" / "toy_gt" / "results" / "custom" / "*.obj"))) == 2, out
+
+
+def test_reconstruct_fails_loudly_without_a_checkpoint(tmp_path):
+    """A wrong --name_ckpt must not produce meshes from random weights (the reference's torch.load raises too)."""
+    work = tmp_path / "work"
+    work.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "reg_slices", "reconstruct.py"), "--name_dataset", "synthetic",
+                        "--synthetic_len", "1", "--img_size", "32", "--name_exp", "nock", "--name_ckpt", "typo.ckpt",
+                        "--mode", "test"], cwd=str(work), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "FileNotFoundError" in r.stderr
+    assert not glob.glob(str(work / "experiments" / "nock" / "results" / "*" / "*.obj"))
 
 
 def test_reconstruct_slices_writes_the_twelve_slice_images(tmp_path):
     work = tmp_path / "work"
     work.mkdir()
     run([os.path.join(ROOT, "reg_slices", "reconstruct_slices.py"), "--name_dataset", "synthetic", "--synthetic_len", "2",
-         "--img_size", "32", "--name_exp", "sl", "--name_ckpt", "none.ckpt", "--mode", "test"], str(work))
+         "--img_size", "32", "--name_exp", "sl", "--name_ckpt", "none.ckpt", "--mode", "test", "--synthetic_weights"],
+        str(work))
     names = sorted(os.path.basename(p) for p in glob.glob(str(work / "experiments" / "sl" / "img_slices" / "synthetic_0001" / "*.png")))
     assert names == sorted(["%s_%d.png" % (a, i) for a in "XYZ" for i in range(1, 5)])
 

@@ -72,3 +72,26 @@ def test_gt_decode_is_bit_reproducible_run_to_run():
     first = m(fd)["sdf_pred"].clone()
     for _ in range(19):
         assert torch.equal(m(fd)["sdf_pred"], first)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_gt_white_noise_images_within_the_reference_rounding_floor(prec):
+    """White-noise slice images: the bound is stated against an fp64 evaluation of the oracle,
+    max|hip - ref_fp64| <= max|ref_fp32 - ref_fp64| + 5e-5, median error fp32-class (see the twin test of
+    Slices3DRegModel in test_gpu_parity.py)."""
+    from oracle import ref_cpu
+    from helpers import seeded_sd_from_shapes
+    from slice3d_amd.synth import make_feed_dict
+    fd = make_feed_dict(1, 128, 5000, 12, seed=1235, smooth=False)
+    sd = seeded_sd_from_shapes(gt_shapes())
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    with torch.no_grad():
+        r32, _ = ref_cpu.gt_forward(sd, fd, "test", 12)
+        r64, _ = ref_cpu.gt_forward(sd64, {k: v.double() for k, v in fd.items()}, "test", 12)
+    m = make_model(12, prec, "test")
+    hip = m({k: v.cuda() for k, v in fd.items()})["sdf_pred"].cpu().double()
+    e_hip, e_ref = (hip - r64).abs(), (r32.double() - r64).abs()
+    print("GT white noise (%s): max|hip-f64| %.3e  max|ref32-f64| %.3e  median %.3e / %.3e" %
+          (prec, float(e_hip.max()), float(e_ref.max()), float(e_hip.median()), float(e_ref.median())))
+    assert float(e_hip.max()) <= float(e_ref.max()) + 5e-5
+    assert float(e_hip.median()) < 1e-5

@@ -27,17 +27,18 @@ def _shapes(n_slices):
     return shapes
 
 
-def make_trainer(ns):
+def make_trainer(ns, prec="f32"):
     from slice3d_amd.models import Slices3DRegModel
     from slice3d_amd.trainer import HipTrainer
     from slice3d_amd.weights import load_seeded
     m = load_seeded(Slices3DRegModel(n_slices=ns, mode="train"), 0).cuda()
-    return m, HipTrainer(m)
+    return m, HipTrainer(m, prec=prec)
 
 
-def test_train_step_matches_reference_golden():
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_train_step_matches_reference_golden(prec):
     z = np.load(os.path.join(GOLDEN, "g5_train_s32_n12_q128_b2.npz"))
-    m, tr = make_trainer(12)
+    m, tr = make_trainer(12, prec)
     batch = {k: torch.from_numpy(z[k]).cuda() for k in
              ("img_input", "img_slices", "qry_norot", "sdf", "obj_rot_mat", "trans_mat_wo_rot_tp")}
     losses, sdf_pred, rec = tr.forward_backward(batch, want_outputs=True)
@@ -70,11 +71,12 @@ def test_train_step_matches_reference_golden():
 
 
 # q >= 4096 exercises the locality-sorted token order (s3d_query_sort) and the tiled sampling backward
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("b,s,q,ns", [(1, 32, 50, 12), (2, 48, 33, 4), (2, 32, 4200, 3)])
-def test_train_grads_match_oracle_autograd(b, s, q, ns):
+def test_train_grads_match_oracle_autograd(b, s, q, ns, prec):
     from oracle import ref_cpu
     from slice3d_amd.synth import make_feed_dict
-    m, tr = make_trainer(ns)
+    m, tr = make_trainer(ns, prec)
     fd = make_feed_dict(b, s, q, ns, seed=200 + q)
     sd = seeded_sd_from_shapes(_shapes(ns))
     for k, v in sd.items():
@@ -234,3 +236,98 @@ def test_training_reduces_the_loss():
     m.eval()
     out = m(batch)            # eval-mode forward works after training (repacks with the new running stats)
     assert torch.isfinite(out["sdf_pred"]).all()
+
+
+_big_oracle = {}
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_train_step_matches_oracle_autograd_128_16k(prec):
+    """A train step at a size where the loss gradients are small (1/n = 6e-5 on sdf, 1.7e-6 on the slice images:
+    f16-subnormal territory, the regime where the split-precision backward needs its power-of-two scale) against
+    CPU autograd through the oracle: 128^2 x 12 slices x 16 384 queries, dropout 0.  Both arithmetic modes are
+    compared with the same oracle gradients — not with each other."""
+    from oracle import ref_cpu
+    from slice3d_amd.models import Slices3DRegModel
+    from slice3d_amd.synth import make_feed_dict
+    from slice3d_amd.trainer import HipTrainer
+    from slice3d_amd.weights import load_seeded
+    ns, s, q = 12, 128, 16384
+    fd = make_feed_dict(1, s, q, ns, seed=777)
+    if "ref" not in _big_oracle:
+        sd = seeded_sd_from_shapes(_shapes(ns))
+        for k, v in sd.items():
+            if v.is_floating_point() and "running" not in k and not k.startswith("vggptlossfunc"):
+                v.requires_grad_(True)
+        loss, parts, out, ts = ref_cpu.forward_train(sd, fd, ns, 0.0)
+        loss.backward()
+        _big_oracle["ref"] = ([float(p) for p in parts], out["sdf_pred"].detach(),
+                              {k: v.grad for k, v in sd.items() if v.grad is not None})
+        del loss, out, ts
+    parts, sdf_ref, grads = _big_oracle["ref"]
+    m = load_seeded(Slices3DRegModel(n_slices=ns, mode="train"), 0).cuda()
+    tr = HipTrainer(m, prec=prec)
+    losses, sdf_pred, rec = tr.forward_backward({k: v.cuda() for k, v in fd.items()}, want_outputs=True)
+    got = losses.cpu().numpy()
+    assert (sdf_pred.cpu() - sdf_ref).abs().max() < 1e-4
+    for i in range(3):
+        assert abs(got[i] - parts[i]) < 2e-5 * abs(parts[i]) + 1e-7, (i, got[i], parts[i])
+    worst, worst_k = 0.0, None
+    for k, p in m.named_parameters():
+        if k not in tr.offsets or k not in grads:
+            continue
+        if k in PRE_BN_BIASES:
+            assert float(p.grad.abs().max()) < 1e-4
+            continue
+        rel = float((p.grad.cpu() - grads[k]).norm() / grads[k].norm())
+        if rel > worst:
+            worst, worst_k = rel, k
+        assert rel < 2e-2, (k, rel)
+    print("train 128^2/16k (%s): worst relative gradient error %.2e (%s)" % (prec, worst, worst_k))
+
+
+def test_optimizer_state_round_trips_through_torch_adam():
+    """The 'opt' checkpoint entry is torch.optim.Adam(model.parameters())'s state_dict (train.py:136,174-176): all 179
+    parameters numbered in model.parameters() order, state only for tensors that got a gradient.  (1) the trainer's
+    state loads into a real torch Adam over the same parameter list; (2) a torch Adam stepped with the same gradients
+    produces a state the trainer loads, and both then take the same next step."""
+    from slice3d_amd.synth import make_feed_dict
+    m, tr = make_trainer(12)
+    n_all = len(list(m.parameters()))
+    assert n_all == 179 and len(tr.params) == 137
+    batch = {k: v.cuda() for k, v in make_feed_dict(1, 32, 64, 12, seed=8).items()}
+    # reference-side twin: CPU copies of all parameters, torch Adam over ALL of them (frozen ones never get a grad)
+    twin = [p.detach().cpu().clone().requires_grad_(p.requires_grad) for p in m.parameters()]
+    pos = {id(p): i for i, p in enumerate(m.parameters())}
+    opt = torch.optim.Adam(twin, lr=3e-4)
+    for _ in range(2):
+        tr.forward_backward(batch)
+        for p in tr.params:
+            twin[pos[id(p)]].grad = p.grad.detach().cpu().clone()
+        opt.step()
+        tr.adam_step()
+    sd = tr.state_dict()
+    assert sorted(sd["state"]) == sorted(opt.state_dict()["state"])          # same sparse numbering
+    assert sd["param_groups"][0]["params"] == list(range(n_all))
+    fresh = torch.optim.Adam([t.detach().clone().requires_grad_(t.requires_grad) for t in twin], lr=1.0)
+    fresh.load_state_dict(sd)                                                   # (1) torch accepts it
+    for i, st in opt.state_dict()["state"].items():
+        assert (sd["state"][i]["exp_avg"].cpu() - st["exp_avg"]).abs().max() < 1e-6
+        assert float(sd["state"][i]["step"]) == float(st["step"]) == 2.0
+    m2, tr2 = make_trainer(12)                                                  # (2) torch's state into a new trainer
+    with torch.no_grad():
+        for a, b in zip(m2.parameters(), m.parameters()):
+            a.copy_(b)
+    tr2.load_state_dict(opt.state_dict())
+    assert tr2.step == 2
+    tr.forward_backward(batch)
+    tr2.grad_flat.copy_(tr.grad_flat)
+    tr.adam_step()
+    tr2.adam_step()
+    for a, b in zip(tr.params, tr2.params):
+        assert torch.equal(a, b)
+    bad = opt.state_dict()
+    bad["state"][0]["exp_avg"] = torch.zeros(3)
+    bad["state"][0]["exp_avg_sq"] = torch.zeros(3)
+    with pytest.raises(Exception):
+        tr2.load_state_dict(bad)
