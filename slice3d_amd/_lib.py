@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libslice3d_hip.so")
+LIB_PATH = os.environ.get("S3D_HIP_LIB") or os.path.join(_HERE, "csrc", "libslice3d_hip.so")   # override: kernel experiments
 
 N_LEVELS = 5
 N_LAYERS = 3

@@ -11,6 +11,8 @@
 // the hidden tile never leaves registers.  For K=32 MFMAs a lane (m = l&15, g = l>>4) owns the 8
 // consecutive channels {32u + 8g .. +7}; the output-channel permutation of W2's rows is chosen so that
 // GEMM2's D registers land on exactly those channels again (residual, LayerNorm, 32-byte stores).
+#include <stdlib.h>
+
 #include "decode.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -258,6 +260,311 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_kernel(const f
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined inference FFN (MODE 0: layer, 1: last layer + fc_out).  Same tiling, same weight image and the
+// same products as ffn_layer_f16x3_kernel (lin1's bias now opens the accumulation instead of closing it), but GEMM1
+// runs ONE CHUNK AHEAD of GEMM2:
+//     phase A (iteration c):  hn = W1(c+1) x^T + b1(c+1)     [48 MFMAs]   ||   relu + hi/lo split of h(c)  [VALU]
+//     phase B              :  acc += W2(c) h(c)              [48 MFMAs]   ||   fragment reads, next chunk's LDS-DMA
+// In the plain kernel the ~80 VALU instructions of the split sit between GEMM1(c) and GEMM2(c), which both depend on
+// them: the wave's matrix pipe idles for the whole block and only the SIMD's other wave can fill it (MFMA pipe 52-63 %
+// busy, 27 cycles per MFMA against 17).  Here every MFMA phase has independent VALU / LDS work to issue beside it.
+// The LDS buffer of iteration c therefore holds W1(c+1) | W2(c): the two 16 KiB halves of a buffer are fetched from
+// different chunks of the (unchanged) image.  lin1's bias is the accumulator's initial value.  Fragment reads are
+// issued one 12-MFMA group ahead; sched_group_barrier pins the interleave.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define SG_MFMA 0x008
+#define SG_VALU 0x002
+#define SG_DSRD 0x100
+#define SG_VMEM 0x020
+
+// pieces [p0, p1) (1 KiB each) of one chunk image -> the same pieces of an LDS buffer, spread over the waves
+__device__ __forceinline__ void dma_pieces(const _Float16* gchunk, _Float16* lbuf, int p0, int p1, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 16 / F16_WAVES; ++i) {   // p1 - p0 == 16 pieces, wave-uniform LDS address (M0)
+        const int piece = p0 + wave + i * F16_WAVES;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gchunk + piece * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(lbuf + piece * 512), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ half8 cat4(half2v a, half2v b, half2v c, half2v d) {
+    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+    const half4v ab = __builtin_shufflevector(a, b, 0, 1, 2, 3), cd = __builtin_shufflevector(c, d, 0, 1, 2, 3);
+    return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// relu + split of the 4 pre-activations of one D tile: hi = f16(max(v,0)), lo = f16(max(v,0) - hi)
+__device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h1, half2v& l0, half2v& l1) {
+    // relu as one v_med3_f32 (fmaxf on an MFMA result costs a canonicalising v_max first)
+    const float inf = __builtin_inff();
+    const float a0 = __builtin_amdgcn_fmed3f(v[0], 0.f, inf), a1 = __builtin_amdgcn_fmed3f(v[1], 0.f, inf),
+                a2 = __builtin_amdgcn_fmed3f(v[2], 0.f, inf), a3 = __builtin_amdgcn_fmed3f(v[3], 0.f, inf);
+    h0 = __builtin_convertvector(float2v{a0, a1}, half2v);
+    h1 = __builtin_convertvector(float2v{a2, a3}, half2v);
+    l0 = __builtin_convertvector(float2v{a0 - (float)h0[0], a1 - (float)h0[1]}, half2v);
+    l1 = __builtin_convertvector(float2v{a2 - (float)h1[0], a3 - (float)h1[1]}, half2v);
+}
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+// LDS fragment reads and their waits are issued by hand.  hipcc models a pending LDS-DMA as an LDS access of unknown
+// order: while the refill of the other buffer is in flight it either degrades every LDS wait to lgkmcnt(0) (waiting
+// for the reads it has just issued for the NEXT group) or guards each read with vmcnt(0) (waiting for the refill) —
+// measured in the ISA of three variants of this loop.  An asm read is invisible to that bookkeeping; DS_WAIT names the
+// registers it releases, so their consumers cannot be scheduled above it.  LDS returns in order: lgkmcnt(2) leaves
+// exactly the two reads of the next group outstanding.
+#define DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define DS_WAIT2(n, r0, r1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(n))
+#define DS_WAIT4(n, r0, r1, r2, r3) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(n))
+
+// phase A group K = (u, a): reads of group K+1 (or of phase B's first tile), 6 MFMAs, VALU slice on even K
+#define FFN_GROUP_A(K)                                                                                               \
+    {                                                                                                                \
+        constexpr int u = (K) >> 1, a = (K) & 1, s = (K) & 1;                                                        \
+        if (!LAST) {                                                                                                 \
+            if ((K) < 7) {                                                                                           \
+                DS_READ(fh[s ^ 1], lw, ((((K) + 1) & 1) * 4 + (((K) + 1) >> 1)) * 1024);                             \
+                DS_READ(fl[s ^ 1], lw, ((((K) + 1) & 1) * 4 + (((K) + 1) >> 1)) * 1024 + 8192);                      \
+            } else {                                                                                                 \
+                DS_READ(vh[0], lw, 16384);                                                                           \
+                DS_READ(vl[0], lw, 24576);                                                                           \
+            }                                                                                                        \
+            if ((K) == 0) {                                                                                          \
+                DS_WAIT4(2, bq[0], bq[1], fh[0], fl[0]);                                                             \
+                _Pragma("unroll") for (int r = 0; r < F16_R; ++r) { hn[0][r] = bq[0]; hn[1][r] = bq[1]; }            \
+            } else {                                                                                                 \
+                DS_WAIT2(2, fh[s], fl[s]);                                                                           \
+            }                                                                                                        \
+            _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                        \
+                hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xl[r][u], hn[a][r], 0, 0, 0);               \
+            _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                        \
+                hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s], xh[r][u], hn[a][r], 0, 0, 0);               \
+            _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                        \
+                hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xh[r][u], hn[a][r], 0, 0, 0);               \
+        } else if ((K) == 7) {                                                                                       \
+            DS_READ(vh[0], lw, 16384);                                                                               \
+            DS_READ(vl[0], lw, 24576);                                                                               \
+        }                                                                                                            \
+        if (((K) & 1) == 0) {                                                                                        \
+            constexpr int a2 = (K) >> 2, r2 = ((K) >> 1) & 1;                                                        \
+            relu_split4(hd[a2][r2], hh2[r2][2 * a2], hh2[r2][2 * a2 + 1], hl2[r2][2 * a2], hl2[r2][2 * a2 + 1]);     \
+            /* tie the results into the side-effect chain: otherwise the low halves are emitted where they are */   \
+            /* first USED (phase B), outside the MFMA cover */                                                       \
+            asm volatile("" : "+v"(hl2[r2][2 * a2]), "+v"(hl2[r2][2 * a2 + 1]), "+v"(hh2[r2][2 * a2]),               \
+                         "+v"(hh2[r2][2 * a2 + 1]));                                                                 \
+        }                                                                                                            \
+        if (!LAST) {                                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                          \
+                SGB(SG_MFMA, 1);                                                                                     \
+                SGB(SG_VALU, 3);                                                                                     \
+            }                                                                                                        \
+        }                                                                                                            \
+        SB();                                                                                                        \
+    }
+// phase B group J = output tile
+#define FFN_GROUP_B(J)                                                                                               \
+    {                                                                                                                \
+        constexpr int s = (J) & 1;                                                                                   \
+        if ((J) < 7) {                                                                                               \
+            DS_READ(vh[s ^ 1], lw, 16384 + ((J) + 1) * 1024);                                                        \
+            DS_READ(vl[s ^ 1], lw, 24576 + ((J) + 1) * 1024);                                                        \
+            DS_WAIT2(2, vh[s], vl[s]);                                                                               \
+        } else {                                                                                                     \
+            DS_WAIT2(0, vh[s], vl[s]);                                                                               \
+        }                                                                                                            \
+        _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                            \
+            acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[s], hl[r], acc[r][J], 0, 0, 0);                    \
+        _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                            \
+            acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[s], hh[r], acc[r][J], 0, 0, 0);                    \
+        _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                            \
+            acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[s], hh[r], acc[r][J], 0, 0, 0);                    \
+        SB();                                                                                                        \
+    }
+
+// One iteration of the pipelined loop (force-inlined twice per trip with hd / hn exchanged, so the hand-over of the
+// pre-activations costs no moves).  Every group of 6 MFMAs is its own scheduling region (sched_barrier): the order
+// written here IS the issue order.  lw = LDS byte address of this lane's fragment slot in the current weight buffer,
+// lb = of its bias quad of the NEXT chunk.
+template <bool LAST>
+__device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned lb, const half8 (&xh)[F16_R][4],
+                                              const half8 (&xl)[F16_R][4], f32x4 (&acc)[F16_R][8],
+                                              const f32x4 (&hd)[2][F16_R], f32x4 (&hn)[2][F16_R]) {
+    half2v hh2[F16_R][4], hl2[F16_R][4];
+    half8 fh[2], fl[2], vh[2], vl[2];
+    f32x4 bq[2];
+    if (!LAST) {
+        DS_READ(bq[0], lb, 0);
+        DS_READ(bq[1], lb, 64);
+        DS_READ(fh[0], lw, 0);
+        DS_READ(fl[0], lw, 8192);
+    }
+    SB();
+    // ---- phase A: hn = W1(c+1) x^T + b1(c+1)   beside   relu / split of hd (chunk c)
+    FFN_GROUP_A(0) FFN_GROUP_A(1) FFN_GROUP_A(2) FFN_GROUP_A(3) FFN_GROUP_A(4) FFN_GROUP_A(5) FFN_GROUP_A(6) FFN_GROUP_A(7)
+    // ---- phase B: acc += W2(c) h(c)
+    half8 hh[F16_R], hl[F16_R];
+#pragma unroll
+    for (int r = 0; r < F16_R; ++r) {
+        hh[r] = cat4(hh2[r][0], hh2[r][1], hh2[r][2], hh2[r][3]);
+        hl[r] = cat4(hl2[r][0], hl2[r][1], hl2[r][2], hl2[r][3]);
+    }
+    FFN_GROUP_B(0) FFN_GROUP_B(1) FFN_GROUP_B(2) FFN_GROUP_B(3) FFN_GROUP_B(4) FFN_GROUP_B(5) FFN_GROUP_B(6) FFN_GROUP_B(7)
+}
+
+template <int MODE>
+__global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_pipe_kernel(const float* X, float* Yout, long rows,
+                                                                   const _Float16* wimg, const LayerPtrs w,
+                                                                   const float* fco_w, const float* fco_b,
+                                                                   float* sdf_out, float sign, long groups_per_batch,
+                                                                   long n_qry, long g_begin, const int* perm) {
+    constexpr bool FINAL = MODE == 1;
+    constexpr int NC = S3D_FFN_NCHUNK;
+    // THREE distinct LDS objects: hipcc tags their accesses with alias scopes, so a ds_read of one weight buffer is not
+    // guarded (s_waitcnt vmcnt(0)) against the LDS-DMA refill of the OTHER buffer in flight — with one two-buffer array
+    // it is, or, when the array is the kernel's only LDS object, every LDS wait degrades to lgkmcnt(0)
+    __shared__ __attribute__((aligned(16))) _Float16 s_w0[F16_CHUNK_HALFS], s_w1[F16_CHUNK_HALFS];   // 2 x 32 KiB
+    __shared__ __attribute__((aligned(16))) float s_b1[S3D_FFN];                                     // 8 KiB
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const long row0 = ((long)blockIdx.x * F16_WAVES + wave) * (F16_R * 16);
+
+    // prologue DMA: W1(0) -> buffer 1 (W1 half);  buffer 0 <- W1(1) | W2(0)
+    dma_pieces(wimg, s_w1, 0, 16, wave, lane);
+    dma_pieces(wimg + F16_CHUNK_HALFS, s_w0, 0, 16, wave, lane);
+    dma_pieces(wimg, s_w0, 16, 32, wave, lane);
+    for (int i = threadIdx.x; i < S3D_FFN / 4; i += F16_THREADS) st4(s_b1 + 4 * i, ld4(w.b1 + 4 * i));
+
+    half8 xh[F16_R][4], xl[F16_R][4];
+    f32x4 acc[F16_R][8];
+#pragma unroll
+    for (int r = 0; r < F16_R; ++r) {
+        long row = row0 + r * 16 + m;
+        if (row >= rows) row = rows - 1;
+        const float* p = X + row * 128 + 8 * g;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
+            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            split8(v, xh[r][u], xl[r][u]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
+    }
+    dma_publish_barrier();
+    const float* sb = s_b1 + 4 * g;     // this lane's bias quad of D tile 0 of chunk 0; tile 1 at +16, chunk c at +32c
+    const unsigned lw0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_w0 + lane * 8);
+    const unsigned lw1 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_w1 + lane * 8);
+    const unsigned lb0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_b1 + 4 * g);
+    f32x4 hdA[2][F16_R], hdB[2][F16_R];   // pre-activations (bias included) of the current / next chunk, D tiles a = 0,1
+    {
+        const _Float16* sw = s_w1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < F16_R; ++r) hdA[a][r] = *reinterpret_cast<const f32x4*>(sb + 16 * a);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const half8 fh = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8), fl = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xl[r][u], hdA[a][r], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, xh[r][u], hdA[a][r], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < F16_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xh[r][u], hdA[a][r], 0, 0, 0);
+            }
+    }
+    __syncthreads();   // every wave is done with buffer 1 before the first refill overwrites it
+
+    // buffer c & 1 holds W1(c+1) | W2(c); the refill of the other buffer (W1(c+2) | W2(c+1)) is requested at the top of
+    // iteration c and published by the barrier at its end.  Two iterations per trip: the buffers are distinct objects
+    // (see above) and hd / hn exchange roles without moves.
+#pragma unroll 1
+    for (int c = 0; c < NC - 2; c += 2) {
+        dma_pieces(wimg + (size_t)(c + 2) * F16_CHUNK_HALFS, s_w1, 0, 16, wave, lane);
+        dma_pieces(wimg + (size_t)(c + 1) * F16_CHUNK_HALFS, s_w1, 16, 32, wave, lane);
+        SB();
+        ffn_pipe_iter<false>(lw0, lb0 + (c + 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB);
+        dma_publish_barrier();
+        dma_pieces(wimg + (size_t)(c + 3) * F16_CHUNK_HALFS, s_w0, 0, 16, wave, lane);
+        dma_pieces(wimg + (size_t)(c + 2) * F16_CHUNK_HALFS, s_w0, 16, 32, wave, lane);
+        SB();
+        ffn_pipe_iter<false>(lw1, lb0 + (c + 2) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdB, hdA);
+        dma_publish_barrier();
+    }
+    // c = NC-2: buffer 0 holds W1(NC-1) | W2(NC-2); only W2(NC-1) is left to fetch (the W1 half: any valid chunk)
+    dma_pieces(wimg + (size_t)(NC - 1) * F16_CHUNK_HALFS, s_w1, 0, 16, wave, lane);
+    dma_pieces(wimg + (size_t)(NC - 1) * F16_CHUNK_HALFS, s_w1, 16, 32, wave, lane);
+    SB();
+    ffn_pipe_iter<false>(lw0, lb0 + (NC - 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB);
+    dma_publish_barrier();
+    ffn_pipe_iter<true>(lw1, lb0, xh, xl, acc, hdB, hdA);
+
+    // epilogue (identical to ffn_layer_f16x3_kernel): tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
+#pragma unroll
+    for (int r = 0; r < F16_R; ++r) {
+        const long row = row0 + r * 16 + m;
+        f32x4 y[8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
+            const f32x4 b2 = ld4(w.b2 + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 4 * (j & 1) + i;
+                const float f = acc[r][j][i] + b2[i];
+                y[j][i] = f + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
+                s += y[j][i];
+            }
+        }
+        const float mean = quad_sum16(s) * (1.f / 128.f);
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = y[j][i] - mean;
+                v += d * d;
+            }
+        const float rstd = 1.f / sqrtf(quad_sum16(v) * (1.f / 128.f) + 1e-5f);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
+            const f32x4 ga = ld4(w.ln2g + col), be = ld4(w.ln2b + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[j][i] = (y[j][i] - mean) * rstd * ga[i] + be[i];
+            if (FINAL) {
+                const f32x4 wo = ld4(fco_w + col);
+                dot += y[j][0] * wo[0] + y[j][1] * wo[1] + y[j][2] * wo[2] + y[j][3] * wo[3];
+            } else if (row < rows) {
+                st4(Yout + row * 128 + col, y[j]);
+            }
+        }
+        if (FINAL) {
+            dot = quad_sum16(dot) + fco_b[0];
+            if (g == 0 && row < rows) {
+                const long grp = g_begin + row / S3D_GROUP;
+                const long b = grp / groups_per_batch;
+                const long q = (grp % groups_per_batch) * S3D_GROUP + (row % S3D_GROUP);
+                if (q < n_qry) sdf_out[b * n_qry + (perm ? perm[b * n_qry + q] : q)] = sign * dot;
+            }
+        }
+    }
+}
+
+static bool ffn_pipelined() {
+    static const bool on = [] {
+        const char* e = getenv("S3D_FFN_PIPE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
                            long g_begin, const int* perm, hipStream_t stream) {
@@ -265,6 +572,16 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
     const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
     const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
     FfnTrainArgs ta = {};
+    if (ffn_pipelined()) {
+        if (sdf_out)
+            hipLaunchKernelGGL(ffn_layer_f16x3_pipe_kernel<1>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X,
+                               rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
+        else
+            hipLaunchKernelGGL(ffn_layer_f16x3_pipe_kernel<0>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X,
+                               rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
+        S3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (sdf_out)
         hipLaunchKernelGGL(ffn_layer_f16x3_kernel<1>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
                            w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta);
