@@ -359,6 +359,45 @@ int s3d_sample_pyramid_fwd(const S3dPyramid* pyr, const float* grid, float* out,
 int s3d_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, void* stream);
 int s3d_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Mesh extraction on the device — the step right after the hot path in
+ * Generator3D.generate_from_latent / extract_mesh (reg_slices/reconstruct.py:148-243).
+ *
+ * MISE: replaces reg_slices/src_convonet/utils/libmise/mise.pyx:33-368 (MISE.query / update / to_dense).
+ * The octree lives in a caller-owned device workspace; a round's points are returned as ascending linear
+ * grid indices ((r*x + y)*r + z, r = resolution + 1) in a device buffer and never visit the host.  Same
+ * point SET per round and same dense grid as the reference (its order within a round is insertion order).
+ * The handle is a small host descriptor; s3d_mise_dev_query / _update synchronise the stream once each
+ * (round count / error flag).  Host-side twin (bit-exact order): include/slice3d_mesh.h.
+ * ------------------------------------------------------------------------------------------- */
+size_t s3d_mise_dev_workspace_bytes(int resolution0, int depth);
+void* s3d_mise_dev_create(void* workspace, size_t workspace_bytes, int resolution0, int depth,
+                          double threshold, void* stream);            /* NULL on error (s3d_last_error) */
+void s3d_mise_dev_destroy(void* handle);
+int s3d_mise_dev_resolution(void* handle);                            /* resolution0 << depth */
+/* unknown points of the next round -> idx_out[min(*n_out, capacity)] (device), *n_out (host) */
+int s3d_mise_dev_query(void* handle, int* idx_out, long capacity, long* n_out, void* stream);
+/* their coordinates as reconstruct.py:160-161 forms them in float32: box*(p/resolution - 0.5) -> qry_out (n,3) */
+int s3d_mise_dev_points(void* handle, const int* idx, long n, float box, float* qry_out, void* stream);
+/* mise.update(points, values) + one refinement step; values = the logits of the points (device) */
+int s3d_mise_dev_update(void* handle, const int* idx, const float* values, long n, void* stream);
+int s3d_mise_dev_update_f64(void* handle, const int* idx, const double* values, long n, void* stream);
+/* mise.to_dense(): (r,r,r) float64, unknown entries forward-filled along x, then y, then z */
+int s3d_mise_dev_to_dense(void* handle, double* out, void* stream);
+
+/* Marching cubes: replaces libmcubes.marching_cubes (libmcubes/pywrapper.cpp:90-127 driving
+ * marchingcubes.h:23-193) as classify -> scan -> emit.  Vertices and faces are bit-identical to the
+ * reference's and in its order.  grid: device (nx,ny,nz) float32 (is_f64 = 0) or float64, C order; pad != 0
+ * evaluates the grid as if np.pad(grid, 1, constant_values=pad_value) had been applied (reconstruct.py:189)
+ * without materialising it.  Pass 1 returns the counts (one stream synchronisation), pass 2 — same arguments —
+ * fills vertices (V,3) float64 in index units + 0.5 of the padded grid (libmcubes' convention, undone by the
+ * caller: reconstruct.py:199-201) and triangles (F,3) int64, both device buffers. */
+size_t s3d_mc_dev_workspace_bytes(int nx, int ny, int nz, int pad);
+int s3d_mc_dev_count(const void* grid, int is_f64, int nx, int ny, int nz, int pad, double pad_value, double iso,
+                     void* workspace, size_t workspace_bytes, long* n_vertices, long* n_triangles, void* stream);
+int s3d_mc_dev_emit(const void* grid, int is_f64, int nx, int ny, int nz, int pad, double pad_value, double iso,
+                    void* workspace, size_t workspace_bytes, double* vertices, long long* triangles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

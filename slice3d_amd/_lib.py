@@ -138,6 +138,19 @@ SYMBOLS = {
     "s3d_sample_pyramid_workspace_bytes": (_sz, [_i, _l]),
     "s3d_sample_pyramid_fwd": (_i, [C.POINTER(S3dPyramid), _vp, _vp, _i, _i, _l, _vp, _sz, _vp]),
     "s3d_sample_planes_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _vp]),
+    "s3d_mise_dev_workspace_bytes": (_sz, [_i, _i]),
+    "s3d_mise_dev_create": (_vp, [_vp, _sz, _i, _i, C.c_double, _vp]),
+    "s3d_mise_dev_destroy": (None, [_vp]),
+    "s3d_mise_dev_resolution": (_i, [_vp]),
+    "s3d_mise_dev_query": (_i, [_vp, _vp, _l, C.POINTER(C.c_long), _vp]),
+    "s3d_mise_dev_points": (_i, [_vp, _vp, _l, _f, _vp, _vp]),
+    "s3d_mise_dev_update": (_i, [_vp, _vp, _vp, _l, _vp]),
+    "s3d_mise_dev_update_f64": (_i, [_vp, _vp, _vp, _l, _vp]),
+    "s3d_mise_dev_to_dense": (_i, [_vp, _vp, _vp]),
+    "s3d_mc_dev_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "s3d_mc_dev_count": (_i, [_vp, _i, _i, _i, _i, _i, C.c_double, C.c_double, _vp, _sz, C.POINTER(C.c_long),
+                              C.POINTER(C.c_long), _vp]),
+    "s3d_mc_dev_emit": (_i, [_vp, _i, _i, _i, _i, _i, C.c_double, C.c_double, _vp, _sz, _vp, _vp, _vp]),
     "s3d_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "s3d_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
 }

@@ -22,10 +22,14 @@ class Generator3D(object):
     def __init__(self, model, points_batch_size=100000, threshold=0.5, refinement_step=0, device=None,
                  resolution0=64, upsampling_steps=2, chunk_size=3000, with_normals=False, padding=0.0,
                  sample=False, input_type=None, vol_info=None, vol_bound=None, simplify_nfaces=None,
-                 pred_type="occ", process_group=None, shard_queries=True):
+                 pred_type="occ", process_group=None, shard_queries=True, mesh_backend="device"):
         self.model = model
         self.process_group = process_group
         self.shard_queries = shard_queries
+        if mesh_backend not in ("device", "host"):
+            raise ValueError("mesh_backend must be 'device' (HIP MISE + marching cubes, csrc/mesh.hip) or 'host' "
+                             "(libslice3d_mesh.so, the reference's exact point order)")
+        self.mesh_backend = mesh_backend
         self.points_batch_size = points_batch_size
         self.refinement_step = refinement_step
         self.threshold = threshold
@@ -78,8 +82,54 @@ class Generator3D(object):
         local = self.model.decode_grid(code, nx, box=box_size, trans_mat_wo_rot_tp=trans, q_range=(lo, hi))
         return gather_slabs(local, nx ** 3, self.process_group).view(nx, nx, nx)
 
+    def _eval_round(self, d, code):
+        """Logits of one MISE round's points d['qry_norot'] (1,n,3): one decode call (the reference chunks for its own
+        memory's sake), split over the ranks of the process group when there is one."""
+        chunk = self.chunk_size
+        self.chunk_size = max(chunk, 1 << 18)
+        try:
+            world, _ = self._world()
+            if world > 1:      # one object's round of points split over the ranks, values gathered on all
+                from .parallel import decode_points_sharded
+                return decode_points_sharded(
+                    lambda slab: self.eval_points(dict(d, qry_norot=slab), code).view(1, -1), d["qry_norot"],
+                    self.process_group).view(-1)
+            return self.eval_points(d, code)
+        finally:
+            self.chunk_size = chunk
+
+    def generate_value_grid_device(self, data, stats_dict=None):
+        """The (n+1)^3 / n^3 grid of logits as a DEVICE tensor (float32 dense grid / float64 MISE grid): neither
+        the points nor the values of a MISE round leave the GPU (s3d_mise_dev_*, csrc/mesh.hip)."""
+        stats_dict = {} if stats_dict is None else stats_dict
+        t0 = time.time()
+        box_size = 1 + self.padding
+        code = self.encode(data)
+        if self.upsampling_steps == 0:
+            grid = self.decode_dense_grid(code, self.resolution0, box_size, data["trans_mat_wo_rot_tp"])
+        else:
+            from .mesh import DeviceMISE
+            threshold = np.log(self.threshold) - np.log(1.0 - self.threshold)
+            mise = DeviceMISE(self.resolution0, self.upsampling_steps, threshold, device=data["img_input"].device)
+            rounds = n_pts = 0
+            idx = mise.query()
+            while idx.numel() != 0:
+                d = dict(data)
+                d["qry_norot"] = mise.points(idx, box_size).unsqueeze(0)
+                mise.update(idx, self._eval_round(d, code))
+                rounds, n_pts = rounds + 1, n_pts + idx.numel()
+                idx = mise.query()
+            grid = mise.to_dense()
+            stats_dict["mise rounds"], stats_dict["mise points"] = rounds, n_pts
+        torch.cuda.synchronize(grid.device)
+        stats_dict["time (eval points)"] = time.time() - t0
+        return grid
+
     def generate_value_grid(self, data, stats_dict=None):
-        """The (n+1)^3 / n^3 grid of logits the reference hands to marching cubes (reconstruct.py:121-170)."""
+        """The (n+1)^3 / n^3 grid of logits the reference hands to marching cubes (reconstruct.py:121-170), as a
+        host array."""
+        if self.mesh_backend == "device":
+            return self.generate_value_grid_device(data, stats_dict).cpu().numpy()
         stats_dict = {} if stats_dict is None else stats_dict
         t0 = time.time()
         box_size = 1 + self.padding
@@ -96,18 +146,7 @@ class Generator3D(object):
                 pointsf = box_size * (points.astype(np.float32) / mise.resolution - 0.5)
                 d = dict(data)
                 d["qry_norot"] = torch.from_numpy(pointsf).unsqueeze(0).to(data["img_input"].device)
-                chunk = self.chunk_size
-                self.chunk_size = max(chunk, 1 << 18)      # chunking is for the reference's memory, not ours
-                world, _ = self._world()
-                if world > 1:      # one object's round of points split over the ranks, values gathered on all
-                    from .parallel import decode_points_sharded
-                    values = decode_points_sharded(
-                        lambda slab: self.eval_points(dict(d, qry_norot=slab), code).view(1, -1), d["qry_norot"],
-                        self.process_group).view(-1)
-                else:
-                    values = self.eval_points(d, code)
-                values = values.cpu().numpy().astype(np.float64)
-                self.chunk_size = chunk
+                values = self._eval_round(d, code).cpu().numpy().astype(np.float64)
                 mise.update(points, values)
                 points = mise.query()
             value_grid = mise.to_dense()
@@ -116,21 +155,27 @@ class Generator3D(object):
 
     def generate_mesh(self, data, return_stats=True):
         stats_dict = {}
-        value_grid = self.generate_value_grid(data, stats_dict)
-        mesh = self.extract_mesh(value_grid, stats_dict=stats_dict)
+        if self.mesh_backend == "device":
+            mesh = self.extract_mesh(self.generate_value_grid_device(data, stats_dict), stats_dict=stats_dict)
+        else:
+            mesh = self.extract_mesh(self.generate_value_grid(data, stats_dict), stats_dict=stats_dict)
         return (mesh, stats_dict) if return_stats else mesh
 
     def extract_mesh(self, occ_hat, c=None, stats_dict=None):
         """Marching cubes at logit(threshold) on the -1e6-padded grid, vertices mapped back to the unit
         cube exactly as reconstruct.py:175-243 does."""
-        from .mesh import Mesh, marching_cubes
+        from .mesh import Mesh, marching_cubes, marching_cubes_device
         stats_dict = {} if stats_dict is None else stats_dict
         n_x, n_y, n_z = occ_hat.shape
         box_size = 1 + self.padding
         threshold = np.log(self.threshold) - np.log(1.0 - self.threshold)
         t0 = time.time()
-        padded = np.pad(occ_hat, 1, "constant", constant_values=-1e6)
-        vertices, triangles = marching_cubes(padded, threshold)
+        if torch.is_tensor(occ_hat) and occ_hat.is_cuda:   # classify / scan / emit on the device, the -1e6 pad implicit
+            v_dev, t_dev = marching_cubes_device(occ_hat, threshold, pad_value=-1e6)
+            vertices, triangles = v_dev.cpu().numpy(), t_dev.cpu().numpy()
+        else:
+            padded = np.pad(np.asarray(occ_hat), 1, "constant", constant_values=-1e6)
+            vertices, triangles = marching_cubes(padded, threshold)
         stats_dict["time (marching cubes)"] = time.time() - t0
         vertices -= 0.5      # libmcubes places vertices at cell centres
         vertices -= 1        # undo padding

@@ -52,6 +52,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.s3d_head_packed_bytes() > 4 * 3 * (2 * 128 * 2048)
 
 
+def test_mesh_library_exports_every_declared_symbol():
+    """include/slice3d_mesh.h <-> slice3d_amd/mesh.py's binding table <-> libslice3d_mesh.so (host C++, loads anywhere)."""
+    from slice3d_amd import mesh
+    hdr = open(os.path.join(ROOT, "include", "slice3d_mesh.h")).read()
+    declared = set(re.findall(r"\b(s3d_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(mesh._SIG), declared ^ set(mesh._SIG)
+    lib = mesh.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
 def test_no_cpu_fallback():
     m = Slices3DRegModel(n_slices=12, backend="none").eval()
     fd = make_feed_dict(1, 32, 10, 12)
