@@ -273,6 +273,13 @@ typedef struct {
     const float* rot;          /* (B,3,3)              obj_rot_mat          */
     const float* trans;        /* (B,4,3)              trans_mat_wo_rot_tp  */
     const float* sdf;          /* (B,Q)                sdf                  */
+    /* Optional hipEvent_t handles (NULL = none), recorded on the call's stream the moment a BUCKET of parameter
+     * gradients is final, in the order the backward finishes them, so a data-parallel host can all-reduce bucket k on
+     * another stream while the rest of the backward runs (replaces the backward-hook bucketing of
+     * torch DDP for train.py:131-132).  [0] transformer decoder + fc_p / fc_s / fc_out; [1] the U-Net's decoder
+     * half (trans_c, up*, trans_up*, outc, emds); [2] encoder convs 7..12 + their BatchNorms (13 of the encoder's
+     * 14.7 M parameters); the rest (encoder convs 0..6) is final when the call's work is. */
+    void* ev_grad_ready[3];
 } S3dTrainBatch;
 size_t s3d_train_workspace_bytes(int batch, int size, long n_qry, int n_slices);
 int s3d_train_fwd_bwd(const S3dUNetParams* unet, const S3dHeadParams* head, const S3dVggParams* vgg,
@@ -280,6 +287,25 @@ int s3d_train_fwd_bwd(const S3dUNetParams* unet, const S3dHeadParams* head, cons
                       const S3dTrainBatch* batch, int batch_size, int size, long n_qry, int n_slices,
                       float dropout_p, unsigned long long seed, int prec, float* losses_out, float* sdf_pred_out,
                       float* slices_rec_out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same step as two calls, for a host that owns the loss — the reference's contract `x = model(batch);
+ * loss(x).backward(); opt.step()` (train.py:41-53) behind a torch.autograd.Function:
+ *   s3d_train_fwd : train-mode forward (batch-statistics BatchNorm with running-stat updates, dropout from `seed`);
+ *                   outputs sdf_pred (B,Q), slices_rec (B*n_slices,3,S,S), vgg_loss (device scalar, already x0.001 as
+ *                   models.py:92); every activation the backward needs stays in `workspace`.
+ *   s3d_train_bwd : from d loss/d sdf_pred, d loss/d slices_rec (device, either may be NULL = zero) and
+ *                   d loss/d vgg_loss (host scalar) to the parameter gradients (written, not accumulated).  Same
+ *                   dims / dropout_p / seed / prec / workspace as the forward; slices_rec = the forward's output.
+ *                   grad_scale: power of two applied to the incoming gradients inside the split-precision (f16x3)
+ *                   backward and removed from the results; 0 selects 2^k ~ 8*B*Q, right for mean-reduced losses. */
+int s3d_train_fwd(const S3dUNetParams* unet, const S3dHeadParams* head, const S3dVggParams* vgg,
+                  const S3dTrainBatch* batch, int batch_size, int size, long n_qry, int n_slices, float dropout_p,
+                  unsigned long long seed, int prec, float* vgg_loss_out, float* sdf_pred_out, float* slices_rec_out,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int s3d_train_bwd(const S3dUNetParams* unet, const S3dHeadParams* head, const S3dVggParams* vgg,
+                  const S3dUNetParams* unet_grad, const S3dHeadParams* head_grad, const S3dTrainBatch* batch,
+                  int batch_size, int size, long n_qry, int n_slices, float dropout_p, unsigned long long seed,
+                  int prec, const float* d_sdf_pred, const float* d_slices_rec, float d_vgg_loss, float grad_scale,
+                  float* slices_rec, void* workspace, size_t workspace_bytes, void* stream);
 /* Slices3DGTModel training step — reg_slices/train_gt.py:38-52 (train_step: zero_grad, model(batch), L1 on the
  * sdf, backward) without opt.step (s3d_adam_step).  Train-mode forward of model_gt.py:59-111: batch-statistics
  * BatchNorm in the VGG16-BN encoder over the B*n_slices slice images (running statistics updated in place through

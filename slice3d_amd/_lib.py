@@ -51,7 +51,8 @@ class S3dVggParams(C.Structure):
 
 
 class S3dTrainBatch(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("img", "img_slices", "qry", "rot", "trans", "sdf")]
+    _fields_ = [(n, C.c_void_p) for n in ("img", "img_slices", "qry", "rot", "trans", "sdf")] + \
+               [("ev_grad_ready", C.c_void_p * 3)]
 
 
 class S3dVgg16BnParams(C.Structure):
@@ -123,6 +124,11 @@ SYMBOLS = {
     "s3d_train_fwd_bwd": (_i, [C.POINTER(S3dUNetParams), C.POINTER(S3dHeadParams), C.POINTER(S3dVggParams),
                                C.POINTER(S3dUNetParams), C.POINTER(S3dHeadParams), C.POINTER(S3dTrainBatch),
                                _i, _i, _l, _i, _f, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "s3d_train_fwd": (_i, [C.POINTER(S3dUNetParams), C.POINTER(S3dHeadParams), C.POINTER(S3dVggParams),
+                           C.POINTER(S3dTrainBatch), _i, _i, _l, _i, _f, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "s3d_train_bwd": (_i, [C.POINTER(S3dUNetParams), C.POINTER(S3dHeadParams), C.POINTER(S3dVggParams),
+                           C.POINTER(S3dUNetParams), C.POINTER(S3dHeadParams), C.POINTER(S3dTrainBatch),
+                           _i, _i, _l, _i, _f, C.c_ulonglong, _i, _vp, _vp, _f, _f, _vp, _vp, _sz, _vp]),
     "s3d_gt_train_workspace_bytes": (_sz, [_i, _i, _l, _i]),
     "s3d_gt_train_fwd_bwd": (_i, [C.POINTER(S3dVgg16BnParams), C.POINTER(S3dGtHeadParams),
                                   C.POINTER(S3dVgg16BnParams), C.POINTER(S3dGtHeadParams), C.POINTER(S3dTrainBatch),

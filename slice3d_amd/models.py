@@ -159,6 +159,34 @@ class LatentCode:
         return self.slices_rec_flat.view(self.batch, self.n_slices * 3, s, s)
 
 
+class _TrainForward(torch.autograd.Function):
+    """Train-mode `model(batch)` for autograd (the reference's contract, train.py:41-53: `x = model(batch)`,
+    `loss(x).backward()`, `opt.step()`): forward = s3d_train_fwd, backward = s3d_train_bwd on the engine's
+    workspace.  The parameters are inputs only so that autograd routes their gradients; the gradients come back as
+    copies of the engine's flat buffer (param.grad then accumulates like any torch gradient)."""
+
+    @staticmethod
+    def forward(ctx, engine, batch, *params):
+        sdf, rec, vgg, tctx = engine.forward_only(batch)
+        ctx.engine, ctx.tctx = engine, tctx
+        ctx.n_params = len(params)
+        return sdf, rec, vgg
+
+    @staticmethod
+    def backward(ctx, d_sdf, d_rec, d_vgg):
+        eng = ctx.engine
+        if eng._last_ctx is not ctx.tctx:
+            raise RuntimeError("backward through an older train-mode forward: the activations of this model's "
+                               "workspace belong to the most recent model(batch) call")
+        flat = eng.backward_from(ctx.tctx, d_sdf, d_rec, float(d_vgg) if d_vgg is not None else 0.0,
+                                 grad_scale=eng.auto_grad_scale(d_sdf))
+        grads = []
+        for k, p in zip(eng.names, eng.params):
+            off = eng.offsets[k]
+            grads.append(flat[off:off + p.numel()].view_as(p).clone())
+        return (None, None) + tuple(grads)
+
+
 class Slices3DRegModel(nn.Module):
     def __init__(self, img_size=128, n_slices=12, mode="train", backend="hip", prec="f32"):
         super().__init__()
@@ -174,6 +202,10 @@ class Slices3DRegModel(nn.Module):
         self.n_slices = n_slices
         self.backend = backend
         self.prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}[prec]
+        self.prec_name = prec
+        self.train_dropout = 0.1     # nn.TransformerEncoderLayer's default, what the reference trains with (models.py:18)
+        self.train_seed = 0
+        self._engine = None
         import weakref
         self.slices_generator._owner = weakref.ref(self)
         # engine state (never part of state_dict)
@@ -195,9 +227,31 @@ class Slices3DRegModel(nn.Module):
     def _require_eval(self):
         if self.training:
             raise RuntimeError(
-                "this module computes the eval-mode forward (running-stat BatchNorm, no dropout); the train-mode "
-                "step (batch-stat BatchNorm, dropout, backward, Adam) runs through slice3d_amd.trainer.HipTrainer — "
-                "call model.eval() for inference")
+                "encode / decode compute the eval-mode forward (running-stat BatchNorm, no dropout): call "
+                "model.eval() for inference.  In train mode use model(batch) (autograd) or "
+                "slice3d_amd.trainer.HipTrainer.train_step (the fused step)")
+
+    def _train_engine(self):
+        """The HIP training engine behind train-mode model(batch): its own flat gradient buffer (param.grad is left
+        to autograd), dropout = self.train_dropout, dropout streams from self.train_seed."""
+        from .trainer import HipTrainer
+        self._require_lib()
+        if self._engine is None or self._engine.grad_flat.device != self._device():
+            self._engine = HipTrainer(self, dropout=self.train_dropout, seed=self.train_seed, prec=self.prec_name,
+                                      bind_grads=False)
+        self._engine.dropout = self.train_dropout
+        return self._engine
+
+    def _forward_train(self, feed_dict):
+        """models.py:48-94 in training mode, differentiable w.r.t. the parameters (not the inputs)."""
+        if "img_slices" not in feed_dict:
+            raise KeyError("img_slices")      # the reference computes vgg_loss from it unconditionally (models.py:90-92)
+        eng = self._train_engine()
+        if not torch.is_grad_enabled():
+            sdf, rec, vgg, _ = eng.forward_only(feed_dict)
+        else:
+            sdf, rec, vgg = _TrainForward.apply(eng, feed_dict, *eng.params)
+        return {"sdf_pred": sdf, "slices_rec": rec, "vgg_loss": vgg}
 
     def _device(self):
         return self.fc_p.weight.device
@@ -465,7 +519,11 @@ class Slices3DRegModel(nn.Module):
     # reference forward (models.py:48-94)
     # ------------------------------------------------------------------------------------------
     def forward(self, feed_dict):
-        """Unlike the reference, `qry_norot` is NOT modified in place in mode='test' (models.py:55)."""
+        """Unlike the reference, `qry_norot` is NOT modified in place in mode='test' (models.py:55).  In training mode
+        (model.train()) this is the train-mode forward — batch-statistics BatchNorm, dropout — and the outputs carry
+        autograd history back to the parameters."""
+        if self.training:
+            return self._forward_train(feed_dict)
         code = self.encode(feed_dict, want_slices=True)
         sdf = self.decode_sdf(feed_dict["qry_norot"], code,
                               obj_rot_mat=feed_dict.get("obj_rot_mat"),

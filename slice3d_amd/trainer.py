@@ -13,15 +13,39 @@ from . import _lib
 from .models import _VGG16_CFG, _VGG16_SLICES, _VGG19_CONVS, _VGG19_SLICES, _slice_of
 
 
+def bucket_ranges(names, sizes):
+    """Contiguous [lo, hi) ranges of the flat gradient buffer (parameters laid out in `names` order, which is
+    model.named_parameters() order) for the four buckets the backward finishes in this order (include/slice3d_hip.h,
+    S3dTrainBatch.ev_grad_ready): 0 transformer decoder + fc_*, 1 the U-Net's decoder half, 2 encoder convs 7..12
+    (torchvision indices >= 24) with their BatchNorms, 3 the shallow encoder.  Returned in that order."""
+    def bucket(k):
+        if not k.startswith("slices_generator."):
+            return 0
+        part = k.split(".")[1]
+        if not part.startswith("down"):
+            return 1
+        return 2 if int(k.split(".")[2]) >= 24 else 3
+    ranges, off = {}, 0
+    for k, n in zip(names, sizes):
+        b = bucket(k)
+        lo, hi = ranges.get(b, (off, off))
+        if hi != off:
+            raise AssertionError("bucket %d is not contiguous in the flat gradient buffer (at %s)" % (b, k))
+        ranges[b] = (lo, off + n)
+        off += n
+    return [ranges[b] for b in range(4) if b in ranges]
+
+
 class HipTrainer:
     def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, dropout=0.0, process_group=None, seed=0,
-                 prec="f32"):
+                 prec="f32", bind_grads=True, overlap_all_reduce=True):
         self.model = model
         self.lib = _lib.load()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.dropout = dropout
         self.prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}[prec]   # conv / linear GEMMs; wgrad stays fp32
         self.group = process_group
+        self.overlap_all_reduce = overlap_all_reduce
         self.step = 0
         self.seed, self._calls, self.last_seed = seed, 0, 0
         dev = model.fc_out[0].weight.device
@@ -35,15 +59,31 @@ class HipTrainer:
             self.params.append(p)
         n_total = sum(p.numel() for p in self.params)
         self.grad_flat = torch.zeros(n_total, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros_like(self.grad_flat)
-        self.exp_avg_sq = torch.zeros_like(self.grad_flat)
-        self.offsets, off = {}, 0
+        self._exp_avg = self._exp_avg_sq = None      # Adam moments: allocated on first use
+        self.offsets, self._gmap, off = {}, {}, 0
         for k, p in zip(self.names, self.params):
             self.offsets[k] = off
-            p.grad = self.grad_flat[off:off + p.numel()].view_as(p)
+            self._gmap[id(p)] = self.grad_flat.data_ptr() + 4 * off
+            if bind_grads:   # param.grad are views into the flat buffer the library writes (optimisers see them)
+                p.grad = self.grad_flat[off:off + p.numel()].view_as(p)
             off += p.numel()
         self._losses = torch.zeros(4, dtype=torch.float32, device=dev)
         self._ws = None
+        self._buckets = None
+        self._events = None
+        self._comm_stream = None
+
+    @property
+    def exp_avg(self):
+        if self._exp_avg is None:
+            self._exp_avg = torch.zeros_like(self.grad_flat)
+        return self._exp_avg
+
+    @property
+    def exp_avg_sq(self):
+        if self._exp_avg_sq is None:
+            self._exp_avg_sq = torch.zeros_like(self.grad_flat)
+        return self._exp_avg_sq
 
     @staticmethod
     def _trainable(k):
@@ -53,7 +93,7 @@ class HipTrainer:
 
     # -- struct builders ------------------------------------------------------------------------
     def _gptr(self, t):
-        return t.grad.data_ptr() if t.grad is not None else None
+        return self._gmap.get(id(t))
 
     def _conv(self, conv, bn, grad):
         cp = _lib.S3dConvParams()
@@ -139,9 +179,11 @@ class HipTrainer:
         tb = _lib.S3dTrainBatch()
         tb.img, tb.img_slices, tb.qry = img.data_ptr(), sl.data_ptr(), qry.data_ptr()
         tb.rot, tb.trans, tb.sdf = rot.data_ptr(), tm.data_ptr(), sdf.data_ptr()
-        nb = lib.s3d_train_workspace_bytes(b, s, q, ns)
-        if self._ws is None or self._ws.numel() < nb:
-            self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        if self.overlap_all_reduce and self._world() > 1:
+            for k, e in enumerate(self._ddp_events()):
+                tb.ev_grad_ready[k] = e.cuda_event
+            self._events_armed = True
+        self._workspace(b, s, q, ns)
         sdf_pred = torch.empty((b, q), dtype=torch.float32, device=dev) if want_outputs else None
         rec = torch.empty((b * ns, 3, s, s), dtype=torch.float32, device=dev) if want_outputs else None
         u, h, v = self._unet_struct(False), self._head_struct(False), self._vgg_struct()
@@ -158,10 +200,128 @@ class HipTrainer:
             return self._losses, sdf_pred, rec.view(b, ns * 3, s, s)
         return self._losses
 
+    # -- autograd-style halves of the step (s3d_train_fwd / s3d_train_bwd) ----------------------------
+    def _batch_struct(self, batch, need_sdf):
+        dev = self.grad_flat.device
+        f = lambda k: batch[k].to(device=dev, dtype=torch.float32).contiguous()
+        keys = ["img_input", "img_slices", "qry_norot", "obj_rot_mat", "trans_mat_wo_rot_tp"] + (["sdf"] if need_sdf else [])
+        t = {k: f(k) for k in keys}
+        tb = _lib.S3dTrainBatch()
+        tb.img, tb.img_slices, tb.qry = t["img_input"].data_ptr(), t["img_slices"].data_ptr(), t["qry_norot"].data_ptr()
+        tb.rot, tb.trans = t["obj_rot_mat"].data_ptr(), t["trans_mat_wo_rot_tp"].data_ptr()
+        tb.sdf = t["sdf"].data_ptr() if need_sdf else None
+        return tb, t
+
+    def _workspace(self, b, s, q, ns):
+        nb = self.lib.s3d_train_workspace_bytes(b, s, q, ns)
+        if self._ws is None or self._ws.numel() < nb:
+            self._ws = None                      # release before growing (tens of GB at full size)
+            self._ws = torch.empty(nb, dtype=torch.uint8, device=self.grad_flat.device)
+        return self._ws
+
+    def forward_only(self, batch):
+        """Train-mode forward (models.py:48-94 with batch-statistics BatchNorm and dropout): returns
+        (sdf_pred (B,Q), slices_rec (B,3*ns,S,S), vgg_loss ()) and a context for backward_from; every activation the
+        backward needs stays in this trainer's workspace until the next forward."""
+        m, lib, dev = self.model, self.lib, self.grad_flat.device
+        tb, t = self._batch_struct(batch, need_sdf=False)
+        b, _, s, _ = t["img_input"].shape
+        q, ns = t["qry_norot"].shape[1], m.n_slices
+        ws = self._workspace(b, s, q, ns)
+        sdf_pred = torch.empty((b, q), dtype=torch.float32, device=dev)
+        rec = torch.empty((b * ns, 3, s, s), dtype=torch.float32, device=dev)
+        vgg = torch.empty((), dtype=torch.float32, device=dev)
+        seed = self._next_seed()
+        u, h, v = self._unet_struct(False), self._head_struct(False), self._vgg_struct()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.s3d_train_fwd(C.byref(u), C.byref(h), C.byref(v), C.byref(tb), b, s, q, ns, float(self.dropout),
+                                     seed, self.prec, vgg.data_ptr(), sdf_pred.data_ptr(), rec.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), stream), "s3d_train_fwd")
+        m._packed_key = None   # BN running statistics changed in place: eval-mode packs are stale
+        ctx = {"t": t, "dims": (b, s, q, ns), "seed": seed, "rec": rec, "dropout": float(self.dropout)}
+        self._last_ctx = ctx
+        return sdf_pred, rec.view(b, ns * 3, s, s), vgg, ctx
+
+    _last_ctx = None
+
+    def auto_grad_scale(self, d_sdf):
+        """Power-of-two backward scale for the split-precision path from the incoming gradient itself: puts
+        max|d sdf| in [8, 16) (one host sync; the fused step knows 1/n in advance).  0 = let the library choose."""
+        if self.prec != _lib.PREC_F16X3 or d_sdf is None:
+            return 0.0
+        mx = float(d_sdf.abs().max())
+        if not (mx > 0.0) or mx != mx or mx == float("inf"):
+            return 0.0
+        import math
+        return float(2.0 ** (3 - math.floor(math.log2(mx))))
+
+    def backward_from(self, ctx, d_sdf=None, d_rec=None, d_vgg=0.0, grad_scale=0.0):
+        """Backward of forward_only from the output gradients; WRITES the parameter gradients into grad_flat
+        (param.grad views when bind_grads).  grad_scale: see s3d_train_bwd (0 = automatic)."""
+        lib, dev = self.lib, self.grad_flat.device
+        b, s, q, ns = ctx["dims"]
+        t = ctx["t"]
+        tb = _lib.S3dTrainBatch()
+        tb.img, tb.img_slices, tb.qry = t["img_input"].data_ptr(), t["img_slices"].data_ptr(), t["qry_norot"].data_ptr()
+        tb.rot, tb.trans = t["obj_rot_mat"].data_ptr(), t["trans_mat_wo_rot_tp"].data_ptr()
+        g = lambda x, shape: None if x is None else x.to(device=dev, dtype=torch.float32).reshape(shape).contiguous()
+        d_sdf, d_rec = g(d_sdf, (b, q)), g(d_rec, (b * ns, 3, s, s))
+        u, h, v = self._unet_struct(False), self._head_struct(False), self._vgg_struct()
+        du, dh = self._unet_struct(True), self._head_struct(True)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.s3d_train_bwd(C.byref(u), C.byref(h), C.byref(v), C.byref(du), C.byref(dh), C.byref(tb), b, s, q,
+                                     ns, ctx["dropout"], ctx["seed"], self.prec,
+                                     d_sdf.data_ptr() if d_sdf is not None else None,
+                                     d_rec.data_ptr() if d_rec is not None else None, float(d_vgg), float(grad_scale),
+                                     ctx["rec"].data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream),
+                   "s3d_train_bwd")
+        return self.grad_flat
+
+    # -- data-parallel exchange step ------------------------------------------------------------------
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
+
+    def _ddp_events(self):
+        """hipEvent handles the library records when a gradient bucket is final (S3dTrainBatch.ev_grad_ready)."""
+        if self._events is None:
+            dev = self.grad_flat.device
+            self._events = [torch.cuda.Event() for _ in range(3)]
+            for e in self._events:
+                e.record(torch.cuda.current_stream(dev))      # instantiates the underlying hipEvent
+            self._comm_stream = torch.cuda.Stream(device=dev)
+            self._buckets = bucket_ranges(self.names, [p.numel() for p in self.params])
+        return self._events
+
     def all_reduce_grads(self):
-        """Data-parallel exchange step: mean of the gradients over ranks (one flat 83 MB bucket)."""
-        from .parallel import all_reduce_mean_
-        all_reduce_mean_(self.grad_flat, self.group)
+        """Data-parallel exchange step (replaces train.py:131-132): mean of the gradients over ranks.
+        After a forward_backward that recorded the bucket events, buckets 0-2 (decoder 7.6 MB, U-Net decoder half,
+        deep encoder 52 MB) are all-reduced on a side stream as the backward finishes them, under the remaining
+        backward; the shallow-encoder bucket follows the last kernel.  Otherwise: one flat all-reduce."""
+        import torch.distributed as dist
+        world = self._world()
+        if world == 1:
+            return
+        if not (self.overlap_all_reduce and self._events_armed):
+            from .parallel import all_reduce_mean_
+            all_reduce_mean_(self.grad_flat, self.group)
+            return
+        main = torch.cuda.current_stream(self.grad_flat.device)
+        comm = self._comm_stream
+        with torch.cuda.stream(comm):
+            for k, (lo, hi) in enumerate(self._buckets):
+                if k < 3:
+                    comm.wait_event(self._events[k])
+                else:
+                    comm.wait_stream(main)
+                dist.all_reduce(self.grad_flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        main.wait_stream(comm)
+        self.grad_flat.div_(world)
+        self._events_armed = False
+
+    _events_armed = False
 
     def adam_step(self):
         self.step += 1

@@ -65,22 +65,35 @@ def test_query_parallel_decode_gloo_world2(n_qry):
 
 
 def _grad_worker(rank, world, port, ret):
+    """Rank r holds the REAL reference's gradients of shard r (tests/golden/g6_ddp_*: one-sample shards of a two-sample
+    batch, train mode, dropout 0) in a flat buffer laid out like HipTrainer's; the exchange step (all_reduce_mean_,
+    bucket by bucket as HipTrainer.all_reduce_grads does) must produce the golden mean-of-shards gradient, and the
+    oracle's Adam restatement the parameters torch.optim.Adam gives the reference (train.py:136)."""
+    import numpy as np
+    from helpers import GOLDEN
+    from oracle.ref_cpu import adam_step
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    # per-rank "gradients" of a flat bucket: the all-reduced bucket must equal the mean over shards
-    g = torch.Generator().manual_seed(100 + rank)
-    flat = torch.randn(10007, generator=g)
-    want = sum(torch.randn(10007, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
-    all_reduce_mean_(flat)
-    ok = torch.allclose(flat, want, atol=1e-6)
-    # identical parameters after an identical Adam update on every rank (oracle restatement of Adam)
-    from oracle.ref_cpu import adam_step
-    p0 = torch.linspace(-1, 1, 10007)
-    p1, m1, v1 = adam_step(p0, flat, torch.zeros_like(p0), torch.zeros_like(p0), 1)
-    gathered = [torch.empty_like(p1) for _ in range(world)]
-    dist.all_gather(gathered, p1)
-    ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
+    z = np.load(os.path.join(GOLDEN, "g6_ddp_shards_s32_n12_q160_b2.npz"))
+    names = [str(k) for k in z["full_names"]]
+    sizes = [z["p0:" + k].size for k in names]
+    flat = torch.cat([torch.from_numpy(z["g%d:%s" % (rank, k)]).reshape(-1) for k in names])
+    want = torch.cat([torch.from_numpy((z["g0:" + k] + z["g1:" + k]) / 2).reshape(-1) for k in names])
+    # three uneven buckets, reduced in the order the backward would finish them (last one first)
+    cuts = [0, sum(sizes[:5]), sum(sizes[:14]), sum(sizes)]
+    for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):
+        all_reduce_mean_(flat[lo:hi])
+    ok = torch.allclose(flat, want, rtol=0, atol=1e-9)
+    off = 0
+    for k, n in zip(names, sizes):
+        p0 = torch.from_numpy(z["p0:" + k]).reshape(-1)
+        p1, _, _ = adam_step(p0, flat[off:off + n], torch.zeros(n), torch.zeros(n), 1)
+        ok = ok and bool((p1 - torch.from_numpy(z["p1:" + k]).reshape(-1)).abs().max() < 1e-7)
+        gathered = [torch.empty_like(p1) for _ in range(world)]
+        dist.all_gather(gathered, p1)
+        ok = ok and all(torch.equal(gathered[0], t) for t in gathered)      # replicas stay bit-identical
+        off += n
     t = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -89,11 +102,84 @@ def _grad_worker(rank, world, port, ret):
 
 
 def test_gradient_all_reduce_gloo_world2():
-    """C3 exchange step on CPU: mean of per-shard gradients, replicas stay bit-identical after Adam."""
+    """C3 exchange step on CPU with the reference's own per-shard gradients as payload (SURVEY.md 8(e) parity oracle;
+    the HIP step is tied to the same goldens by tests/test_gpu_train.py::test_shard_gradients_match_ddp_golden)."""
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=10) == 1.0
+
+
+def test_gradient_buckets_partition_the_flat_buffer():
+    """HipTrainer's four all-reduce buckets (finish order of the backward) are contiguous, disjoint and cover every
+    trainable parameter of the reference's state_dict order; sizes as DESIGN.md section 6 quotes them."""
+    from slice3d_amd.models import Slices3DRegModel
+    from slice3d_amd.trainer import HipTrainer, bucket_ranges
+    m = Slices3DRegModel(n_slices=12, backend="none")
+    named = [(k, p.numel()) for k, p in m.named_parameters() if HipTrainer._trainable(k)]
+    r = bucket_ranges([k for k, _ in named], [n for _, n in named])
+    assert len(r) == 4
+    assert sorted(r) == [(r[3][0], r[3][1]), (r[2][0], r[2][1]), (r[1][0], r[1][1]), (r[0][0], r[0][1])]
+    assert r[3][0] == 0 and r[0][1] == sum(n for _, n in named) == 20182116
+    assert r[3][1] == r[2][0] and r[2][1] == r[1][0] and r[1][1] == r[0][0]
+    off = {}
+    o = 0
+    for k, n in named:
+        off[k] = o
+        o += n
+    inside = lambda k, b: r[b][0] <= off[k] < r[b][1]
+    assert inside("fc_out.0.weight", 0) and inside("att_decoder.layers.1.linear1.weight", 0)
+    assert inside("slices_generator.up3.conv.double_conv.0.weight", 1) and inside("slices_generator.emds.weight", 1)
+    assert inside("slices_generator.down4.24.weight", 2) and inside("slices_generator.down5.40.bias", 2)
+    assert inside("slices_generator.down1.0.weight", 3) and inside("slices_generator.down4.21.weight", 3) and inside("slices_generator.down3.20.weight", 3)
+
+
+class _FakeModel:
+    """Stands in for Slices3DRegModel in Generator3D's sharding logic: analytic 'logits' of the grid index."""
+    mode = "test"
+
+    def encode(self, data):
+        return "code"
+
+    @staticmethod
+    def _f(i):
+        return torch.sin(i.double() * 0.37).float() + (i % 7).float()
+
+    def decode_grid(self, code, nx, box=1.0, trans_mat_wo_rot_tp=None, q_range=None):
+        lo, hi = (0, nx ** 3) if q_range is None else q_range
+        out = self._f(torch.arange(lo, hi))
+        return out.view(nx, nx, nx) if q_range is None else out
+
+
+def _gen_worker(rank, world, port, nx, ret):
+    from slice3d_amd.generator import Generator3D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gen = Generator3D(_FakeModel(), resolution0=nx, upsampling_steps=0, pred_type="sdf")
+    grid = gen.decode_dense_grid("code", nx, 1.0, None)
+    ok = torch.equal(grid, _FakeModel().decode_grid("code", nx))
+    t = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        ret.put(float(t))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nx", [5, 16])
+def test_generator3d_dense_grid_is_sharded_over_ranks_gloo_world2(nx):
+    """Generator3D.decode_dense_grid under torch.distributed: each rank decodes its slab of the grid's linear index
+    (model.decode_grid(q_range=...)), one all_gather, every rank ends with the full grid."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gen_worker, args=(r, 2, port, nx, ret)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
