@@ -266,6 +266,19 @@ int s3d_nchw_to_nhwc_pad(const float* in, float* out, int n, int c, int h, int w
  * s3d_adam_step.  dropout_p is nn.TransformerEncoderLayer's dropout (reference default 0.1); masks are
  * counter-based functions of (seed, site, element index), regenerated in the backward pass.
  * ------------------------------------------------------------------------------------------- */
+/* Cross-rank BatchNorm statistics (train.py has no counterpart: the reference's nn.DataParallel replicas use
+ * per-replica statistics, like torch DDP by default; `--sync_bn` is SURVEY.md 8(e)'s option).  The library computes
+ * the per-rank partial statistics, calls all_reduce_sum on `n_floats` floats of `scratch` (device memory, >= 2048
+ * floats, owned by the caller) on the call's stream, and continues with the reduced values: 21 small all-reduces
+ * in the forward, 21 in the backward of a train step.  The callback must enqueue the collective so that later work
+ * on `stream` sees its result (torch.distributed.all_reduce on the current stream does) and return 0. */
+typedef int (*s3d_all_reduce_sum_fn)(void* user, float* device_buf, long n_floats, void* stream);
+typedef struct {
+    s3d_all_reduce_sum_fn all_reduce_sum;
+    void* user;
+    int world_size;
+    float* scratch;
+} S3dSyncBn;
 typedef struct {
     const float* img;          /* (B,3,S,S)            img_input            */
     const float* img_slices;   /* (B,3*n_slices,S,S)   img_slices           */
@@ -280,6 +293,7 @@ typedef struct {
      * half (trans_c, up*, trans_up*, outc, emds); [2] encoder convs 7..12 + their BatchNorms (13 of the encoder's
      * 14.7 M parameters); the rest (encoder convs 0..6) is final when the call's work is. */
     void* ev_grad_ready[3];
+    const S3dSyncBn* sync_bn;  /* NULL: per-rank BatchNorm statistics */
 } S3dTrainBatch;
 size_t s3d_train_workspace_bytes(int batch, int size, long n_qry, int n_slices);
 int s3d_train_fwd_bwd(const S3dUNetParams* unet, const S3dHeadParams* head, const S3dVggParams* vgg,

@@ -58,7 +58,8 @@ def train(args):
     if world > 1:   # identical initial weights on every rank
         for t in list(model.parameters()) + list(model.buffers()):
             torch.distributed.broadcast(t.data, 0)
-    trainer = HipGtTrainer(model, lr=args.lr, dropout=args.dropout, seed=args.seed * 65537 + rank)   # per-rank dropout streams
+    trainer = HipGtTrainer(model, lr=args.lr, dropout=args.dropout, seed=args.seed * 65537 + rank,   # per-rank dropout streams
+                         sync_bn=args.sync_bn)
     epoch_latest, n_iter = 0, 0
     if args.resume:
         ckpts = glob.glob(os.path.join(dir_ckpt, "*"))

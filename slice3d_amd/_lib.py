@@ -50,9 +50,17 @@ class S3dVggParams(C.Structure):
     _fields_ = [("conv", S3dConvParams * 14), ("mean", C.c_void_p), ("std", C.c_void_p)]
 
 
+ALL_REDUCE_SUM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p)
+
+
+class S3dSyncBn(C.Structure):
+    _fields_ = [("all_reduce_sum", ALL_REDUCE_SUM_FN), ("user", C.c_void_p), ("world_size", C.c_int),
+                ("scratch", C.c_void_p)]
+
+
 class S3dTrainBatch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("img", "img_slices", "qry", "rot", "trans", "sdf")] + \
-               [("ev_grad_ready", C.c_void_p * 3)]
+               [("ev_grad_ready", C.c_void_p * 3), ("sync_bn", C.POINTER(S3dSyncBn))]
 
 
 class S3dVgg16BnParams(C.Structure):

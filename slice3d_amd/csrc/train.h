@@ -60,9 +60,13 @@ int launch_colsum(const float* in, long P, int cstride, int coff, int C, float* 
                   float* partial, hipStream_t stream);
 
 // ---- BatchNorm2d, train mode (NHWC, statistics over all pixels of all images) ----
+// sync (data-parallel --sync_bn): statistics over the batches of ALL ranks.  The forward all-reduces per channel
+// [mean_r, var_r + mean_r^2] (equal element counts per rank), the backward [sum g, sum g*xhat]; the collective is the
+// host's (S3dSyncBn callback: RCCL through torch.distributed), issued on the launch stream between two kernels.
+typedef S3dSyncBn BnSync;
 // stats: mean[c], rstd[c] (biased variance), and the running-stat update torch does (momentum .1, unbiased)
 int launch_bn_stats(const float* z, long P, int C, float* mean, float* rstd, float* running_mean,
-                    float* running_var, float* partial, hipStream_t stream);
+                    float* running_var, float* partial, hipStream_t stream, const BnSync* sync = nullptr);
 // y = relu(gamma*(z-mean)*rstd + beta)            (pool = 0)
 // y = maxpool2x2(relu(...))                       (pool = 1; z is (N,H,W,C), y is (N,H/2,W/2,C))
 int launch_bn_apply(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
@@ -73,7 +77,8 @@ int launch_conv3x3_first(const float* img_nchw, int cin, const float* w_oihw, co
                          int n, int h, int w, hipStream_t stream);
 int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   const float* dy, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c, int pool,
-                  float* partial, hipStream_t stream, const float* add = nullptr);   // dz += add (same grid) if set
+                  float* partial, hipStream_t stream, const float* add = nullptr,    // dz += add (same grid) if set
+                  const BnSync* sync = nullptr);
 
 // ---- misc elementwise ----
 int launch_axpy(float* y, const float* x, float alpha, long n, hipStream_t stream);            // y += alpha*x

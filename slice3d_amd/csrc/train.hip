@@ -1105,12 +1105,77 @@ __global__ void bn_finalize_shift_kernel(const float* __restrict__ z, long P, in
     }
 }
 
+// cross-rank statistics: this rank's [mean, var + mean^2] -> buf[0..2C) ...
+__global__ void bn_sync_pack_kernel(const float* __restrict__ z, long P, int C, const float* __restrict__ m1v,
+                                    const float* __restrict__ m2v, float* __restrict__ buf) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float k = 0.f;
+    for (int j = 0; j < BN_PILOT_ROWS; ++j) k += z[bn_pilot_row(j, P) * C + c];
+    k *= 1.f / BN_PILOT_ROWS;
+    const float m1 = m1v[c], m2 = m2v[c];
+    const float mu = k + m1, var = fmaxf(m2 - m1 * m1, 0.f);
+    buf[c] = mu;
+    buf[C + c] = var + mu * mu;
+}
+// ... and, after the all-reduce (sums over `world` ranks of equal element count P): the global statistics
+__global__ void bn_sync_finalize_kernel(const float* __restrict__ buf, long P, int C, int world,
+                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                        float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float inv = 1.f / (float)world;
+    const float mu = buf[c] * inv;
+    const float var = fmaxf(buf[C + c] * inv - mu * mu, 0.f);
+    mean[c] = mu;
+    rstd[c] = 1.f / sqrtf(var + 1e-5f);
+    if (running_mean) {
+        const float n = (float)P * (float)world;
+        running_mean[c] = 0.9f * running_mean[c] + 0.1f * mu;
+        running_var[c] = 0.9f * running_var[c] + 0.1f * (n > 1.f ? var * n / (n - 1.f) : var);
+    }
+}
+__global__ void pack2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ buf, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        buf[c] = a[c];
+        buf[C + c] = b[c];
+    }
+}
+static int bn_sync_all_reduce(const BnSync* sync, int C, hipStream_t stream) {
+    S3D_CHECK_ARG(sync->all_reduce_sum && sync->scratch && sync->world_size >= 1 && 2 * C <= 2048,
+                  "sync_bn: bad descriptor (C = %d)", C);
+    const int rc = sync->all_reduce_sum(sync->user, sync->scratch, 2L * C, (void*)stream);
+    if (rc != 0) {
+        s3d_set_error("sync_bn: the all-reduce callback returned %d", rc);
+        return S3D_E_ARG;
+    }
+    return 0;
+}
+
 int launch_bn_stats(const float* z, long P, int C, float* mean, float* rstd, float* running_mean,
-                    float* running_var, float* partial, hipStream_t stream) {
+                    float* running_var, float* partial, hipStream_t stream, const BnSync* sync) {
     S3D_CHECK_ARG(C % 4 == 0 && P > 0, "bn_stats: bad dims");
     long rpc;
     const int n = colsum_chunks(P, rpc);
     static const bool two_pass = getenv("S3D_BN_TWO_PASS") != nullptr;
+    if (sync) {
+        hipLaunchKernelGGL((colsum_kernel<4>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, nullptr,
+                           nullptr, partial, rpc, nullptr, nullptr);
+        S3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial, n, C,
+                           1.f / (float)P, mean, 0);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial + (size_t)n * C,
+                           n, C, 1.f / (float)P, rstd, 0);
+        hipLaunchKernelGGL(bn_sync_pack_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, z, P, C, mean, rstd,
+                           sync->scratch);
+        S3D_LAUNCH_CHECK();
+        TRY_RET(bn_sync_all_reduce(sync, C, stream));
+        hipLaunchKernelGGL(bn_sync_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sync->scratch, P, C,
+                           sync->world_size, mean, rstd, running_mean, running_var);
+        S3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (!two_pass) {
         hipLaunchKernelGGL((colsum_kernel<4>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, nullptr,
                            nullptr, partial, rpc, nullptr, nullptr);
@@ -1282,10 +1347,10 @@ __global__ void bn_bwd_pool_apply_kernel(const float* __restrict__ z, const floa
                                          const float* __restrict__ beta, const float* __restrict__ dy,
                                          const float* __restrict__ dbeta, const float* __restrict__ dgamma,
                                          float* __restrict__ dz, const float* __restrict__ add, int n, int h, int w,
-                                         int c) {
+                                         int c, float inv_count) {
     const int c4 = c >> 2, ho = h >> 1, wo = w >> 1;
     const long total = (long)n * ho * wo * c4;
-    const float invP = 1.f / (float)((long)n * h * w);
+    const float invP = inv_count > 0.f ? inv_count : 1.f / (float)((long)n * h * w);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const int cc = (int)(idx % c4) * 4;
@@ -1317,10 +1382,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* dy,
                                     const float* __restrict__ dbeta, const float* __restrict__ dgamma,
-                                    float* g_dz, const float* __restrict__ add, long P, int c) {
+                                    float* g_dz, const float* __restrict__ add, long P, int c, float inv_count = 0.f) {
     const int c4 = c >> 2;
     const long total = P * c4;
-    const float invP = 1.f / (float)P;
+    const float invP = inv_count > 0.f ? inv_count : 1.f / (float)P;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const int cc = (int)(idx % c4) * 4;
@@ -1345,11 +1410,26 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __
 
 int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   const float* dy, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c, int pool,
-                  float* partial, hipStream_t stream, const float* add) {
+                  float* partial, hipStream_t stream, const float* add, const BnSync* sync) {
     S3D_CHECK_ARG(c % 4 == 0, "bn_bwd: C %% 4");
     S3D_CHECK_ARG(!pool || (h % 2 == 0 && w % 2 == 0), "bn_bwd: pooled map %d x %d must be even", h, w);
     const long P = (long)n * h * w;
     long rpc;
+    // cross-rank statistics: dz needs the sums over ALL ranks (and their element count); the parameter gradients
+    // dgamma / dbeta stay this rank's sums (the gradient all-reduce averages them like every other gradient)
+    const float* sum_b = dbeta;
+    const float* sum_g = dgamma;
+    float inv_count = 0.f;
+    auto sync_sums = [&]() -> int {
+        if (!sync) return 0;
+        hipLaunchKernelGGL(pack2_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, dbeta, dgamma, sync->scratch, c);
+        S3D_LAUNCH_CHECK();
+        TRY_RET(bn_sync_all_reduce(sync, c, stream));
+        sum_b = sync->scratch;
+        sum_g = sync->scratch + c;
+        inv_count = 1.f / ((float)P * (float)sync->world_size);
+        return 0;
+    };
     if (pool) {   // both passes walk the pooled grid and redo the window comparison
         const long Pp = (long)n * (h / 2) * (w / 2);
         const int nch = colsum_chunks(Pp, rpc);
@@ -1364,8 +1444,9 @@ int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const fl
         S3D_LAUNCH_CHECK();
         const long tot = Pp * (c / 4);
         const int ba = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+        TRY_RET(sync_sums());
         hipLaunchKernelGGL(bn_bwd_pool_apply_kernel, dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy,
-                           dbeta, dgamma, dz, add, n, h, w, c);
+                           sum_b, sum_g, dz, add, n, h, w, c, inv_count);
         S3D_LAUNCH_CHECK();
         return 0;
     }
@@ -1382,8 +1463,9 @@ int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const fl
     S3D_LAUNCH_CHECK();
     const long tot = P * (c / 4);
     const int ba = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+    TRY_RET(sync_sums());
     hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), dim3(ba), dim3(256), 0, stream, z, mean, rstd, gamma, beta, dy,
-                       dbeta, dgamma, dz, add, P, c);
+                       sum_b, sum_g, dz, add, P, c, inv_count);
     S3D_LAUNCH_CHECK();
     return 0;
 }

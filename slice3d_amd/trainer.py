@@ -38,7 +38,7 @@ def bucket_ranges(names, sizes):
 
 class HipTrainer:
     def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, dropout=0.0, process_group=None, seed=0,
-                 prec="f32", bind_grads=True, overlap_all_reduce=True):
+                 prec="f32", bind_grads=True, overlap_all_reduce=True, sync_bn=False):
         self.model = model
         self.lib = _lib.load()
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -46,6 +46,8 @@ class HipTrainer:
         self.prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}[prec]   # conv / linear GEMMs; wgrad stays fp32
         self.group = process_group
         self.overlap_all_reduce = overlap_all_reduce
+        self.sync_bn = sync_bn          # BatchNorm statistics over the batches of all ranks (train.py --sync_bn)
+        self._sync = None
         self.step = 0
         self.seed, self._calls, self.last_seed = seed, 0, 0
         dev = model.fc_out[0].weight.device
@@ -183,6 +185,7 @@ class HipTrainer:
             for k, e in enumerate(self._ddp_events()):
                 tb.ev_grad_ready[k] = e.cuda_event
             self._events_armed = True
+        self._attach_sync(tb)
         self._workspace(b, s, q, ns)
         sdf_pred = torch.empty((b, q), dtype=torch.float32, device=dev) if want_outputs else None
         rec = torch.empty((b * ns, 3, s, s), dtype=torch.float32, device=dev) if want_outputs else None
@@ -210,6 +213,7 @@ class HipTrainer:
         tb.img, tb.img_slices, tb.qry = t["img_input"].data_ptr(), t["img_slices"].data_ptr(), t["qry_norot"].data_ptr()
         tb.rot, tb.trans = t["obj_rot_mat"].data_ptr(), t["trans_mat_wo_rot_tp"].data_ptr()
         tb.sdf = t["sdf"].data_ptr() if need_sdf else None
+        self._attach_sync(tb)
         return tb, t
 
     def _workspace(self, b, s, q, ns):
@@ -264,6 +268,7 @@ class HipTrainer:
         tb = _lib.S3dTrainBatch()
         tb.img, tb.img_slices, tb.qry = t["img_input"].data_ptr(), t["img_slices"].data_ptr(), t["qry_norot"].data_ptr()
         tb.rot, tb.trans = t["obj_rot_mat"].data_ptr(), t["trans_mat_wo_rot_tp"].data_ptr()
+        self._attach_sync(tb)
         g = lambda x, shape: None if x is None else x.to(device=dev, dtype=torch.float32).reshape(shape).contiguous()
         d_sdf, d_rec = g(d_sdf, (b, q)), g(d_rec, (b * ns, 3, s, s))
         u, h, v = self._unet_struct(False), self._head_struct(False), self._vgg_struct()
@@ -276,6 +281,37 @@ class HipTrainer:
                                      ctx["rec"].data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream),
                    "s3d_train_bwd")
         return self.grad_flat
+
+    # -- cross-rank BatchNorm statistics ----------------------------------------------------------------
+    def _sync_bn_struct(self):
+        """S3dSyncBn descriptor (include/slice3d_hip.h) whose callback all-reduces a slice of a device scratch buffer
+        with torch.distributed on the current stream — 42 small collectives per step, issued from inside the library
+        call between the kernel that produces the per-rank statistics and the one that consumes the global ones."""
+        if not self.sync_bn or self._world() == 1:
+            return None
+        if self._sync is None:
+            import torch.distributed as dist
+            buf = torch.zeros(2048, dtype=torch.float32, device=self.grad_flat.device)
+            state = {"error": None}
+
+            def all_reduce_sum(user, ptr, n, stream):
+                try:
+                    off = (ptr - buf.data_ptr()) // 4
+                    dist.all_reduce(buf[off:off + n], op=dist.ReduceOp.SUM, group=self.group)
+                    return 0
+                except Exception as e:      # never let an exception cross the C frame
+                    state["error"] = e
+                    return 1
+            cb = _lib.ALL_REDUCE_SUM_FN(all_reduce_sum)
+            st = _lib.S3dSyncBn()
+            st.all_reduce_sum, st.user, st.world_size, st.scratch = cb, None, self._world(), buf.data_ptr()
+            self._sync = (st, cb, buf, state)          # keep the callback and the buffer alive
+        return self._sync[0]
+
+    def _attach_sync(self, tb):
+        st = self._sync_bn_struct()
+        if st is not None:
+            tb.sync_bn = C.pointer(st)
 
     # -- data-parallel exchange step ------------------------------------------------------------------
     def _world(self):
@@ -443,6 +479,7 @@ class HipGtTrainer(HipTrainer):
         tb = _lib.S3dTrainBatch()
         tb.img_slices, tb.qry = sl.data_ptr(), qry.data_ptr()
         tb.rot, tb.trans, tb.sdf = rot.data_ptr(), tm.data_ptr(), sdf.data_ptr()
+        self._attach_sync(tb)
         nb = lib.s3d_gt_train_workspace_bytes(b, s, q, ns)
         if self._ws is None or self._ws.numel() < nb:
             self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
