@@ -438,6 +438,22 @@ int s3d_mc_dev_count(const void* grid, int is_f64, int nx, int ny, int nz, int p
 int s3d_mc_dev_emit(const void* grid, int is_f64, int nx, int ny, int nz, int pad, double pad_value, double iso,
                     void* workspace, size_t workspace_bytes, double* vertices, long long* triangles, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dataset staging on the device — the per-sample tensor work of Slice3DDataset.__getitem__
+ * (reg_slices/src/datasets.py:89-179) from pre-packed uint8 shards (slice3d_amd/shards.py: PNG decode, alpha
+ * compositing datasets.py:73-88 and the PIL bilinear resize are done ONCE at pack time with the reference's own
+ * operations, so the 13 PNG decodes per sample leave the loader's critical path).
+ * ------------------------------------------------------------------------------------------- */
+/* T.ToTensor() + T.Normalize(.5,.5) (datasets.py:31-34): imgs (B, 1+n_slices, S, S, 3) uint8 HWC (image 0 = input
+ * view, then the slices in the order X1..X4, Z4..Z1, Y1..Y4, datasets.py:106-120) -> img_input (B,3,S,S) and
+ * img_slices (B,3*n_slices,S,S) float32, bit-identical to the reference's tensors. */
+int s3d_dataset_images_fwd(const unsigned char* imgs, float* img_input, float* img_slices, int batch,
+                           int n_slices, int size, void* stream);
+/* the query subset (datasets.py:153-165): pts (N,4) = (qry xyz, sdf) float32 as packed, idx (n) ->
+ * qry (n,3), sdf (n), occ (n) = (sdf <= 0) (optional) */
+int s3d_dataset_points_fwd(const float* pts, const int* idx, long n, float* qry, float* sdf, float* occ,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,9 @@ _BUILD_FLAGS = [
     ("seed", dict(type=int, default=0, help="[build] base seed of the dropout streams (mixed with the rank)")),
     ("synthetic_weights", dict(action=_BOOL, help="[build] reconstruct*.py: run on name-seeded random weights when "
                                                   "no checkpoint is given (smoke tests only; meshes are meaningless)")),
+    ("shards", dict(type=str, default="", help="[build] directory of pre-packed uint8 shards (reg_slices/pack_shards.py): "
+                                               "batches are staged on the GPU instead of decoding 13 PNGs per sample")),
+    ("shards_in_hbm", dict(action=_BOOL, help="[build] keep the packed split resident in GPU memory")),
     ("sync_bn", dict(action=_BOOL, help="[build] data-parallel training: BatchNorm statistics over all ranks")),
 ]
 

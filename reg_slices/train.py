@@ -48,6 +48,12 @@ def val_step(model, val_loader, pred_type="sdf"):
 
 
 def make_loaders(args, rank, world):
+    if args.shards:   # pre-packed uint8 shards, staged on the GPU (slice3d_amd/shards.py)
+        from slice3d_amd.shards import ShardLoader
+        mk = lambda split: ShardLoader(args.shards, split, args.n_bs, args.n_qry, device="cuda", seed=args.seed,
+                                       rank=rank if split == "train" else 0, world=world if split == "train" else 1,
+                                       cache_on_device=args.shards_in_hbm)
+        return mk("train"), mk("val")
     if args.name_dataset != "synthetic":   # on-disk dataset in the reference's layout (train.py:123-127)
         from slice3d_amd.datasets import Slice3DDataset
 
@@ -97,8 +103,9 @@ def train(args):
     n_epoch = epoch_latest
     for _ in range(epoch_latest, args.n_epochs):
         model.train()
-        if hasattr(train_loader.sampler, "set_epoch"):
-            train_loader.sampler.set_epoch(n_epoch)   # a fresh shuffle per epoch (DistributedSampler replays epoch 0 otherwise)
+        sampler = getattr(train_loader, "sampler", train_loader)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(n_epoch)   # a fresh shuffle per epoch (DistributedSampler replays epoch 0 otherwise)
         for batch in train_loader:
             batch = {k: v.cuda() for k, v in batch.items()}
             loss_pred, loss_img, loss_img_vgg, acc = train_step(batch, trainer, args)

@@ -70,8 +70,9 @@ def train(args):
     n_epoch = epoch_latest
     for _ in range(epoch_latest, args.n_epochs):
         model.train()
-        if hasattr(train_loader.sampler, "set_epoch"):
-            train_loader.sampler.set_epoch(n_epoch)   # a fresh shuffle per epoch (DistributedSampler replays epoch 0 otherwise)
+        sampler = getattr(train_loader, "sampler", train_loader)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(n_epoch)   # a fresh shuffle per epoch (DistributedSampler replays epoch 0 otherwise)
         for batch in train_loader:
             batch = {k: v.cuda() for k, v in batch.items()}
             loss_pred, acc = train_step(batch, trainer, args)

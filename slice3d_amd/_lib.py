@@ -165,6 +165,8 @@ SYMBOLS = {
     "s3d_mc_dev_count": (_i, [_vp, _i, _i, _i, _i, _i, C.c_double, C.c_double, _vp, _sz, C.POINTER(C.c_long),
                               C.POINTER(C.c_long), _vp]),
     "s3d_mc_dev_emit": (_i, [_vp, _i, _i, _i, _i, _i, C.c_double, C.c_double, _vp, _sz, _vp, _vp, _vp]),
+    "s3d_dataset_images_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "s3d_dataset_points_fwd": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp]),
     "s3d_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "s3d_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
 }

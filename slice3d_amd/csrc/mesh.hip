@@ -619,3 +619,60 @@ extern "C" int s3d_mc_dev_emit(const void* grid, int is_f64, int nx, int ny, int
     S3D_LAUNCH_CHECK();
     return 0;
 }
+
+// =============================================================================================
+// Dataset staging: the tensor contract of Slice3DDataset.__getitem__
+// (reg_slices/src/datasets.py:89-179) from PRE-PACKED uint8 shards (slice3d_amd/shards.py), on the device.
+// PNG decode, alpha compositing and the PIL resize were done once at pack time with the reference's own operations;
+// what is left per sample is T.ToTensor() + T.Normalize(.5,.5) (datasets.py:31-34) and the query subset.
+// =============================================================================================
+// u8 (n_img, S, S, 3) HWC  ->  out (n_img*3, S, S) CHW float:  ((u8 / 255) - 0.5) / 0.5 in the reference's fp32 steps
+__global__ void u8_hwc_to_norm_chw_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, long n_img,
+                                          int S) {
+    const long px = (long)S * S;
+    const long total = n_img * px;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long img = i / px, p = i % px;
+        const unsigned char* s = in + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float t = __fdiv_rn((float)s[c], 255.0f);
+            out[(img * 3 + c) * px + p] = __fdiv_rn(t - 0.5f, 0.5f);
+        }
+    }
+}
+// imgs: (B, 1 + n_slices, S, S, 3) uint8, image 0 = the input view, 1.. = the slices in the reference's order
+// -> img_input (B,3,S,S), img_slices (B,3*n_slices,S,S)
+extern "C" int s3d_dataset_images_fwd(const unsigned char* imgs, float* img_input, float* img_slices, int batch,
+                                      int n_slices, int size, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    S3D_CHECK_ARG(imgs && img_input && img_slices && batch >= 1 && n_slices >= 1 && size >= 1, "dataset_images: bad argument");
+    const size_t per = (size_t)size * size * 3;
+    for (int b = 0; b < batch; ++b) {
+        const unsigned char* src = imgs + (size_t)b * (1 + n_slices) * per;
+        hipLaunchKernelGGL(u8_hwc_to_norm_chw_kernel, dim3(64), dim3(256), 0, st, src, img_input + (size_t)b * per, 1L, size);
+        hipLaunchKernelGGL(u8_hwc_to_norm_chw_kernel, dim3(256), dim3(256), 0, st, src + per,
+                           img_slices + (size_t)b * n_slices * per, (long)n_slices, size);
+    }
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+// pts (N,4) = (x, y, z, sdf) as the reference's float tensors hold them, idx (n) -> qry (n,3), sdf (n), occ (n) = sdf <= 0
+__global__ void gather_points_kernel(const float* __restrict__ pts, const int* __restrict__ idx, long n,
+                                     float* __restrict__ qry, float* __restrict__ sdf, float* __restrict__ occ) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f32x4 p = ld4(pts + 4L * idx[i]);
+    qry[3 * i + 0] = p[0]; qry[3 * i + 1] = p[1]; qry[3 * i + 2] = p[2];
+    sdf[i] = p[3];
+    if (occ) occ[i] = p[3] <= 0.f ? 1.f : 0.f;
+}
+extern "C" int s3d_dataset_points_fwd(const float* pts, const int* idx, long n, float* qry, float* sdf, float* occ,
+                                      void* stream) {
+    S3D_CHECK_ARG(pts && idx && qry && sdf && n >= 0, "dataset_points: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gather_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts, idx,
+                       n, qry, sdf, occ);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
