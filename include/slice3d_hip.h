@@ -364,7 +364,8 @@ int s3d_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
 #define S3D_PROF_FFN 4           /* ffn_layer_kernel, full-row layers */
 #define S3D_PROF_FFN_FINAL 5     /* ffn_layer_kernel, token-0 rows of the last layer (+fc_out) */
 #define S3D_PROF_VGG 6           /* whole s3d_vgg_loss_fwd */
-#define S3D_PROF_N 7
+#define S3D_PROF_SAMPLE_PYR 7    /* sample_pyramid_kernel of s3d_sample_pyramid_fwd (without the locality sort) */
+#define S3D_PROF_N 8
 int s3d_prof_enable(int on);
 int s3d_prof_read(int id, double* total_ms, long* count);
 

@@ -884,6 +884,8 @@ extern "C" int s3d_sample_pyramid_fwd(const S3dPyramid* pyr, const float* grid, 
         TRY(launch_query_sort(grid, nullptr, nullptr, 0, batch, n_qry, pm, pm + (size_t)batch * n_qry + 4, st));
         perm = pm;
     }
+    TRY(launch_sample_pyramid_points(grid, perm, pts, batch, n_qry, st));
+    ProfScope prof_(S3D_PROF_SAMPLE_PYR, st);
     return launch_sample_pyramid(pyr->level, grid, perm, pts, out, batch, n_slices, pyr->size, n_qry, st);
 }
 

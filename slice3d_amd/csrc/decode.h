@@ -103,6 +103,9 @@ struct GtPointArgs {
     float *h1_out, *h2_out;  // optional (training): hidden activations per query row, [rows][32] and [rows][64]
 };
 int launch_gt_point_tokens(const GtPointArgs& a, hipStream_t stream);
+// point records (gx, gy, original index) in visiting order, then the gather / row-store kernel over them
+int launch_sample_pyramid_points(const float* grid, const int* perm, float* pts, int batch, long n_qry,
+                                 hipStream_t stream);
 int launch_sample_pyramid(const float* const* level, const float* grid, const int* perm, float* pts, float* out,
                           int batch, int n_slices, int size, long n_qry, hipStream_t stream);
 int launch_query_sort(const float* qry, const float* rot, const float* trans, int flip_yz, int batch, long n_qry,

@@ -912,12 +912,24 @@ __global__ void sample_pyramid_pts_kernel(const SamplePyrArgs a) {
         a.pts[i] = make_float4(gp[0], gp[1], __int_as_float(q), 0.f);
     }
 }
-#define SP_ROWS 4   // rows per pass: 4 point records and 16 tap loads in flight per thread (8 measured slower)
+// A workgroup owns SP_CHUNK consecutive rows = points that follow each other in the image-space locality order of ONE
+// image; thread = channel quad (248 of 256 threads: [512 | 256 | 128 | 64 | 32] channels).  Consecutive points share
+// their tap pixels on the coarse levels almost always (a level-0 pixel cell spans 16x16 of the sort's 256^2 bins: a few
+// hundred points in a row), so a thread keeps its four tap vectors in registers and re-reads them only when the cell of
+// its level changes: the gather traffic through L1 / L2 — 4 taps x 3 968 B per row, four times the bytes written, and
+// what bound the previous one-row-at-a-time kernel at 3.3 TB/s — drops to a few per cent, and the kernel is left with
+// its 3 968-byte non-temporal row stores.
+// The footprints (4 tap offsets + 4 weights per level) of the chunk's rows are computed ONCE, cooperatively, into LDS
+// (128 rows x 5 levels x 32 B = 20 KiB); in the row loop a thread reads its level's record with two broadcast
+// ds_read_b128 — with every lane recomputing make_taps per row the kernel was VALU-bound (60 instructions per row and
+// wave), not write-bound.
+#define SP_CHUNK 128
 __global__ __launch_bounds__(256) void sample_pyramid_kernel(const SamplePyrArgs a) {
-    const long rows = (long)a.batch * a.n_slices * a.n_qry;
-    // a workgroup handles whole rows: 248 quads per row, 256 threads -> thread t < 248 active
+    __shared__ __attribute__((aligned(16))) int4 s_off[SP_CHUNK][5];      // off0, off1, off2, cell id
+    __shared__ __attribute__((aligned(16))) float4 s_w[SP_CHUNK][5];
+    __shared__ int s_q[SP_CHUNK];
     const int cq = threadIdx.x;
-    if (cq >= 248) return;
+    const bool active = cq < 248;
     int l, c0;   // level and first channel inside the level
     if (cq < 128) { l = 0; c0 = 4 * cq; }
     else if (cq < 192) { l = 1; c0 = 4 * (cq - 128); }
@@ -925,38 +937,55 @@ __global__ __launch_bounds__(256) void sample_pyramid_kernel(const SamplePyrArgs
     else if (cq < 240) { l = 3; c0 = 4 * (cq - 224); }
     else { l = 4; c0 = 4 * (cq - 240); }
     const int C = 512 >> l, W = (a.size / 16) << l;
-    const float* plane = a.level[l];
-    // row order: (image, point in visiting order): consecutive rows = neighbouring points of ONE image, their
-    // taps meet in L1 / L2.  SP_ROWS rows per pass: the point records and the tap loads are each one batch.
-    for (long r0 = (long)blockIdx.x * SP_ROWS; r0 < rows; r0 += (long)gridDim.x * SP_ROWS) {
-        long img[SP_ROWS];
-        float4 pt[SP_ROWS];
-#pragma unroll
-        for (int u = 0; u < SP_ROWS; ++u) {
-            const long r = r0 + u < rows ? r0 + u : rows - 1;
-            img[u] = r / a.n_qry;
-            pt[u] = a.pts[(img[u] / a.n_slices) * a.n_qry + (r - img[u] * a.n_qry)];
+    const long chunks_per_img = (a.n_qry + SP_CHUNK - 1) / SP_CHUNK;
+    const long n_img = (long)a.batch * a.n_slices;
+    for (long ch = blockIdx.x; ch < n_img * chunks_per_img; ch += gridDim.x) {
+        const long img = ch / chunks_per_img;
+        const long p0 = (ch - img * chunks_per_img) * SP_CHUNK;
+        const int nrows = (int)(p0 + SP_CHUNK < a.n_qry ? SP_CHUNK : a.n_qry - p0);
+        const float4* pts = a.pts + (img / a.n_slices) * a.n_qry + p0;
+        __syncthreads();   // the previous chunk's records are no longer read
+        for (int i = threadIdx.x; i < nrows * 5; i += 256) {
+            const int row = i / 5, lv = i - row * 5;
+            const float4 pt = pts[row];
+            const int Wl = (a.size / 16) << lv;
+            const Tap4 tp = make_taps(pt.x, pt.y, Wl, Wl);
+            const int id = tp.off[0] * 4 + (tp.off[1] != tp.off[0] ? 1 : 0) + (tp.off[2] != tp.off[0] ? 2 : 0);
+            s_off[row][lv] = make_int4(tp.off[0], tp.off[1], tp.off[2], id);
+            s_w[row][lv] = make_float4(tp.w[0], tp.w[1], tp.w[2], tp.w[3]);
+            if (lv == 0) s_q[row] = __float_as_int(pt.z);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 t[SP_ROWS][4];
-        float w[SP_ROWS][4];
-#pragma unroll
-        for (int u = 0; u < SP_ROWS; ++u) {
-            const Tap4 tp = make_taps(pt[u].x, pt[u].y, W, W);
-            const float* base = plane + img[u] * (long)W * W * C + c0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                t[u][k] = ld4(base + (long)tp.off[k] * C);
-                w[u][k] = tp.w[k];
+        __syncthreads();
+        if (!active) continue;
+        const float* plane = a.level[l] + img * (long)W * W * C + c0;
+        float* out = a.out + img * a.n_qry * 992 + 4 * cq;
+        int cell = -1;
+        f32x4 t0 = zero4(), t1 = zero4(), t2 = zero4(), t3 = zero4();
+        for (int row = 0; row < nrows; ++row) {
+            const int4 o = s_off[row][l];
+            const float4 w = s_w[row][l];
+            if (o.w != cell) {                                      // uniform over the lanes of a level
+                cell = o.w;
+                t0 = ld4(plane + (long)o.x * C);
+                t1 = ld4(plane + (long)o.y * C);
+                t2 = ld4(plane + (long)o.z * C);
+                t3 = ld4(plane + (long)(o.y + o.z - o.x) * C);
             }
+            __builtin_nontemporal_store((t0 * w.x + t1 * w.y) + (t2 * w.z + t3 * w.w),
+                                        reinterpret_cast<f32x4*>(out + (long)s_q[row] * 992));
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < SP_ROWS; ++u)
-            if (r0 + u < rows)
-                __builtin_nontemporal_store((t[u][0] * w[u][0] + t[u][1] * w[u][1]) + (t[u][2] * w[u][2] + t[u][3] * w[u][3]),
-                                            reinterpret_cast<f32x4*>(a.out + (img[u] * a.n_qry + __float_as_int(pt[u].z)) * 992 + 4 * cq));
     }
+}
+int launch_sample_pyramid_points(const float* grid, const int* perm, float* pts, int batch, long n_qry,
+                                 hipStream_t stream) {
+    SamplePyrArgs a = {};
+    a.grid = grid; a.perm = perm; a.pts = reinterpret_cast<float4*>(pts); a.batch = batch; a.n_qry = n_qry;
+    const long np = (long)batch * n_qry;
+    if (np <= 0) return 0;
+    hipLaunchKernelGGL(sample_pyramid_pts_kernel, dim3((unsigned)((np + 255) / 256 < 4096 ? (np + 255) / 256 : 4096)),
+                       dim3(256), 0, stream, a);
+    S3D_LAUNCH_CHECK();
+    return 0;
 }
 int launch_sample_pyramid(const float* const* level, const float* grid, const int* perm, float* pts, float* out,
                           int batch, int n_slices, int size, long n_qry, hipStream_t stream) {
@@ -966,11 +995,8 @@ int launch_sample_pyramid(const float* const* level, const float* grid, const in
     a.size = size; a.n_slices = n_slices; a.batch = batch; a.n_qry = n_qry;
     const long rows = (long)batch * n_slices * n_qry;
     if (rows <= 0) return 0;
-    const long np = (long)batch * n_qry;
-    hipLaunchKernelGGL(sample_pyramid_pts_kernel, dim3((unsigned)((np + 255) / 256 < 4096 ? (np + 255) / 256 : 4096)),
-                       dim3(256), 0, stream, a);
-    S3D_LAUNCH_CHECK();
-    const long blocks = (rows + SP_ROWS - 1) / SP_ROWS < 32768 ? (rows + SP_ROWS - 1) / SP_ROWS : 32768;
+    const long chunks = (long)batch * n_slices * ((n_qry + SP_CHUNK - 1) / SP_CHUNK);
+    const long blocks = chunks < 65536 ? chunks : 65536;
     hipLaunchKernelGGL(sample_pyramid_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     S3D_LAUNCH_CHECK();
     return 0;
