@@ -346,7 +346,7 @@ def main():
             wl = pmc["workload"]
             if (wl["img_size"], wl["n_slices"], wl["n_qry"], wl.get("batch", 1)) == (args.img_size, args.n_slices,
                                                                                       args.n_qry, args.batch):
-                kname = "ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_kernel<false>"
+                kname = "ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_pipe_kernel<false>"
                 traffic = pmc["kernels"][args.prec][kname]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -364,7 +364,7 @@ def main():
                                       "(fp32-class accuracy, passes the 1e-4 parity gate)"),
                        "img_size": args.img_size, "n_slices": args.n_slices, "n_qry": args.n_qry,
                        "objects_per_step": world * args.batch, "parallelism": "objects x%d (no collective)" % world},
-            "roofline": {"kernel": ("ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_kernel<false>")
+            "roofline": {"kernel": ("ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_pipe_kernel<0>")
                                    + " (decoder FFN 128->2048->128 + residual + LN2)",
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,

@@ -273,6 +273,9 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_kernel(const f
 // different chunks of the (unchanged) image.  lin1's bias is the accumulator's initial value.  Fragment reads are
 // issued one 12-MFMA group ahead; sched_group_barrier pins the interleave.
 // ---------------------------------------------------------------------------------------------
+#ifndef PIPE_R
+#define PIPE_R 2     // 16-row tiles per wave: 2 = two workgroups per CU (256 VGPRs), 4 = one (512 VGPRs, half the LDS / L2 traffic)
+#endif
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
@@ -333,22 +336,22 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
             }                                                                                                        \
             if ((K) == 0) {                                                                                          \
                 DS_WAIT4(2, bq[0], bq[1], fh[0], fl[0]);                                                             \
-                _Pragma("unroll") for (int r = 0; r < F16_R; ++r) { hn[0][r] = bq[0]; hn[1][r] = bq[1]; }            \
+                _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r) { hn[0][r] = bq[0]; hn[1][r] = bq[1]; }            \
             } else {                                                                                                 \
                 DS_WAIT2(2, fh[s], fl[s]);                                                                           \
             }                                                                                                        \
-            _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                        \
+            _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
                 hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xl[r][u], hn[a][r], 0, 0, 0);               \
-            _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                        \
+            _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
                 hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s], xh[r][u], hn[a][r], 0, 0, 0);               \
-            _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                        \
+            _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
                 hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xh[r][u], hn[a][r], 0, 0, 0);               \
         } else if ((K) == 7) {                                                                                       \
             DS_READ(vh[0], lw, 16384);                                                                               \
             DS_READ(vl[0], lw, 24576);                                                                               \
         }                                                                                                            \
-        if (((K) & 1) == 0) {                                                                                        \
-            constexpr int a2 = (K) >> 2, r2 = ((K) >> 1) & 1;                                                        \
+        if ((K) % (4 / PIPE_R) == 0) {   /* 2 * PIPE_R D tiles over the 8 groups */                                   \
+            constexpr int tile = (K) / (4 / PIPE_R), a2 = tile / PIPE_R, r2 = tile % PIPE_R;                         \
             relu_split4(hd[a2][r2], hh2[r2][2 * a2], hh2[r2][2 * a2 + 1], hl2[r2][2 * a2], hl2[r2][2 * a2 + 1]);     \
             /* tie the results into the side-effect chain: otherwise the low halves are emitted where they are */   \
             /* first USED (phase B), outside the MFMA cover */                                                       \
@@ -356,7 +359,7 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
                          "+v"(hh2[r2][2 * a2 + 1]));                                                                 \
         }                                                                                                            \
         if (!LAST) {                                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                          \
+            _Pragma("unroll") for (int i = 0; i < 3 * PIPE_R; ++i) {                                                 \
                 SGB(SG_MFMA, 1);                                                                                     \
                 SGB(SG_VALU, 3);                                                                                     \
             }                                                                                                        \
@@ -374,11 +377,11 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
         } else {                                                                                                     \
             DS_WAIT2(0, vh[s], vl[s]);                                                                               \
         }                                                                                                            \
-        _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                            \
+        _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                            \
             acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[s], hl[r], acc[r][J], 0, 0, 0);                    \
-        _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                            \
+        _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                            \
             acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[s], hh[r], acc[r][J], 0, 0, 0);                    \
-        _Pragma("unroll") for (int r = 0; r < F16_R; ++r)                                                            \
+        _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                            \
             acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[s], hh[r], acc[r][J], 0, 0, 0);                    \
         SB();                                                                                                        \
     }
@@ -388,10 +391,10 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
 // written here IS the issue order.  lw = LDS byte address of this lane's fragment slot in the current weight buffer,
 // lb = of its bias quad of the NEXT chunk.
 template <bool LAST>
-__device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned lb, const half8 (&xh)[F16_R][4],
-                                              const half8 (&xl)[F16_R][4], f32x4 (&acc)[F16_R][8],
-                                              const f32x4 (&hd)[2][F16_R], f32x4 (&hn)[2][F16_R]) {
-    half2v hh2[F16_R][4], hl2[F16_R][4];
+__device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned lb, const half8 (&xh)[PIPE_R][4],
+                                              const half8 (&xl)[PIPE_R][4], f32x4 (&acc)[PIPE_R][8],
+                                              const f32x4 (&hd)[2][PIPE_R], f32x4 (&hn)[2][PIPE_R]) {
+    half2v hh2[PIPE_R][4], hl2[PIPE_R][4];
     half8 fh[2], fl[2], vh[2], vl[2];
     f32x4 bq[2];
     if (!LAST) {
@@ -404,9 +407,9 @@ __device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned 
     // ---- phase A: hn = W1(c+1) x^T + b1(c+1)   beside   relu / split of hd (chunk c)
     FFN_GROUP_A(0) FFN_GROUP_A(1) FFN_GROUP_A(2) FFN_GROUP_A(3) FFN_GROUP_A(4) FFN_GROUP_A(5) FFN_GROUP_A(6) FFN_GROUP_A(7)
     // ---- phase B: acc += W2(c) h(c)
-    half8 hh[F16_R], hl[F16_R];
+    half8 hh[PIPE_R], hl[PIPE_R];
 #pragma unroll
-    for (int r = 0; r < F16_R; ++r) {
+    for (int r = 0; r < PIPE_R; ++r) {
         hh[r] = cat4(hh2[r][0], hh2[r][1], hh2[r][2], hh2[r][3]);
         hl[r] = cat4(hl2[r][0], hl2[r][1], hl2[r][2], hl2[r][3]);
     }
@@ -414,7 +417,7 @@ __device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_pipe_kernel(const float* X, float* Yout, long rows,
+__global__ __launch_bounds__(F16_THREADS, PIPE_R == 2 ? 2 : 1) void ffn_layer_f16x3_pipe_kernel(const float* X, float* Yout, long rows,
                                                                    const _Float16* wimg, const LayerPtrs w,
                                                                    const float* fco_w, const float* fco_b,
                                                                    float* sdf_out, float sign, long groups_per_batch,
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_pipe_kernel(co
     __shared__ __attribute__((aligned(16))) float s_b1[S3D_FFN];                                     // 8 KiB
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, g = lane >> 4;
-    const long row0 = ((long)blockIdx.x * F16_WAVES + wave) * (F16_R * 16);
+    const long row0 = ((long)blockIdx.x * F16_WAVES + wave) * (PIPE_R * 16);
 
     // prologue DMA: W1(0) -> buffer 1 (W1 half);  buffer 0 <- W1(1) | W2(0)
     dma_pieces(wimg, s_w1, 0, 16, wave, lane);
@@ -436,10 +439,10 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_pipe_kernel(co
     dma_pieces(wimg, s_w0, 16, 32, wave, lane);
     for (int i = threadIdx.x; i < S3D_FFN / 4; i += F16_THREADS) st4(s_b1 + 4 * i, ld4(w.b1 + 4 * i));
 
-    half8 xh[F16_R][4], xl[F16_R][4];
-    f32x4 acc[F16_R][8];
+    half8 xh[PIPE_R][4], xl[PIPE_R][4];
+    f32x4 acc[PIPE_R][8];
 #pragma unroll
-    for (int r = 0; r < F16_R; ++r) {
+    for (int r = 0; r < PIPE_R; ++r) {
         long row = row0 + r * 16 + m;
         if (row >= rows) row = rows - 1;
         const float* p = X + row * 128 + 8 * g;
@@ -457,24 +460,24 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_pipe_kernel(co
     const unsigned lw0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_w0 + lane * 8);
     const unsigned lw1 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_w1 + lane * 8);
     const unsigned lb0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_b1 + 4 * g);
-    f32x4 hdA[2][F16_R], hdB[2][F16_R];   // pre-activations (bias included) of the current / next chunk, D tiles a = 0,1
+    f32x4 hdA[2][PIPE_R], hdB[2][PIPE_R];   // pre-activations (bias included) of the current / next chunk, D tiles a = 0,1
     {
         const _Float16* sw = s_w1;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int r = 0; r < F16_R; ++r) hdA[a][r] = *reinterpret_cast<const f32x4*>(sb + 16 * a);
+            for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = *reinterpret_cast<const f32x4*>(sb + 16 * a);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const half8 fh = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8), fl = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
 #pragma unroll
-                for (int r = 0; r < F16_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xl[r][u], hdA[a][r], 0, 0, 0);
+                for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xl[r][u], hdA[a][r], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < F16_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, xh[r][u], hdA[a][r], 0, 0, 0);
+                for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, xh[r][u], hdA[a][r], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < F16_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xh[r][u], hdA[a][r], 0, 0, 0);
+                for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xh[r][u], hdA[a][r], 0, 0, 0);
             }
     }
     __syncthreads();   // every wave is done with buffer 1 before the first refill overwrites it
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_pipe_kernel(co
 
     // epilogue (identical to ffn_layer_f16x3_kernel): tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
 #pragma unroll
-    for (int r = 0; r < F16_R; ++r) {
+    for (int r = 0; r < PIPE_R; ++r) {
         const long row = row0 + r * 16 + m;
         f32x4 y[8];
         float s = 0.f;
@@ -573,6 +576,7 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
     const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
     FfnTrainArgs ta = {};
     if (ffn_pipelined()) {
+        const long blocks = (rows + F16_WAVES * PIPE_R * 16 - 1) / (F16_WAVES * PIPE_R * 16);
         if (sdf_out)
             hipLaunchKernelGGL(ffn_layer_f16x3_pipe_kernel<1>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X,
                                rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
