@@ -43,6 +43,11 @@ extern "C" {
 #define S3D_PREC_F32 0           /* v_mfma_f32_16x16x4_f32: exact fp32, the parity mode */
 #define S3D_PREC_F16X3 1         /* fp32 operands split into f16 hi+lo, 3 f16 MFMAs per product (22-bit
                                     significands, fp32 accumulate): fp32-class results; conv / attention / FFN */
+#define S3D_PREC_F16 2           /* THROUGHPUT MODE, not fp32-class: operands rounded to f16, ONE f16 MFMA per product,
+                                  * fp32 accumulation and fp32 everywhere else (LayerNorm, softmax, sampling).  What
+                                  * BASELINE configs[1]'s "bf16" names; fails the 1e-4 parity gate by construction and is
+                                  * reported separately with its measured error (bench.py `throughput_mode_f16`).
+                                  * Inference entry points of Slices3DRegModel / Slices3DGTModel only. */
 
 int s3d_version(void);
 const char* s3d_last_error(void);           /* thread-local, valid until the next failing call */

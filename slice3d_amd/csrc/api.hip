@@ -271,7 +271,8 @@ extern "C" size_t s3d_unet_workspace_bytes(int batch, int size, int n_slices) {
 static int g_desc_prec = S3D_PREC_F32;   // set by the entry point that builds descriptors (host, single stream)
 static ConvLaunch conv_desc(const float* base, const PackedConv& pc, int N, int H, int W, int ks, int act) {
     ConvLaunch c = {};
-    c.wpk16 = g_desc_prec == S3D_PREC_F16X3 ? (const void*)(base + pc.w16) : nullptr;
+    c.wpk16 = g_desc_prec != S3D_PREC_F32 ? (const void*)(base + pc.w16) : nullptr;
+    c.single_pass = g_desc_prec == S3D_PREC_F16;
     c.N = N; c.H = H; c.W = W; c.ks = ks;
     c.CoutPad = pc.cout_pad; c.wpk = base + pc.w; c.KU = pc.KU;
     c.scale = base + pc.scale; c.shift = base + pc.shift;
@@ -284,7 +285,7 @@ extern "C" int s3d_unet_encode_fwd(const void* packed, const float* img, const S
                                    float* slices_rec, int B, int S, int ns, int prec, void* workspace,
                                    size_t workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3, "unet_encode: precision mode %d", prec);
+    S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3 || prec == S3D_PREC_F16, "unet_encode: precision mode %d", prec);
     struct PrecScope { PrecScope(int p) { g_desc_prec = p; } ~PrecScope() { g_desc_prec = S3D_PREC_F32; } } ps_(prec);
     S3D_CHECK_ARG(packed && img && out && workspace, "unet_encode: null argument");
     S3D_CHECK_ARG(B >= 1 && S >= 16 && S % 16 == 0, "unet_encode: B=%d S=%d (S must be a multiple of 16)", B, S);
@@ -639,7 +640,8 @@ extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, 
         ConvLaunch c = {};
         c.N = pyr->n_img; c.H = r; c.W = r; c.ks = 1;
         c.CoutPad = 128; c.wpk = b + H.wproj[l]; c.KU = lc[l] / 16;
-        c.wpk16 = prec == S3D_PREC_F16X3 ? (const void*)(b + H.wproj16[l]) : nullptr;
+        c.wpk16 = prec != S3D_PREC_F32 ? (const void*)(b + H.wproj16[l]) : nullptr;
+        c.single_pass = prec == S3D_PREC_F16;
         c.scale = nullptr; c.shift = nullptr;  // identity epilogue: fc_s bias is added by the sampler
         c.act = S3D_ACT_NONE; c.out_mode = S3D_OUT_NHWC; c.cout_store = 128; c.out_cstride = 128;
         c.nsrc = 1;
@@ -712,7 +714,8 @@ static int rows_linear(const float* b, size_t w32, size_t w16, int n, int k, con
     ConvLaunch c = {};
     c.N = 1; c.H = 1; c.W = (int)nrows; c.ks = 1;
     c.CoutPad = n; c.wpk = b + w32; c.KU = k / 16;
-    c.wpk16 = prec == S3D_PREC_F16X3 ? (const void*)(b + w16) : nullptr;
+    c.wpk16 = prec != S3D_PREC_F32 ? (const void*)(b + w16) : nullptr;
+        c.single_pass = prec == S3D_PREC_F16;
     c.shift = bias; c.act = S3D_ACT_NONE;
     c.out_mode = S3D_OUT_NHWC; c.cout_store = n; c.out_cstride = n;
     c.nsrc = 1;
@@ -745,7 +748,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
     S3D_CHECK_ARG(batch >= 1 && n_qry >= 1, "decode: batch=%d n_qry=%ld", batch, n_qry);
     S3D_CHECK_ARG(ns >= 1 && ns <= 12, "decode: n_slices %d", ns);
     S3D_CHECK_ARG(lat->n_img == batch * ns, "decode: latent has %d images, expected %d", lat->n_img, batch * ns);
-    S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3, "decode: precision mode %d not built", prec);
+    S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3 || prec == S3D_PREC_F16, "decode: precision mode %d not built", prec);
     const DecodeWs W = decode_ws(batch, n_qry, ns);
     if (workspace_bytes < W.total * sizeof(float)) {
         s3d_set_error("decode: workspace %zu < %zu bytes", workspace_bytes, W.total * sizeof(float));
@@ -786,9 +789,9 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
                 ProfScope prof_(S3D_PROF_ATTN, st);
                 if (last && attn_last_absorbed())
                     TRY(attn_last_layer(b, H, lp, X, X0, gc, T, (float*)workspace + W.last, prec, st));
-                else if (prec == S3D_PREC_F16X3 && !last && attn_query_major())
-                    TRY(launch_attn_layer_q(X, gc, T, lp, st));
-                else if (prec == S3D_PREC_F16X3)
+                else if (prec != S3D_PREC_F32 && !last && attn_query_major())
+                    TRY(launch_attn_layer_q(X, gc, T, lp, st, prec == S3D_PREC_F16));
+                else if (prec != S3D_PREC_F32)
                     TRY(launch_attn_layer_f16x3(X, last ? X0 : nullptr, gc, T, lp, st));
                 else
                     TRY(launch_attn_layer(X, last ? X0 : nullptr, gc, T, lp, st));

@@ -28,6 +28,7 @@ struct ConvLaunch {
     int KU;              // total K chunks = sum over sources of ks*ks*C/16
     const void* wpk16;   // optional split-precision image: f16 hi/lo fragment pairs [CoutPad/16][KU/2][2][64][8]
                          // (K chunks of 32); used when non-NULL and every source has C % 32 == 0
+    int single_pass;     // with wpk16: only the hi*hi product (one f16 MFMA per product, S3D_PREC_F16: NOT fp32-class)
     const float* scale;  // [CoutPad]  y = acc*scale + shift   (BN folded / bias)
     const float* shift;  // [CoutPad]
     int act;

@@ -265,12 +265,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
+                    if (!a.single_pass) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bl[mt], acc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bl[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bh[mt], acc[mt][nt], 0, 0, 0);
@@ -364,12 +366,14 @@ __global__ __launch_bounds__(256, 2) void lin_rows_f16x3_kernel(const ConvLaunch
                 }
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
+                    if (!a.single_pass) {
 #pragma unroll
-                    for (int mt = 0; mt < LR_MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1][nt], LR_XL(mt, u), acc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt < LR_MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1][nt], LR_XL(mt, u), acc[mt][nt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < LR_MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u & 1][nt], LR_XH(mt, u), acc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt < LR_MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u & 1][nt], LR_XH(mt, u), acc[mt][nt], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int mt = 0; mt < LR_MT; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1][nt], LR_XH(mt, u), acc[mt][nt], 0, 0, 0);
@@ -527,12 +531,14 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                if (!a.single_pass) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bl[mt], acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bl[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bh[mt], acc[mt][nt], 0, 0, 0);

@@ -128,7 +128,7 @@ int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipS
 int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
                                  const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
                                  hipStream_t stream);
-int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream);
+int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass = false);
 // Last layer, token 0 only (models.py:83 consumes nothing else), with the projections absorbed.  Per head h, with
 // q = Wq_h x0 + bq_h:   score_h[t] = q . (Wk_h x_t + bk_h) = (M_h x0 + m_h) . x_t + const   (const cancels in the softmax)
 //                       M_h = Wk_h^T Wq_h (128x128),  m_h = Wk_h^T bq_h
@@ -146,7 +146,7 @@ int launch_absorb_last(const float* in_w, const float* in_b, const float* out_w,
 int launch_pack_attn_q_f16x3(const float* win, const float* wout, float* out, hipStream_t stream);
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
-                           long g_begin, const int* perm, hipStream_t stream);
+                           long g_begin, const int* perm, hipStream_t stream, bool single_pass = false);
 int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream);
 int launch_attn_layer_f16x3(float* X, float* x0_out, long groups, int T, const LayerPtrs& w, hipStream_t stream);
 int launch_pack_attn_f16x3(const float* win, const float* wout, float* out, hipStream_t stream);

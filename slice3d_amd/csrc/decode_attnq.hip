@@ -31,9 +31,12 @@ __device__ __forceinline__ void splitq8(const float (&x)[8], half8q& hi, half8q&
         lo[t] = (_Float16)(x[t] - (float)h);
     }
 }
+template <bool SINGLE>
 __device__ __forceinline__ f32x4 mfma3q(const half8q ah, const half8q al, const half8q bh, const half8q bl, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+    if (!SINGLE) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+    }
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
     return c;
 }
@@ -59,6 +62,7 @@ __device__ __forceinline__ float colmax16(float v) {
 // ---------------------------------------------------------------------------------------------
 #define AQ3_SLOT_HALFS (8 * 1024)    // 8 fragment pairs = 16 KiB
 #define AQ3_XROW_HALFS (4 * 1024)    // per wave: 2 tiles x 4 k-steps x 64 lanes x 8 halfs
+template <bool SINGLE>   // SINGLE: S3D_PREC_F16, one f16 MFMA per projection product (the 13x13 core stays on the fp32 MFMA)
 __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long groups, int T, const _Float16* wimg,
                                                                const LayerPtrs w) {
     extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // ring 2 x 16 KiB, then the rows 4 x 8 KiB
@@ -150,11 +154,11 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         if (part < 2) {   // D^T = W X^T
-                            d[0][j] = mfma3q(fh[u & 1][j], fl[u & 1][j], x0, xl[0][u], d[0][j]);
-                            d[1][j] = mfma3q(fh[u & 1][j], fl[u & 1][j], x1, xl[1][u], d[1][j]);
+                            d[0][j] = mfma3q<SINGLE>(fh[u & 1][j], fl[u & 1][j], x0, xl[0][u], d[0][j]);
+                            d[1][j] = mfma3q<SINGLE>(fh[u & 1][j], fl[u & 1][j], x1, xl[1][u], d[1][j]);
                         } else {          // D = X W^T
-                            d[0][j] = mfma3q(x0, xl[0][u], fh[u & 1][j], fl[u & 1][j], d[0][j]);
-                            d[1][j] = mfma3q(x1, xl[1][u], fh[u & 1][j], fl[u & 1][j], d[1][j]);
+                            d[0][j] = mfma3q<SINGLE>(x0, xl[0][u], fh[u & 1][j], fl[u & 1][j], d[0][j]);
+                            d[1][j] = mfma3q<SINGLE>(x1, xl[1][u], fh[u & 1][j], fl[u & 1][j], d[1][j]);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                         for (int r = 0; r < 2; ++r)
-                            acc_o[r][4 * half + jj] = mfma3q(wh[jj], wl[jj], oh[r], ol[r], acc_o[r][4 * half + jj]);
+                            acc_o[r][4 * half + jj] = mfma3q<SINGLE>(wh[jj], wl[jj], oh[r], ol[r], acc_o[r][4 * half + jj]);
                 }
             }
             ++ps;
@@ -277,18 +281,23 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
     }
 }
 
-int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream) {
+int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass) {
     if (groups <= 0) return 0;
     S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr, "attn_q: T %d", T);
     const size_t lds = (size_t)(2 * AQ3_SLOT_HALFS + 4 * AQ3_XROW_HALFS) * 2;   // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long blocks = 2 * groups < 4096 ? 2 * groups : 4096;
-    hipLaunchKernelGGL(attn_layer_q_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T,
-                       reinterpret_cast<const _Float16*>(w.aq16), w);
+    if (single_pass)
+        hipLaunchKernelGGL(attn_layer_q_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T,
+                           reinterpret_cast<const _Float16*>(w.aq16), w);
+    else
+        hipLaunchKernelGGL(attn_layer_q_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T,
+                           reinterpret_cast<const _Float16*>(w.aq16), w);
     S3D_LAUNCH_CHECK();
     return 0;
 }

@@ -340,10 +340,12 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
             } else {                                                                                                 \
                 DS_WAIT2(2, fh[s], fl[s]);                                                                           \
             }                                                                                                        \
-            _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
-                hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xl[r][u], hn[a][r], 0, 0, 0);               \
-            _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
-                hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s], xh[r][u], hn[a][r], 0, 0, 0);               \
+            if (!SINGLE) {                                                                                           \
+                _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                    \
+                    hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xl[r][u], hn[a][r], 0, 0, 0);           \
+                _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                    \
+                    hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s], xh[r][u], hn[a][r], 0, 0, 0);           \
+            }                                                                                                        \
             _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
                 hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xh[r][u], hn[a][r], 0, 0, 0);               \
         } else if ((K) == 7) {                                                                                       \
@@ -359,9 +361,9 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
                          "+v"(hh2[r2][2 * a2 + 1]));                                                                 \
         }                                                                                                            \
         if (!LAST) {                                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < 3 * PIPE_R; ++i) {                                                 \
+            _Pragma("unroll") for (int i = 0; i < (SINGLE ? 1 : 3) * PIPE_R; ++i) {                                  \
                 SGB(SG_MFMA, 1);                                                                                     \
-                SGB(SG_VALU, 3);                                                                                     \
+                SGB(SG_VALU, SINGLE ? 9 : 3);                                                                        \
             }                                                                                                        \
         }                                                                                                            \
         SB();                                                                                                        \
@@ -377,10 +379,12 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
         } else {                                                                                                     \
             DS_WAIT2(0, vh[s], vl[s]);                                                                               \
         }                                                                                                            \
-        _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                            \
-            acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[s], hl[r], acc[r][J], 0, 0, 0);                    \
-        _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                            \
-            acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[s], hh[r], acc[r][J], 0, 0, 0);                    \
+        if (!SINGLE) {                                                                                               \
+            _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
+                acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[s], hl[r], acc[r][J], 0, 0, 0);                \
+            _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
+                acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[s], hh[r], acc[r][J], 0, 0, 0);                \
+        }                                                                                                            \
         _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                            \
             acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[s], hh[r], acc[r][J], 0, 0, 0);                    \
         SB();                                                                                                        \
@@ -390,7 +394,7 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
 // pre-activations costs no moves).  Every group of 6 MFMAs is its own scheduling region (sched_barrier): the order
 // written here IS the issue order.  lw = LDS byte address of this lane's fragment slot in the current weight buffer,
 // lb = of its bias quad of the NEXT chunk.
-template <bool LAST>
+template <bool LAST, bool SINGLE>
 __device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned lb, const half8 (&xh)[PIPE_R][4],
                                               const half8 (&xl)[PIPE_R][4], f32x4 (&acc)[PIPE_R][8],
                                               const f32x4 (&hd)[2][PIPE_R], f32x4 (&hn)[2][PIPE_R]) {
@@ -416,7 +420,8 @@ __device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned 
     FFN_GROUP_B(0) FFN_GROUP_B(1) FFN_GROUP_B(2) FFN_GROUP_B(3) FFN_GROUP_B(4) FFN_GROUP_B(5) FFN_GROUP_B(6) FFN_GROUP_B(7)
 }
 
-template <int MODE>
+// SINGLE: S3D_PREC_F16 — only the hi*hi product of every split (one MFMA per product; not fp32-class)
+template <int MODE, bool SINGLE>
 __global__ __launch_bounds__(F16_THREADS, PIPE_R == 2 ? 2 : 1) void ffn_layer_f16x3_pipe_kernel(const float* X, float* Yout, long rows,
                                                                    const _Float16* wimg, const LayerPtrs w,
                                                                    const float* fco_w, const float* fco_b,
@@ -473,9 +478,11 @@ __global__ __launch_bounds__(F16_THREADS, PIPE_R == 2 ? 2 : 1) void ffn_layer_f1
             for (int a = 0; a < 2; ++a) {
                 const half8 fh = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8), fl = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
 #pragma unroll
-                for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xl[r][u], hdA[a][r], 0, 0, 0);
+                for (int r = 0; r < PIPE_R; ++r)
+                    if (!SINGLE) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xl[r][u], hdA[a][r], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, xh[r][u], hdA[a][r], 0, 0, 0);
+                for (int r = 0; r < PIPE_R; ++r)
+                    if (!SINGLE) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, xh[r][u], hdA[a][r], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xh[r][u], hdA[a][r], 0, 0, 0);
             }
@@ -490,21 +497,21 @@ __global__ __launch_bounds__(F16_THREADS, PIPE_R == 2 ? 2 : 1) void ffn_layer_f1
         dma_pieces(wimg + (size_t)(c + 2) * F16_CHUNK_HALFS, s_w1, 0, 16, wave, lane);
         dma_pieces(wimg + (size_t)(c + 1) * F16_CHUNK_HALFS, s_w1, 16, 32, wave, lane);
         SB();
-        ffn_pipe_iter<false>(lw0, lb0 + (c + 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB);
+        ffn_pipe_iter<false, SINGLE>(lw0, lb0 + (c + 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB);
         dma_publish_barrier();
         dma_pieces(wimg + (size_t)(c + 3) * F16_CHUNK_HALFS, s_w0, 0, 16, wave, lane);
         dma_pieces(wimg + (size_t)(c + 2) * F16_CHUNK_HALFS, s_w0, 16, 32, wave, lane);
         SB();
-        ffn_pipe_iter<false>(lw1, lb0 + (c + 2) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdB, hdA);
+        ffn_pipe_iter<false, SINGLE>(lw1, lb0 + (c + 2) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdB, hdA);
         dma_publish_barrier();
     }
     // c = NC-2: buffer 0 holds W1(NC-1) | W2(NC-2); only W2(NC-1) is left to fetch (the W1 half: any valid chunk)
     dma_pieces(wimg + (size_t)(NC - 1) * F16_CHUNK_HALFS, s_w1, 0, 16, wave, lane);
     dma_pieces(wimg + (size_t)(NC - 1) * F16_CHUNK_HALFS, s_w1, 16, 32, wave, lane);
     SB();
-    ffn_pipe_iter<false>(lw0, lb0 + (NC - 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB);
+    ffn_pipe_iter<false, SINGLE>(lw0, lb0 + (NC - 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB);
     dma_publish_barrier();
-    ffn_pipe_iter<true>(lw1, lb0, xh, xl, acc, hdB, hdA);
+    ffn_pipe_iter<true, SINGLE>(lw1, lb0, xh, xl, acc, hdB, hdA);
 
     // epilogue (identical to ffn_layer_f16x3_kernel): tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
 #pragma unroll
@@ -570,18 +577,29 @@ static bool ffn_pipelined() {
 
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
-                           long g_begin, const int* perm, hipStream_t stream) {
+                           long g_begin, const int* perm, hipStream_t stream, bool single_pass) {
     if (rows <= 0) return 0;
     const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
     const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
     FfnTrainArgs ta = {};
+    if (single_pass) {
+        const long blocks = (rows + F16_WAVES * PIPE_R * 16 - 1) / (F16_WAVES * PIPE_R * 16);
+        if (sdf_out)
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, true>), dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream,
+                               X, X, rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
+        else
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, true>), dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream,
+                               X, X, rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
+        S3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (ffn_pipelined()) {
         const long blocks = (rows + F16_WAVES * PIPE_R * 16 - 1) / (F16_WAVES * PIPE_R * 16);
         if (sdf_out)
-            hipLaunchKernelGGL(ffn_layer_f16x3_pipe_kernel<1>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X,
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, false>), dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X,
                                rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
         else
-            hipLaunchKernelGGL(ffn_layer_f16x3_pipe_kernel<0>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X,
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, false>), dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X,
                                rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
         S3D_LAUNCH_CHECK();
         return 0;

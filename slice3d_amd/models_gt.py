@@ -100,7 +100,7 @@ class Slices3DGTModel(nn.Module):
         return t.to(device=self._device(), dtype=torch.float32).contiguous()
 
     def _prec(self):
-        return _lib.PREC_F16X3 if self.prec == "f16x3" else _lib.PREC_F32
+        return {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16": _lib.PREC_F16}[self.prec]
 
     def _params_key(self):
         return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))

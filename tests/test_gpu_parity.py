@@ -484,3 +484,25 @@ def test_white_noise_images_within_the_reference_rounding_floor(prec):
     e_img = (out["slices_rec"].cpu().double() - r64["slices_rec"]).abs().max()
     e_img_ref = (r32["slices_rec"].double() - r64["slices_rec"]).abs().max()
     assert float(e_img) <= float(e_img_ref) + 5e-5
+
+
+def test_single_pass_f16_throughput_mode_runs_and_reports_its_error():
+    """prec='f16' (S3D_PREC_F16): operands rounded to f16, ONE MFMA per product — the "bf16" of BASELINE configs[1].
+    Not fp32-class: it must NOT be expected to meet the 1e-4 gate; this test pins that it runs through every kernel
+    (U-Net convs, latent build, attention, FFN, last-layer GEMMs), stays a sane approximation (1e-2 on sdf, 5e-3 on the
+    slice images, for these weights) and is measurably different from the split-precision mode."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    m16 = get_model(12, "test", "f16")
+    m3 = get_model(12, "test", "f16x3")
+    sd = seeded_sd_from_shapes(_shapes(12))
+    fd = make_feed_dict(1, 64, 6000, 12, seed=55, with_slices=False)
+    a = m16(to_gpu(fd))
+    b = m3(to_gpu(fd))
+    ref = ref_cpu.forward(sd, fd, mode="test", n_slices=12, with_vgg=False)
+    e_sdf = float((a["sdf_pred"].cpu() - ref["sdf_pred"]).abs().max())
+    e_img = float((a["slices_rec"].cpu() - ref["slices_rec"]).abs().max())
+    e3 = float((b["sdf_pred"].cpu() - ref["sdf_pred"]).abs().max())
+    print("single-pass f16: max|sdf - oracle| %.3e (f16x3: %.3e), max|slices_rec - oracle| %.3e" % (e_sdf, e3, e_img))
+    assert torch.isfinite(a["sdf_pred"]).all()
+    assert e3 < TOL < e_sdf < 1e-2 and e_img < 5e-3
