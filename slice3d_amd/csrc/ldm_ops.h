@@ -3,7 +3,8 @@
 #include "common.h"
 
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
-                      int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream);
+                      int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream,
+                      const float* x1 = nullptr, int C0 = 0);   // x1: second source, channels [C0, C) of the input
 int launch_qkv_attention(const float* qkv, float* out, int N, int T, int heads, int ch, int prec, hipStream_t stream);
 int launch_resample2x(const float* x, float* y, int N, int H, int W, int C, int up, hipStream_t stream);
 int launch_small_linear(const float* x, const float* w, const float* b, float* out, int N, int K, int M, int silu_in,

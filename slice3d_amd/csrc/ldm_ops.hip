@@ -11,14 +11,25 @@
 // Stage 1: block (image, group, slice) -> (count, mean, M2) of its slice of the HW pixels (two passes over the slice,
 // which stays in L2).  Stage 2 (inside the apply kernel): the slices are merged with Chan's parallel-variance formula.
 #define GN_SLICES 16
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int HW, int C, int groups,
+// Input = channel concatenation of x (C0 channels) and x1 (C - C0 channels; NULL when C0 == C): the th.cat([h, hs.pop()],
+// dim=1) in front of the output blocks' first ResBlock (openaimodel.py:750) is never materialised — the GroupNorm groups
+// straddle the two tensors, so the concatenation happens in this kernel's loads (its OUTPUT is one tensor).
+struct GnSrc {
+    const float* x;
+    const float* x1;
+    int C0;
+    __device__ __forceinline__ float at(long n_hw_p, int c, int C) const {   // element (pixel index over N*HW, channel)
+        return c < C0 ? x[n_hw_p * C0 + c] : x1[n_hw_p * (C - C0) + (c - C0)];
+    }
+};
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnSrc src, int HW, int C, int groups,
                                                        float* __restrict__ part) {
     __shared__ float red[4];
     const int sl = blockIdx.x % GN_SLICES;
     const int gidx = (blockIdx.x / GN_SLICES) % groups, n = blockIdx.x / (GN_SLICES * groups);
     const int cpg = C / groups;
     const int p0 = (int)((long)HW * sl / GN_SLICES), p1 = (int)((long)HW * (sl + 1) / GN_SLICES);
-    const float* base = x + ((long)n * HW + p0) * C + gidx * cpg;
+    const long pbase = (long)n * HW + p0;
     const long total = (long)(p1 - p0) * cpg;
     auto block_sum = [&](float v) {
 #pragma unroll
@@ -29,11 +40,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         return (red[0] + red[1]) + (red[2] + red[3]);
     };
     float s = 0.f;
-    for (long i = threadIdx.x; i < total; i += 256) s += base[(i / cpg) * C + i % cpg];
+    for (long i = threadIdx.x; i < total; i += 256) s += src.at(pbase + i / cpg, gidx * cpg + (int)(i % cpg), C);
     const float mean = total > 0 ? block_sum(s) / (float)total : 0.f;
     float v = 0.f;
     for (long i = threadIdx.x; i < total; i += 256) {
-        const float d = base[(i / cpg) * C + i % cpg] - mean;
+        const float d = src.at(pbase + i / cpg, gidx * cpg + (int)(i % cpg), C) - mean;
         v += d * d;
     }
     const float m2 = block_sum(v);
@@ -45,7 +56,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 }
 // y = gn(x) * gamma + beta ; optional FiLM (ResBlock use_scale_shift_norm): y = y * (1 + scale[n,c]) + shift[n,c]
 // with film = [N][2C] (scale | shift) ; optional SiLU.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ part,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnSrc src, const float* __restrict__ part,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ film, float* __restrict__ y, int N,
                                                        int HW, int C, int groups, float eps, int silu) {
@@ -72,7 +83,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         const int c = (int)(idx % c4n) * 4;
         const long p = idx / c4n;
         const int n = (int)(p / HW);
-        const f32x4 v = ld4(x + p * C + c);
+        const f32x4 v = c < src.C0 ? ld4(src.x + p * src.C0 + c) : ld4(src.x1 + p * (C - src.C0) + (c - src.C0));   // C0 % 4 == 0
         const f32x4 ga = ld4(gamma + c), be = ld4(beta + c);
         f32x4 o;
 #pragma unroll
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 // the normalised values - statistics, apply, FiLM and SiLU in one pass over the data instead of two launches
 // (the denoising step has 92 GroupNorms, most of them a few microseconds of launch latency each).
 template <int EPT>
-__global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ film,
                                                         float* __restrict__ y, int HW, int C, int groups, float eps,
                                                         int silu) {
@@ -101,7 +112,6 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
     const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
     const int cpg = C / groups;
     const long total = (long)HW * cpg;
-    const float* base = x + (long)n * HW * C + gidx * cpg;
     float* obase = y + (long)n * HW * C + gidx * cpg;
     auto block_sum = [&](float v) {
 #pragma unroll
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         const long i = threadIdx.x + 1024L * k;
-        v[k] = i < total ? base[(i / cpg) * C + i % cpg] : 0.f;
+        v[k] = i < total ? src.at((long)n * HW + i / cpg, gidx * cpg + (int)(i % cpg), C) : 0.f;
         s += v[k];
     }
     const float mean = block_sum(s) / (float)total;
@@ -145,8 +155,12 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
 }
 
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
-                      int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream) {
+                      int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream, const float* x1,
+                      int C0) {
     S3D_CHECK_ARG(C % groups == 0 && C % 4 == 0 && N >= 1 && HW >= 1, "group_norm: C=%d groups=%d", C, groups);
+    if (!x1) C0 = C;
+    S3D_CHECK_ARG(C0 >= 4 && C0 <= C && C0 % 4 == 0 && (C - C0) % 4 == 0, "group_norm: source split %d | %d", C0, C - C0);
+    const GnSrc src = {x, x1, C0};
     {
         static const bool two_pass = getenv("S3D_GN_TWO_PASS") != nullptr;
         const long per_thread = ((long)HW * (C / groups) + 1023) / 1024;
@@ -154,7 +168,7 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
             const dim3 grid((unsigned)(N * groups));
 #define GN_CASE(e)                                                                                                     \
     if (per_thread <= e) {                                                                                             \
-        hipLaunchKernelGGL((gn_fused_kernel<e>), grid, dim3(1024), 0, stream, x, gamma, beta, film, y, HW, C, groups, eps, \
+        hipLaunchKernelGGL((gn_fused_kernel<e>), grid, dim3(1024), 0, stream, src, gamma, beta, film, y, HW, C, groups, eps, \
                            silu);                                                                                      \
         S3D_LAUNCH_CHECK();                                                                                            \
         return 0;                                                                                                      \
@@ -164,11 +178,11 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
         }
     }
     S3D_CHECK_ARG((size_t)N * groups * 2 * sizeof(float) <= 48 * 1024, "group_norm: N*groups %d too large", N * groups);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, x, HW, C, groups, stats);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, src, HW, C, groups, stats);
     S3D_LAUNCH_CHECK();
     const long total = (long)N * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), (size_t)N * groups * 2 * sizeof(float), stream, x, stats,
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), (size_t)N * groups * 2 * sizeof(float), stream, src, stats,
                        gamma, beta, film, y, N, HW, C, groups, eps, silu);
     S3D_LAUNCH_CHECK();
     return 0;

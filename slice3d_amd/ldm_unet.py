@@ -41,6 +41,7 @@ class ResBlock(nn.Module):
                                         nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1))
         self.skip_connection = (nn.Identity() if self.out_channels == channels
                                 else nn.Conv2d(channels, self.out_channels, 1))
+        self.cat_split = None     # (C_h, C_skip) when the block's input is th.cat([h, hs.pop()]) (output blocks)
 
 
 class AttentionBlock(nn.Module):
@@ -90,6 +91,7 @@ class UNetModel(nn.Module):
             for i in range(num_res_blocks + 1):
                 ich = chans.pop()
                 layers = [ResBlock(ch + ich, ted, dropout, model_channels * mult, use_scale_shift_norm)]
+                layers[0].cat_split = (ch, ich)
                 ch = model_channels * mult
                 if ds in attention_resolutions:
                     layers.append(AttentionBlock(ch, num_heads))
@@ -148,8 +150,8 @@ class UNetModel(nn.Module):
             if isinstance(mod, ResBlock):
                 self._packed[id(mod.in_layers[2])] = self._pack_conv(mod.in_layers[2])
                 self._packed[id(mod.out_layers[3])] = self._pack_conv(mod.out_layers[3])
-                if isinstance(mod.skip_connection, nn.Conv2d):
-                    self._packed[id(mod.skip_connection)] = self._pack_conv(mod.skip_connection)
+                if isinstance(mod.skip_connection, nn.Conv2d):   # two-source K loop over (h, skip) for the output blocks
+                    self._packed[id(mod.skip_connection)] = self._pack_conv(mod.skip_connection, split=mod.cat_split)
             elif isinstance(mod, AttentionBlock):
                 self._packed[id(mod.qkv)] = self._pack_conv(mod.qkv)
                 self._packed[id(mod.proj_out)] = self._pack_conv(mod.proj_out)
@@ -182,11 +184,21 @@ class UNetModel(nn.Module):
                                     self._stream()), "s3d_conv_fwd")
         return out
 
-    def _group_norm(self, gn, x, film=None, silu=True):
+    def _group_norm(self, gn, x, film=None, silu=True, x1=None):
+        """GroupNorm(+FiLM)(+SiLU) of x, or of the channel concatenation [x, x1] (never materialised)."""
         lib = self._lib
         n, h, w, c = x.shape
-        y = torch.empty_like(x)
         stats = torch.empty((n, gn.num_groups, 50), dtype=torch.float32, device=x.device)
+        if x1 is not None:
+            c1 = x1.shape[-1]
+            y = torch.empty((n, h, w, c + c1), dtype=torch.float32, device=x.device)
+            _lib.check(lib.s3d_group_norm2_fwd(x.data_ptr(), c, x1.data_ptr(), c1, gn.weight.data_ptr(),
+                                               gn.bias.data_ptr(), film.data_ptr() if film is not None else None,
+                                               y.data_ptr(), stats.data_ptr(), n, h * w, gn.num_groups,
+                                               C.c_float(gn.eps), 1 if silu else 0, self._stream()),
+                       "s3d_group_norm2_fwd")
+            return y
+        y = torch.empty_like(x)
         _lib.check(lib.s3d_group_norm_fwd(x.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(),
                                           film.data_ptr() if film is not None else None, y.data_ptr(), stats.data_ptr(),
                                           n, h * w, c, gn.num_groups, C.c_float(gn.eps), 1 if silu else 0,
@@ -231,17 +243,15 @@ class UNetModel(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _res_block(self, blk, x, emb, skip=None):
         """ResBlock._forward (openaimodel.py:253-275); x (and skip: the block input is cat([x, skip]))."""
-        if skip is not None:
-            # th.cat([h, hs.pop()], dim=1) (openaimodel.py:750): GroupNorm groups straddle the two sources, so the
-            # concatenation is materialised (a copy, no arithmetic)
-            xin = torch.cat([x, skip], dim=-1)
-        else:
-            xin = x
-        h = self._group_norm(blk.in_layers[0], xin, silu=True)
-        xs = xin
+        # th.cat([h, hs.pop()], dim=1) (openaimodel.py:750) is never built: the GroupNorm reads both tensors (its groups
+        # straddle them) and the 1x1 skip_connection walks them as the two sources of its K loop
+        h = self._group_norm(blk.in_layers[0], x, silu=True, x1=skip)
+        xs = x
         if blk.up or blk.down:
+            if skip is not None:
+                raise NotImplementedError("resampling ResBlock on a concatenated input (not in this architecture)")
             h = self._resample(h, blk.up)
-            xs = self._resample(xin, blk.up)
+            xs = self._resample(x, blk.up)
         h = self._conv(blk.in_layers[2], h)
         off, rows = self._film_off[id(blk)]
         film = self._film_all[:, off:off + rows].contiguous()               # (N, 2*Cout) = scale | shift
@@ -249,7 +259,9 @@ class UNetModel(nn.Module):
             raise NotImplementedError("ResBlock without use_scale_shift_norm is not built")
         h = self._group_norm(blk.out_layers[0], h, film=film, silu=True)
         if isinstance(blk.skip_connection, nn.Conv2d):
-            res = self._conv(blk.skip_connection, xs)
+            res = self._conv(blk.skip_connection, xs, x1=skip)
+        elif skip is not None:
+            raise NotImplementedError("identity skip connection on a concatenated input (not in this architecture)")
         else:
             res = xs
         return self._conv(blk.out_layers[3], h, residual=res)
