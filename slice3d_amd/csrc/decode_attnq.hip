@@ -60,6 +60,13 @@ __device__ __forceinline__ float colmax16(float v) {
 // (Earlier versions: eight waves / whole-head slots / rows re-read per head: 1.16 ms per layer; four waves / half-head
 // slots: 1.13 ms; this one 0.94 ms.)
 // ---------------------------------------------------------------------------------------------
+// LDS reads and their counted waits are issued by hand (same finding as in decode_f16.hip's pipelined FFN): with an
+// LDS-DMA refill in flight hipcc turns every LDS wait of this single-LDS-object kernel into lgkmcnt(0), i.e. it waits
+// for the fragment reads it has just issued for the NEXT k-step (all 42 waits of the previous build were lgkmcnt(0)).
+#define AQ_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define AQ_WAIT6(n, a, b, c, d, e, f) \
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(n))
+#define AQ_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
 #define AQ3_SLOT_HALFS (8 * 1024)    // 8 fragment pairs = 16 KiB
 #define AQ3_XROW_HALFS (4 * 1024)    // per wave: 2 tiles x 4 k-steps x 64 lanes x 8 halfs
 template <bool SINGLE>   // SINGLE: S3D_PREC_F16, one f16 MFMA per projection product (the 13x13 core stays on the fp32 MFMA)
@@ -67,21 +74,26 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                                                                const LayerPtrs w) {
     extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // ring 2 x 16 KiB, then the rows 4 x 8 KiB
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: no waterfall around M0
     const int m = lane & 15, g = lane >> 4;
     const float scale = 0.17677669529663687f;   // 1/sqrt(32)
     const _Float16* g_in = wimg;
     const _Float16* g_out = wimg + 4 * AQ_WIN_HALFS;
     _Float16* s_x = s_win + 2 * AQ3_SLOT_HALFS + wave * AQ3_XROW_HALFS;
+    const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_win + lane * 8);
+    const unsigned lxa = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_x + lane * 8);
     // phase ph = 4*h + {0 q, 1 k, 2 v, 3 out_proj}: 16 chunks of 1 KiB
     auto dma_phase = [&](int ph, int buf) {
         const int h = ph >> 2, part = ph & 3;
         const _Float16* src0 = part < 3 ? g_in + (size_t)h * AQ_WIN_HALFS + part * AQ3_SLOT_HALFS
                                         : g_out + (size_t)h * AQ_WO_HALFS;
-        for (int i = wave; i < 16; i += 4)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = wave + 4 * k;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + i * 512 + lane * 8),
                                              (__attribute__((address_space(3))) void*)(s_win + buf * AQ3_SLOT_HALFS + i * 512),
                                              16, 0, 0);
+        }
     };
     const long items = 2 * groups;
     long ps = 0;   // running phase count: slot = ps & 1
@@ -112,7 +124,6 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 *reinterpret_cast<half8q*>(s_x + ((r * 4 + u) * 64 + lane) * 8) = hi;
             }
         }
-        auto xh_at = [&](int r, int u) { return ldq8(s_x + ((r * 4 + u) * 64 + lane) * 8); };
 #pragma unroll 1
         for (int h = 0; h < 4; ++h) {
             f32x4 qd[2][2], kd[2][2], vd[2][2];
@@ -131,38 +142,47 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                     }
                 }
                 dma_phase(4 * h + part + 1, (int)((ps + 1) & 1));
-                const _Float16* sw = s_win + (ps & 1) * AQ3_SLOT_HALFS;
+                const unsigned lwa = lds_ring + (unsigned)(ps & 1) * (AQ3_SLOT_HALFS * 2);
                 f32x4 d[2][2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) d[r][j] = zero4();
-                half8q fh[2][2], fl[2][2];
-                auto load_f = [&](int u, int b) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        fh[b][j] = ldq8(sw + (j * 4 + u) * 1024 + lane * 8);
-                        fl[b][j] = ldq8(sw + (j * 4 + u) * 1024 + 512 + lane * 8);
-                    }
-                };
-                load_f(0, 0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const half8q x0 = xh_at(0, u), x1 = xh_at(1, u);
-                    if (u < 3) load_f(u + 1, (u + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (part < 2) {   // D^T = W X^T
-                            d[0][j] = mfma3q<SINGLE>(fh[u & 1][j], fl[u & 1][j], x0, xl[0][u], d[0][j]);
-                            d[1][j] = mfma3q<SINGLE>(fh[u & 1][j], fl[u & 1][j], x1, xl[1][u], d[1][j]);
-                        } else {          // D = X W^T
-                            d[0][j] = mfma3q<SINGLE>(x0, xl[0][u], fh[u & 1][j], fl[u & 1][j], d[0][j]);
-                            d[1][j] = mfma3q<SINGLE>(x1, xl[1][u], fh[u & 1][j], fl[u & 1][j], d[1][j]);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                // fragment pairs (hi | lo) of the two 16-row tiles j and the high halves of the wave's two row tiles for
+                // k-step U, all read one k-step ahead (6 reads in flight under the 12 MFMAs of the current step)
+                half8q fh[2][2], fl[2][2], xq[2][2];
+#define AQ_STEP_READS(B, U)                                          \
+    AQ_READ(fh[B][0], lwa, (U) * 2048);                              \
+    AQ_READ(fl[B][0], lwa, (U) * 2048 + 1024);                       \
+    AQ_READ(fh[B][1], lwa, (4 + (U)) * 2048);                        \
+    AQ_READ(fl[B][1], lwa, (4 + (U)) * 2048 + 1024);                 \
+    AQ_READ(xq[B][0], lxa, (U) * 1024);                              \
+    AQ_READ(xq[B][1], lxa, (4 + (U)) * 1024);
+#define AQ_STEP_MFMA(B, U)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+        if (part < 2) { /* D^T = W X^T */                                                                    \
+            d[0][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xq[B][0], xl[0][U], d[0][j]);                       \
+            d[1][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xq[B][1], xl[1][U], d[1][j]);                       \
+        } else { /* D = X W^T */                                                                             \
+            d[0][j] = mfma3q<SINGLE>(xq[B][0], xl[0][U], fh[B][j], fl[B][j], d[0][j]);                       \
+            d[1][j] = mfma3q<SINGLE>(xq[B][1], xl[1][U], fh[B][j], fl[B][j], d[1][j]);                       \
+        }                                                                                                    \
+    }                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);
+                AQ_STEP_READS(0, 0)
+                AQ_STEP_READS(1, 1)
+                AQ_WAIT6(6, fh[0][0], fl[0][0], fh[0][1], fl[0][1], xq[0][0], xq[0][1]);
+                AQ_STEP_MFMA(0, 0)
+                AQ_STEP_READS(0, 2)
+                AQ_WAIT6(6, fh[1][0], fl[1][0], fh[1][1], fl[1][1], xq[1][0], xq[1][1]);
+                AQ_STEP_MFMA(1, 1)
+                AQ_STEP_READS(1, 3)
+                AQ_WAIT6(6, fh[0][0], fl[0][0], fh[0][1], fl[0][1], xq[0][0], xq[0][1]);
+                AQ_STEP_MFMA(0, 2)
+                AQ_WAIT6(0, fh[1][0], fl[1][0], fh[1][1], fl[1][1], xq[1][0], xq[1][1]);
+                AQ_STEP_MFMA(1, 3)
+#undef AQ_STEP_READS
+#undef AQ_STEP_MFMA
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -223,21 +243,32 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 if (more_h || more_i) dma_phase(more_h ? 4 * (h + 1) : 0, (int)((ps + 1) & 1));
             }
             {
-                const _Float16* gw = s_win + (ps & 1) * AQ3_SLOT_HALFS;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    half8q wh[4], wl[4];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        wh[jj] = ldq8(gw + (4 * half + jj) * 1024 + lane * 8);
-                        wl[jj] = ldq8(gw + (4 * half + jj) * 1024 + 512 + lane * 8);
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r)
-                            acc_o[r][4 * half + jj] = mfma3q<SINGLE>(wh[jj], wl[jj], oh[r], ol[r], acc_o[r][4 * half + jj]);
-                }
+                const unsigned lwa = lds_ring + (unsigned)(ps & 1) * (AQ3_SLOT_HALFS * 2);
+                half8q wh[2][2], wl[2][2];   // [buffer][tile of the pair]
+#define AQ_O_READS(B, G)                                             \
+    AQ_READ(wh[B][0], lwa, (2 * (G)) * 2048);                        \
+    AQ_READ(wl[B][0], lwa, (2 * (G)) * 2048 + 1024);                 \
+    AQ_READ(wh[B][1], lwa, (2 * (G) + 1) * 2048);                    \
+    AQ_READ(wl[B][1], lwa, (2 * (G) + 1) * 2048 + 1024);
+#define AQ_O_MFMA(B, G)                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
+        _Pragma("unroll") for (int r = 0; r < 2; ++r)                                                        \
+            acc_o[r][2 * (G) + q] = mfma3q<SINGLE>(wh[B][q], wl[B][q], oh[r], ol[r], acc_o[r][2 * (G) + q]); \
+    __builtin_amdgcn_sched_barrier(0);
+                AQ_O_READS(0, 0)
+                AQ_O_READS(1, 1)
+                AQ_WAIT4(4, wh[0][0], wl[0][0], wh[0][1], wl[0][1]);
+                AQ_O_MFMA(0, 0)
+                AQ_O_READS(0, 2)
+                AQ_WAIT4(4, wh[1][0], wl[1][0], wh[1][1], wl[1][1]);
+                AQ_O_MFMA(1, 1)
+                AQ_O_READS(1, 3)
+                AQ_WAIT4(4, wh[0][0], wl[0][0], wh[0][1], wl[0][1]);
+                AQ_O_MFMA(0, 2)
+                AQ_WAIT4(0, wh[1][0], wl[1][0], wh[1][1], wl[1][1]);
+                AQ_O_MFMA(1, 3)
+#undef AQ_O_READS
+#undef AQ_O_MFMA
             }
             ++ps;
         }
