@@ -98,6 +98,7 @@ struct UNetLayout {
     size_t pool_scale[4], pool_shift[4];  // BN that follows tap convs 1,3,6,9 (applied by the pool kernel)
     PackedConv trans_c, trans_up[4], up_t[4], up_c1[4], up_c2[4], outc;
     size_t emds;
+    size_t enc0_raw;   // conv1_1's weight as is, (64,3,3,3): the 3-channel first layer runs a direct fp32 kernel on the NCHW image
     size_t total;
 };
 
@@ -135,6 +136,7 @@ static UNetLayout unet_layout(int n_slices) {
     }
     conv(L.outc, 16, 32 / 16);
     L.emds = take((size_t)n_slices * 128);
+    L.enc0_raw = take(64 * 27);
     L.total = off;
     return L;
 }
@@ -187,6 +189,10 @@ extern "C" int s3d_unet_pack(const S3dUNetParams* P, void* packed, size_t packed
         else
             TRY(launch_fold_bn(P->enc[i].b, P->enc[i].bn, base + pc.scale, base + pc.shift, kEncCout[i],
                                pc.cout_pad, 1, 1, st));
+    }
+    if (hipMemcpyAsync(base + L.enc0_raw, P->enc[0].w, 64 * 27 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        s3d_set_error("unet_pack: copy of conv1_1's weight failed");
+        return S3D_E_ARG;
     }
     const int tapi[4] = {1, 3, 6, 9};
     for (int i = 0; i < 4; ++i)
@@ -301,13 +307,21 @@ extern "C" int s3d_unet_encode_fwd(const void* packed, const float* img, const S
     float* ws = (float*)workspace;
 
     ProfScope prof_(S3D_PROF_UNET, st);
-    TRY(launch_nchw_to_nhwc(img, ws + W.in16, B, 3, S, S, 16, st));
     // ---- VGG16-BN encoder (unet_custom.py:43-47) ----
     const float* cur = ws + W.in16;
     int curC = 16, res = S, tap_i = 0;
     float* pp[2] = {ws + W.a, ws + W.b};
     int flip = 0;
     for (int i = 0; i < 13; ++i) {
+        if (i == 0) {   // 3 -> 64 straight from the NCHW image: a direct fp32 kernel bound by its 64-channel write
+                        // (the padded implicit GEMM spent 100 us on 0.9 GFLOP); folded BN + ReLU in its epilogue
+            TRY(launch_conv3x3_first(img, 3, base + L.enc0_raw, nullptr, pp[flip], B, S, S, st, base + L.enc[0].scale,
+                                     base + L.enc[0].shift, 1));
+            cur = pp[flip];
+            curC = kEncCout[0];
+            flip ^= 1;
+            continue;
+        }
         ConvLaunch c = conv_desc(base, L.enc[i], B, res, res, 3, kEncTap[i] ? S3D_ACT_NONE : S3D_ACT_RELU);
         c.nsrc = 1;
         c.src[0] = plain_src(cur, curC);

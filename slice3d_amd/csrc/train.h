@@ -73,8 +73,10 @@ int launch_bn_apply(const float* z, const float* mean, const float* rstd, const 
                     float* y, int n, int h, int w, int c, int pool, hipStream_t stream);
 // backward of y = relu(bn(z)) [+ maxpool]: given dy (grid of y), writes dz (grid of z), dgamma, dbeta.
 // 3x3 / pad 1 conv of an NCHW image with 1 or 3 channels to 64 NHWC channels + bias, exact fp32 (first VGG conv)
+// optional epilogue (inference): y = acc * scale[c] + shift[c] (folded BatchNorm; bias then NULL), ReLU
 int launch_conv3x3_first(const float* img_nchw, int cin, const float* w_oihw, const float* bias, float* out_nhwc,
-                         int n, int h, int w, hipStream_t stream);
+                         int n, int h, int w, hipStream_t stream, const float* scale = nullptr,
+                         const float* shift = nullptr, int relu = 0);
 int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   const float* dy, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c, int pool,
                   float* partial, hipStream_t stream, const float* add = nullptr,    // dz += add (same grid) if set

@@ -1479,7 +1479,8 @@ template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restrict__ img,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                            int n, int H, int W) {
+                                                            int n, int H, int W, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu) {
     __shared__ f32x4 s_w[9 * CIN][16];   // [tap * CIN + ci][channel quad]
     for (int idx = threadIdx.x; idx < 9 * CIN * 64; idx += 256) {
         const int co = idx & 63, k = idx >> 6, tap = k / CIN, ci = k - tap * CIN;
@@ -1517,22 +1518,32 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
             }
         }
         float* o = out + ((ni * H + y) * W + x0) * 64 + cq * 4;
+        if (scale) {   // inference epilogue: folded BatchNorm (+ ReLU)
+            const f32x4 sc = ld4(scale + cq * 4), sh = ld4(shift + cq * 4);
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                acc[px] = acc[px] * sc + sh;
+                if (relu)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[px][i] = fmaxf(acc[px][i], 0.f);
+            }
+        }
 #pragma unroll
         for (int px = 0; px < 4; ++px) st4(o + px * 64, acc[px]);
     }
 }
 
 int launch_conv3x3_first(const float* img_nchw, int cin, const float* w_oihw, const float* bias, float* out_nhwc,
-                         int n, int h, int w, hipStream_t stream) {
+                         int n, int h, int w, hipStream_t stream, const float* scale, const float* shift, int relu) {
     S3D_CHECK_ARG((cin == 1 || cin == 3) && w % 4 == 0, "conv3x3_first: C_in %d, W %d", cin, w);
     const long groups = (long)n * h * (w / 4);
     const int blocks = (int)((groups + 15) / 16 < 16384 ? (groups + 15) / 16 : 16384);
     if (cin == 1)
         hipLaunchKernelGGL((conv3x3_first_kernel<1>), dim3(blocks), dim3(256), 0, stream, img_nchw, w_oihw, bias,
-                           out_nhwc, n, h, w);
+                           out_nhwc, n, h, w, scale, shift, relu);
     else
         hipLaunchKernelGGL((conv3x3_first_kernel<3>), dim3(blocks), dim3(256), 0, stream, img_nchw, w_oihw, bias,
-                           out_nhwc, n, h, w);
+                           out_nhwc, n, h, w, scale, shift, relu);
     S3D_LAUNCH_CHECK();
     return 0;
 }
