@@ -417,12 +417,16 @@ static int launch_lin_rows(const ConvLaunch& a, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 #define C3_PXS 40            // halfs per pixel in LDS (32 + 8 pad)
 #define C3_HALO (10 * 18)    // pixels of the halo tile
-template <int MT, int WP, int WC>
+// NBUF = 2: the next chunk's halo is parked while this one is consumed (57.6 KiB, two workgroups per CU).  NBUF = 1:
+// one buffer (28.8 KiB, five workgroups per CU) for layers whose K is one or two chunks — there a workgroup's life is a
+// fetch, a split and 108-216 MFMAs per wave, nothing overlaps inside it, and what hides the fetch latency is the number
+// of OTHER workgroups on the CU (the 32- and 64-channel layers at full resolution: 0.51 / 0.34 ms -> see DESIGN.md).
+template <int MT, int WP, int WC, int NBUF>
 __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch a, int tiles_x, int tiles_y,
                                                                 int chunks_per_split) {
     static_assert(MT * WP == 8 && WP * WC == 4, "tile is 8 rows, 4 waves");
     constexpr int NT = 2, CO_WG = WC * NT * 16;
-    __shared__ __attribute__((aligned(16))) _Float16 s_in[2][2][C3_HALO * C3_PXS];   // [buf][hi|lo]  57.6 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 s_in[NBUF][2][C3_HALO * C3_PXS];   // [buf][hi|lo]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int wp = wave % WP, wc = wave / WP;
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
     const int ch_lo = blockIdx.y * chunks_per_split;
     const int nchunk = min(cu0 + cu1, ch_lo + chunks_per_split);
     fetch(a.src[ch_lo < cu0 ? 0 : 1], ch_lo < cu0 ? ch_lo : ch_lo - cu0);
-    park(ch_lo & 1);
+    park(ch_lo & (NBUF - 1));
     __syncthreads();
 #pragma unroll 1
     for (int ch = ch_lo; ch < nchunk; ++ch) {
@@ -508,8 +512,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
             const int s1 = ch + 1 < cu0 ? 0 : 1;
             fetch(a.src[s1], s1 ? ch + 1 - cu0 : ch + 1);
         }
-        const _Float16* sh = s_in[ch & 1][0];
-        const _Float16* sl = s_in[ch & 1][1];
+        const _Float16* sh = s_in[ch & (NBUF - 1)][0];
+        const _Float16* sl = s_in[ch & (NBUF - 1)][1];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;   // halo-relative: output (r, m) reads halo (r + dy, m + dx)
@@ -551,7 +555,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
                 }
             }
         }
-        if (ch + 1 < nchunk) park((ch + 1) & 1);
+        if (NBUF == 1) __syncthreads();   // everyone is done reading the single buffer before it is refilled
+        if (ch + 1 < nchunk) park((ch + 1) & (NBUF - 1));
         __syncthreads();
     }
     int pn[MT], py[MT], px[MT];
@@ -627,10 +632,17 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     const int cps = (nchunk + splits - 1) / splits;
     splits = (nchunk + cps - 1) / cps;
     dim3 grid((unsigned)nblk, (unsigned)splits);
-    if (co_wg == 64)
-        hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<4, 2, 2>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
-    else
-        hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<2, 4, 1>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
+    static const int one_buf_max = [] {
+        const char* e = getenv("S3D_CONV_ONEBUF");   // chunks per workgroup up to which the single-buffer variant runs
+        return e ? atoi(e) : 2;
+    }();
+    const bool one = cps <= one_buf_max;   // 32-channel-output layers only: measured -13 % there, +5 % on the 64-wide tile
+    if (co_wg == 64) {
+        hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<4, 2, 2, 2>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
+    } else {
+        if (one) hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<2, 4, 1, 1>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
+        else hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<2, 4, 1, 2>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
+    }
     S3D_LAUNCH_CHECK();
     if (splits > 1) {
         const long total = (long)(out_floats >> 2);
