@@ -139,11 +139,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    # S3D_BENCH_BACKEND=gloo: smoke-test the N-rank code path with several processes on ONE GPU (no RCCL between ranks
+    # that share a device); never set by the driver — a real run is one rank per GPU over RCCL
+    backend = os.environ.get("S3D_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from slice3d_amd import _lib
     from slice3d_amd.models import Slices3DRegModel
@@ -321,7 +329,7 @@ def main():
         from slice3d_amd.models_gt import Slices3DGTModel
         from slice3d_amd.trainer import HipGtTrainer
         gm = load_seeded(Slices3DGTModel(img_size=128, n_slices=args.n_slices, mode="train"), 0).cuda()
-        gtr = HipGtTrainer(gm, dropout=0.1, seed=0, prec=args.prec)
+        gtr = HipGtTrainer(gm, dropout=0.1, seed=0, prec=args.prec, process_group=False)   # rank 0 alone: no exchange
         gfd = make_feed_dict(16, 128, 256, args.n_slices, seed=99, device="cuda")
         gtr.train_step(gfd)
         torch.cuda.synchronize()

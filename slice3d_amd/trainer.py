@@ -316,6 +316,8 @@ class HipTrainer:
     # -- data-parallel exchange step ------------------------------------------------------------------
     def _world(self):
         import torch.distributed as dist
+        if self.group is False:          # process_group=False: a lone replica inside a distributed job (no exchange)
+            return 1
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.group)
         return 1
