@@ -40,15 +40,77 @@ __device__ __forceinline__ f32x4 mfma3q(const half8q ah, const half8q al, const 
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
     return c;
 }
-__device__ __forceinline__ float colsum16(float v) {   // sum over the 4 lane groups g of one column (l & 15)
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+// hi/lo split of a pair: one v_cvt_pk_f16_f32 + two v_fma_mix{lo,hi}_f16 (lo = f16(x - f32(hi)), the subtraction is
+// exact, one rounding: the same value the scalar convert-subtract-convert of splitq8 produces)
+typedef _Float16 half2q __attribute__((ext_vector_type(2)));
+typedef float float2q __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2q(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(float2q{a, b}, half2q));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+}
+typedef unsigned uint4q __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split8pk(const f32x4 a, const f32x4 b, half8q& hi, half8q& lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split2q(a[0], a[1], h0, l0);
+    split2q(a[2], a[3], h1, l1);
+    split2q(b[0], b[1], h2, l2);
+    split2q(b[2], b[3], h3, l3);
+    hi = __builtin_bit_cast(half8q, uint4q{h0, h1, h2, h3});
+    lo = __builtin_bit_cast(half8q, uint4q{l0, l1, l2, l3});
+}
+// four values -> the A / B operand of the 16-deep MFMA (v_mfma_f32_16x16x16_f16: lane group g carries k = 4g..4g+3)
+typedef _Float16 half4q __attribute__((ext_vector_type(4)));
+typedef unsigned uint2q __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4pk(const f32x4 a, half4q& hi, half4q& lo) {
+    unsigned h0, h1, l0, l1;
+    split2q(a[0], a[1], h0, l0);
+    split2q(a[2], a[3], h1, l1);
+    hi = __builtin_bit_cast(half4q, uint2q{h0, h1});
+    lo = __builtin_bit_cast(half4q, uint2q{l0, l1});
+}
+template <bool SINGLE>
+__device__ __forceinline__ f32x4 mfma3h(const half4q ah, const half4q al, const half4q bh, const half4q bl, f32x4 c) {
+    if (!SINGLE) {
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+// x + f32(h[lo half]) / x + f32(h[hi half])
+__device__ __forceinline__ float add_h0(float x, unsigned h) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
+    return d;
+}
+__device__ __forceinline__ float add_h1(float x, unsigned h) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
+    return d;
+}
+// reductions over the 4 lane groups g of one column (l & 15) with the gfx950 lane-swap instructions (no LDS crossbar):
+// v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second, so two copies
+// of v become {lo, lo} and {hi, hi}; v_permlane16_swap does the same with odd / even rows of 16.  Issued as asm: the
+// __builtin_amdgcn_permlane*_swap builtins of this hipcc return the FIRST result for both elements (checked on the
+// GPU with build/t-style unit kernels); s_nop 1 = the VALU-write -> permlane hazard the compiler would have padded.
+__device__ __forceinline__ void lane_swap32(float& x, float& y) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+__device__ __forceinline__ void lane_swap16(float& x, float& y) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+__device__ __forceinline__ float colsum16(float v) {
+    float x = v, y = v;
+    lane_swap32(x, y);
+    x += y;
+    y = x;
+    lane_swap16(x, y);
+    return x + y;
 }
 __device__ __forceinline__ float colmax16(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    float x = v, y = v;
+    lane_swap32(x, y);
+    x = fmaxf(x, y);
+    y = x;
+    lane_swap16(x, y);
+    return fmaxf(x, y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -67,6 +129,11 @@ __device__ __forceinline__ float colmax16(float v) {
 #define AQ_WAIT6(n, a, b, c, d, e, f) \
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(n))
 #define AQ_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
+#ifdef AQ_ABL_NOBAR   // timing ablations (tools/attn_abl.sh): wrong results, never shipped
+#define AQ_BARRIER() ((void)0)
+#else
+#define AQ_BARRIER() dma_publish_barrier()
+#endif
 #define AQ3_SLOT_HALFS (8 * 1024)    // 8 fragment pairs = 16 KiB
 #define AQ3_XROW_HALFS (4 * 1024)    // per wave: 2 tiles x 4 k-steps x 64 lanes x 8 halfs
 template <bool SINGLE>   // SINGLE: S3D_PREC_F16, one f16 MFMA per projection product (the 13x13 core stays on the fp32 MFMA)
@@ -76,14 +143,23 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: no waterfall around M0
     const int m = lane & 15, g = lane >> 4;
-    const float scale = 0.17677669529663687f;   // 1/sqrt(32)
+    const float scale = 0.17677669529663687f * 1.4426950408889634f;   // log2(e) / sqrt(32)
     const _Float16* g_in = wimg;
     const _Float16* g_out = wimg + 4 * AQ_WIN_HALFS;
     _Float16* s_x = s_win + 2 * AQ3_SLOT_HALFS + wave * AQ3_XROW_HALFS;
+    // in_proj bias | out_proj bias | LayerNorm1 gamma | beta: 768 floats behind the rows (published by the first barrier)
+    float* s_par = reinterpret_cast<float*>(s_win + 2 * AQ3_SLOT_HALFS + 4 * AQ3_XROW_HALFS);
+    for (int i = tid; i < 192; i += 256) {
+        const float* src = i < 96 ? w.inb + 4 * i : i < 128 ? w.outb + 4 * (i - 96) : i < 160 ? w.ln1g + 4 * (i - 128) : w.ln1b + 4 * (i - 160);
+        st4(s_par + 4 * i, ld4(src));
+    }
     const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_win + lane * 8);
     const unsigned lxa = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_x + lane * 8);
     // phase ph = 4*h + {0 q, 1 k, 2 v, 3 out_proj}: 16 chunks of 1 KiB
     auto dma_phase = [&](int ph, int buf) {
+#ifdef AQ_ABL_NODMA
+        return;
+#endif
         const int h = ph >> 2, part = ph & 3;
         const _Float16* src0 = part < 3 ? g_in + (size_t)h * AQ_WIN_HALFS + part * AQ3_SLOT_HALFS
                                         : g_out + (size_t)h * AQ_WO_HALFS;
@@ -101,6 +177,28 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
     const bool row_ok = m < T;
     const int mt = row_ok ? m : T - 1;
 
+    // raw fp32 rows of the NEXT item, requested in the epilogue of the current one (the first item's here)
+    f32x4 xf[2][4][2];
+    auto load_rows = [&](long it) {
+        const float* Xn = X + (it >> 1) * T * S3D_GROUP * 128;
+        const int qn = 8 * (int)(it & 1) + 2 * wave;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float* p = Xn + (mt * S3D_GROUP + qn + r) * 128 + 8 * g;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#ifdef AQ_ABL_NOROWS
+                xf[r][u][0] = f32x4{0.1f * g, 0.2f * m, 0.3f, (float)it};
+                xf[r][u][1] = f32x4{0.5f * u, 0.25f, 0.125f * r, 1.f};
+#else
+                xf[r][u][0] = ld4(p + 32 * u);
+                xf[r][u][1] = ld4(p + 32 * u + 4);
+#endif
+            }
+        }
+    };
+    if ((long)blockIdx.x < items) load_rows(blockIdx.x);
+
     for (long item = blockIdx.x; item < items; item += gridDim.x) {
         const long grp = item >> 1;
         const int q0 = 8 * (int)(item & 1) + 2 * wave;
@@ -113,17 +211,14 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
         // rows of the item: low halves in registers for the whole item, high halves parked in LDS
         half8q xl[2][4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const float* p = Xg + (mt * S3D_GROUP + q0 + r) * 128 + 8 * g;
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
-                const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
                 half8q hi;
-                splitq8(v, hi, xl[r][u]);
+                split8pk(xf[r][u][0], xf[r][u][1], hi, xl[r][u]);
                 *reinterpret_cast<half8q*>(s_x + ((r * 4 + u) * 64 + lane) * 8) = hi;
             }
-        }
+        const bool more_items = item + gridDim.x < items;
 #pragma unroll 1
         for (int h = 0; h < 4; ++h) {
             f32x4 qd[2][2], kd[2][2], vd[2][2];
@@ -132,13 +227,13 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             // =============== phases q, k, v: one swapped (q, k) or plain (v) GEMM each ===============
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                dma_publish_barrier();   // this phase's fragments have landed; the other slot is free
-                if (part == 0) {   // the head's biases: requested three phases before the attention core needs them
+                AQ_BARRIER();   // this phase's fragments have landed; the other slot is free
+                if (part == 0) {   // the head's biases (LDS copy): they open the accumulations below
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        bq[j] = ld4(w.inb + 32 * h + 16 * j + 4 * g);
-                        bk[j] = ld4(w.inb + 128 + 32 * h + 16 * j + 4 * g);
-                        bv[j] = w.inb[256 + 32 * h + 16 * j + m];
+                        bq[j] = *reinterpret_cast<const f32x4*>(s_par + 32 * h + 16 * j + 4 * g);
+                        bk[j] = *reinterpret_cast<const f32x4*>(s_par + 128 + 32 * h + 16 * j + 4 * g);
+                        bv[j] = s_par[256 + 32 * h + 16 * j + m];
                     }
                 }
                 dma_phase(4 * h + part + 1, (int)((ps + 1) & 1));
@@ -147,7 +242,8 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) d[r][j] = zero4();
+                    for (int j = 0; j < 2; ++j)
+                        d[r][j] = part == 0 ? bq[j] : part == 1 ? bk[j] : f32x4{bv[j], bv[j], bv[j], bv[j]};
                 // fragment pairs (hi | lo) of the two 16-row tiles j and the high halves of the wave's two row tiles for
                 // k-step U, all read one k-step ahead (6 reads in flight under the 12 MFMAs of the current step)
                 half8q fh[2][2], fl[2][2], xq[2][2];
@@ -194,22 +290,101 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 ++ps;
             }
             // =============== attention core, then phase out_proj ===============
+            // The 13x13 core on the same split-precision 16x16x32 MFMA as the projections: the head's 32 dims are
+            // exactly one k-step (k-slot 8g + t <-> dim 16(t>>2) + 4g + (t&3), the registers as they are), and the 16
+            // keys of P V fill k-slots 8g + {0..3} (key 4g + t) with 4..7 zero.  9 MFMAs of 4 passes per query instead
+            // of 16 fp32 MFMAs of 8.  Scores in log2 units (the scale carries log2 e), softmax by v_exp_f32.
             half8q oh[2], ol[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    qd[r][j] = (qd[r][j] + bq[j]) * scale;
-                    kd[r][j] = kd[r][j] + bk[j];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) vd[r][j][i] += bv[j];
+#ifdef AQ_ABL_NOCORE
+                split8pk(qd[r][0] + kd[r][0] + vd[r][0], qd[r][1] + kd[r][1] + vd[r][1], oh[r], ol[r]);
+                continue;
+#endif
+#ifdef AQ_DBG_OLDCORE
+                {
+                    f32x4 s = zero4();
+#if AQ_DBG_OLDCORE & 4
+                    {
+                        half8q kh, kl, qh, ql;
+                        split8pk(kd[r][0], kd[r][1], kh, kl);
+                        split8pk(qd[r][0] * scale, qd[r][1] * scale, qh, ql);
+                        s = mfma3q<SINGLE>(kh, kl, qh, ql, zero4());
+                    }
+#else
+                    for (int j = 0; j < 2; ++j)
+                        for (int i = 0; i < 4; ++i)
+                            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kd[r][j][i], qd[r][j][i] * scale, s, 0, 0, 0);
+#endif
+                    float e[4];
+                    float mx = -1e30f;
+                    for (int i = 0; i < 4; ++i) {
+                        e[i] = (4 * g + i < T) ? s[i] : -1e30f;
+                        mx = fmaxf(mx, e[i]);
+                    }
+#if AQ_DBG_OLDCORE & 1
+                    mx = colmax16(mx);
+#else
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#endif
+                    float den = 0.f;
+                    for (int i = 0; i < 4; ++i) {
+#if AQ_DBG_OLDCORE & 2
+                        e[i] = __builtin_amdgcn_exp2f(e[i] - mx);
+#else
+                        e[i] = (4 * g + i < T) ? exp2f(e[i] - mx) : 0.f;
+#endif
+                        den += e[i];
+                    }
+#if AQ_DBG_OLDCORE & 1
+                    den = colsum16(den);
+#else
+                    den += __shfl_xor(den, 16, 64);
+                    den += __shfl_xor(den, 32, 64);
+#endif
+                    const float inv = 1.f / den;
+                    f32x4 od[2];
+#if AQ_DBG_OLDCORE & 8
+                    {
+                        half4q ph, pl;
+                        split4pk(f32x4{e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv}, ph, pl);
+                        for (int j = 0; j < 2; ++j) {
+                            half4q vh, vl;
+                            split4pk(vd[r][j], vh, vl);
+                            od[j] = mfma3h<SINGLE>(vh, vl, ph, pl, zero4());
+                        }
+                    }
+#else
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 o = zero4();
+                        for (int i = 0; i < 4; ++i)
+                            o = __builtin_amdgcn_mfma_f32_16x16x4f32(vd[r][j][i], e[i] * inv, o, 0, 0, 0);
+                        od[j] = o;
+                    }
+#endif
+#if AQ_DBG_OLDCORE & 32
+                    if (blockIdx.x == 0 && wave == 0 && h == 0 && r == 0 && item == 0) {
+                        f32x4 oo[2];
+                        for (int j = 0; j < 2; ++j) {
+                            f32x4 o = zero4();
+                            for (int i = 0; i < 4; ++i)
+                                o = __builtin_amdgcn_mfma_f32_16x16x4f32(vd[r][j][i], e[i] * inv, o, 0, 0, 0);
+                            oo[j] = o;
+                        }
+                        if (lane < 3 || lane == 17 || lane == 40) printf("lane %2d new %9.5f %9.5f %9.5f %9.5f | %9.5f  old %9.5f %9.5f %9.5f %9.5f | %9.5f  p %g %g %g %g v %g %g\n", lane,
+                               od[0][0], od[0][1], od[0][2], od[0][3], od[1][0], oo[0][0], oo[0][1], oo[0][2], oo[0][3], oo[1][0],
+                               e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv, vd[r][0][0], vd[r][0][1]);
+                    }
+#endif
+                    split8pk(od[0], od[1], oh[r], ol[r]);
+                    continue;
                 }
-                f32x4 s = zero4();
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kd[r][j][i], qd[r][j][i], s, 0, 0, 0);
+#endif
+                half8q kh, kl, qh, ql;
+                split8pk(kd[r][0], kd[r][1], kh, kl);
+                split8pk(qd[r][0] * scale, qd[r][1] * scale, qh, ql);
+                const f32x4 s = mfma3q<SINGLE>(kh, kl, qh, ql, zero4());
                 float e[4];
                 float mx = -1e30f;
 #pragma unroll
@@ -221,23 +396,22 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 float den = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    e[i] = (4 * g + i < T) ? expf(e[i] - mx) : 0.f;
+                    e[i] = __builtin_amdgcn_exp2f(e[i] - mx);   // masked keys: exp2(-1e30) = 0
                     den += e[i];
                 }
                 const float inv = 1.f / colsum16(den);
+                half4q ph, pl;
+                split4pk(f32x4{e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv}, ph, pl);
                 f32x4 od[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    f32x4 o = zero4();
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vd[r][j][i], e[i] * inv, o, 0, 0, 0);
-                    od[j] = o;
+                    half4q vh, vl;
+                    split4pk(vd[r][j], vh, vl);
+                    od[j] = mfma3h<SINGLE>(vh, vl, ph, pl, zero4());
                 }
-                const float ov[8] = {od[0][0], od[0][1], od[0][2], od[0][3], od[1][0], od[1][1], od[1][2], od[1][3]};
-                splitq8(ov, oh[r], ol[r]);
+                split8pk(od[0], od[1], oh[r], ol[r]);
             }
-            dma_publish_barrier();   // out_proj fragments have landed; the v slot is free
+            AQ_BARRIER();   // out_proj fragments have landed; the v slot is free
             {
                 const bool more_h = h < 3, more_i = item + gridDim.x < items;
                 if (more_h || more_i) dma_phase(more_h ? 4 * (h + 1) : 0, (int)((ps + 1) & 1));
@@ -272,20 +446,36 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             }
             ++ps;
         }
-        // ---- residual + LayerNorm1, store ----
+        // the next item's rows: requested here, where the q / k / v and fragment registers are free; the LayerNorm
+        // below covers most of their latency
+        load_rows(more_items ? item + gridDim.x : item);   // unconditional: a conditional load keeps the OLD rows live through the heads
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- residual + LayerNorm1, store.  The residual rows are rebuilt from their halves (hi from the LDS park, lo
+        //      from the registers: x = hi + lo to 2^-22, what the projections saw) instead of a second trip to HBM ----
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
+            // opaque per-tile base: keeps the 24 parameter quads from being loaded once and held for both tiles (96 VGPRs)
+            unsigned par_off = 0;
+            asm volatile("" : "+v"(par_off));
+            const float* spar = s_par + par_off;
+            uint4q xh4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xh4[u] = *reinterpret_cast<const uint4q*>(s_x + ((r * 4 + u) * 64 + lane) * 8);
             f32x4 y[8];
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
-                const f32x4 bo = ld4(w.outb + col);
-                const f32x4 xr = ld4(Xg + (mt * S3D_GROUP + q0 + r) * 128 + col);
+                const f32x4 bo = *reinterpret_cast<const f32x4*>(spar + 384 + col);
+                const uint4q xl4 = __builtin_bit_cast(uint4q, xl[r][j >> 1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    y[j][i] = acc_o[r][j][i] + bo[i] + xr[i];
-                    s += y[j][i];
+                    const int wd = 2 * (j & 1) + (i >> 1);
+                    float f = acc_o[r][j][i] + bo[i];
+                    f = (i & 1) ? add_h1(f, xl4[wd]) : add_h0(f, xl4[wd]);
+                    f = (i & 1) ? add_h1(f, xh4[j >> 1][wd]) : add_h0(f, xh4[j >> 1][wd]);
+                    y[j][i] = f;
+                    s += f;
                 }
             }
             const float mean = colsum16(s) * (1.f / 128.f);
@@ -302,12 +492,18 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
-                const f32x4 ga = ld4(w.ln1g + col), be = ld4(w.ln1b + col);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(spar + 512 + col);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(spar + 640 + col);
                 f32x4 rr;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rr[i] = (y[j][i] - mean) * rstd * ga[i] + be[i];
+#ifdef AQ_ABL_NOROWS
+                if (row_ok && rr[0] == 1234.5f) st4(o + col, rr);
+#else
                 if (row_ok) st4(o + col, rr);
+#endif
             }
+            __builtin_amdgcn_sched_barrier(0);   // one row tile at a time: y[] of both would not fit beside the prefetch
         }
     }
 }
@@ -315,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
 int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass) {
     if (groups <= 0) return 0;
     S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr, "attn_q: T %d", T);
-    const size_t lds = (size_t)(2 * AQ3_SLOT_HALFS + 4 * AQ3_XROW_HALFS) * 2;   // 64 KiB
+    const size_t lds = (size_t)(2 * AQ3_SLOT_HALFS + 4 * AQ3_XROW_HALFS) * 2 + 768 * 4;   // 64 KiB + the small vectors
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
