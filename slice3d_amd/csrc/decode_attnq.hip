@@ -153,23 +153,28 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
         const float* src = i < 96 ? w.inb + 4 * i : i < 128 ? w.outb + 4 * (i - 96) : i < 160 ? w.ln1g + 4 * (i - 128) : w.ln1b + 4 * (i - 160);
         st4(s_par + 4 * i, ld4(src));
     }
+    __syncthreads();   // the first item's accumulators read the out_proj bias before the first ring barrier
     const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_win + lane * 8);
     const unsigned lxa = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_x + lane * 8);
-    // phase ph = 4*h + {0 q, 1 k, 2 v, 3 out_proj}: 16 chunks of 1 KiB
-    auto dma_phase = [&](int ph, int buf) {
+    const unsigned lpar = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_par + 8 * g);
+    // phase ph = 4*h + {0 q, 1 k, 2 v, 3 out_proj}: 16 chunks of 1 KiB, four per wave.  A wave issues its four one at a
+    // time BETWEEN the MFMA groups of the phase before (dma_piece(ph, buf, k) after the first half of k-step k): issued
+    // back to back at the top of the phase, with the matrix pipe empty, they cost the wave ~60 issue cycles each
+    auto dma_piece = [&](int ph, int buf, int k) {
 #ifdef AQ_ABL_NODMA
         return;
 #endif
         const int h = ph >> 2, part = ph & 3;
         const _Float16* src0 = part < 3 ? g_in + (size_t)h * AQ_WIN_HALFS + part * AQ3_SLOT_HALFS
                                         : g_out + (size_t)h * AQ_WO_HALFS;
+        const int i = wave + 4 * k;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + i * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(s_win + buf * AQ3_SLOT_HALFS + i * 512),
+                                         16, 0, 0);
+    };
+    auto dma_phase = [&](int ph, int buf) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = wave + 4 * k;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + i * 512 + lane * 8),
-                                             (__attribute__((address_space(3))) void*)(s_win + buf * AQ3_SLOT_HALFS + i * 512),
-                                             16, 0, 0);
-        }
+        for (int k = 0; k < 4; ++k) dma_piece(ph, buf, k);
     };
     const long items = 2 * groups;
     long ps = 0;   // running phase count: slot = ps & 1
@@ -203,11 +208,19 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
         const long grp = item >> 1;
         const int q0 = 8 * (int)(item & 1) + 2 * wave;
         float* Xg = X + grp * T * S3D_GROUP * 128;
+        // out_proj accumulators open with residual row + out_proj bias (exact fp32 rows: tile j of the accumulator is
+        // columns 32(j>>1) + 8g + 4(j&1) + i, i.e. xf[r][j>>1][j&1]), so the epilogue is LayerNorm only
         f32x4 acc_o[2][8];
+        {
+            unsigned par_off = 0;
+            asm volatile("" : "+v"(par_off));   // opaque: re-read per item instead of 32 pinned VGPRs
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 bo = *reinterpret_cast<const f32x4*>(s_par + par_off + 384 + 32 * (j >> 1) + 8 * g + 4 * (j & 1));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc_o[r][j] = zero4();
+                for (int r = 0; r < 2; ++r) acc_o[r][j] = xf[r][j >> 1][j & 1] + bo;
+            }
+        }
         // rows of the item: low halves in registers for the whole item, high halves parked in LDS
         half8q xl[2][4];
 #pragma unroll
@@ -227,8 +240,9 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             // =============== phases q, k, v: one swapped (q, k) or plain (v) GEMM each ===============
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                AQ_BARRIER();   // this phase's fragments have landed; the other slot is free
-                if (part == 0) {   // the head's biases (LDS copy): they open the accumulations below
+                if (part == 0) {   // the head's biases (LDS copy) open the accumulations below; read BEFORE the barrier, whose
+                                   // LDS fence the compiler knows about (a later read would be waited for with lgkmcnt(0)
+                                   // at the first MFMA, i.e. behind the hand-issued fragment reads of two k-steps)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         bq[j] = *reinterpret_cast<const f32x4*>(s_par + 32 * h + 16 * j + 4 * g);
@@ -236,14 +250,12 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                         bv[j] = s_par[256 + 32 * h + 16 * j + m];
                     }
                 }
-                dma_phase(4 * h + part + 1, (int)((ps + 1) & 1));
+                AQ_BARRIER();   // this phase's fragments have landed; the other slot is free
+                const int nph = 4 * h + part + 1, nbuf = (int)((ps + 1) & 1);
                 const unsigned lwa = lds_ring + (unsigned)(ps & 1) * (AQ3_SLOT_HALFS * 2);
-                f32x4 d[2][2];
+                f32x4 d[2][2], c0[2];   // c0: the bias opens both row tiles' accumulations (C operand of k-step 0, no copies)
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        d[r][j] = part == 0 ? bq[j] : part == 1 ? bk[j] : f32x4{bv[j], bv[j], bv[j], bv[j]};
+                for (int j = 0; j < 2; ++j) c0[j] = part == 0 ? bq[j] : part == 1 ? bk[j] : f32x4{bv[j], bv[j], bv[j], bv[j]};
                 // fragment pairs (hi | lo) of the two 16-row tiles j and the high halves of the wave's two row tiles for
                 // k-step U, all read one k-step ahead (6 reads in flight under the 12 MFMAs of the current step)
                 half8q fh[2][2], fl[2][2], xq[2][2];
@@ -256,12 +268,17 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
     AQ_READ(xq[B][1], lxa, (4 + (U)) * 1024);
 #define AQ_STEP_MFMA(B, U)                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+        if (j == 1) {                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+            dma_piece(nph, nbuf, U);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
         if (part < 2) { /* D^T = W X^T */                                                                    \
-            d[0][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xq[B][0], xl[0][U], d[0][j]);                       \
-            d[1][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xq[B][1], xl[1][U], d[1][j]);                       \
+            d[0][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xq[B][0], xl[0][U], (U) == 0 ? c0[j] : d[0][j]);    \
+            d[1][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xq[B][1], xl[1][U], (U) == 0 ? c0[j] : d[1][j]);    \
         } else { /* D = X W^T */                                                                             \
-            d[0][j] = mfma3q<SINGLE>(xq[B][0], xl[0][U], fh[B][j], fl[B][j], d[0][j]);                       \
-            d[1][j] = mfma3q<SINGLE>(xq[B][1], xl[1][U], fh[B][j], fl[B][j], d[1][j]);                       \
+            d[0][j] = mfma3q<SINGLE>(xq[B][0], xl[0][U], fh[B][j], fl[B][j], (U) == 0 ? c0[j] : d[0][j]);    \
+            d[1][j] = mfma3q<SINGLE>(xq[B][1], xl[1][U], fh[B][j], fl[B][j], (U) == 0 ? c0[j] : d[1][j]);    \
         }                                                                                                    \
     }                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);
@@ -290,132 +307,71 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 ++ps;
             }
             // =============== attention core, then phase out_proj ===============
-            // The 13x13 core on the same split-precision 16x16x32 MFMA as the projections: the head's 32 dims are
-            // exactly one k-step (k-slot 8g + t <-> dim 16(t>>2) + 4g + (t&3), the registers as they are), and the 16
-            // keys of P V fill k-slots 8g + {0..3} (key 4g + t) with 4..7 zero.  9 MFMAs of 4 passes per query instead
-            // of 16 fp32 MFMAs of 8.  Scores in log2 units (the scale carries log2 e), softmax by v_exp_f32.
+            // The 13x13 core on the same split-precision f16 MFMA as the projections: the head's 32 dims are exactly one
+            // k-step of v_mfma_f32_16x16x32_f16 (k-slot 8g + t <-> dim 16(t>>2) + 4g + (t&3): the registers as they
+            // are), and P V runs on v_mfma_f32_16x16x16_f16 (k-slot 4g + t <-> key 4g + t).  9 MFMAs of 4 passes per
+            // query instead of 16 fp32 MFMAs of 8.  Scores in log2 units (the scale carries log2 e), softmax by v_exp_f32.
+            // Both queries of the wave go through each stage together (independent chains), and every group of splits
+            // is followed by AQ_SETTLE before the MFMAs that read it: the halves are written by 16-bit partial-register
+            // asm ops (v_fma_mixlo/hi_f16) whose write -> MFMA-read spacing the compiler does not pad (one wait state
+            // measured as too few on gfx950: wrong P V products in some schedules, fixed by the padding alone).
+#define AQ_SETTLE()                                 \
+    __builtin_amdgcn_sched_barrier(0);              \
+    asm volatile("s_nop 7" ::: "memory");           \
+    __builtin_amdgcn_sched_barrier(0);
             half8q oh[2], ol[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
 #ifdef AQ_ABL_NOCORE
-                split8pk(qd[r][0] + kd[r][0] + vd[r][0], qd[r][1] + kd[r][1] + vd[r][1], oh[r], ol[r]);
-                continue;
-#endif
-#ifdef AQ_DBG_OLDCORE
-                {
-                    f32x4 s = zero4();
-#if AQ_DBG_OLDCORE & 4
-                    {
-                        half8q kh, kl, qh, ql;
-                        split8pk(kd[r][0], kd[r][1], kh, kl);
-                        split8pk(qd[r][0] * scale, qd[r][1] * scale, qh, ql);
-                        s = mfma3q<SINGLE>(kh, kl, qh, ql, zero4());
-                    }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) split8pk(qd[r][0] + kd[r][0] + vd[r][0], qd[r][1] + kd[r][1] + vd[r][1], oh[r], ol[r]);
 #else
-                    for (int j = 0; j < 2; ++j)
-                        for (int i = 0; i < 4; ++i)
-                            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kd[r][j][i], qd[r][j][i] * scale, s, 0, 0, 0);
-#endif
+            {
+                half8q kh[2], kl[2], qh[2], ql[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    split8pk(kd[r][0], kd[r][1], kh[r], kl[r]);
+                    split8pk(qd[r][0] * scale, qd[r][1] * scale, qh[r], ql[r]);
+                }
+                AQ_SETTLE()
+                f32x4 s[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) s[r] = mfma3q<SINGLE>(kh[r], kl[r], qh[r], ql[r], zero4());
+                half4q ph[2], pl[2], vh[2][2], vl[2][2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
                     float e[4];
                     float mx = -1e30f;
+#pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        e[i] = (4 * g + i < T) ? s[i] : -1e30f;
+                        e[i] = (4 * g + i < T) ? s[r][i] : -1e30f;
                         mx = fmaxf(mx, e[i]);
                     }
-#if AQ_DBG_OLDCORE & 1
                     mx = colmax16(mx);
-#else
-                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#endif
                     float den = 0.f;
+#pragma unroll
                     for (int i = 0; i < 4; ++i) {
-#if AQ_DBG_OLDCORE & 2
-                        e[i] = __builtin_amdgcn_exp2f(e[i] - mx);
-#else
-                        e[i] = (4 * g + i < T) ? exp2f(e[i] - mx) : 0.f;
-#endif
+                        e[i] = __builtin_amdgcn_exp2f(e[i] - mx);   // masked keys: exp2(-1e30) = 0
                         den += e[i];
                     }
-#if AQ_DBG_OLDCORE & 1
-                    den = colsum16(den);
-#else
-                    den += __shfl_xor(den, 16, 64);
-                    den += __shfl_xor(den, 32, 64);
-#endif
-                    const float inv = 1.f / den;
-                    f32x4 od[2];
-#if AQ_DBG_OLDCORE & 8
-                    {
-                        half4q ph, pl;
-                        split4pk(f32x4{e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv}, ph, pl);
-                        for (int j = 0; j < 2; ++j) {
-                            half4q vh, vl;
-                            split4pk(vd[r][j], vh, vl);
-                            od[j] = mfma3h<SINGLE>(vh, vl, ph, pl, zero4());
-                        }
-                    }
-#else
-                    for (int j = 0; j < 2; ++j) {
-                        f32x4 o = zero4();
-                        for (int i = 0; i < 4; ++i)
-                            o = __builtin_amdgcn_mfma_f32_16x16x4f32(vd[r][j][i], e[i] * inv, o, 0, 0, 0);
-                        od[j] = o;
-                    }
-#endif
-#if AQ_DBG_OLDCORE & 32
-                    if (blockIdx.x == 0 && wave == 0 && h == 0 && r == 0 && item == 0) {
-                        f32x4 oo[2];
-                        for (int j = 0; j < 2; ++j) {
-                            f32x4 o = zero4();
-                            for (int i = 0; i < 4; ++i)
-                                o = __builtin_amdgcn_mfma_f32_16x16x4f32(vd[r][j][i], e[i] * inv, o, 0, 0, 0);
-                            oo[j] = o;
-                        }
-                        if (lane < 3 || lane == 17 || lane == 40) printf("lane %2d new %9.5f %9.5f %9.5f %9.5f | %9.5f  old %9.5f %9.5f %9.5f %9.5f | %9.5f  p %g %g %g %g v %g %g\n", lane,
-                               od[0][0], od[0][1], od[0][2], od[0][3], od[1][0], oo[0][0], oo[0][1], oo[0][2], oo[0][3], oo[1][0],
-                               e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv, vd[r][0][0], vd[r][0][1]);
-                    }
-#endif
-                    split8pk(od[0], od[1], oh[r], ol[r]);
-                    continue;
-                }
-#endif
-                half8q kh, kl, qh, ql;
-                split8pk(kd[r][0], kd[r][1], kh, kl);
-                split8pk(qd[r][0] * scale, qd[r][1] * scale, qh, ql);
-                const f32x4 s = mfma3q<SINGLE>(kh, kl, qh, ql, zero4());
-                float e[4];
-                float mx = -1e30f;
+                    const float inv = __builtin_amdgcn_rcpf(colsum16(den));   // v_rcp_f32, 1 ulp
+                    split4pk(f32x4{e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv}, ph[r], pl[r]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    e[i] = (4 * g + i < T) ? s[i] : -1e30f;
-                    mx = fmaxf(mx, e[i]);
+                    for (int j = 0; j < 2; ++j) split4pk(vd[r][j], vh[r][j], vl[r][j]);
                 }
-                mx = colmax16(mx);
-                float den = 0.f;
+                AQ_SETTLE()
+                f32x4 od[2][2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    e[i] = __builtin_amdgcn_exp2f(e[i] - mx);   // masked keys: exp2(-1e30) = 0
-                    den += e[i];
-                }
-                const float inv = 1.f / colsum16(den);
-                half4q ph, pl;
-                split4pk(f32x4{e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv}, ph, pl);
-                f32x4 od[2];
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    half4q vh, vl;
-                    split4pk(vd[r][j], vh, vl);
-                    od[j] = mfma3h<SINGLE>(vh, vl, ph, pl, zero4());
-                }
-                split8pk(od[0], od[1], oh[r], ol[r]);
+                    for (int j = 0; j < 2; ++j) od[r][j] = mfma3h<SINGLE>(vh[r][j], vl[r][j], ph[r], pl[r], zero4());
+#pragma unroll
+                for (int r = 0; r < 2; ++r) split8pk(od[r][0], od[r][1], oh[r], ol[r]);
             }
+#endif
+#undef AQ_SETTLE
             AQ_BARRIER();   // out_proj fragments have landed; the v slot is free
-            {
-                const bool more_h = h < 3, more_i = item + gridDim.x < items;
-                if (more_h || more_i) dma_phase(more_h ? 4 * (h + 1) : 0, (int)((ps + 1) & 1));
-            }
+            // the next phase is the next head's q, or phase 0 of the next item (issued even after the last item: no
+            // branch in the MFMA stream; the kernel drains vmcnt before it ends)
+            const int oph = h < 3 ? 4 * (h + 1) : 0, obuf = (int)((ps + 1) & 1);
             {
                 const unsigned lwa = lds_ring + (unsigned)(ps & 1) * (AQ3_SLOT_HALFS * 2);
                 half8q wh[2][2], wl[2][2];   // [buffer][tile of the pair]
@@ -425,9 +381,15 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
     AQ_READ(wh[B][1], lwa, (2 * (G) + 1) * 2048);                    \
     AQ_READ(wl[B][1], lwa, (2 * (G) + 1) * 2048 + 1024);
 #define AQ_O_MFMA(B, G)                                                                                      \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                          \
+        if (q == 1) {                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+            dma_piece(oph, obuf, G);                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
         _Pragma("unroll") for (int r = 0; r < 2; ++r)                                                        \
             acc_o[r][2 * (G) + q] = mfma3q<SINGLE>(wh[B][q], wl[B][q], oh[r], ol[r], acc_o[r][2 * (G) + q]); \
+    }                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);
                 AQ_O_READS(0, 0)
                 AQ_O_READS(1, 1)
@@ -450,62 +412,47 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
         // below covers most of their latency
         load_rows(more_items ? item + gridDim.x : item);   // unconditional: a conditional load keeps the OLD rows live through the heads
         __builtin_amdgcn_sched_barrier(0);
-        // ---- residual + LayerNorm1, store.  The residual rows are rebuilt from their halves (hi from the LDS park, lo
-        //      from the registers: x = hi + lo to 2^-22, what the projections saw) instead of a second trip to HBM ----
+        // ---- LayerNorm1 (the accumulators already hold out_proj + bias + residual), store.  f32x4 arithmetic: packed
+        //      fp32 VALU ops.  gamma / beta are fetched by hand-issued reads, all 16 up front under the statistics of
+        //      the first tile (compiler-issued ones are sunk next to each store and waited for one by one) ----
+        f32x4 ga[8], be[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            AQ_READ(ga[j], lpar, (512 + 32 * (j >> 1) + 4 * (j & 1)) * 4);
+            AQ_READ(be[j], lpar, (640 + 32 * (j >> 1) + 4 * (j & 1)) * 4);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            // opaque per-tile base: keeps the 24 parameter quads from being loaded once and held for both tiles (96 VGPRs)
-            unsigned par_off = 0;
-            asm volatile("" : "+v"(par_off));
-            const float* spar = s_par + par_off;
-            uint4q xh4[4];
+            f32x4 s4 = acc_o[r][0];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xh4[u] = *reinterpret_cast<const uint4q*>(s_x + ((r * 4 + u) * 64 + lane) * 8);
-            f32x4 y[8];
-            float s = 0.f;
+            for (int j = 1; j < 8; ++j) s4 += acc_o[r][j];
+            const float mean = colsum16((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.f / 128.f);
+            f32x4 v4 = zero4();
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
-                const f32x4 bo = *reinterpret_cast<const f32x4*>(spar + 384 + col);
-                const uint4q xl4 = __builtin_bit_cast(uint4q, xl[r][j >> 1]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int wd = 2 * (j & 1) + (i >> 1);
-                    float f = acc_o[r][j][i] + bo[i];
-                    f = (i & 1) ? add_h1(f, xl4[wd]) : add_h0(f, xl4[wd]);
-                    f = (i & 1) ? add_h1(f, xh4[j >> 1][wd]) : add_h0(f, xh4[j >> 1][wd]);
-                    y[j][i] = f;
-                    s += f;
-                }
+                acc_o[r][j] -= mean;
+                v4 += acc_o[r][j] * acc_o[r][j];
             }
-            const float mean = colsum16(s) * (1.f / 128.f);
-            float v = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float dd = y[j][i] - mean;
-                    v += dd * dd;
-                }
-            const float rstd = 1.f / sqrtf(colsum16(v) * (1.f / 128.f) + 1e-5f);
+            const float rstd = __builtin_amdgcn_rsqf(colsum16((v4[0] + v4[1]) + (v4[2] + v4[3])) * (1.f / 128.f) + 1e-5f);
             float* o = Xg + (mt * S3D_GROUP + q0 + r) * 128;
+            if (r == 0)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]), "+v"(ga[4]), "+v"(ga[5]), "+v"(ga[6]), "+v"(ga[7]),
+                               "+v"(be[0]), "+v"(be[1]), "+v"(be[2]), "+v"(be[3]), "+v"(be[4]), "+v"(be[5]), "+v"(be[6]), "+v"(be[7]));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
-                const f32x4 ga = *reinterpret_cast<const f32x4*>(spar + 512 + col);
-                const f32x4 be = *reinterpret_cast<const f32x4*>(spar + 640 + col);
-                f32x4 rr;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rr[i] = (y[j][i] - mean) * rstd * ga[i] + be[i];
+                const f32x4 rr = acc_o[r][j] * (ga[j] * rstd) + be[j];
 #ifdef AQ_ABL_NOROWS
                 if (row_ok && rr[0] == 1234.5f) st4(o + col, rr);
 #else
                 if (row_ok) st4(o + col, rr);
 #endif
             }
-            __builtin_amdgcn_sched_barrier(0);   // one row tile at a time: y[] of both would not fit beside the prefetch
+            __builtin_amdgcn_sched_barrier(0);   // one row tile at a time
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last phase-0 prefetch must not outlive the workgroup's LDS
 }
 
 int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass) {
