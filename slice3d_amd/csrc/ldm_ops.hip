@@ -541,10 +541,13 @@ __global__ __launch_bounds__(256) void qkv_attention_f16x3_kernel(const float* _
 int launch_qkv_attention(const float* qkv, float* out, int N, int T, int heads, int ch, int prec, hipStream_t stream) {
     S3D_CHECK_ARG(N >= 1 && T >= 1 && heads >= 1, "qkv_attention: bad dims");
     const int blocks = N * heads * ((T + 63) / 64);
-    // The split-precision kernel is opt-in (S3D_LDM_ATTN_F16X3=1): it is 20 % faster on the 4096-token maps and passes
-    // the full-model parity tests, but on random inputs its output is off by up to 2e-5 where the fp32 kernel and a
-    // CPU emulation of the same algorithm are at 5e-7 — not understood yet (tools/dbg_ldm_attn.py), so not the default.
-    static const bool f16x3_on = getenv("S3D_LDM_ATTN_F16X3") != nullptr;
+    // The split-precision kernel stays opt-in (S3D_LDM_ATTN_F16X3=1): 3 % on the denoise step (5.05 vs 5.22 ms).  On
+    // N(0,1) inputs its output is up to 3e-5 from an fp64 softmax where the fp32-MFMA kernel is at 5e-7: the hi+lo
+    // operands carry 22 bits, so a score (sum |q k| ~ 9 for a 96-wide head) moves by ~5e-6 and a peaked softmax hands
+    // that on to the output.  That is the split's precision — deterministic run to run, unchanged by hazard padding
+    // between the P split and the MFMAs (tools/dbg_ldm_attn.py) — and the full-model parity tests (2e-4) pass with it,
+    // but the primitive test (tests/test_ldm.py, 2e-5 on random inputs) does not, so the default keeps the fp32 core.
+    static const bool f16x3_on = getenv("S3D_LDM_ATTN_F16X3") && getenv("S3D_LDM_ATTN_F16X3")[0] == '1';
     if (prec == S3D_PREC_F16X3 && f16x3_on) {
 #define QA16_CASE(c)                                                                                              \
     if (ch == c) {                                                                                                \

@@ -1,5 +1,8 @@
+# kernel trace of the LDM denoise step (bench.py's ldm leg, 20 steps + 2 warm-up) -> gpurun_out/r02/r02_ldm_kernel_stats.md
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-python tools/time_ldm.py 1; python tools/time_ldm.py 4
-rm -rf /tmp/pl; (cd /tmp && rocprofv3 --kernel-trace -d /tmp/pl -o b -- python $GRAFT_REPO_ROOT/tools/time_ldm.py 1 > /dev/null 2>&1)
-python tools/rocpd_summary.py $(find /tmp/pl -name "*.db" | head -1) > gpurun_out/ldm_kernels.md
-awk -F'|' 'NR>2 {printf "%-60s %5s calls %8s ms avg %8s us\n", substr($2,1,60), $3, $4, $5}' gpurun_out/ldm_kernels.md | head -16
+mkdir -p gpurun_out/r02
+(cd /tmp && rm -rf /tmp/pl && rocprofv3 --kernel-trace -d /tmp/pl -o l -- python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --train-steps 0 --gt-train-steps 0 --c4-steps 0 --f16-steps 0 --steps 1 --warmup 0 --n-qry 2048 --batch 1 --ldm-steps 20 > /tmp/pl.json 2>/dev/null)
+python tools/rocpd_summary.py $(find /tmp/pl -name "*.db" | head -1) > gpurun_out/r02/r02_ldm_kernel_stats.md
+python -c "
+import json; r = json.loads(open('/tmp/pl.json').read().strip().splitlines()[-1]); print(r['ldm_denoise_step'])" >> gpurun_out/r02/r02_ldm_kernel_stats.md
+head -32 gpurun_out/r02/r02_ldm_kernel_stats.md | cut -c1-170
