@@ -2,7 +2,7 @@
 # dominant kernels, clock/power under load.  One rocprofv3 --pmc set per run (no trace domains mixed in).
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 mkdir -p gpurun_out/r02
-BENCH="$GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --train-steps 0 --gt-train-steps 0 --ldm-steps 0 --c4-steps 0"
+BENCH="$GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --train-steps 0 --gt-train-steps 0 --ldm-steps 0 --c4-steps 0 --f16-steps 0"
 (cd /tmp && rm -rf /tmp/p1 && rocprofv3 --kernel-trace -d /tmp/p1 -o b -- python $BENCH --steps 10 --warmup 2 > /tmp/p1.json 2>/dev/null)
 python tools/rocpd_summary.py $(find /tmp/p1 -name "*.db" | head -1) > gpurun_out/r02/r02_bench_f16x3_kernel_stats.md
 echo >> gpurun_out/r02/r02_bench_f16x3_kernel_stats.md; echo "bench line of the traced run:" >> gpurun_out/r02/r02_bench_f16x3_kernel_stats.md; tail -c 2500 /tmp/p1.json >> gpurun_out/r02/r02_bench_f16x3_kernel_stats.md
@@ -17,8 +17,8 @@ python - > gpurun_out/r02/r02_bench_f16x3_sq_counters.md <<'PY'
 import csv, glob, collections
 print("# SQ counters of the decoder kernels (rocprofv3 --pmc, two passes of 8 counters, `bench.py --steps 3 --warmup 1`, inference legs only)\n")
 print("Per-launch averages.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles per wave; SQ_VALU_MFMA_BUSY_CYCLES and")
-print("SQ_BUSY_CYCLES count cycles (MI355X_MICROARCH.md).  MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES * 4 SIMDs / ... ) is")
-print("reported below as MFMA_BUSY / (GRBM_GUI_ACTIVE * 1024 SIMDs).\n")
+print("SQ_BUSY_CYCLES count cycles (MI355X_MICROARCH.md).  MFMA pipe busy below = SQ_VALU_MFMA_BUSY_CYCLES (16 cycles per four-pass MFMA,")
+print("summed over the SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): GRBM_GUI_ACTIVE comes back summed over the 8 XCDs.\n")
 for d in ('/tmp/psq', '/tmp/psq2'):
     fs = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
     if not fs:
@@ -36,7 +36,7 @@ for d in ('/tmp/psq', '/tmp/psq2'):
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in dd and 'GRBM_GUI_ACTIVE' in dd:
             m = sum(dd['SQ_VALU_MFMA_BUSY_CYCLES']) / len(dd['SQ_VALU_MFMA_BUSY_CYCLES'])
             g = sum(dd['GRBM_GUI_ACTIVE']) / len(dd['GRBM_GUI_ACTIVE'])
-            print("\nMFMA pipe busy = %.1f %% of GRBM_GUI_ACTIVE x 1024 SIMDs" % (100.0 * m / (g * 1024)))
+            print("\nMFMA pipe busy = %.1f %% of the launch's SIMD cycles" % (100.0 * m / (g / 8 * 1024)))
         if 'SQ_INSTS_VALU' in dd and 'SQ_INSTS_MFMA' in dd:
             print("\nVALU (non-MFMA) instructions per MFMA = %.2f" % ((sum(dd['SQ_INSTS_VALU']) / len(dd['SQ_INSTS_VALU'])) / (sum(dd['SQ_INSTS_MFMA']) / len(dd['SQ_INSTS_MFMA'])) - 1.0))
 PY
