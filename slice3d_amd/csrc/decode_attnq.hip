@@ -7,9 +7,10 @@
 // without exchanging anything with the other waves:
 //   Q^T, K^T  swapped form   D^T = W X^T   (f16x3 MFMA): lane (token, g) holds head dims {16j + 4g + i}
 //   V         plain form     D   = X W^T   (same fragments, operands exchanged): lane (dim, g) holds tokens 4g+i
-//   S^T = K Q^T   fp32 MFMA 16x16x4: the k-slot of lane g at step (j,i) is dim 16j+4g+i — exactly the Q / K registers
-//   softmax over the keys = registers i and lane groups g of one query column (two shuffles)
-//   O^T = V^T P^T fp32 MFMA: A = the V registers, B = the P registers; result lane (token, g) holds dims 4g+i
+//   S^T = K Q^T   f16x3 MFMA 16x16x32: one k-step, k-slot 8g+t <-> dim 16(t>>2)+4g+(t&3) = the Q / K registers as they are
+//   softmax over the keys = registers i and lane groups g of one query column (two lane swaps)
+//   O^T = V^T P^T f16x3 MFMA 16x16x16: A = the V registers, B = the P registers (k-slot 4g+t <-> key 4g+t); result lane
+//                 (token, g) holds dims 4g+i
 //   out_proj      f16x3 MFMA: O^T registers are its B operand (k-slot 8g+t <-> dim 16(t>>2) + 4g + (t&3), folded
 //                 into the packed W_o columns), accumulated over heads
 // No Q/K/V/O ever touches LDS; LDS holds weight fragments (LDS-DMA ring of quarter-head slots) and the high halves of
@@ -23,14 +24,6 @@ typedef _Float16 half8q __attribute__((ext_vector_type(8)));
 #define AQ_WO_HALFS (8 * 1024)     // per head: 8 fragment pairs = 16 KiB
 
 __device__ __forceinline__ half8q ldq8(const _Float16* p) { return *reinterpret_cast<const half8q*>(p); }
-__device__ __forceinline__ void splitq8(const float (&x)[8], half8q& hi, half8q& lo) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const _Float16 h = (_Float16)x[t];
-        hi[t] = h;
-        lo[t] = (_Float16)(x[t] - (float)h);
-    }
-}
 template <bool SINGLE>
 __device__ __forceinline__ f32x4 mfma3q(const half8q ah, const half8q al, const half8q bh, const half8q bl, f32x4 c) {
     if (!SINGLE) {
@@ -41,7 +34,7 @@ __device__ __forceinline__ f32x4 mfma3q(const half8q ah, const half8q al, const 
     return c;
 }
 // hi/lo split of a pair: one v_cvt_pk_f16_f32 + two v_fma_mix{lo,hi}_f16 (lo = f16(x - f32(hi)), the subtraction is
-// exact, one rounding: the same value the scalar convert-subtract-convert of splitq8 produces)
+// exact, one rounding: the same value a scalar convert - subtract - convert produces)
 typedef _Float16 half2q __attribute__((ext_vector_type(2)));
 typedef float float2q __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2q(float a, float b, unsigned& hi, unsigned& lo) {
@@ -77,17 +70,6 @@ __device__ __forceinline__ f32x4 mfma3h(const half4q ah, const half4q al, const 
     }
     c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
     return c;
-}
-// x + f32(h[lo half]) / x + f32(h[hi half])
-__device__ __forceinline__ float add_h0(float x, unsigned h) {
-    float d;
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
-    return d;
-}
-__device__ __forceinline__ float add_h1(float x, unsigned h) {
-    float d;
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
-    return d;
 }
 // reductions over the 4 lane groups g of one column (l & 15) with the gfx950 lane-swap instructions (no LDS crossbar):
 // v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second, so two copies
