@@ -273,6 +273,11 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_kernel(const f
 // different chunks of the (unchanged) image.  lin1's bias is the accumulator's initial value.  Fragment reads are
 // issued one 12-MFMA group ahead; sched_group_barrier pins the interleave.
 // ---------------------------------------------------------------------------------------------
+#ifndef PIPE_WAVES
+#define PIPE_WAVES 4   // waves per workgroup: 4 = two workgroups per CU, each streaming the weights; 8 = one workgroup and one
+                       // weight stream per CU (half the L2 -> LDS traffic): measured identical, 6.15 vs 6.16 ms (tools/ffn_w8.sh)
+#endif
+#define PIPE_THREADS (PIPE_WAVES * 64)
 #ifndef PIPE_R
 #define PIPE_R 2     // 16-row tiles per wave: 2 = two workgroups per CU (256 VGPRs), 4 = one (512 VGPRs, half the LDS / L2 traffic)
 #endif
@@ -287,8 +292,8 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // pieces [p0, p1) (1 KiB each) of one chunk image -> the same pieces of an LDS buffer, spread over the waves
 __device__ __forceinline__ void dma_pieces(const _Float16* gchunk, _Float16* lbuf, int p0, int p1, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 16 / F16_WAVES; ++i) {   // p1 - p0 == 16 pieces, wave-uniform LDS address (M0)
-        const int piece = p0 + wave + i * F16_WAVES;
+    for (int i = 0; i < 16 / PIPE_WAVES; ++i) {   // p1 - p0 == 16 pieces, wave-uniform LDS address (M0)
+        const int piece = p0 + wave + i * PIPE_WAVES;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gchunk + piece * 512 + lane * 8),
                                          (__attribute__((address_space(3))) void*)(lbuf + piece * 512), 16, 0, 0);
     }
@@ -422,7 +427,7 @@ __device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned 
 
 // SINGLE: S3D_PREC_F16 — only the hi*hi product of every split (one MFMA per product; not fp32-class)
 template <int MODE, bool SINGLE>
-__global__ __launch_bounds__(F16_THREADS, PIPE_R == 2 ? 2 : 1) void ffn_layer_f16x3_pipe_kernel(const float* X, float* Yout, long rows,
+__global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 : 1) void ffn_layer_f16x3_pipe_kernel(const float* X, float* Yout, long rows,
                                                                    const _Float16* wimg, const LayerPtrs w,
                                                                    const float* fco_w, const float* fco_b,
                                                                    float* sdf_out, float sign, long groups_per_batch,
@@ -436,13 +441,13 @@ __global__ __launch_bounds__(F16_THREADS, PIPE_R == 2 ? 2 : 1) void ffn_layer_f1
     __shared__ __attribute__((aligned(16))) float s_b1[S3D_FFN];                                     // 8 KiB
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, g = lane >> 4;
-    const long row0 = ((long)blockIdx.x * F16_WAVES + wave) * (PIPE_R * 16);
+    const long row0 = ((long)blockIdx.x * PIPE_WAVES + wave) * (PIPE_R * 16);
 
     // prologue DMA: W1(0) -> buffer 1 (W1 half);  buffer 0 <- W1(1) | W2(0)
     dma_pieces(wimg, s_w1, 0, 16, wave, lane);
     dma_pieces(wimg + F16_CHUNK_HALFS, s_w0, 0, 16, wave, lane);
     dma_pieces(wimg, s_w0, 16, 32, wave, lane);
-    for (int i = threadIdx.x; i < S3D_FFN / 4; i += F16_THREADS) st4(s_b1 + 4 * i, ld4(w.b1 + 4 * i));
+    for (int i = threadIdx.x; i < S3D_FFN / 4; i += PIPE_THREADS) st4(s_b1 + 4 * i, ld4(w.b1 + 4 * i));
 
     half8 xh[PIPE_R][4], xl[PIPE_R][4];
     f32x4 acc[PIPE_R][8];
@@ -583,23 +588,23 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
     const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
     FfnTrainArgs ta = {};
     if (single_pass) {
-        const long blocks = (rows + F16_WAVES * PIPE_R * 16 - 1) / (F16_WAVES * PIPE_R * 16);
+        const long blocks = (rows + PIPE_WAVES * PIPE_R * 16 - 1) / (PIPE_WAVES * PIPE_R * 16);
         if (sdf_out)
-            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, true>), dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream,
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, true>), dim3((unsigned)blocks), dim3(PIPE_THREADS), 0, stream,
                                X, X, rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
         else
-            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, true>), dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream,
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, true>), dim3((unsigned)blocks), dim3(PIPE_THREADS), 0, stream,
                                X, X, rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
         S3D_LAUNCH_CHECK();
         return 0;
     }
     if (ffn_pipelined()) {
-        const long blocks = (rows + F16_WAVES * PIPE_R * 16 - 1) / (F16_WAVES * PIPE_R * 16);
+        const long blocks = (rows + PIPE_WAVES * PIPE_R * 16 - 1) / (PIPE_WAVES * PIPE_R * 16);
         if (sdf_out)
-            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, false>), dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X,
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, false>), dim3((unsigned)blocks), dim3(PIPE_THREADS), 0, stream, X, X,
                                rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
         else
-            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, false>), dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X,
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, false>), dim3((unsigned)blocks), dim3(PIPE_THREADS), 0, stream, X, X,
                                rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
         S3D_LAUNCH_CHECK();
         return 0;
