@@ -408,17 +408,20 @@ static int launch_lin_rows(const ConvLaunch& a, hipStream_t stream) {
 // LDS-staged 3x3 convolution (stride 1, "same"), split precision.
 // A workgroup (4 waves) owns an 8-row x 16-column pixel tile of one image and CO_WG output channels.  Per
 // 32-channel K chunk the (8+2) x (16+2) input halo is fetched ONCE (coalesced 16 B/lane), split into f16 hi/lo
-// ONCE and parked in LDS ([pixel][40 halfs]: an 80-byte pixel stride makes both the staging writes and the
-// 16-lane fragment reads conflict-free); the nine taps then read their B fragments from LDS at shifted pixel
-// offsets.  The direct kernel above loads and splits every input value 9 x (Cout / CO_WG) times instead.
+// ONCE and parked in LDS as [pixel][32 halfs] with the four 16-byte quarters of a pixel XOR-swizzled by
+// (pixel >> 1) & 3: ds_read_b128 is served in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... and with that
+// swizzle the 16 lanes of every group fall on 16 distinct bank quads for ANY pixel offset of a tap (the earlier
+// 80-byte padded stride did not: SQ_LDS_BANK_CONFLICT was 2.3x the LDS-active cycles); the staging writes cover whole
+// 64-byte pixels either way.  The nine taps read their B fragments from LDS at shifted pixel offsets.  The direct kernel above loads and splits every input value 9 x (Cout / CO_WG) times instead.
 // Zero padding = zeros written for halo pixels outside the image.  Waves are arranged WP x WC: wave (wp, wc) owns
 // pixel rows {MT*wp .. +MT-1} of the tile and NT = 2 output-channel tiles; weight fragments come straight from
 // the packed image (L2), requested one tap ahead.  The next chunk's halo is in flight under the MFMAs.
 // ---------------------------------------------------------------------------------------------
-#define C3_PXS 40            // halfs per pixel in LDS (32 + 8 pad)
+#define C3_PXS 32            // halfs per pixel in LDS (swizzled quarters, no padding)
+#define C3_SWZ(pix, q) (((q) ^ (((pix) >> 1) & 3)) * 8)   // half offset of 16-byte quarter q of a pixel
 #define C3_HALO (10 * 18)    // pixels of the halo tile
-// NBUF = 2: the next chunk's halo is parked while this one is consumed (57.6 KiB, two workgroups per CU).  NBUF = 1:
-// one buffer (28.8 KiB, five workgroups per CU) for layers whose K is one or two chunks — there a workgroup's life is a
+// NBUF = 2: the next chunk's halo is parked while this one is consumed (45 KiB, three workgroups per CU).  NBUF = 1:
+// one buffer (22.5 KiB, seven workgroups per CU) for layers whose K is one or two chunks — there a workgroup's life is a
 // fetch, a split and 108-216 MFMAs per wave, nothing overlaps inside it, and what hides the fetch latency is the number
 // of OTHER workgroups on the CU (the 32- and 64-channel layers at full resolution: 0.51 / 0.34 ms -> see DESIGN.md).
 template <int MT, int WP, int WC, int NBUF>
@@ -481,8 +484,9 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
                     hi[t] = h;
                     lo[t] = (_Float16)(pre[i][t] - (float)h);
                 }
-                *reinterpret_cast<half4_t*>(&s_in[buf][0][pix * C3_PXS + 4 * q4]) = hi;
-                *reinterpret_cast<half4_t*>(&s_in[buf][1][pix * C3_PXS + 4 * q4]) = lo;
+                const int po = pix * C3_PXS + C3_SWZ(pix, q4 >> 1) + 4 * (q4 & 1);
+                *reinterpret_cast<half4_t*>(&s_in[buf][0][po]) = hi;
+                *reinterpret_cast<half4_t*>(&s_in[buf][1][po]) = lo;
             }
         }
     };
@@ -530,8 +534,9 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int pix = (MT * wp + mt + dy) * 18 + m + dx;
-                bh[mt] = *reinterpret_cast<const chalf8*>(sh + pix * C3_PXS + 8 * g);
-                bl[mt] = *reinterpret_cast<const chalf8*>(sl + pix * C3_PXS + 8 * g);
+                const int po = pix * C3_PXS + C3_SWZ(pix, g);
+                bh[mt] = *reinterpret_cast<const chalf8*>(sh + po);
+                bl[mt] = *reinterpret_cast<const chalf8*>(sl + po);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
