@@ -29,6 +29,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f3
 F16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (spec); 16x16x32 f16 measures 1955
 FFN_FLOP_PER_ROW = 2 * 2 * 128 * 2048   # two 128x2048 GEMMs, 2 FLOP/MAC (FFN = 88 %)
 F_MIN_PER_QUERY = 35.96e6           # exact decoder FLOPs/query with last-layer pruning
+ATTN_FLOP_PER_TOKEN = 2 * (3 * 128 * 128 + 128 * 128) + 2 * 2 * 13 * 128   # in_proj + out_proj + (QK^T, PV) over 13 keys
 
 
 def _cpu_model():
@@ -129,6 +130,8 @@ def main():
                                                               "separately with its error (0 = skip)")
     ap.add_argument("--c4-steps", type=int, default=2, help="timed dense 256^3 grid evaluations (BASELINE configs[3]; 0 = skip)")
     ap.add_argument("--c4-res", type=int, default=256)
+    ap.add_argument("--mesh-steps", type=int, default=2, help="timed reconstruct.py-default mesh extractions (MISE 64 -> 256 + "
+                    "marching cubes on the device; 0 = skip)")
     ap.add_argument("--ldm-steps", type=int, default=5, help="timed LDM denoising steps (BASELINE configs[4]; 0 = skip)")
     ap.add_argument("--train-steps", type=int, default=3, help="timed training steps for train_samples_per_s (0 = skip)")
     ap.add_argument("--gt-train-steps", type=int, default=5, help="timed Slices3DGTModel training steps (0 = skip)")
@@ -296,6 +299,32 @@ def main():
               "scaling": "strong", "dtype": args.prec}
         del grid, host
 
+    # ---- reconstruct.py at its default options (mc_res0 64, two upsampling steps): MISE refinement on the
+    #      device + HIP marching cubes, one object, rank 0 ----
+    mesh_leg = None
+    if args.mesh_steps > 0 and rank == 0 and args.img_size == 256:
+        try:
+            from slice3d_amd.generator import Generator3D
+            fdm = {k: v[:1].contiguous() for k, v in make_feed_dict(1, args.img_size, 16, args.n_slices, seed=3, with_slices=False,
+                                                                     device="cuda").items()}
+            gm = Generator3D(model, threshold=0.5, resolution0=64, upsampling_steps=2, pred_type="sdf", mesh_backend="device")
+            gm.generate_mesh(fdm)
+            tms = []
+            for _ in range(args.mesh_steps):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                mesh, mst = gm.generate_mesh(fdm)
+                torch.cuda.synchronize()
+                tms.append(time.perf_counter() - t1)
+            mesh_leg = {"workload": "Generator3D.generate_mesh, reconstruct.py defaults (MISE 64 -> 256, threshold 0.5), device MISE + "
+                                    "HIP marching cubes, random-weight field",
+                        "seconds_per_mesh": sorted(tms)[len(tms) // 2], "seconds_eval_points": mst.get("time (eval points)"),
+                        "seconds_marching_cubes": mst.get("time (marching cubes)"), "vertices": int(len(mesh.vertices)),
+                        "faces": int(len(mesh.faces))}
+            del gm, mesh
+        except Exception as e:   # the mesh library is a separate .so (csrc_mesh); the headline does not depend on it
+            mesh_leg = {"error": repr(e)[:200]}
+
     # ---- BASELINE configs[4]: one denoising step of the gen_slices latent-diffusion U-Net (295 M parameters,
     #      64x64x4 latent mosaic + 4 conditioning channels, 21 attention blocks), batch 1 per GPU ----
     ldm = None
@@ -419,10 +448,17 @@ def main():
                  "peak": peak, "unit": "TFLOP/s",
                  "frac": args.batch * UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"] / peak,
                  "note": "algorithmic FLOPs 241.97 GFLOP/object at 256^2 (SURVEY 8d) / whole unet_encode stage time"},
+                {"kernel": "attention stage (attn_layer_q_kernel, layers 0-1, + the absorbed-form last layer)", "bound": "mfma",
+                 "achieved": args.n_qry * args.batch * 2 * (args.n_slices + 1) * ATTN_FLOP_PER_TOKEN / (stage_ms["attn_layer"] * 1e-3) / 1e12,
+                 "peak": peak, "unit": "TFLOP/s",
+                 "frac": args.n_qry * args.batch * 2 * (args.n_slices + 1) * ATTN_FLOP_PER_TOKEN / (stage_ms["attn_layer"] * 1e-3) / 1e12 / peak,
+                 "note": "algorithmic FLOPs of layers 0-1 only (in_proj 98 304 + out_proj 32 768 + 13-key core 6 656 per token; the "
+                         "last layer's token-0 form is not counted) / the whole attn_layer stage time"},
             ],
             "throughput_mode_f16": f16_mode,
             "c4_dense_grid": c4,
             "ldm_denoise_step": ldm,
+            "mesh_extraction": mesh_leg,
             "gt_train_step": gt_train,
             "stage_ms_per_step": stage_ms,
             "decode_tflops_fmin": args.n_qry * args.batch * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,
