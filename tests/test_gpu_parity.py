@@ -102,10 +102,12 @@ def test_helper_ops_match_golden(prec):
 
 @pytest.mark.parametrize("b,s,q,ns,mode", [(1, 64, 1500, 12, "test"), (3, 48, 257, 12, "train"),
                                            (1, 96, 33, 7, "train"), (2, 16, 1, 12, "test"),
-                                           (1, 32, 16, 1, "train")])
+                                           (1, 32, 16, 1, "train"), (1, 32, 1000, 11, "test"),
+                                           (2, 32, 700, 2, "train")])
 @pytest.mark.parametrize("prec", PRECS)
 def test_forward_matches_oracle(b, s, q, ns, mode, prec):
-    """Ragged / edge shapes: Q not a multiple of 16, Q=1, 1 and 7 slices, 16^2 images, B=3."""
+    """Ragged / edge shapes: Q not a multiple of 16, Q=1, 1 / 2 / 7 / 11 slices (2: three valid rows of the sixteen-row
+    attention tile; the C ABI stops at the reference's 12), 16^2 images, B=3, several attention items per workgroup."""
     from oracle import ref_cpu
     from slice3d_amd.synth import make_feed_dict
     model = get_model(ns, mode, prec)
