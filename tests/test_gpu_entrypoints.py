@@ -83,3 +83,30 @@ def test_train_gt_then_reconstruct_from_given_slices(tmp_path):
               ["--name_model", "gtslice", "--name_ckpt", os.path.basename(ckpts[0]), "--mode", "test", "--mc_res0", "8",
                "--mc_up_steps", "0"], str(work))
     assert len(glob.glob(str(work / "experiments" / "toy_gt" / "results" / "custom" / "*.obj"))) == 2, out
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """bench.py's contract on a reduced workload: one JSON line on stdout with the metric / config / roofline /
+    cpu_baseline fields the driver and the judge read, whole-job value consistent with ms_per_step, parity inside."""
+    import json
+    out = run([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "1", "--n-qry", "4096",
+               "--img-size", "64", "--cpu-sample", "256", "--train-steps", "1", "--c4-steps", "1", "--c4-res", "32",
+               "--ldm-steps", "0", "--gt-train-steps", "0", "--f16-steps", "1", "--mesh-steps", "0"], ROOT)
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["unit"] == "query-points/s" and r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and r["data"] == "synthetic"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    assert abs(r["value"] - 4096 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    rf = r["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert "traffic" in rf
+    cb = r["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert r["parity_vs_oracle"]["max_abs_err"] < r["parity_vs_oracle"]["tol"]
+    assert r["train_samples_per_s"] > 0 and r["c4_dense_grid"]["query_points_per_s"] > 0
+    assert r["throughput_mode_f16"]["max_abs_diff_vs_headline_mode"] > 0
