@@ -518,15 +518,26 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
     dma_publish_barrier();
     ffn_pipe_iter<true, SINGLE>(lw1, lb0, xh, xl, acc, hdB, hdA);
 
-    // epilogue (identical to ffn_layer_f16x3_kernel): tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
+    // epilogue (identical to ffn_layer_f16x3_kernel): tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i.
+    // The lane's column offset is re-derived from an opaque copy of g: otherwise the ten loop-invariant 64-bit addresses
+    // of this epilogue are computed in the prologue and spilled across the loop (20 dwords of scratch per lane, written
+    // and read back by every wave: +0.4 GB of HBM writes per launch in the PMC pass)
+    int ge = g, me = m;
+    asm volatile("" : "+v"(ge), "+v"(me));
+    // ... and the rows' halves are made opaque here: left alone, the residual f32(hi) + f32(lo) of all 64 values is
+    // formed BEFORE the loop (it is loop-invariant), held in registers through it and partly spilled
+#pragma unroll
+    for (int r = 0; r < PIPE_R; ++r)
+        asm volatile("" : "+v"(xh[r][0]), "+v"(xh[r][1]), "+v"(xh[r][2]), "+v"(xh[r][3]), "+v"(xl[r][0]), "+v"(xl[r][1]), "+v"(xl[r][2]),
+                     "+v"(xl[r][3]));
 #pragma unroll
     for (int r = 0; r < PIPE_R; ++r) {
-        const long row = row0 + r * 16 + m;
+        const long row = row0 + r * 16 + me;
         f32x4 y[8];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
+            const int col = 32 * (j >> 1) + 8 * ge + 4 * (j & 1);
             const f32x4 b2 = ld4(w.b2 + col);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
         float dot = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
+            const int col = 32 * (j >> 1) + 8 * ge + 4 * (j & 1);
             const f32x4 ga = ld4(w.ln2g + col), be = ld4(w.ln2b + col);
 #pragma unroll
             for (int i = 0; i < 4; ++i) y[j][i] = (y[j][i] - mean) * rstd * ga[i] + be[i];
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
         }
         if (FINAL) {
             dot = quad_sum16(dot) + fco_b[0];
-            if (g == 0 && row < rows) {
+            if (ge == 0 && row < rows) {
                 const long grp = g_begin + row / S3D_GROUP;
                 const long b = grp / groups_per_batch;
                 const long q = (grp % groups_per_batch) * S3D_GROUP + (row % S3D_GROUP);
