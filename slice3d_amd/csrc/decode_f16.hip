@@ -202,7 +202,12 @@ __global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_kernel(const f
     }
 
     if (MODE == 3) return;
-    // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
+    // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i.  The rows' halves are made opaque first: the
+    // residual f32(hi) + f32(lo) is loop-invariant and would otherwise be formed before the loop and held through it
+#pragma unroll
+    for (int r = 0; r < F16_R; ++r)
+        asm volatile("" : "+v"(xh[r][0]), "+v"(xh[r][1]), "+v"(xh[r][2]), "+v"(xh[r][3]), "+v"(xl[r][0]), "+v"(xl[r][1]), "+v"(xl[r][2]),
+                     "+v"(xl[r][3]));
 #pragma unroll
     for (int r = 0; r < F16_R; ++r) {
         const long row = row0 + r * 16 + m;
