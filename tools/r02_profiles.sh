@@ -2,7 +2,7 @@
 # dominant kernels, clock/power under load.  One rocprofv3 --pmc set per run (no trace domains mixed in).
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 mkdir -p gpurun_out/r02
-BENCH="$GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --train-steps 0 --gt-train-steps 0 --ldm-steps 0 --c4-steps 0 --f16-steps 0"
+BENCH="$GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --train-steps 0 --gt-train-steps 0 --ldm-steps 0 --c4-steps 0 --f16-steps 0 --mesh-steps 0"
 (cd /tmp && rm -rf /tmp/p1 && rocprofv3 --kernel-trace -d /tmp/p1 -o b -- python $BENCH --steps 10 --warmup 2 > /tmp/p1.json 2>/dev/null)
 python tools/rocpd_summary.py $(find /tmp/p1 -name "*.db" | head -1) > gpurun_out/r02/r02_bench_f16x3_kernel_stats.md
 echo >> gpurun_out/r02/r02_bench_f16x3_kernel_stats.md; echo "bench line of the traced run:" >> gpurun_out/r02/r02_bench_f16x3_kernel_stats.md; tail -c 2500 /tmp/p1.json >> gpurun_out/r02/r02_bench_f16x3_kernel_stats.md
