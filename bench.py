@@ -434,7 +434,8 @@ def main():
                          "frac": achieved / peak, "traffic": traffic,
                          "note": ("algorithmic FLOPs (one product = one MAC); in f16x3 mode each product costs 3 f16 "
                                   "MFMA MACs, so the matrix pipe executes 3x `achieved`; under this load the chip "
-                                  "sustains ~1.96 GHz at its ~1.24 kW limit (profiles/r02_clock_power_under_load.md; the "
+                                  "sustains ~1.96-2.0 GHz under its 1400 W power cap (1.24 kW averaged over the step, "
+                                  "profiles/r02_clock_power_under_load.md; the "
                                   "same kernel on all-zero operands runs 2.35 GHz and 0.24 of peak, "
                                   "profiles/r02_ffn_data_power.md), peak is quoted at 2.4 GHz" if args.prec != "f32" else "exact fp32 MFMA"),
                          "mfma_pipe_tflops": achieved * (3 if args.prec != "f32" else 1),
