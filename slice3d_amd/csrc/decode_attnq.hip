@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             // measured as too few on gfx950: wrong P V products in some schedules, fixed by the padding alone).
 #define AQ_SETTLE()                                 \
     __builtin_amdgcn_sched_barrier(0);              \
-    asm volatile("s_nop 7" ::: "memory");           \
+    asm volatile("s_nop 15" ::: "memory");          \
     __builtin_amdgcn_sched_barrier(0);
             half8q oh[2], ol[2];
 #ifdef AQ_ABL_NOCORE
