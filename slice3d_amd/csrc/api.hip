@@ -669,7 +669,9 @@ extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, 
 // =============================================================================================
 // decode
 // =============================================================================================
+#ifndef S3D_CHUNK_GROUPS
 #define S3D_CHUNK_GROUPS 16384  // 262144 queries per pass: X = 16384*13*16*128*4 B = 1.74 GB
+#endif
 
 struct DecodeWs {
     size_t X, X0, perm, sortws, last, total;
