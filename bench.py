@@ -349,7 +349,21 @@ def main():
         lms = (time.perf_counter() - t1) / args.ldm_steps * 1e3
         ldm = {"workload": "gen_slices LDM UNetModel denoise step, objaverse-ldm-kl-8.yaml, batch 1 (222 GFLOP)",
                "ms_per_step": lms, "tflops_algorithmic": 0.222 / lms * 1e3, "dtype": args.prec}
-        del um, lx, lc
+        # the same step on a batch of 4 latents (the sampler's classifier-free pair x 2 objects): what the small kernels of
+        # the batch-1 step cost in utilisation
+        lx4, lt4 = lx.repeat(4, 1, 1, 1).contiguous(), lt.repeat(4)
+        lc4 = {k: v.repeat(4, 1, 1, 1).contiguous() for k, v in lc.items()}
+        for _ in range(2):
+            um(lx4, lt4, c_fmaps=lc4)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.ldm_steps):
+            um(lx4, lt4, c_fmaps=lc4)
+        torch.cuda.synchronize()
+        lms4 = (time.perf_counter() - t1) / args.ldm_steps * 1e3
+        ldm["batch4_ms_per_step"] = lms4
+        ldm["batch4_tflops_algorithmic"] = 4 * 0.222 / lms4 * 1e3
+        del um, lx, lc, lx4, lc4
 
     # ---- secondary metric: Slices3DGTModel training (train_gt.py:38-52) at the reference's default options
     #      (options.py: n_bs 16, img_size 128, n_qry 256), rank 0 only (the other ranks wait at the next leg's barrier) ----
