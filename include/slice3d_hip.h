@@ -253,6 +253,12 @@ int s3d_group_norm2_fwd(const float* x0, int c0, const float* x1, int c1, const 
 /* QKVAttentionLegacy.forward (openaimodel.py:362-377): qkv (N, T, heads*3*ch) -> out (N, T, heads*ch);
  * prec: S3D_PREC_F32 = fp32 MFMA, S3D_PREC_F16X3 = split-precision f16 MFMA (fp32-class accuracy) */
 int s3d_qkv_attention_fwd(const float* qkv, float* out, int N, int T, int heads, int ch, int prec, void* stream);
+/* The same operator for head widths 8 / 16 / 24 / 32 on the f16 MFMA with fp32-class logits (q, k split three ways,
+ * p, v two ways; replaces the same reference lines, openaimodel.py:353-381).  ws: s3d_qkv_attention_ws_bytes() bytes of
+ * scratch for the pre-split K / V block images (0 = width not served). */
+size_t s3d_qkv_attention_ws_bytes(int N, int T, int heads, int ch);
+int s3d_qkv_attention_ws_fwd(const float* qkv, float* out, int N, int T, int heads, int ch, void* ws, size_t ws_bytes,
+                             void* stream);
 /* Upsample / Downsample with use_conv=False (openaimodel.py:108-158): up != 0: nearest 2x; else 2x2 average pool */
 int s3d_resample2x_fwd(const float* x, float* y, int N, int H, int W, int C, int up, void* stream);
 /* linear(SiLU?(x)): time_embed (:506-510) and ResBlock.emb_layers (:222-228); x (N,K), w (M,K) */

@@ -122,6 +122,8 @@ SYMBOLS = {
     "s3d_group_norm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "s3d_group_norm2_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "s3d_qkv_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "s3d_qkv_attention_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "s3d_qkv_attention_ws_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "s3d_resample2x_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "s3d_small_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "s3d_timestep_embedding_fwd": (_i, [_vp, _vp, _i, _i, _f, _vp]),

@@ -6,6 +6,10 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
                       int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream,
                       const float* x1 = nullptr, int C0 = 0);   // x1: second source, channels [C0, C) of the input
 int launch_qkv_attention(const float* qkv, float* out, int N, int T, int heads, int ch, int prec, hipStream_t stream);
+// ldm_attn.hip: long-sequence attention on the f16 MFMA with fp32-class logits; workspace = pre-split K / V block images
+size_t qkv_attention_ws_bytes(int N, int T, int heads, int ch);   // 0: head width not served (use launch_qkv_attention)
+int launch_qkv_attention_ws(const float* qkv, float* out, int N, int T, int heads, int ch, void* ws, size_t ws_bytes,
+                            hipStream_t stream);
 int launch_resample2x(const float* x, float* y, int N, int H, int W, int C, int up, hipStream_t stream);
 int launch_small_linear(const float* x, const float* w, const float* b, float* out, int N, int K, int M, int silu_in,
                         hipStream_t stream);

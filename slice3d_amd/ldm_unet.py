@@ -101,6 +101,7 @@ class UNetModel(nn.Module):
                 self.output_blocks.append(nn.Sequential(*layers))
         self.out = nn.Sequential(_gn(ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
         self._lib = _lib.load() if backend == "hip" else None
+        self._attn_ws = {}   # device -> scratch of the long-sequence attention kernel (pre-split K / V block images)
         self._packed = {}
         self._packed_key = None
         self._ws = None
@@ -273,8 +274,18 @@ class UNetModel(nn.Module):
         hn = self._group_norm(blk.norm, x, silu=False)
         qkv = self._conv(blk.qkv, hn)                                        # (N, H, W, 3C), heads x (q|k|v) x ch
         att = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
-        _lib.check(lib.s3d_qkv_attention_fwd(qkv.data_ptr(), att.data_ptr(), n, h * w, blk.num_heads,
-                                             c // blk.num_heads, self._precv(), self._stream()), "s3d_qkv_attention_fwd")
+        ch = c // blk.num_heads
+        # long sequences of narrow heads: the f16-MFMA kernel with fp32-class logits and pre-split K / V (ldm_attn.hip)
+        ws_bytes = lib.s3d_qkv_attention_ws_bytes(n, h * w, blk.num_heads, ch) if self._precv() == _lib.PREC_F16X3 else 0
+        if ws_bytes and h * w >= 1024:
+            ws = self._attn_ws.get(x.device)
+            if ws is None or ws.numel() < ws_bytes:
+                ws = self._attn_ws[x.device] = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            _lib.check(lib.s3d_qkv_attention_ws_fwd(qkv.data_ptr(), att.data_ptr(), n, h * w, blk.num_heads, ch, ws.data_ptr(),
+                                                    ws_bytes, self._stream()), "s3d_qkv_attention_ws_fwd")
+        else:
+            _lib.check(lib.s3d_qkv_attention_fwd(qkv.data_ptr(), att.data_ptr(), n, h * w, blk.num_heads, ch, self._precv(),
+                                                 self._stream()), "s3d_qkv_attention_fwd")
         return self._conv(blk.proj_out, att, residual=x)
 
     def _run(self, seq, h, emb, skip=None):

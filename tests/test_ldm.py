@@ -151,6 +151,24 @@ def test_ldm_primitives_match_torch():
         out2 = torch.empty(1, T2, 2 * ch2, device="cuda")
         _lib.check(lib.s3d_qkv_attention_fwd(qc2.data_ptr(), out2.data_ptr(), 1, T2, 2, ch2, _lib.PREC_F16X3, None), "attn")
         assert (out2.cpu() - want2).abs().max() < 2e-5, (ch2, float((out2.cpu() - want2).abs().max()))
+    # the f16-MFMA attention with three-way split logits (ldm_attn.hip) holds the SAME 2e-5 bound on random inputs; ragged T
+    # (tails of the 64-key blocks and of the 128-query workgroups), all four head widths, batch 2
+    for heads3, ch3, T3, n3 in ((4, 24, 150, 2), (8, 24, 1100, 1), (2, 32, 64, 1), (3, 16, 257, 1), (2, 8, 129, 2)):
+        qkv3 = torch.randn(n3, heads3 * 3 * ch3, T3, generator=g)
+        q3, k3, v3 = qkv3.double().reshape(n3 * heads3, ch3 * 3, T3).split(ch3, dim=1)
+        sc3 = 1 / math.sqrt(math.sqrt(ch3))
+        w3 = torch.softmax(torch.einsum("bct,bcs->bts", q3 * sc3, k3 * sc3), dim=-1)
+        want3 = torch.einsum("bts,bcs->bct", w3, v3).reshape(n3, -1, T3).permute(0, 2, 1).contiguous()
+        qc3 = qkv3.permute(0, 2, 1).contiguous().cuda()
+        out3 = torch.zeros(n3, T3, heads3 * ch3, device="cuda")
+        nb = lib.s3d_qkv_attention_ws_bytes(n3, T3, heads3, ch3)
+        assert nb > 0
+        ws3 = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.s3d_qkv_attention_ws_fwd(qc3.data_ptr(), out3.data_ptr(), n3, T3, heads3, ch3, ws3.data_ptr(), nb, None),
+                   "attn_ws")
+        err3 = float((out3.cpu().double() - want3).abs().max())
+        assert err3 < 2e-5, (heads3, ch3, T3, err3)
+    assert lib.s3d_qkv_attention_ws_bytes(1, 64, 8, 96) == 0      # wide heads stay on s3d_qkv_attention_fwd
     up = torch.empty(n, 2 * h, 2 * w, c, device="cuda")
     _lib.check(lib.s3d_resample2x_fwd(xc.data_ptr(), up.data_ptr(), n, h, w, c, 1, None), "up")
     assert torch.equal(up.cpu(), F.interpolate(x, scale_factor=2, mode="nearest").permute(0, 2, 3, 1))
