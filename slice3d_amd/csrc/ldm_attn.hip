@@ -1,14 +1,14 @@
 // ldm_attn.hip — QKVAttentionLegacy (openaimodel.py:353-381) for the long-sequence attention blocks of the gen_slices
 // U-Net on the f16 MFMA, fp32-class in BOTH products:
 //   qkv [N][T][heads][3][ch] (token-major output of the qkv 1x1 conv)  ->  out [N][T][heads][ch]
-//   S^T = K Q^T   operands split THREE ways (hi + mid 2^-11 + lo 2^-22, the lower parts stored scaled so that none is
-//                 subnormal): six f16 MFMAs per product into three accumulators, recombined once per tile.  A two-way
+//   S^T = K Q^T   operands split THREE ways (hi + mid + lo, lo stored scaled by 2^22 so that it is not subnormal): six f16
+//                 MFMAs per product, the four unscaled ones into one accumulator, the two with lo into another.  A two-way
 //                 split carries 22 bits per operand; a score of sum|q k| ~ 9 then moves by ~5e-6 and a peaked softmax
 //                 hands that to the output (3e-5 on N(0,1) inputs, ldm_ops.hip) — the logits need fp32 operands.
 //   O^T = V^T P^T two-way split (three MFMAs): its error is relative to the output.
 // K and V are split ONCE by a pre-pass into the LDS image of each 64-key block (rows padded to 96 / 160 bytes:
 // conflict-free 16-byte fragment reads), which the main kernel streams with LDS-DMA, double buffered.  A workgroup is four
-// waves x 32 queries (two 16-query tiles per wave share every K / V fragment read); online softmax per 32 keys; the S^T
+// waves x 32 queries (two 16-query tiles per wave share every K / V fragment read); online softmax per 64 keys; the S^T
 // registers (lane (query, g): keys 16 kt + 4g + i) become the B operand of the second product after one split.
 // Head widths up to 32 (one k-step); wider heads (1 024 tokens and fewer) stay on the kernels of ldm_ops.hip.
 #include "ldm_ops.h"
@@ -31,52 +31,60 @@ struct LaGeom {
     static constexpr int PIECES = IMG / 512;
 };
 
+// x = h + m + l 2^-22 to 33 bits: h, m plain f16 (m is subnormal only for |x| < 0.125, where its 6e-8 granularity is an
+// absolute error far below the logits' resolution), l stored scaled by 2^22 so that it is a normal number
 __device__ __forceinline__ void la_split3(float x, _Float16& h, _Float16& m, _Float16& l) {
     h = (_Float16)x;
-    const float r = (x - (float)h) * 2048.f;   // exact: the remainder of an f16 rounding, scaled by a power of two
+    const float r = x - (float)h;   // exact
     m = (_Float16)r;
-    l = (_Float16)((r - (float)m) * 2048.f);
+    l = (_Float16)((r - (float)m) * 4194304.f);
 }
 
-// ---- pre-pass: one thread per half of the block images (gather form: padding and tails come out as zeros) ----
+// ---- pre-pass: one workgroup per 64-key block image: zero it (padding, tails), then one thread per (key, 8 channels)
+//      writes the three K parts as 16-byte rows and scatters the two V^T parts into the key-slot order P^T is produced in
 template <int CH>
-__global__ void la_pack_kernel(const float* __restrict__ qkv, _Float16* __restrict__ img, int T, int heads, int nblk,
-                               long total) {
+__global__ __launch_bounds__(256) void la_pack_kernel(const float* __restrict__ qkv, _Float16* __restrict__ img, int T, int heads,
+                                                      int nblk) {
     typedef LaGeom<CH> G;
+    const long b = blockIdx.x;
+    const int kb = (int)(b % nblk);
+    const int hh = (int)((b / nblk) % heads), n = (int)(b / ((long)nblk * heads));
     const int C3 = heads * 3 * CH;
     const float scale = 1.f / sqrtf(sqrtf((float)CH));
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx % G::IMG);
-        const long b = idx / G::IMG;
-        const int kb = (int)(b % nblk);
-        const int hh = (int)((b / nblk) % heads), n = (int)(b / ((long)nblk * heads));
-        const float* base = qkv + (long)n * T * C3 + hh * 3 * CH;
-        _Float16 v = (_Float16)0.f;
-        if (e < 3 * LA_K_PART) {
-            const int part = e / LA_K_PART, r = e % LA_K_PART;
-            const int key = r / LA_KLD, c = r % LA_KLD;
-            const int kg = kb * LA_KB + key;
-            if (c < CH && kg < T) {
-                _Float16 h, m, l;
-                la_split3(base[(long)kg * C3 + CH + c] * scale, h, m, l);
-                v = part == 0 ? h : part == 1 ? m : l;
-            }
-        } else if (e < G::RAW) {
-            const int r0 = e - 3 * LA_K_PART;
-            const int part = r0 / G::V_PART, r = r0 % G::V_PART;
-            const int d = r / LA_VLD, slot = r % LA_VLD;
-            if (d < CH && slot < LA_KB) {
-                // slot 32 (kt >> 1) + 8 g' + 4 (kt & 1) + i  <-  key 16 kt + 4 g' + i   (the order P^T is produced in)
-                const int kk = slot >> 5, g2 = (slot >> 3) & 3, kt = 2 * kk + ((slot >> 2) & 1), i = slot & 3;
-                const int kg = kb * LA_KB + 16 * kt + 4 * g2 + i;
-                if (kg < T) {
-                    const float x = base[(long)kg * C3 + 2 * CH + d];
-                    const _Float16 h = (_Float16)x;
-                    v = part == 0 ? h : (_Float16)(x - (float)h);
-                }
-            }
+    const float* base = qkv + (long)n * T * C3 + hh * 3 * CH;
+    _Float16* dst = img + b * G::IMG;
+    for (int i = threadIdx.x; i < G::IMG / 8; i += 256) *reinterpret_cast<lu4*>(dst + 8 * i) = lu4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    constexpr int C8 = CH / 8;
+    for (int i = threadIdx.x; i < LA_KB * C8; i += 256) {
+        const int key = i / C8, c0 = (i % C8) * 8;
+        const int kg = kb * LA_KB + key;
+        if (kg >= T) continue;
+        const float* row = base + (long)kg * C3;
+        const f32x4 ka = ld4(row + CH + c0), kc = ld4(row + CH + c0 + 4);
+        const f32x4 va = ld4(row + 2 * CH + c0), vc = ld4(row + 2 * CH + c0 + 4);
+        lh8 h, m, l;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            _Float16 a, bb, c;
+            la_split3((t < 4 ? ka[t] : kc[t - 4]) * scale, a, bb, c);
+            h[t] = a;
+            m[t] = bb;
+            l[t] = c;
         }
-        img[idx] = v;
+        *reinterpret_cast<lh8*>(dst + key * LA_KLD + c0) = h;
+        *reinterpret_cast<lh8*>(dst + LA_K_PART + key * LA_KLD + c0) = m;
+        *reinterpret_cast<lh8*>(dst + 2 * LA_K_PART + key * LA_KLD + c0) = l;
+        // key = 16 kt + 4 g' + i  ->  slot 32 (kt >> 1) + 8 g' + 4 (kt & 1) + i   (the order P^T is produced in)
+        const int kt = key >> 4, slot = 32 * (kt >> 1) + 8 * ((key >> 2) & 3) + 4 * (kt & 1) + (key & 3);
+        _Float16* v0 = dst + 3 * LA_K_PART + c0 * LA_VLD + slot;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float x = t < 4 ? va[t] : vc[t - 4];
+            const _Float16 xh = (_Float16)x;
+            v0[t * LA_VLD] = xh;
+            v0[G::V_PART + t * LA_VLD] = (_Float16)(x - (float)xh);
+        }
     }
 }
 
@@ -164,67 +172,74 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
 
     auto compute = [&](const _Float16* buf, int k0) {
         const bool partial = k0 + LA_KB > T;
+        // ---- S^T for the 4 key tiles x 2 query tiles: six products, the unscaled four into one accumulator ----
+        f32x4 s[2][4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f32x4 s[2][2];   // [query tile][key tile of the pair]
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const int ro = ((2 * kk + k2) * 16 + m) * LA_KLD + 8 * g;
-                const lh8 kh = *reinterpret_cast<const lh8*>(buf + ro);
-                const lh8 km = *reinterpret_cast<const lh8*>(buf + LA_K_PART + ro);
-                const lh8 kl = *reinterpret_cast<const lh8*>(buf + 2 * LA_K_PART + ro);
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    f32x4 a2 = LA_MFMA(kh, ql[qt], zero4());
-                    a2 = LA_MFMA(km, qm[qt], a2);
-                    a2 = LA_MFMA(kl, qh[qt], a2);
-                    f32x4 a1 = LA_MFMA(kh, qm[qt], zero4());
-                    a1 = LA_MFMA(km, qh[qt], a1);
-                    const f32x4 a0 = LA_MFMA(kh, qh[qt], zero4());
-                    s[qt][k2] = a0 + (a1 + a2 * (1.f / 2048.f)) * (1.f / 2048.f);
-                }
-            }
-            lh8 ph[2], pl[2];
+        for (int kt = 0; kt < 4; ++kt) {
+            const int ro = (kt * 16 + m) * LA_KLD + 8 * g;
+            const lh8 kh = *reinterpret_cast<const lh8*>(buf + ro);
+            const lh8 km = *reinterpret_cast<const lh8*>(buf + LA_K_PART + ro);
+            const lh8 kl = *reinterpret_cast<const lh8*>(buf + 2 * LA_K_PART + ro);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                float e[8];
-                float bmax = -1e30f;
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = s[qt][k2][i];
-                        if (partial && k0 + (2 * kk + k2) * 16 + 4 * g + i >= T) v = -1e30f;
-                        e[4 * k2 + i] = v;
-                        bmax = fmaxf(bmax, v);
-                    }
-                bmax = la_colmax(bmax);
-                const float mnew = fmaxf(mx[qt], bmax);
-                const float corr = __builtin_amdgcn_exp2f(mx[qt] - mnew);
-                mx[qt] = mnew;
-                float bsum = 0.f;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    e[t] = __builtin_amdgcn_exp2f(e[t] - mnew);   // masked keys: exp2(-1e30 - m) = 0
-                    bsum += e[t];
-                }
-                den[qt] = den[qt] * corr + bsum;
-#pragma unroll
-                for (int d = 0; d < DT; ++d) acc[d][qt] *= corr;
-                // probabilities are split after a 2^14 scale (removed with 1/den at the end): small ones would otherwise
-                // sit in f16's subnormal range and lose their low half
-                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-                la_split2(e[0] * 16384.f, e[1] * 16384.f, h0, l0);
-                la_split2(e[2] * 16384.f, e[3] * 16384.f, h1, l1);
-                la_split2(e[4] * 16384.f, e[5] * 16384.f, h2, l2);
-                la_split2(e[6] * 16384.f, e[7] * 16384.f, h3, l3);
-                ph[qt] = __builtin_bit_cast(lh8, lu4{h0, h1, h2, h3});
-                pl[qt] = __builtin_bit_cast(lh8, lu4{l0, l1, l2, l3});
+                f32x4 a2 = LA_MFMA(kh, ql[qt], zero4());
+                a2 = LA_MFMA(kl, qh[qt], a2);
+                f32x4 a0 = LA_MFMA(km, qm[qt], zero4());
+                a0 = LA_MFMA(kh, qm[qt], a0);
+                a0 = LA_MFMA(km, qh[qt], a0);
+                a0 = LA_MFMA(kh, qh[qt], a0);
+                s[qt][kt] = a0 + a2 * (1.f / 4194304.f);
             }
-            // partial-register asm writes -> MFMA reads: pad (decode_attnq.hip, AQ_SETTLE)
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 15" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- online softmax over the block's 64 keys; P is produced scaled by 2^14 (exponent bias, removed with 1/den at
+        //      the end): small probabilities would otherwise sit in f16's subnormal range and lose their low half ----
+        lh8 ph[2][2], pl[2][2];   // [query tile][k-step of the P V product]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (partial) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (k0 + kt * 16 + 4 * g + i >= T) s[qt][kt][i] = -1e30f;
+            }
+            float bmax = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt)
+                bmax = fmaxf(bmax, fmaxf(fmaxf(s[qt][kt][0], s[qt][kt][1]), fmaxf(s[qt][kt][2], s[qt][kt][3])));
+            bmax = la_colmax(bmax);
+            const float mnew = fmaxf(mx[qt], bmax);
+            const float corr = __builtin_amdgcn_exp2f(mx[qt] - mnew);
+            mx[qt] = mnew;
+            const float bias = 14.f - mnew;
+            float bsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s[qt][kt][i] = __builtin_amdgcn_exp2f(s[qt][kt][i] + bias);   // masked keys: exp2(-1e30) = 0
+                    bsum += s[qt][kt][i];
+                }
+            den[qt] = den[qt] * corr + bsum;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) acc[d][qt] *= corr;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                la_split2(s[qt][2 * kk][0], s[qt][2 * kk][1], h0, l0);
+                la_split2(s[qt][2 * kk][2], s[qt][2 * kk][3], h1, l1);
+                la_split2(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1], h2, l2);
+                la_split2(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3], h3, l3);
+                ph[qt][kk] = __builtin_bit_cast(lh8, lu4{h0, h1, h2, h3});
+                pl[qt][kk] = __builtin_bit_cast(lh8, lu4{l0, l1, l2, l3});
+            }
+        }
+        // partial-register asm writes -> MFMA reads: pad (decode_attnq.hip, AQ_SETTLE)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 const int vo = 3 * LA_K_PART + (16 * d + m) * LA_VLD + 32 * kk + 8 * g;
@@ -232,12 +247,11 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
                 const lh8 vl = *reinterpret_cast<const lh8*>(buf + G::V_PART + vo);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
-                    f32x4 o = LA_MFMA(vh, pl[qt], acc[d][qt]);
-                    o = LA_MFMA(vl, ph[qt], o);
-                    acc[d][qt] = LA_MFMA(vh, ph[qt], o);
+                    f32x4 o = LA_MFMA(vh, pl[qt][kk], acc[d][qt]);
+                    o = LA_MFMA(vl, ph[qt][kk], o);
+                    acc[d][qt] = LA_MFMA(vh, ph[qt][kk], o);
                 }
             }
-        }
     };
 
     for (int kb = 0; kb < nblk; kb += 2) {
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        const float inv = (1.f / 16384.f) / la_colsum(den[qt]);
+        const float inv = 1.f / la_colsum(den[qt]);   // den carries the same 2^14 as P
         if (qrow[qt] < T) {
             float* o = out + ((long)n * T + qrow[qt]) * (heads * CH) + hh * CH;
 #pragma unroll
@@ -277,9 +291,8 @@ int launch_qkv_attention_ws(const float* qkv, float* out, int N, int T, int head
     const int nblk = (T + LA_KB - 1) / LA_KB;
 #define LA_CASE(c)                                                                                                         \
     if (ch == c) {                                                                                                         \
-        const long total = (long)N * heads * nblk * LaGeom<c>::IMG;                                                        \
-        const int pb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);                                     \
-        hipLaunchKernelGGL((la_pack_kernel<c>), dim3(pb), dim3(256), 0, stream, qkv, (_Float16*)ws, T, heads, nblk, total); \
+        hipLaunchKernelGGL((la_pack_kernel<c>), dim3((unsigned)(N * heads * nblk)), dim3(256), 0, stream, qkv, (_Float16*)ws, T, \
+                           heads, nblk);                                                                                   \
         S3D_LAUNCH_CHECK();                                                                                                \
         const int blocks = N * heads * ((T + 127) / 128);                                                                  \
         hipLaunchKernelGGL((la_attention_kernel<c>), dim3(blocks), dim3(256), 0, stream, qkv, (const _Float16*)ws, out, T, \
