@@ -114,7 +114,9 @@ __device__ __forceinline__ float la_colsum(float v) {
 }
 #define LA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
-template <int CH>
+// QT: 16-query tiles per wave (2: every fragment read feeds two tiles; 1: twice the workgroups, for grids that would not
+// give every SIMD two waves otherwise — batch 1 at 4 096 tokens is 256 workgroups of 128 queries)
+template <int CH, int QT>
 __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __restrict__ qkv, const _Float16* __restrict__ img,
                                                               float* __restrict__ out, int T, int heads, int nblk) {
     typedef LaGeom<CH> G;
@@ -123,7 +125,8 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
     __shared__ __attribute__((aligned(16))) _Float16 s_b0[G::IMG], s_b1[G::IMG];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, g = lane >> 4;
-    const int qblocks = (T + 127) / 128;
+    constexpr int QW = 64 * QT;   // queries per workgroup
+    const int qblocks = (T + QW - 1) / QW;
     const int qb = blockIdx.x % qblocks;
     const int hh = (blockIdx.x / qblocks) % heads, n = blockIdx.x / (qblocks * heads);
     const int C3 = heads * 3 * CH;
@@ -144,11 +147,11 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
     dma_block(0, s_b0);
 
     // the wave's 2 x 16 queries: q (scaled) split three ways, k-slot 8g + t <-> channel 8g + t
-    lh8 qh[2], qm[2], ql[2];
-    int qrow[2];
+    lh8 qh[QT], qm[QT], ql[QT];
+    int qrow[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int q = qb * 128 + wave * 32 + qt * 16 + m;
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = qb * QW + wave * (16 * QT) + qt * 16 + m;
         qrow[qt] = q;
         const int qc = q < T ? q : T - 1;
 #pragma unroll
@@ -162,18 +165,23 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
             ql[qt][t] = l;
         }
     }
-    f32x4 acc[DT][2];
+    f32x4 acc[DT][QT];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) acc[d][qt] = zero4();
-    float mx[2] = {-1e30f, -1e30f}, den[2] = {0.f, 0.f};   // den: this lane's keys only, reduced over g at the end
+        for (int qt = 0; qt < QT; ++qt) acc[d][qt] = zero4();
+    float mx[QT], den[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        mx[qt] = -1e30f;
+        den[qt] = 0.f;
+    }   // den: this lane's keys only, reduced over g at the end
     dma_publish_barrier();
 
     auto compute = [&](const _Float16* buf, int k0) {
         const bool partial = k0 + LA_KB > T;
         // ---- S^T for the 4 key tiles x 2 query tiles: six products, the unscaled four into one accumulator ----
-        f32x4 s[2][4];
+        f32x4 s[QT][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             const int ro = (kt * 16 + m) * LA_KLD + 8 * g;
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
             const lh8 km = *reinterpret_cast<const lh8*>(buf + LA_K_PART + ro);
             const lh8 kl = *reinterpret_cast<const lh8*>(buf + 2 * LA_K_PART + ro);
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 f32x4 a2 = LA_MFMA(kh, ql[qt], zero4());
                 a2 = LA_MFMA(kl, qh[qt], a2);
                 f32x4 a0 = LA_MFMA(km, qm[qt], zero4());
@@ -193,9 +201,9 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
         }
         // ---- online softmax over the block's 64 keys; P is produced scaled by 2^14 (exponent bias, removed with 1/den at
         //      the end): small probabilities would otherwise sit in f16's subnormal range and lose their low half ----
-        lh8 ph[2][2], pl[2][2];   // [query tile][k-step of the P V product]
+        lh8 ph[QT][2], pl[QT][2];   // [query tile][k-step of the P V product]
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             if (partial) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
                 const lh8 vh = *reinterpret_cast<const lh8*>(buf + vo);
                 const lh8 vl = *reinterpret_cast<const lh8*>(buf + G::V_PART + vo);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     f32x4 o = LA_MFMA(vh, pl[qt][kk], acc[d][qt]);
                     o = LA_MFMA(vl, ph[qt][kk], o);
                     acc[d][qt] = LA_MFMA(vh, ph[qt][kk], o);
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
         }
     }
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const float inv = 1.f / la_colsum(den[qt]);   // den carries the same 2^14 as P
         if (qrow[qt] < T) {
             float* o = out + ((long)n * T + qrow[qt]) * (heads * CH) + hh * CH;
@@ -294,9 +302,13 @@ int launch_qkv_attention_ws(const float* qkv, float* out, int N, int T, int head
         hipLaunchKernelGGL((la_pack_kernel<c>), dim3((unsigned)(N * heads * nblk)), dim3(256), 0, stream, qkv, (_Float16*)ws, T, \
                            heads, nblk);                                                                                   \
         S3D_LAUNCH_CHECK();                                                                                                \
-        const int blocks = N * heads * ((T + 127) / 128);                                                                  \
-        hipLaunchKernelGGL((la_attention_kernel<c>), dim3(blocks), dim3(256), 0, stream, qkv, (const _Float16*)ws, out, T, \
-                           heads, nblk);                                                                                   \
+        const int blocks2 = N * heads * ((T + 127) / 128);                                                                 \
+        if (blocks2 >= 512)                                                                                                \
+            hipLaunchKernelGGL((la_attention_kernel<c, 2>), dim3(blocks2), dim3(256), 0, stream, qkv, (const _Float16*)ws, \
+                               out, T, heads, nblk);                                                                       \
+        else                                                                                                               \
+            hipLaunchKernelGGL((la_attention_kernel<c, 1>), dim3(N * heads * ((T + 63) / 64)), dim3(256), 0, stream, qkv,  \
+                               (const _Float16*)ws, out, T, heads, nblk);                                                  \
         S3D_LAUNCH_CHECK();                                                                                                \
         return 0;                                                                                                          \
     }
