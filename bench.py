@@ -339,28 +339,42 @@ def main():
         lt = torch.tensor([500]).cuda()
         lc = {k: (torch.randn(1, c, r, r, generator=g) * 0.5).cuda()
               for k, (c, r) in (("f1", (192, 64)), ("f2", (384, 32)), ("f3", (384, 16)), ("f4", (768, 8)), ("f5", (768, 4)))}
-        for _ in range(2):
-            um(lx, lt, c_fmaps=lc)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.ldm_steps):
-            um(lx, lt, c_fmaps=lc)
-        torch.cuda.synchronize()
-        lms = (time.perf_counter() - t1) / args.ldm_steps * 1e3
+        def time_ldm(x, t, cf):
+            """ms per step: the step's ~480 launches captured once into a HIP graph and replayed, as a sampler loop over
+            fixed shapes would run it (eager launches from Python are CPU-bound on some hosts: 4.7 vs 5.7 ms here)."""
+            for _ in range(2):
+                um(x, t, c_fmaps=cf)
+            torch.cuda.synchronize()
+            mode = "hip-graph replay"
+            try:
+                gr = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    um(x, t, c_fmaps=cf)
+                torch.cuda.current_stream().wait_stream(side)
+                with torch.cuda.graph(gr):
+                    um(x, t, c_fmaps=cf)
+                run = gr.replay
+                run()
+            except Exception:
+                mode = "eager launches"
+                run = lambda: um(x, t, c_fmaps=cf)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.ldm_steps):
+                run()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / args.ldm_steps * 1e3, mode
+
+        lms, lmode = time_ldm(lx, lt, lc)
         ldm = {"workload": "gen_slices LDM UNetModel denoise step, objaverse-ldm-kl-8.yaml, batch 1 (222 GFLOP)",
-               "ms_per_step": lms, "tflops_algorithmic": 0.222 / lms * 1e3, "dtype": args.prec}
+               "ms_per_step": lms, "tflops_algorithmic": 0.222 / lms * 1e3, "dtype": args.prec, "launch": lmode}
         # the same step on a batch of 4 latents (the sampler's classifier-free pair x 2 objects): what the small kernels of
         # the batch-1 step cost in utilisation
         lx4, lt4 = lx.repeat(4, 1, 1, 1).contiguous(), lt.repeat(4)
         lc4 = {k: v.repeat(4, 1, 1, 1).contiguous() for k, v in lc.items()}
-        for _ in range(2):
-            um(lx4, lt4, c_fmaps=lc4)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.ldm_steps):
-            um(lx4, lt4, c_fmaps=lc4)
-        torch.cuda.synchronize()
-        lms4 = (time.perf_counter() - t1) / args.ldm_steps * 1e3
+        lms4, _ = time_ldm(lx4, lt4, lc4)
         ldm["batch4_ms_per_step"] = lms4
         ldm["batch4_tflops_algorithmic"] = 4 * 0.222 / lms4 * 1e3
         del um, lx, lc, lx4, lc4
