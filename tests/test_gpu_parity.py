@@ -508,3 +508,41 @@ def test_single_pass_f16_throughput_mode_runs_and_reports_its_error():
     print("single-pass f16: max|sdf - oracle| %.3e (f16x3: %.3e), max|slices_rec - oracle| %.3e" % (e_sdf, e3, e_img))
     assert torch.isfinite(a["sdf_pred"]).all()
     assert e3 < TOL < e_sdf < 5e-2 and e_img < 1e-2
+
+
+def _sweep_cases(seed, n):
+    """Deterministic pseudo-random shape sweep: image sizes that are multiples of 16, ragged query counts around the
+    16-query group / 8-query attention item / chunk boundaries, every slice count the C ABI accepts, both prologues."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        ns = int(rng.integers(1, 13))
+        s = int(rng.choice([16, 32, 48, 64, 80, 96]))
+        b = int(rng.integers(1, 4))
+        q = int(rng.choice([1, 7, 8, 9, 15, 16, 17, 31, 33, 127, 129, 255, 500, 1023, 2049, 4100]))
+        mode = "test" if rng.random() < 0.5 else "train"
+        cases.append((b, s, q, ns, mode))
+    return cases
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_shape_sweep_matches_oracle(prec):
+    """24 shapes drawn from a fixed seed (new ones each round would make the suite a moving target): the C-ABI path against
+    the oracle on every one of them, in both arithmetic modes."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    worst = 0.0
+    for i, (b, s, q, ns, mode) in enumerate(_sweep_cases(20260928, 24)):
+        model = get_model(ns, mode, prec)
+        key = ("sweep", i)
+        if key not in _oracle_cache:
+            sd = seeded_sd_from_shapes(_shapes(ns))
+            fd = make_feed_dict(b, s, q, ns, seed=7000 + i, with_slices=False)
+            _oracle_cache[key] = (fd, ref_cpu.forward(sd, fd, mode=mode, n_slices=ns, with_vgg=False))
+        fd, ref = _oracle_cache[key]
+        out = model(to_gpu(fd))
+        e_sdf = float((out["sdf_pred"].cpu() - ref["sdf_pred"]).abs().max())
+        e_img = float((out["slices_rec"].cpu() - ref["slices_rec"]).abs().max())
+        assert e_sdf < TOL and e_img < TOL, ((b, s, q, ns, mode), e_sdf, e_img)
+        worst = max(worst, e_sdf, e_img)
+    print("shape sweep (%s): worst deviation %.2e over 24 shapes" % (prec, worst))
