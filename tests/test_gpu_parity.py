@@ -532,7 +532,8 @@ def test_shape_sweep_matches_oracle(prec):
     from oracle import ref_cpu
     from slice3d_amd.synth import make_feed_dict
     worst = 0.0
-    for i, (b, s, q, ns, mode) in enumerate(_sweep_cases(20260928, 24)):
+    n_cases = int(os.environ.get("S3D_SWEEP_N", "24"))   # a longer one-off sweep: S3D_SWEEP_N=200 (profiles/r02_shape_sweep.md)
+    for i, (b, s, q, ns, mode) in enumerate(_sweep_cases(20260928, n_cases)):
         model = get_model(ns, mode, prec)
         key = ("sweep", i)
         if key not in _oracle_cache:
@@ -545,4 +546,4 @@ def test_shape_sweep_matches_oracle(prec):
         e_img = float((out["slices_rec"].cpu() - ref["slices_rec"]).abs().max())
         assert e_sdf < TOL and e_img < TOL, ((b, s, q, ns, mode), e_sdf, e_img)
         worst = max(worst, e_sdf, e_img)
-    print("shape sweep (%s): worst deviation %.2e over 24 shapes" % (prec, worst))
+    print("shape sweep (%s): worst deviation %.2e over %d shapes" % (prec, worst, n_cases))
