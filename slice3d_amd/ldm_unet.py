@@ -16,6 +16,8 @@ use_new_attention_order, conv_resample down/up-sampling, fp16 torso, dims != 2.
 """
 import ctypes as C
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -276,7 +278,8 @@ class UNetModel(nn.Module):
         att = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
         ch = c // blk.num_heads
         # long sequences of narrow heads: the f16-MFMA kernel with fp32-class logits and pre-split K / V (ldm_attn.hip)
-        ws_bytes = lib.s3d_qkv_attention_ws_bytes(n, h * w, blk.num_heads, ch) if self._precv() == _lib.PREC_F16X3 else 0
+        use_mfma = self._precv() == _lib.PREC_F16X3 and os.environ.get("S3D_LDM_ATTN_MFMA", "1") != "0"   # 0: A/B against the fp32 core
+        ws_bytes = lib.s3d_qkv_attention_ws_bytes(n, h * w, blk.num_heads, ch) if use_mfma else 0
         if ws_bytes and h * w >= 1024:
             ws = self._attn_ws.get(x.device)
             if ws is None or ws.numel() < ws_bytes:
