@@ -25,6 +25,7 @@ typedef unsigned lu4 __attribute__((ext_vector_type(4)));
 template <int CH>
 struct LaGeom {
     static constexpr int DT = (CH + 15) / 16;
+    static constexpr bool SPARE = CH % 16 != 0;   // a free channel / row in the 32-wide K rows and the 16-row V^T tiles
     static constexpr int V_PART = DT * 16 * LA_VLD;
     static constexpr int RAW = 3 * LA_K_PART + 2 * V_PART;
     static constexpr int IMG = (RAW + 511) / 512 * 512;   // halfs per block image: whole 1 KiB DMA pieces
@@ -55,6 +56,13 @@ __global__ __launch_bounds__(256) void la_pack_kernel(const float* __restrict__ 
     _Float16* dst = img + b * G::IMG;
     for (int i = threadIdx.x; i < G::IMG / 8; i += 256) *reinterpret_cast<lu4*>(dst + 8 * i) = lu4{0u, 0u, 0u, 0u};
     __syncthreads();
+    if (G::SPARE && threadIdx.x < LA_KB) {
+        // spare channel CH of the K rows: 0 for a key, -30000 for a key slot beyond T (q carries 1 there: the score of a
+        // missing key comes out of the MFMA as -30000, no masking instructions); spare row CH of V^T: all ones, so that
+        // row CH of O^T accumulates sum(p) — the softmax denominator, rescaled with the rest
+        if (kb * LA_KB + threadIdx.x >= T) dst[threadIdx.x * LA_KLD + CH] = (_Float16)(-30000.f);
+        dst[3 * LA_K_PART + CH * LA_VLD + threadIdx.x] = (_Float16)1.f;
+    }
     constexpr int C8 = CH / 8;
     for (int i = threadIdx.x; i < LA_KB * C8; i += 256) {
         const int key = i / C8, c0 = (i % C8) * 8;
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int c = 8 * g + t;
-            const float v = c < CH ? base[(long)qc * C3 + c] * qscale : 0.f;
+            const float v = c < CH ? base[(long)qc * C3 + c] * qscale : (G::SPARE && c == CH) ? 1.f : 0.f;
             _Float16 h, md, l;
             la_split3(v, h, md, l);
             qh[qt][t] = h;
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
         lh8 ph[QT][2], pl[QT][2];   // [query tile][k-step of the P V product]
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            if (partial) {
+            if (!G::SPARE && partial) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -225,10 +233,10 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    s[qt][kt][i] = __builtin_amdgcn_exp2f(s[qt][kt][i] + bias);   // masked keys: exp2(-1e30) = 0
-                    bsum += s[qt][kt][i];
+                    s[qt][kt][i] = __builtin_amdgcn_exp2f(s[qt][kt][i] + bias);   // missing keys: exp2(-30000) = 0
+                    if (!G::SPARE) bsum += s[qt][kt][i];
                 }
-            den[qt] = den[qt] * corr + bsum;
+            if (!G::SPARE) den[qt] = den[qt] * corr + bsum;
 #pragma unroll
             for (int d = 0; d < DT; ++d) acc[d][qt] *= corr;
 #pragma unroll
@@ -274,12 +282,15 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        const float inv = 1.f / la_colsum(den[qt]);   // den carries the same 2^14 as P
+        // den carries the same 2^14 as P.  With a spare V^T row it is row CH of O^T: element CH % 4 of the last tile's
+        // accumulator in lane group (CH % 16) / 4; the other groups hold 0 there after the select
+        const float dsel = G::SPARE ? (g == (CH % 16) / 4 ? acc[DT - 1][qt][CH % 4] : 0.f) : den[qt];
+        const float inv = 1.f / la_colsum(dsel);
         if (qrow[qt] < T) {
             float* o = out + ((long)n * T + qrow[qt]) * (heads * CH) + hh * CH;
 #pragma unroll
             for (int d = 0; d < DT; ++d)
-                if (d * 16 + 4 * g + 3 < CH) st4(o + d * 16 + 4 * g, acc[d][qt] * inv);
+                if (d * 16 + 4 * g + 3 < CH) st4(o + d * 16 + 4 * g, acc[d][qt] * inv);   // CH % 4 == 0: the spare row is never stored
         }
     }
 }
