@@ -6,8 +6,8 @@
 //                 split carries 22 bits per operand; a score of sum|q k| ~ 9 then moves by ~5e-6 and a peaked softmax
 //                 hands that to the output (3e-5 on N(0,1) inputs, ldm_ops.hip) — the logits need fp32 operands.
 //   O^T = V^T P^T two-way split (three MFMAs): its error is relative to the output.
-// K and V are split ONCE by a pre-pass into the LDS image of each 64-key block (rows padded to 96 / 160 bytes:
-// conflict-free 16-byte fragment reads), which the main kernel streams with LDS-DMA, double buffered.  A workgroup is four
+// K and V are split ONCE by a pre-pass into the LDS image of each 64-key block (K rows of 64 bytes with swizzled quarters,
+// V^T rows padded to 160 bytes: conflict-free 16-byte fragment reads), which the main kernel streams with LDS-DMA, double buffered.  A workgroup is four
 // waves x 32 queries (two 16-query tiles per wave share every K / V fragment read); online softmax per 64 keys; the S^T
 // registers (lane (query, g): keys 16 kt + 4g + i) become the B operand of the second product after one split.
 // Head widths up to 32 (one k-step); wider heads (1 024 tokens and fewer) stay on the kernels of ldm_ops.hip.
@@ -19,7 +19,10 @@ typedef float lf2 __attribute__((ext_vector_type(2)));
 typedef unsigned lu4 __attribute__((ext_vector_type(4)));
 
 #define LA_KB 64                 // keys per block
-#define LA_KLD 48                // halfs per K row: 32 + 16 pad = 96 B
+#define LA_KLD 32                // halfs per K row (64 B); its four 16-byte quarters are XOR-swizzled by (key >> 1) & 3:
+                                 // conflict-free fragment reads without padding (conv.hip), 22 KiB per block image ->
+                                 // three workgroups per CU
+#define LA_KSWZ(key, q) ((((q) ^ (((key) >> 1) & 3))) * 8)   // half offset of quarter q in the row of `key`
 #define LA_VLD 80                // halfs per V^T row: 64 + 16 pad = 160 B
 #define LA_K_PART (LA_KB * LA_KLD)
 template <int CH>
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void la_pack_kernel(const float* __restrict__ 
         // spare channel CH of the K rows: 0 for a key, -30000 for a key slot beyond T (q carries 1 there: the score of a
         // missing key comes out of the MFMA as -30000, no masking instructions); spare row CH of V^T: all ones, so that
         // row CH of O^T accumulates sum(p) — the softmax denominator, rescaled with the rest
-        if (kb * LA_KB + threadIdx.x >= T) dst[threadIdx.x * LA_KLD + CH] = (_Float16)(-30000.f);
+        if (kb * LA_KB + threadIdx.x >= T) dst[threadIdx.x * LA_KLD + LA_KSWZ(threadIdx.x, CH >> 3) + (CH & 7)] = (_Float16)(-30000.f);
         dst[3 * LA_K_PART + CH * LA_VLD + threadIdx.x] = (_Float16)1.f;
     }
     constexpr int C8 = CH / 8;
@@ -80,9 +83,10 @@ __global__ __launch_bounds__(256) void la_pack_kernel(const float* __restrict__ 
             m[t] = bb;
             l[t] = c;
         }
-        *reinterpret_cast<lh8*>(dst + key * LA_KLD + c0) = h;
-        *reinterpret_cast<lh8*>(dst + LA_K_PART + key * LA_KLD + c0) = m;
-        *reinterpret_cast<lh8*>(dst + 2 * LA_K_PART + key * LA_KLD + c0) = l;
+        const int ko = key * LA_KLD + LA_KSWZ(key, c0 >> 3);
+        *reinterpret_cast<lh8*>(dst + ko) = h;
+        *reinterpret_cast<lh8*>(dst + LA_K_PART + ko) = m;
+        *reinterpret_cast<lh8*>(dst + 2 * LA_K_PART + ko) = l;
         // key = 16 kt + 4 g' + i  ->  slot 32 (kt >> 1) + 8 g' + 4 (kt & 1) + i   (the order P^T is produced in)
         const int kt = key >> 4, slot = 32 * (kt >> 1) + 8 * ((key >> 2) & 3) + 4 * (kt & 1) + (key & 3);
         _Float16* v0 = dst + 3 * LA_K_PART + c0 * LA_VLD + slot;
@@ -125,7 +129,7 @@ __device__ __forceinline__ float la_colsum(float v) {
 // QT: 16-query tiles per wave (2: every fragment read feeds two tiles; 1: twice the workgroups, for grids that would not
 // give every SIMD two waves otherwise — batch 1 at 4 096 tokens is 256 workgroups of 128 queries)
 template <int CH, int QT>
-__global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __restrict__ qkv, const _Float16* __restrict__ img,
+__global__ __launch_bounds__(256, 3) void la_attention_kernel(const float* __restrict__ qkv, const _Float16* __restrict__ img,
                                                               float* __restrict__ out, int T, int heads, int nblk) {
     typedef LaGeom<CH> G;
     constexpr int DT = G::DT;
@@ -186,26 +190,49 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
     }   // den: this lane's keys only, reduced over g at the end
     dma_publish_barrier();
 
+    // Fragment reads and their counted waits are issued by hand (decode_f16.hip): the compiler's own schedule reads the
+    // fragments of two key tiles, waits lgkmcnt(0), multiplies, and only then reads the next two — the LDS latency is
+    // exposed five times per block.  Here the block's 12 K fragments are requested up front, the V^T fragments under the
+    // S^T products and the softmax.
+#define LA_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define LA_WAIT6(n, a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(n))
+#define LA_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
     auto compute = [&](const _Float16* buf, int k0) {
         const bool partial = k0 + LA_KB > T;
-        // ---- S^T for the 4 key tiles x 2 query tiles: six products, the unscaled four into one accumulator ----
+        const unsigned lk = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(const_cast<_Float16*>(buf) + m * LA_KLD + LA_KSWZ(m, g));   // key tile kt adds 16 rows: same swizzle
+        const unsigned lv = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(const_cast<_Float16*>(buf) + 3 * LA_K_PART + m * LA_VLD + 8 * g);
+        lh8 kf[4][3];        // [key tile][hi, mid, lo]
+        lh8 vf[2][DT][2];    // [k-step][dim tile][hi, lo]
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt) LA_RD(kf[kt][pt], lk, (kt * 16 * LA_KLD + pt * LA_K_PART) * 2);
+        // ---- S^T for the 4 key tiles x QT query tiles: six products, the unscaled four into one accumulator ----
         f32x4 s[QT][4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const int ro = (kt * 16 + m) * LA_KLD + 8 * g;
-            const lh8 kh = *reinterpret_cast<const lh8*>(buf + ro);
-            const lh8 km = *reinterpret_cast<const lh8*>(buf + LA_K_PART + ro);
-            const lh8 kl = *reinterpret_cast<const lh8*>(buf + 2 * LA_K_PART + ro);
+        for (int kp = 0; kp < 2; ++kp) {
+            if (kp == 0) LA_WAIT6(6, kf[0][0], kf[0][1], kf[0][2], kf[1][0], kf[1][1], kf[1][2]);
+            else LA_WAIT6(2 * DT, kf[2][0], kf[2][1], kf[2][2], kf[3][0], kf[3][1], kf[3][2]);   // the V^T reads of k-step 0 stay in flight
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                f32x4 a2 = LA_MFMA(kh, ql[qt], zero4());
-                a2 = LA_MFMA(kl, qh[qt], a2);
-                f32x4 a0 = LA_MFMA(km, qm[qt], zero4());
-                a0 = LA_MFMA(kh, qm[qt], a0);
-                a0 = LA_MFMA(km, qh[qt], a0);
-                a0 = LA_MFMA(kh, qh[qt], a0);
-                s[qt][kt] = a0 + a2 * (1.f / 4194304.f);
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int kt = 2 * kp + k2;
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    f32x4 a2 = LA_MFMA(kf[kt][0], ql[qt], zero4());
+                    a2 = LA_MFMA(kf[kt][2], qh[qt], a2);
+                    f32x4 a0 = LA_MFMA(kf[kt][1], qm[qt], zero4());
+                    a0 = LA_MFMA(kf[kt][0], qm[qt], a0);
+                    a0 = LA_MFMA(kf[kt][1], qh[qt], a0);
+                    a0 = LA_MFMA(kf[kt][0], qh[qt], a0);
+                    s[qt][kt] = a0 + a2 * (1.f / 4194304.f);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // V^T fragments of k-step kp: requested here, consumed after the softmax
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) LA_RD(vf[kp][d][pt], lv, (16 * d * LA_VLD + 32 * kp + pt * G::V_PART) * 2);
         }
         // ---- online softmax over the block's 64 keys; P is produced scaled by 2^14 (exponent bias, removed with 1/den at
         //      the end): small probabilities would otherwise sit in f16's subnormal range and lose their low half ----
@@ -255,19 +282,22 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
         asm volatile("s_nop 15" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
+            if (DT == 2) {
+                if (kk == 0) LA_WAIT4(4, vf[0][0][0], vf[0][0][1], vf[0][1][0], vf[0][1][1]);
+                else LA_WAIT4(0, vf[1][0][0], vf[1][0][1], vf[1][1][0], vf[1][1][1]);
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0][0]), "+v"(vf[0][0][1]), "+v"(vf[1][0][0]), "+v"(vf[1][0][1]));
+            }
 #pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                const int vo = 3 * LA_K_PART + (16 * d + m) * LA_VLD + 32 * kk + 8 * g;
-                const lh8 vh = *reinterpret_cast<const lh8*>(buf + vo);
-                const lh8 vl = *reinterpret_cast<const lh8*>(buf + G::V_PART + vo);
+            for (int d = 0; d < DT; ++d)
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
-                    f32x4 o = LA_MFMA(vh, pl[qt][kk], acc[d][qt]);
-                    o = LA_MFMA(vl, ph[qt][kk], o);
-                    acc[d][qt] = LA_MFMA(vh, ph[qt][kk], o);
+                    f32x4 o = LA_MFMA(vf[kk][d][0], pl[qt][kk], acc[d][qt]);
+                    o = LA_MFMA(vf[kk][d][1], ph[qt][kk], o);
+                    acc[d][qt] = LA_MFMA(vf[kk][d][0], ph[qt][kk], o);
                 }
-            }
+        }
     };
 
     for (int kb = 0; kb < nblk; kb += 2) {
@@ -294,6 +324,10 @@ __global__ __launch_bounds__(256, 2) void la_attention_kernel(const float* __res
         }
     }
 }
+
+#undef LA_RD
+#undef LA_WAIT6
+#undef LA_WAIT4
 
 size_t qkv_attention_ws_bytes(int N, int T, int heads, int ch) {
     if (ch > 32 || ch % 8) return 0;
