@@ -378,6 +378,14 @@ def main():
         ldm["batch4_ms_per_step"] = lms4
         ldm["batch4_tflops_algorithmic"] = 4 * 0.222 / lms4 * 1e3
         del um, lx, lc, lx4, lc4
+        # the 128 x 128 latent of 256^2 slice generation (configs[4]): convolutions x4, the 16 384-token attention x16
+        um = load_seeded(UNetModel(prec=args.prec, **dict(cfg, image_size=128)), 0).cuda().eval()
+        lx = torch.randn(1, 8, 128, 128, generator=g).cuda()
+        lc = {k: (torch.randn(1, c, 2 * r, 2 * r, generator=g) * 0.5).cuda()
+              for k, (c, r) in (("f1", (192, 64)), ("f2", (384, 32)), ("f3", (384, 16)), ("f4", (768, 8)), ("f5", (768, 4)))}
+        lms128, _ = time_ldm(lx, lt, lc)
+        ldm["latent128_ms_per_step"] = lms128
+        del um, lx, lc
 
     # ---- secondary metric: Slices3DGTModel training (train_gt.py:38-52) at the reference's default options
     #      (options.py: n_bs 16, img_size 128, n_qry 256), rank 0 only (the other ranks wait at the next leg's barrier) ----
