@@ -115,6 +115,21 @@ def cpu_baseline(sd, fd, n_slices, n_sample, gpu_sdf, runs=5):
     }, err
 
 
+def _self_launch(n):
+    """Re-run this command as an n-rank torch.distributed.run job on this node (127.0.0.1, a free port)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,11 +152,16 @@ def main():
     ap.add_argument("--gt-train-steps", type=int, default=5, help="timed Slices3DGTModel training steps (0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU under torch.distributed.run on
+        # a free local port); rank 0 of the child job prints the one JSON line, this process only forwards the exit code
+        sys.exit(_self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run, or without it: bench.py spawns "
+                         "its own ranks)" % (args.gpus, world))
     # S3D_BENCH_BACKEND=gloo: smoke-test the N-rank code path with several processes on ONE GPU (no RCCL between ranks
     # that share a device); never set by the driver — a real run is one rank per GPU over RCCL
     backend = os.environ.get("S3D_BENCH_BACKEND", "nccl")
@@ -326,15 +346,17 @@ def main():
             mesh_leg = {"error": repr(e)[:200]}
 
     # ---- BASELINE configs[4]: one denoising step of the gen_slices latent-diffusion U-Net (295 M parameters,
-    #      64x64x4 latent mosaic + 4 conditioning channels, 21 attention blocks), batch 1 per GPU ----
+    #      64x64x4 latent mosaic + 4 conditioning channels, 21 attention blocks), batch 1 per GPU.  EVERY rank runs it
+    #      on its own latents (configs[4] "1 -> 8 MI355X": independent samples, no collective); the reported time is the
+    #      slowest rank's, the rate the aggregate over all ranks ----
     ldm = None
-    if args.ldm_steps > 0 and rank == 0:
+    if args.ldm_steps > 0:
         from slice3d_amd.ldm_unet import UNetModel
         cfg = dict(image_size=64, in_channels=8, out_channels=4, model_channels=192, attention_resolutions=[1, 2, 4, 8],
                    num_res_blocks=2, channel_mult=[1, 2, 2, 4, 4], num_heads=8, use_scale_shift_norm=True,
                    resblock_updown=True)
         um = load_seeded(UNetModel(prec=args.prec, **cfg), 0).cuda().eval()
-        g = torch.Generator().manual_seed(0)
+        g = torch.Generator().manual_seed(rank)
         lx = torch.randn(1, 8, 64, 64, generator=g).cuda()
         lt = torch.tensor([500]).cuda()
         lc = {k: (torch.randn(1, c, r, r, generator=g) * 0.5).cuda()
@@ -384,8 +406,18 @@ def main():
         lc = {k: (torch.randn(1, c, 2 * r, 2 * r, generator=g) * 0.5).cuda()
               for k, (c, r) in (("f1", (192, 64)), ("f2", (384, 32)), ("f3", (384, 16)), ("f4", (768, 8)), ("f5", (768, 4)))}
         lms128, _ = time_ldm(lx, lt, lc)
-        ldm["latent128_ms_per_step"] = lms128
         del um, lx, lc
+        if dist is not None:
+            t = torch.tensor([lms, lms4, lms128], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            lms, lms4, lms128 = (float(v) for v in t.tolist())
+            ldm["ms_per_step"], ldm["batch4_ms_per_step"] = lms, lms4
+            ldm["tflops_algorithmic"] = 0.222 / lms * 1e3
+            ldm["batch4_tflops_algorithmic"] = 4 * 0.222 / lms4 * 1e3
+        ldm["latent128_ms_per_step"] = lms128
+        ldm["n_gpus"] = world
+        ldm["steps_per_s_all_gpus"] = world / (lms * 1e-3)
+        ldm["latent128_steps_per_s_all_gpus"] = world / (lms128 * 1e-3)
 
     # ---- secondary metric: Slices3DGTModel training (train_gt.py:38-52) at the reference's default options
     #      (options.py: n_bs 16, img_size 128, n_qry 256), rank 0 only (the other ranks wait at the next leg's barrier) ----

@@ -285,8 +285,9 @@ int s3d_nchw_to_nhwc_pad(const float* in, float* out, int n, int c, int h, int w
 /* Cross-rank BatchNorm statistics (train.py has no counterpart: the reference's nn.DataParallel replicas use
  * per-replica statistics, like torch DDP by default; `--sync_bn` is SURVEY.md 8(e)'s option).  The library computes
  * the per-rank partial statistics, calls all_reduce_sum on `n_floats` floats of `scratch` (device memory, >= 2048
- * floats, owned by the caller) on the call's stream, and continues with the reduced values: 21 small all-reduces
- * in the forward, 21 in the backward of a train step.  The callback must enqueue the collective so that later work
+ * floats, owned by the caller) on the call's stream, and continues with the reduced values: per BatchNorm layer two
+ * small all-reduces in the forward (the means, then var_r + (mu_r - mu)^2: the count-weighted merge of
+ * torch.nn.SyncBatchNorm, free of E[x^2] - mu^2 cancellation) and one in the backward: 42 + 21 per train step.  The callback must enqueue the collective so that later work
  * on `stream` sees its result (torch.distributed.all_reduce on the current stream does) and return 0. */
 typedef int (*s3d_all_reduce_sum_fn)(void* user, float* device_buf, long n_floats, void* stream);
 typedef struct {

@@ -17,6 +17,7 @@
 //     (mise.pyx:182-232); leaves created by a split wait for the next update, as in the reference.
 #include <math.h>
 #include <string.h>
+#include <mutex>
 
 #include "common.h"
 
@@ -396,9 +397,15 @@ __constant__ signed char c_edge[12][7] = {{0, 1, 0, 0, -1, -1, 0}, {1, 2, 1, 0, 
                                           {0, 4, 2, -1, -1, 0, 2}, {1, 5, 2, 0, -1, 0, 2}, {2, 6, 2, 0, 0, 0, 2},  {3, 7, 2, -1, 0, 0, 2}};
 __constant__ signed char c_visit[12] = {6, 5, 10, 0, 1, 2, 3, 4, 7, 8, 9, 11};
 
+// __constant__ memory is per device: the upload is tracked per device id, under a mutex (a process that drives two GPUs,
+// or two threads, must not see a zeroed table on the second one)
 static int mc_tables_ready() {
-    static int state = 0;   // 0 not yet, 1 ok, <0 error
-    if (state) return state;
+    static std::mutex mu;
+    static int state[64] = {};   // per device: 0 not yet, 1 ok, <0 error
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[dev]) return state[dev];
     McTables t;
     memset(&t, 0, sizeof(t));
     for (int c = 0; c < 256; ++c) {
@@ -412,8 +419,8 @@ static int mc_tables_ready() {
         for (; n < 16; ++n) t.tri[c][n] = -1;
     }
     const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_mc), &t, sizeof(t));
-    state = e == hipSuccess ? 1 : -1;
-    return state;
+    state[dev] = e == hipSuccess ? 1 : -1;
+    return state[dev];
 }
 
 struct McDev {

@@ -1105,9 +1105,11 @@ __global__ void bn_finalize_shift_kernel(const float* __restrict__ z, long P, in
     }
 }
 
-// cross-rank statistics: this rank's [mean, var + mean^2] -> buf[0..2C) ...
+// cross-rank statistics, merged the way torch.nn.SyncBatchNorm merges them (no E[x^2] - mu^2 cancellation for channels
+// with |mean| >> std): stage 1 all-reduces the per-rank means; stage 2 all-reduces var_r + (mu_r - mu)^2 (Chan's
+// formula for ranks of equal element count P).  buf: [0,C) sum of means | [C,2C) stage-2 terms | [2C,3C) mu_r, var_r packed
 __global__ void bn_sync_pack_kernel(const float* __restrict__ z, long P, int C, const float* __restrict__ m1v,
-                                    const float* __restrict__ m2v, float* __restrict__ buf) {
+                                    const float* __restrict__ m2v, float* __restrict__ buf, float* __restrict__ keep) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float k = 0.f;
@@ -1116,9 +1118,16 @@ __global__ void bn_sync_pack_kernel(const float* __restrict__ z, long P, int C, 
     const float m1 = m1v[c], m2 = m2v[c];
     const float mu = k + m1, var = fmaxf(m2 - m1 * m1, 0.f);
     buf[c] = mu;
-    buf[C + c] = var + mu * mu;
+    keep[c] = mu;        // this rank's mean and variance stay in the caller's mean / rstd slots until stage 2
+    keep[C + c] = var;
 }
-// ... and, after the all-reduce (sums over `world` ranks of equal element count P): the global statistics
+__global__ void bn_sync_stage2_kernel(float* __restrict__ buf, const float* __restrict__ keep, int C, int world) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mu = buf[c] * (1.f / (float)world), d = keep[c] - mu;
+    buf[C + c] = keep[C + c] + d * d;
+}
+// ... and, after the second all-reduce (sums over `world` ranks of equal element count P): the global statistics
 __global__ void bn_sync_finalize_kernel(const float* __restrict__ buf, long P, int C, int world,
                                         float* __restrict__ mean, float* __restrict__ rstd,
                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
@@ -1126,7 +1135,7 @@ __global__ void bn_sync_finalize_kernel(const float* __restrict__ buf, long P, i
     if (c >= C) return;
     const float inv = 1.f / (float)world;
     const float mu = buf[c] * inv;
-    const float var = fmaxf(buf[C + c] * inv - mu * mu, 0.f);
+    const float var = fmaxf(buf[C + c] * inv, 0.f);
     mean[c] = mu;
     rstd[c] = 1.f / sqrtf(var + 1e-5f);
     if (running_mean) {
@@ -1142,10 +1151,10 @@ __global__ void pack2_kernel(const float* __restrict__ a, const float* __restric
         buf[C + c] = b[c];
     }
 }
-static int bn_sync_all_reduce(const BnSync* sync, int C, hipStream_t stream) {
-    S3D_CHECK_ARG(sync->all_reduce_sum && sync->scratch && sync->world_size >= 1 && 2 * C <= 2048,
+static int bn_sync_all_reduce(const BnSync* sync, int C, hipStream_t stream, int off = 0, int n = 0) {
+    S3D_CHECK_ARG(sync->all_reduce_sum && sync->scratch && sync->world_size >= 1 && 4 * C <= 2048,
                   "sync_bn: bad descriptor (C = %d)", C);
-    const int rc = sync->all_reduce_sum(sync->user, sync->scratch, 2L * C, (void*)stream);
+    const int rc = sync->all_reduce_sum(sync->user, sync->scratch + off, n ? (long)n : 2L * C, (void*)stream);
     if (rc != 0) {
         s3d_set_error("sync_bn: the all-reduce callback returned %d", rc);
         return S3D_E_ARG;
@@ -1168,9 +1177,13 @@ int launch_bn_stats(const float* z, long P, int C, float* mean, float* rstd, flo
         hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial + (size_t)n * C,
                            n, C, 1.f / (float)P, rstd, 0);
         hipLaunchKernelGGL(bn_sync_pack_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, z, P, C, mean, rstd,
-                           sync->scratch);
+                           sync->scratch, sync->scratch + 2 * C);
         S3D_LAUNCH_CHECK();
-        TRY_RET(bn_sync_all_reduce(sync, C, stream));
+        TRY_RET(bn_sync_all_reduce(sync, C, stream, 0, C));          // stage 1: sum of the per-rank means
+        hipLaunchKernelGGL(bn_sync_stage2_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sync->scratch,
+                           sync->scratch + 2 * C, C, sync->world_size);
+        S3D_LAUNCH_CHECK();
+        TRY_RET(bn_sync_all_reduce(sync, C, stream, C, C));          // stage 2: sum of var_r + (mu_r - mu)^2
         hipLaunchKernelGGL(bn_sync_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sync->scratch, P, C,
                            sync->world_size, mean, rstd, running_mean, running_var);
         S3D_LAUNCH_CHECK();

@@ -236,6 +236,8 @@ class Slices3DRegModel(nn.Module):
         to autograd), dropout = self.train_dropout, dropout streams from self.train_seed."""
         from .trainer import HipTrainer
         self._require_lib()
+        if self.prec_name not in ("f32", "f16x3"):
+            raise ValueError("prec=%r is an inference-only throughput mode; train with prec='f16x3' or 'f32'" % self.prec_name)
         if self._engine is None or self._engine.grad_flat.device != self._device():
             self._engine = HipTrainer(self, dropout=self.train_dropout, seed=self.train_seed, prec=self.prec_name,
                                       bind_grads=False)

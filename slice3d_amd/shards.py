@@ -148,9 +148,12 @@ class ShardLoader:
             self._dev_pts = torch.from_numpy(np.array(self.pts)).to(self.device)
             self._dev_perm = torch.from_numpy(np.array(self.perm)).to(self.device)
         self._pin = None
+        self._pin_done = None   # event after the last H2D copy out of _pin: the next batch must not overwrite it earlier
+        self._batch_no = 0
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
+        self._batch_no = 0
 
     def _order(self):
         idx = np.arange(self.n)
@@ -161,7 +164,7 @@ class ShardLoader:
 
     def __len__(self):
         n = len(self._order())
-        return n // self.bs if self.drop_last and n >= self.bs else -(-n // self.bs)
+        return n // self.bs if self.drop_last else -(-n // self.bs)   # drop_last with n < bs: no batch, as DataLoader
 
     def __iter__(self):
         order = self._order()
@@ -184,11 +187,15 @@ class ShardLoader:
         if self._dev_imgs is not None:
             u8 = torch.stack([self._dev_imgs[int(i), int(v)] for i, v in zip(ids, views)])
         else:
+            if self._pin_done is not None:
+                self._pin_done.synchronize()      # the previous batch's async upload still reads the staging buffer
             if self._pin is None or self._pin.shape[0] < b:
                 self._pin = torch.empty((b, 1 + ns, s, s, 3), dtype=torch.uint8).pin_memory()
             for k, (i, v) in enumerate(zip(ids, views)):
                 self._pin[k].copy_(torch.from_numpy(np.array(self.imgs[int(i), int(v)])))
             u8 = self._pin[:b].to(dev, non_blocking=True)
+            self._pin_done = torch.cuda.Event()
+            self._pin_done.record(torch.cuda.current_stream(dev))
         img_input = torch.empty((b, 3, s, s), dtype=torch.float32, device=dev)
         img_slices = torch.empty((b, 3 * ns, s, s), dtype=torch.float32, device=dev)
         _lib.check(lib.s3d_dataset_images_fwd(u8.data_ptr(), img_input.data_ptr(), img_slices.data_ptr(), b, ns, s, st),
@@ -208,7 +215,12 @@ class ShardLoader:
             else:
                 pts = torch.from_numpy(np.array(self.pts[lo:hi])).to(dev, non_blocking=True)
             if self.split == "train":      # np.random.seed(); permutation[:n_qry]  ->  a uniform subset, drawn on the device
-                idx = torch.randperm(n, device=dev)[:self.n_qry].int()
+                # from the loader's own stream: a function of (seed, epoch, rank, batch, item), so ranks draw different
+                # subsets and a resumed epoch replays its own
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(int(np.random.SeedSequence((self.seed, self.epoch, self.rank, self._batch_no, k))
+                                    .generate_state(1, dtype=np.uint64)[0] >> 1))
+                idx = torch.randperm(n, device=dev, generator=gen)[:self.n_qry].int()
             elif self._dev_perm is not None:
                 idx = self._dev_perm[lo:lo + self.n_qry]
             else:
@@ -217,6 +229,7 @@ class ShardLoader:
                                                   qry[k].data_ptr(), sdf[k].data_ptr(),
                                                   occ[k].data_ptr() if occ is not None else None, st),
                        "s3d_dataset_points_fwd")
+        self._batch_no += 1
         batch = {"img_input": img_input, "qry_norot": qry, "obj_rot_mat": cam[:, :9].reshape(b, 3, 3).contiguous(),
                  "trans_mat_wo_rot_tp": cam[:, 9:].reshape(b, 4, 3).contiguous(), "sdf": sdf, "img_slices": img_slices}
         if occ is not None:

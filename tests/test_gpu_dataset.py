@@ -70,3 +70,25 @@ def test_train_py_runs_from_shards(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "[train]" in r.stdout and "[val]" in r.stdout
     assert len(glob.glob(str(work / "experiments" / "toy" / "ckpt" / "*.ckpt"))) == 2
+
+
+@pytest.mark.parametrize("tag,white", [("rgb", False), ("white", True)])
+@pytest.mark.parametrize("in_hbm", [False, True])
+def test_device_batches_equal_the_reference_golden_directly(tmp_path, tag, white, in_hbm):
+    """One step instead of two: the batch staged ON THE DEVICE (uint8 shards -> s3d_dataset_images_fwd /
+    s3d_dataset_points_fwd) against tests/golden/dataset_toy_seed3.npz, the tensors of the REAL reference
+    Slice3DDataset (datasets.py:89-179) on the same toy dataset — bit for bit, every key."""
+    from slice3d_amd.datasets import write_toy_dataset
+    from slice3d_amd.shards import ShardLoader, pack_dataset
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dataset_toy_seed3.npz"))
+    write_toy_dataset(str(tmp_path), "toy", seed=3)
+    args = _args(tmp_path, white)
+    out = pack_dataset(args, str(tmp_path / "packed"), splits=("test",))
+    ld = ShardLoader(out, "test", batch_size=2, n_qry=64, cache_on_device=in_hbm, with_occ=True)
+    batches = list(ld)
+    assert len(batches) == 1
+    for i in range(2):
+        for k in ("img_input", "qry_norot", "obj_rot_mat", "trans_mat_wo_rot_tp", "occ", "sdf", "img_slices"):
+            want = g["%s/%d/%s" % (tag, i, k)]
+            got = batches[0][k][i].cpu().numpy()
+            assert got.shape == want.shape and np.array_equal(got, want), (k, np.abs(got - want).max())

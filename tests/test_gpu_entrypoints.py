@@ -110,3 +110,28 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r["parity_vs_oracle"]["max_abs_err"] < r["parity_vs_oracle"]["tol"]
     assert r["train_samples_per_s"] > 0 and r["c4_dense_grid"]["query_points_per_s"] > 0
     assert r["throughput_mode_f16"]["max_abs_diff_vs_headline_mode"] > 0
+
+
+def test_bench_self_launches_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run: bench.py spawns its two ranks itself (the form the
+    driver's single-GPU command has).  S3D_BENCH_BACKEND=gloo lets both ranks share the one GPU of the test box — every
+    line but the transport is the RCCL path.  Checks the JSON contract, n_gpus == 2, the sharded C4 slab leg, the
+    per-rank LDM leg and the data-parallel train leg."""
+    import json
+    env = dict(os.environ, S3D_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
+                        "--n-qry", "4096", "--img-size", "64", "--cpu-sample", "0", "--train-steps", "1", "--c4-steps", "1",
+                        "--c4-res", "32", "--ldm-steps", "1", "--gt-train-steps", "0", "--f16-steps", "0", "--mesh-steps", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["steps"] == 2
+    assert abs(res["value"] - 2 * 4096 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
+    c4 = res["c4_dense_grid"]
+    assert c4["n_gpus"] == 2 and c4["scaling"] == "strong" and "slab" in c4["split"] and c4["query_points_per_s"] > 0
+    assert res["ldm_denoise_step"]["n_gpus"] == 2 and res["ldm_denoise_step"]["steps_per_s_all_gpus"] > 0
+    assert res["train_samples_per_s"] > 0 and "roofline" in res

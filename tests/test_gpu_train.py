@@ -436,3 +436,57 @@ def test_shard_gradients_match_ddp_golden():
     grads = {k: mean[tr.offsets[k]:tr.offsets[k] + p.numel()].numpy() for k, p in zip(tr.names, tr.params)}
     assert set(grads) == {str(k) for k in z["grad_names"]}
     check_grads_against_golden(z, grads, skip=PRE_BN_BIASES)
+
+
+_smooth_oracle = {}
+
+
+def _smooth_output_grads(b, s, q, ns, seed):
+    """Fixed output gradients with no sign(.) in them: seeded normals of the size the L1 losses hand out."""
+    g = torch.Generator().manual_seed(seed)
+    w_sdf = torch.randn(b, q, generator=g) / (b * q)
+    w_rec = torch.randn(b, 3 * ns, s, s, generator=g) / (b * 3 * ns * s * s)
+    return w_sdf, w_rec, 1.0
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("b,s,q,ns", [(2, 32, 128, 12), (1, 128, 16384, 12)])
+def test_smooth_output_gradients_match_oracle_autograd_tightly(b, s, q, ns, prec):
+    """Gradient parity WITHOUT the L1 losses' sign noise: the same fixed, smooth output gradients (seeded normals on
+    sdf_pred and slices_rec, 1 on vgg_loss) are pushed through the autograd path of the HIP model (s3d_train_fwd /
+    s3d_train_bwd behind _TrainForward) and through CPU autograd of the oracle, dropout 0.  Per-tensor relative L2
+    error <= 1e-3 (the L1 tests keep their 2e-2: there two fp32 evaluations disagree on signs of near-zero residuals)."""
+    from oracle import ref_cpu
+    from slice3d_amd.models import Slices3DRegModel
+    from slice3d_amd.synth import make_feed_dict
+    from slice3d_amd.weights import load_seeded
+    fd = make_feed_dict(b, s, q, ns, seed=4000 + q)
+    w_sdf, w_rec, w_vgg = _smooth_output_grads(b, s, q, ns, seed=q)
+    key = (b, s, q, ns)
+    if key not in _smooth_oracle:
+        sd = seeded_sd_from_shapes(_shapes(ns))
+        for k, v in sd.items():
+            if v.is_floating_point() and "running" not in k and not k.startswith("vggptlossfunc"):
+                v.requires_grad_(True)
+        _, _, out, _ = ref_cpu.forward_train(sd, fd, ns, 0.0)
+        ((out["sdf_pred"] * w_sdf).sum() + (out["slices_rec"] * w_rec).sum() + w_vgg * out["vgg_loss"]).backward()
+        _smooth_oracle[key] = (out["sdf_pred"].detach(), {k: v.grad for k, v in sd.items() if v.grad is not None})
+        del out
+    sdf_ref, grads = _smooth_oracle[key]
+    m = load_seeded(Slices3DRegModel(n_slices=ns, mode="train", prec=prec), 0).cuda().train()
+    m.train_dropout = 0.0
+    out = m({k: v.cuda() for k, v in fd.items()})
+    assert (out["sdf_pred"].detach().cpu() - sdf_ref).abs().max() < 1e-4
+    ((out["sdf_pred"] * w_sdf.cuda()).sum() + (out["slices_rec"] * w_rec.cuda()).sum() + w_vgg * out["vgg_loss"]).backward()
+    worst, worst_k, n = 0.0, None, 0
+    for k, p in m.named_parameters():
+        if p.grad is None or k not in grads:
+            continue
+        if k in PRE_BN_BIASES:      # exact gradient 0 (train-mode BN removes the mean): rounding noise on both sides
+            continue
+        rel = float((p.grad.cpu() - grads[k]).norm() / grads[k].norm())
+        n += 1
+        if rel > worst:
+            worst, worst_k = rel, k
+    print("smooth-gradient parity %s (%s): worst per-tensor relative L2 error %.2e (%s), %d tensors" % (key, prec, worst, worst_k, n))
+    assert n > 100 and worst < 1e-3, (worst_k, worst)
