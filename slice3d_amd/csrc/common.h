@@ -74,6 +74,43 @@ void s3d_set_error(const char* fmt, ...);
         if (rc__) return rc__;   \
     } while (0)
 
+// hi/lo split of a pair for the split-precision MFMA paths: one v_cvt_pk_f16_f32 + two v_fma_mix{lo,hi}_f16
+// (lo = f16(x - f32(hi)): the subtraction is exact, one rounding — the same value a scalar convert - subtract - convert
+// produces), 1.5 VALU per value.  The halves are written by 16-bit partial-register asm ops whose write -> MFMA-read
+// spacing the compiler does not pad: put S3D_SPLIT_SETTLE() between a group of splits and MFMAs that read them straight
+// from registers (values that go through LDS need nothing).
+typedef _Float16 s3d_half2 __attribute__((ext_vector_type(2)));
+typedef _Float16 s3d_half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 s3d_half8 __attribute__((ext_vector_type(8)));
+typedef float s3d_float2 __attribute__((ext_vector_type(2)));
+typedef unsigned s3d_uint2 __attribute__((ext_vector_type(2)));
+typedef unsigned s3d_uint4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s3d_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(s3d_float2{a, b}, s3d_half2));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+}
+__device__ __forceinline__ void s3d_split8(const float (&x)[8], s3d_half8& hi, s3d_half8& lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    s3d_split2(x[0], x[1], h0, l0);
+    s3d_split2(x[2], x[3], h1, l1);
+    s3d_split2(x[4], x[5], h2, l2);
+    s3d_split2(x[6], x[7], h3, l3);
+    hi = __builtin_bit_cast(s3d_half8, s3d_uint4{h0, h1, h2, h3});
+    lo = __builtin_bit_cast(s3d_half8, s3d_uint4{l0, l1, l2, l3});
+}
+__device__ __forceinline__ void s3d_split4(const f32x4 a, s3d_half4& hi, s3d_half4& lo) {
+    unsigned h0, h1, l0, l1;
+    s3d_split2(a[0], a[1], h0, l0);
+    s3d_split2(a[2], a[3], h1, l1);
+    hi = __builtin_bit_cast(s3d_half4, s3d_uint2{h0, h1});
+    lo = __builtin_bit_cast(s3d_half4, s3d_uint2{l0, l1});
+}
+#define S3D_SPLIT_SETTLE()                          \
+    __builtin_amdgcn_sched_barrier(0);              \
+    asm volatile("s_nop 15" ::: "memory");          \
+    __builtin_amdgcn_sched_barrier(0);
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Workgroup barrier that publishes LDS-DMA (global_load_lds) data: a wave must see ITS OWN requests land before it

@@ -120,8 +120,6 @@ int launch_sample_planes(const float* plane, const float* grid, float* out, int 
                          hipStream_t stream);
 
 // decode_f16.hip
-int launch_ffn_hidden_f16x3(const float* Xin, float* Hout, long rows, long row_base, const LayerPtrs& w,
-                            const DropCfg& drop_hidden, hipStream_t stream);
 int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
                             const float* timg, float gate_scale, hipStream_t stream);
 int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipStream_t stream);

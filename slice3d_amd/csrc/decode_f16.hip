@@ -44,236 +44,24 @@ __device__ __forceinline__ float quad_sum16(float v) {
     return v;
 }
 
-#define F16_R 2
-// 4 waves = one per SIMD; two workgroups share a CU (2 x 64 KiB LDS, 2 x 256 VGPRs per SIMD lane).  The two
-// waves of a SIMD then belong to DIFFERENT workgroups: while one sits at its per-chunk barrier / LDS latency, the
-// other keeps the matrix pipe busy (with 8-wave workgroups both waves of a SIMD stalled at the same barrier:
-// 37 % of the wave time parked, MFMA pipe 56 % busy — SQ_WAIT_ANY / SQ_VALU_MFMA_BUSY_CYCLES).
-#define F16_WAVES 4
-#define F16_THREADS (F16_WAVES * 64)
 #define F16_CHUNK_HALFS 16384   // 32 KiB: W1 hi | W1 lo | W2 hi | W2 lo, 4096 halfs each
 
-struct FfnTrainArgs {   // MODE 2: pre-LayerNorm output for the backward pass + train-mode dropout; MODE 3: Hout
-    float* Uout;
-    DropCfg dh, dq;
-    float* Hout;
-    unsigned* Mout;  // MODE 2: activity bits of the hidden units (post-dropout h > 0): dword [row][g][chunk>>2],
-                     // byte chunk&3, bit 4a+i  <->  hidden unit 32*chunk + 16a + 4g + i
-    long row_base;   // row index of X[0] in the dropout counter space (block-wise backward recompute)
-};
-// MODE 0: layer FFN (in place or X -> Yout); 1: last layer + fc_out (FINAL); 2: training forward;
-// 3: backward-pass recompute of the hidden activations only: Hout = dropout(relu(x W1^T + b1)), [rows][2048]
-template <int MODE>
-__global__ __launch_bounds__(F16_THREADS, 2) void ffn_layer_f16x3_kernel(const float* X, float* Yout, long rows,
-                                                              const _Float16* wimg, const LayerPtrs w,
-                                                              const float* fco_w, const float* fco_b,
-                                                              float* sdf_out, float sign, long groups_per_batch,
-                                                              long n_qry, long g_begin, const int* perm,
-                                                              const FfnTrainArgs ta) {
-    constexpr bool FINAL = MODE == 1;
-    __shared__ __attribute__((aligned(16))) _Float16 s_w[2][F16_CHUNK_HALFS];  // 64 KiB
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = lane & 15, g = lane >> 4;
-    const long row0 = ((long)blockIdx.x * F16_WAVES + wave) * (F16_R * 16);
-
-    half8 xh[F16_R][4], xl[F16_R][4];
-    f32x4 acc[F16_R][8];
-#pragma unroll
-    for (int r = 0; r < F16_R; ++r) {
-        long row = row0 + r * 16 + m;
-        if (row >= rows) row = rows - 1;
-        const float* p = X + row * 128 + 8 * g;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
-            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-            split8(v, xh[r][u], xl[r][u]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
-    }
-    // stage chunk 0 (LDS-DMA); chunk c+1 is requested at the top of iteration c into the other buffer
-    dma_chunk32k(wimg, s_w[0], wave, lane, F16_WAVES);
-    dma_publish_barrier();
-
-    unsigned mword[F16_R] = {};
-    // lin1 bias of the NEXT chunk is fetched one iteration ahead and BEFORE the weight prefetch: vmcnt retires
-    // in order, so a bias load issued after the prefetch would make its consumer wait for the whole prefetch
-    f32x4 b1n[2] = {ld4(w.b1 + 4 * g), ld4(w.b1 + 16 + 4 * g)};
-#pragma unroll 1
-    for (int c = 0; c < S3D_FFN_NCHUNK; ++c) {
-        const _Float16* sw = s_w[c & 1];
-        const f32x4 b1c[2] = {b1n[0], b1n[1]};
-        if (c + 1 < S3D_FFN_NCHUNK) {
-            b1n[0] = ld4(w.b1 + (c + 1) * S3D_FFN_CHUNK + 4 * g);
-            b1n[1] = ld4(w.b1 + (c + 1) * S3D_FFN_CHUNK + 16 + 4 * g);
-            dma_chunk32k(wimg + (size_t)(c + 1) * F16_CHUNK_HALFS, s_w[(c + 1) & 1], wave, lane, F16_WAVES);
-        }
-        // GEMM1: hidden^T[32][16 rows] = W1_c x^T ; two 16-row tiles a, K = 128 = 4 x 32
-        float hv[F16_R][8];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            f32x4 hd[F16_R];
-#pragma unroll
-            for (int r = 0; r < F16_R; ++r) hd[r] = zero4();
-            half8 w1h[4], w1l[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                w1h[u] = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8);
-                w1l[u] = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                // three product kinds, each swept over the independent row tiles (no back-to-back
-                // dependent MFMAs on one accumulator)
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[u], xl[r][u], hd[r], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[u], xh[r][u], hd[r], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) hd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[u], xh[r][u], hd[r], 0, 0, 0);
-            }
-            const f32x4 b1 = b1c[a];
-#pragma unroll
-            for (int r = 0; r < F16_R; ++r)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) hv[r][4 * a + i] = fmaxf(hd[r][i] + b1[i], 0.f);
-            if (MODE >= 2 && ta.dh.p > 0.f) {   // hidden-unit dropout, counter = row*2048 + unit
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) {
-                    const unsigned long long base =
-                        (unsigned long long)(ta.row_base + row0 + r * 16 + m) * S3D_FFN + c * S3D_FFN_CHUNK + 16 * a + 4 * g;
-                    float mk4[4];
-                    s3d_drop4(ta.dh, base, mk4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) hv[r][4 * a + i] *= mk4[i];
-                }
-            }
-        }
-        if (MODE == 2 && ta.Mout) {
-#pragma unroll
-            for (int r = 0; r < F16_R; ++r) {
-                unsigned byte = 0;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) byte |= (hv[r][t] > 0.f ? 1u : 0u) << t;
-                mword[r] |= byte << (8 * (c & 3));
-                const long row = row0 + r * 16 + m;
-                if ((c & 3) == 3) {
-                    if (row < rows) ta.Mout[row * 64 + g * 16 + (c >> 2)] = mword[r];
-                    mword[r] = 0;
-                }
-            }
-        }
-        if (MODE == 3) {
-#pragma unroll
-            for (int r = 0; r < F16_R; ++r) {
-                const long row = row0 + r * 16 + m;
-                if (row < rows) {
-                    float* hp = ta.Hout + row * S3D_FFN + c * S3D_FFN_CHUNK + 4 * g;
-                    st4(hp, f32x4{hv[r][0], hv[r][1], hv[r][2], hv[r][3]});
-                    st4(hp + 16, f32x4{hv[r][4], hv[r][5], hv[r][6], hv[r][7]});
-                }
-            }
-        }
-        half8 hh[F16_R], hl[F16_R];
-#pragma unroll
-        for (int r = 0; r < F16_R; ++r) split8(hv[r], hh[r], hl[r]);
-        // GEMM2: acc^T[128][16 rows] += W2_c hidden^T, K = 32
-#pragma unroll
-        for (int jh = 0; jh < (MODE == 3 ? 0 : 2); ++jh) {
-            half8 w2h[4], w2l[4];
-#pragma unroll
-            for (int jq = 0; jq < 4; ++jq) {
-                w2h[jq] = ldh8(sw + 8192 + ((4 * jh + jq) * 64 + lane) * 8);
-                w2l[jq] = ldh8(sw + 12288 + ((4 * jh + jq) * 64 + lane) * 8);
-            }
-#pragma unroll
-            for (int jq = 0; jq < 4; ++jq) {
-                const int j = 4 * jh + jq;
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], hl[r], acc[r][j], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[jq], hh[r], acc[r][j], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], hh[r], acc[r][j], 0, 0, 0);
-            }
-        }
-        dma_publish_barrier();   // chunk c+1 has landed; everyone is done with buffer c & 1
-    }
-
-    if (MODE == 3) return;
-    // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i.  The rows' halves are made opaque first: the
-    // residual f32(hi) + f32(lo) is loop-invariant and would otherwise be formed before the loop and held through it
-#pragma unroll
-    for (int r = 0; r < F16_R; ++r)
-        asm volatile("" : "+v"(xh[r][0]), "+v"(xh[r][1]), "+v"(xh[r][2]), "+v"(xh[r][3]), "+v"(xl[r][0]), "+v"(xl[r][1]), "+v"(xl[r][2]),
-                     "+v"(xl[r][3]));
-#pragma unroll
-    for (int r = 0; r < F16_R; ++r) {
-        const long row = row0 + r * 16 + m;
-        f32x4 y[8];
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
-            const f32x4 b2 = ld4(w.b2 + col);
-            float mq4[4] = {1.f, 1.f, 1.f, 1.f};
-            if (MODE == 2 && ta.dq.p > 0.f) s3d_drop4(ta.dq, (unsigned long long)row * 128 + col, mq4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int t = 4 * (j & 1) + i;
-                float f = acc[r][j][i] + b2[i];
-                if (MODE == 2) f *= mq4[i];
-                y[j][i] = f + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
-                s += y[j][i];
-            }
-            if (MODE == 2 && row < rows) st4(ta.Uout + row * 128 + col, y[j]);
-        }
-        const float mean = quad_sum16(s) * (1.f / 128.f);
-        float v = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float d = y[j][i] - mean;
-                v += d * d;
-            }
-        const float rstd = 1.f / sqrtf(quad_sum16(v) * (1.f / 128.f) + 1e-5f);
-        float dot = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
-            const f32x4 ga = ld4(w.ln2g + col), be = ld4(w.ln2b + col);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[j][i] = (y[j][i] - mean) * rstd * ga[i] + be[i];
-            if (FINAL) {
-                const f32x4 wo = ld4(fco_w + col);
-                dot += y[j][0] * wo[0] + y[j][1] * wo[1] + y[j][2] * wo[2] + y[j][3] * wo[3];
-            } else if (row < rows) {
-                st4(Yout + row * 128 + col, y[j]);
-            }
-        }
-        if (FINAL) {
-            dot = quad_sum16(dot) + fco_b[0];
-            if (g == 0 && row < rows) {
-                const long grp = g_begin + row / S3D_GROUP;
-                const long b = grp / groups_per_batch;
-                const long q = (grp % groups_per_batch) * S3D_GROUP + (row % S3D_GROUP);
-                if (q < n_qry) sdf_out[b * n_qry + (perm ? perm[b * n_qry + q] : q)] = sign * dot;
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Software-pipelined inference FFN (MODE 0: layer, 1: last layer + fc_out).  Same tiling, same weight image and the
-// same products as ffn_layer_f16x3_kernel (lin1's bias now opens the accumulation instead of closing it), but GEMM1
-// runs ONE CHUNK AHEAD of GEMM2:
+// Software-pipelined FFN.  MODE 0: layer (inference), 1: last layer + fc_out, 2 / 3: TRAINING forward with / without
+// dropout (activity bits of the hidden units for the backward, pre-LayerNorm output saved), 4: BACKWARD data path
+//     dA = (dY W2) * (bit ? gate_scale : 0),   dX = dA W1 + Dres
+// on the transposed weight image (W2^T chunks GEMM-1-shaped, W1^T chunks GEMM-2-shaped: launch_pack_ffn_f16x3_bwd), the
+// same loop with the gate in place of bias + ReLU and no LayerNorm.  128 rows per 4-wave workgroup, two workgroups per
+// CU, activations in registers as f16 hi/lo B fragments, W1/W2 stream through LDS in 32-hidden-unit chunks, the hidden
+// tile never leaves registers.  For K=32 MFMAs a lane (m = l&15, g = l>>4) owns the 8 consecutive channels
+// {32u + 8g .. +7}; the output-channel permutation of W2's rows is chosen so that GEMM2's D registers land on exactly
+// those channels again (residual, LayerNorm, 32-byte stores).  GEMM1 runs ONE CHUNK AHEAD of GEMM2:
 //     phase A (iteration c):  hn = W1(c+1) x^T + b1(c+1)     [48 MFMAs]   ||   relu + hi/lo split of h(c)  [VALU]
 //     phase B              :  acc += W2(c) h(c)              [48 MFMAs]   ||   fragment reads, next chunk's LDS-DMA
-// In the plain kernel the ~80 VALU instructions of the split sit between GEMM1(c) and GEMM2(c), which both depend on
-// them: the wave's matrix pipe idles for the whole block and only the SIMD's other wave can fill it (MFMA pipe 52-63 %
-// busy, 27 cycles per MFMA against 17).  Here every MFMA phase has independent VALU / LDS work to issue beside it.
+// Without the pipelining the ~80 VALU instructions of the split (more with dropout) sit between GEMM1(c) and GEMM2(c),
+// which both depend on them: the wave's matrix pipe idles for the whole block and only the SIMD's other wave can fill it
+// (MFMA pipe 52-63 % busy, 27 cycles per MFMA against 17 — the round-1 kernel).  Here every MFMA phase has independent
+// VALU / LDS work to issue beside it.
 // The LDS buffer of iteration c therefore holds W1(c+1) | W2(c): the two 16 KiB halves of a buffer are fetched from
 // different chunks of the (unchanged) image.  lin1's bias is the accumulator's initial value.  Fragment reads are
 // issued one 12-MFMA group ahead; sched_group_barrier pins the interleave.
@@ -321,6 +109,68 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
 }
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
+// EXPERIMENT switch (never set in the product build; result in profiles/r03_ffn_two_product_gemm2.md): GEMM2 of the
+// inference modes with two of the three split products — 1 drops W2_lo * h_hi, 2 drops W2_hi * h_lo
+#ifndef FFN_G2_TWO
+#define FFN_G2_TWO 0
+#endif
+
+struct FfnTrainArgs {   // MODE 2
+    float* Uout;     // pre-LayerNorm output u = x + dropout(FFN(x)), saved for the backward
+    DropCfg dh, dq;  // hidden-unit / output dropout
+    unsigned* Mout;  // activity bits of the hidden units (post-dropout h > 0): dword [row][g][chunk>>2],
+                     // byte chunk&3, bit 4a+i  <->  hidden unit 32*chunk + 16a + 4g + i
+};
+struct FfnBwdArgs {     // MODE 4
+    const float* Dres;     // added to dX (the residual branch's gradient)
+    const unsigned* M;     // activity bits written by the forward
+    float gate_scale;      // value of a kept unit's dropout factor
+};
+// per-wave state of the activation stage between GEMM1 and GEMM2
+struct FfnActState {
+    unsigned mw[PIPE_R];               // MODE 2: bits of the 4-chunk group being produced; MODE 4: of the group being consumed
+    unsigned mw_next[PIPE_R];          // MODE 4: next group's dword (requested one group ahead)
+    unsigned long long ctr[PIPE_R];    // MODE 2: dropout counter of (row, hidden unit 4g)
+};
+// D tile (a2, r2) of chunk c: pre-activation -> f16 hi/lo halves of GEMM2's B operand
+template <int MODE>
+__device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, half2v& l0, half2v& l1, FfnActState& as,
+                                         const FfnTrainArgs& ta, const FfnBwdArgs& ba, int c, int a2, int r2) {
+    if (MODE == 2 || MODE == 3) {
+        const float inf = __builtin_inff();
+        float a[4] = {__builtin_amdgcn_fmed3f(v[0], 0.f, inf), __builtin_amdgcn_fmed3f(v[1], 0.f, inf),
+                      __builtin_amdgcn_fmed3f(v[2], 0.f, inf), __builtin_amdgcn_fmed3f(v[3], 0.f, inf)};
+        if (MODE == 2) {   // hidden-unit dropout, counter = row*2048 + unit (a template mode, not a run-time branch: the
+                           // activation must stay in the MFMA group's basic block to be interleaved with it).  Drawing
+                           // the factors one phase earlier, under GEMM2, measured 2 % slower: the hashes (~550 VALU issue
+                           // slots per two chunks, 32-bit multiplies at quarter rate) exceed the 576 slots the 192 MFMAs
+                           // leave wherever they are placed — this mode is VALU-issue bound (MFMA pipe 53 % busy)
+            float mk4[4];
+            s3d_drop4(ta.dh, as.ctr[r2] + (unsigned)(c * S3D_FFN_CHUNK + 16 * a2), mk4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] *= mk4[i];
+        }
+        unsigned bits = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bits |= (a[i] > 0.f ? 1u : 0u) << i;
+        as.mw[r2] |= bits << (8 * (c & 3) + 4 * a2);
+        h0 = __builtin_convertvector(float2v{a[0], a[1]}, half2v);
+        h1 = __builtin_convertvector(float2v{a[2], a[3]}, half2v);
+        l0 = __builtin_convertvector(float2v{a[0] - (float)h0[0], a[1] - (float)h0[1]}, half2v);
+        l1 = __builtin_convertvector(float2v{a[2] - (float)h1[0], a[3] - (float)h1[1]}, half2v);
+    } else if (MODE == 4) {
+        const unsigned bits = as.mw[r2] >> (8 * (c & 3) + 4 * a2);
+        float a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = ((bits >> i) & 1u) ? v[i] * ba.gate_scale : 0.f;
+        h0 = __builtin_convertvector(float2v{a[0], a[1]}, half2v);
+        h1 = __builtin_convertvector(float2v{a[2], a[3]}, half2v);
+        l0 = __builtin_convertvector(float2v{a[0] - (float)h0[0], a[1] - (float)h0[1]}, half2v);
+        l1 = __builtin_convertvector(float2v{a[2] - (float)h1[0], a[3] - (float)h1[1]}, half2v);
+    } else {
+        relu_split4(v, h0, h1, l0, l1);
+    }
+}
 
 // LDS fragment reads and their waits are issued by hand.  hipcc models a pending LDS-DMA as an LDS access of unknown
 // order: while the refill of the other buffer is in flight it either degrades every LDS wait to lgkmcnt(0) (waiting
@@ -344,7 +194,10 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
                 DS_READ(vh[0], lw, 16384);                                                                           \
                 DS_READ(vl[0], lw, 24576);                                                                           \
             }                                                                                                        \
-            if ((K) == 0) {                                                                                          \
+            if ((K) == 0 && MODE == 4) {                                                                             \
+                DS_WAIT2(2, fh[0], fl[0]);                                                                           \
+                _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r) { hn[0][r] = zero4(); hn[1][r] = zero4(); }        \
+            } else if ((K) == 0) {                                                                                   \
                 DS_WAIT4(2, bq[0], bq[1], fh[0], fl[0]);                                                             \
                 _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r) { hn[0][r] = bq[0]; hn[1][r] = bq[1]; }            \
             } else {                                                                                                 \
@@ -364,7 +217,7 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
         }                                                                                                            \
         if ((K) % (4 / PIPE_R) == 0) {   /* 2 * PIPE_R D tiles over the 8 groups */                                   \
             constexpr int tile = (K) / (4 / PIPE_R), a2 = tile / PIPE_R, r2 = tile % PIPE_R;                         \
-            relu_split4(hd[a2][r2], hh2[r2][2 * a2], hh2[r2][2 * a2 + 1], hl2[r2][2 * a2], hl2[r2][2 * a2 + 1]);     \
+            ffn_act4<MODE>(hd[a2][r2], hh2[r2][2 * a2], hh2[r2][2 * a2 + 1], hl2[r2][2 * a2], hl2[r2][2 * a2 + 1], as, ta, ba, c, a2, r2); \
             /* tie the results into the side-effect chain: otherwise the low halves are emitted where they are */   \
             /* first USED (phase B), outside the MFMA cover */                                                       \
             asm volatile("" : "+v"(hl2[r2][2 * a2]), "+v"(hl2[r2][2 * a2 + 1]), "+v"(hh2[r2][2 * a2]),               \
@@ -373,7 +226,7 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
         if (!LAST) {                                                                                                 \
             _Pragma("unroll") for (int i = 0; i < (SINGLE ? 1 : 3) * PIPE_R; ++i) {                                  \
                 SGB(SG_MFMA, 1);                                                                                     \
-                SGB(SG_VALU, SINGLE ? 9 : 3);                                                                        \
+                SGB(SG_VALU, SINGLE ? 9 : (MODE == 2 ? 5 : 3));                                                      \
             }                                                                                                        \
         }                                                                                                            \
         SB();                                                                                                        \
@@ -389,9 +242,11 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
         } else {                                                                                                     \
             DS_WAIT2(0, vh[s], vl[s]);                                                                               \
         }                                                                                                            \
-        if (!SINGLE) {                                                                                               \
+        if (!SINGLE && FFN_G2_TWO != 2) {                                                                            \
             _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
                 acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[s], hl[r], acc[r][J], 0, 0, 0);                \
+        }                                                                                                            \
+        if (!SINGLE && FFN_G2_TWO != 1) {                                                                            \
             _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
                 acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[s], hh[r], acc[r][J], 0, 0, 0);                \
         }                                                                                                            \
@@ -404,16 +259,19 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
 // pre-activations costs no moves).  Every group of 6 MFMAs is its own scheduling region (sched_barrier): the order
 // written here IS the issue order.  lw = LDS byte address of this lane's fragment slot in the current weight buffer,
 // lb = of its bias quad of the NEXT chunk.
-template <bool LAST, bool SINGLE>
+template <int MODE, bool LAST, bool SINGLE>
 __device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned lb, const half8 (&xh)[PIPE_R][4],
                                               const half8 (&xl)[PIPE_R][4], f32x4 (&acc)[PIPE_R][8],
-                                              const f32x4 (&hd)[2][PIPE_R], f32x4 (&hn)[2][PIPE_R]) {
+                                              const f32x4 (&hd)[2][PIPE_R], f32x4 (&hn)[2][PIPE_R], FfnActState& as,
+                                              const FfnTrainArgs& ta, const FfnBwdArgs& ba, const int c) {
     half2v hh2[PIPE_R][4], hl2[PIPE_R][4];
     half8 fh[2], fl[2], vh[2], vl[2];
     f32x4 bq[2];
     if (!LAST) {
-        DS_READ(bq[0], lb, 0);
-        DS_READ(bq[1], lb, 64);
+        if (MODE != 4) {
+            DS_READ(bq[0], lb, 0);
+            DS_READ(bq[1], lb, 64);
+        }
         DS_READ(fh[0], lw, 0);
         DS_READ(fl[0], lw, 8192);
     }
@@ -436,7 +294,8 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
                                                                    const _Float16* wimg, const LayerPtrs w,
                                                                    const float* fco_w, const float* fco_b,
                                                                    float* sdf_out, float sign, long groups_per_batch,
-                                                                   long n_qry, long g_begin, const int* perm) {
+                                                                   long n_qry, long g_begin, const int* perm,
+                                                                   const FfnTrainArgs ta, const FfnBwdArgs ba) {
     constexpr bool FINAL = MODE == 1;
     constexpr int NC = S3D_FFN_NCHUNK;
     // THREE distinct LDS objects: hipcc tags their accesses with alias scopes, so a ds_read of one weight buffer is not
@@ -452,10 +311,12 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
     dma_pieces(wimg, s_w1, 0, 16, wave, lane);
     dma_pieces(wimg + F16_CHUNK_HALFS, s_w0, 0, 16, wave, lane);
     dma_pieces(wimg, s_w0, 16, 32, wave, lane);
-    for (int i = threadIdx.x; i < S3D_FFN / 4; i += PIPE_THREADS) st4(s_b1 + 4 * i, ld4(w.b1 + 4 * i));
+    if (MODE != 4)
+        for (int i = threadIdx.x; i < S3D_FFN / 4; i += PIPE_THREADS) st4(s_b1 + 4 * i, ld4(w.b1 + 4 * i));
 
     half8 xh[PIPE_R][4], xl[PIPE_R][4];
     f32x4 acc[PIPE_R][8];
+    FfnActState as;
 #pragma unroll
     for (int r = 0; r < PIPE_R; ++r) {
         long row = row0 + r * 16 + m;
@@ -469,6 +330,13 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
+        as.mw[r] = as.mw_next[r] = 0u;
+        as.ctr[r] = 0ull;
+        if (MODE == 2) as.ctr[r] = (unsigned long long)(row0 + r * 16 + m) * S3D_FFN + 4 * g;
+        if (MODE == 4) {   // activity bits: one dword per 4 chunks, the next group's requested one group ahead
+            as.mw[r] = ba.M[row * 64 + g * 16];
+            as.mw_next[r] = ba.M[row * 64 + g * 16 + 1];
+        }
     }
     dma_publish_barrier();
     const float* sb = s_b1 + 4 * g;     // this lane's bias quad of D tile 0 of chunk 0; tile 1 at +16, chunk c at +32c
@@ -481,7 +349,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = *reinterpret_cast<const f32x4*>(sb + 16 * a);
+            for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = MODE == 4 ? zero4() : *reinterpret_cast<const f32x4*>(sb + 16 * a);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -499,6 +367,29 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
     }
     __syncthreads();   // every wave is done with buffer 1 before the first refill overwrites it
 
+    // between two iterations, after chunk c (c & 3 == 3) closed a 4-chunk group of activity bits:
+    //   MODE 2 stores the group's dword, MODE 4 moves on to the next group's and requests the one after
+    auto group_done = [&](int c) {
+        if ((MODE == 2 || MODE == 3) && ta.Mout) {
+#pragma unroll
+            for (int r = 0; r < PIPE_R; ++r) {
+                const long row = row0 + r * 16 + m;
+                if (row < rows) ta.Mout[row * 64 + g * 16 + (c >> 2)] = as.mw[r];
+                as.mw[r] = 0u;
+            }
+        }
+        if (MODE == 4) {
+#pragma unroll
+            for (int r = 0; r < PIPE_R; ++r) {
+                long row = row0 + r * 16 + m;
+                if (row >= rows) row = rows - 1;
+                const int nxt = (c >> 2) + 2;
+                as.mw[r] = as.mw_next[r];
+                as.mw_next[r] = ba.M[row * 64 + g * 16 + (nxt < NC / 4 ? nxt : NC / 4 - 1)];
+            }
+        }
+    };
+
     // buffer c & 1 holds W1(c+1) | W2(c); the refill of the other buffer (W1(c+2) | W2(c+1)) is requested at the top of
     // iteration c and published by the barrier at its end.  Two iterations per trip: the buffers are distinct objects
     // (see above) and hd / hn exchange roles without moves.
@@ -507,28 +398,43 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
         dma_pieces(wimg + (size_t)(c + 2) * F16_CHUNK_HALFS, s_w1, 0, 16, wave, lane);
         dma_pieces(wimg + (size_t)(c + 1) * F16_CHUNK_HALFS, s_w1, 16, 32, wave, lane);
         SB();
-        ffn_pipe_iter<false, SINGLE>(lw0, lb0 + (c + 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB);
+        ffn_pipe_iter<MODE, false, SINGLE>(lw0, lb0 + (c + 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB, as, ta, ba, c);
         dma_publish_barrier();
         dma_pieces(wimg + (size_t)(c + 3) * F16_CHUNK_HALFS, s_w0, 0, 16, wave, lane);
         dma_pieces(wimg + (size_t)(c + 2) * F16_CHUNK_HALFS, s_w0, 16, 32, wave, lane);
         SB();
-        ffn_pipe_iter<false, SINGLE>(lw1, lb0 + (c + 2) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdB, hdA);
+        ffn_pipe_iter<MODE, false, SINGLE>(lw1, lb0 + (c + 2) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdB, hdA, as, ta, ba, c + 1);
+        if ((MODE == 2 || MODE == 3 || MODE == 4) && (c & 2)) group_done(c + 1);
         dma_publish_barrier();
     }
     // c = NC-2: buffer 0 holds W1(NC-1) | W2(NC-2); only W2(NC-1) is left to fetch (the W1 half: any valid chunk)
     dma_pieces(wimg + (size_t)(NC - 1) * F16_CHUNK_HALFS, s_w1, 0, 16, wave, lane);
     dma_pieces(wimg + (size_t)(NC - 1) * F16_CHUNK_HALFS, s_w1, 16, 32, wave, lane);
     SB();
-    ffn_pipe_iter<false, SINGLE>(lw0, lb0 + (NC - 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB);
+    ffn_pipe_iter<MODE, false, SINGLE>(lw0, lb0 + (NC - 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB, as, ta, ba, NC - 2);
     dma_publish_barrier();
-    ffn_pipe_iter<true, SINGLE>(lw1, lb0, xh, xl, acc, hdB, hdA);
+    ffn_pipe_iter<MODE, true, SINGLE>(lw1, lb0, xh, xl, acc, hdB, hdA, as, ta, ba, NC - 1);
+    if (MODE == 2 || MODE == 3) group_done(NC - 1);
 
-    // epilogue (identical to ffn_layer_f16x3_kernel): tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i.
+    // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i.
     // The lane's column offset is re-derived from an opaque copy of g: otherwise the ten loop-invariant 64-bit addresses
     // of this epilogue are computed in the prologue and spilled across the loop (20 dwords of scratch per lane, written
     // and read back by every wave: +0.4 GB of HBM writes per launch in the PMC pass)
     int ge = g, me = m;
     asm volatile("" : "+v"(ge), "+v"(me));
+    if (MODE == 4) {   // dX = dA W1 + Dres
+#pragma unroll
+        for (int r = 0; r < PIPE_R; ++r) {
+            const long row = row0 + r * 16 + me;
+            if (row >= rows) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = 32 * (j >> 1) + 8 * ge + 4 * (j & 1);
+                st4(Yout + row * 128 + col, acc[r][j] + ld4(ba.Dres + row * 128 + col));
+            }
+        }
+        return;
+    }
     // ... and the rows' halves are made opaque here: left alone, the residual f32(hi) + f32(lo) of all 64 values is
     // formed BEFORE the loop (it is loop-invariant), held in registers through it and partly spilled
 #pragma unroll
@@ -544,13 +450,17 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
         for (int j = 0; j < 8; ++j) {
             const int col = 32 * (j >> 1) + 8 * ge + 4 * (j & 1);
             const f32x4 b2 = ld4(w.b2 + col);
+            float mq4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (MODE == 2) s3d_drop4(ta.dq, (unsigned long long)row * 128 + col, mq4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int t = 4 * (j & 1) + i;
-                const float f = acc[r][j][i] + b2[i];
+                float f = acc[r][j][i] + b2[i];
+                if (MODE == 2) f *= mq4[i];
                 y[j][i] = f + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
                 s += y[j][i];
             }
+            if ((MODE == 2 || MODE == 3) && row < rows) st4(ta.Uout + row * 128 + col, y[j]);
         }
         const float mean = quad_sum16(s) * (1.f / 128.f);
         float v = 0.f;
@@ -588,205 +498,73 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
     }
 }
 
-static bool ffn_pipelined() {
-    static const bool on = [] {
-        const char* e = getenv("S3D_FFN_PIPE");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
-
+#define PIPE_ROWS_PER_WG (PIPE_WAVES * PIPE_R * 16)
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
                            long g_begin, const int* perm, hipStream_t stream, bool single_pass) {
     if (rows <= 0) return 0;
-    const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
     const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
-    FfnTrainArgs ta = {};
+    const FfnTrainArgs ta = {};
+    const FfnBwdArgs ba = {};
+    const dim3 grid((unsigned)((rows + PIPE_ROWS_PER_WG - 1) / PIPE_ROWS_PER_WG)), block(PIPE_THREADS);
     if (single_pass) {
-        const long blocks = (rows + PIPE_WAVES * PIPE_R * 16 - 1) / (PIPE_WAVES * PIPE_R * 16);
         if (sdf_out)
-            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, true>), dim3((unsigned)blocks), dim3(PIPE_THREADS), 0, stream,
-                               X, X, rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, true>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
+                               sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba);
         else
-            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, true>), dim3((unsigned)blocks), dim3(PIPE_THREADS), 0, stream,
-                               X, X, rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
-        S3D_LAUNCH_CHECK();
-        return 0;
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, true>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
+                               sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba);
+    } else if (sdf_out) {
+        hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, false>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
+                           sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba);
+    } else {
+        hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, false>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
+                           sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba);
     }
-    if (ffn_pipelined()) {
-        const long blocks = (rows + PIPE_WAVES * PIPE_R * 16 - 1) / (PIPE_WAVES * PIPE_R * 16);
-        if (sdf_out)
-            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, false>), dim3((unsigned)blocks), dim3(PIPE_THREADS), 0, stream, X, X,
-                               rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
-        else
-            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, false>), dim3((unsigned)blocks), dim3(PIPE_THREADS), 0, stream, X, X,
-                               rows, img, w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm);
-        S3D_LAUNCH_CHECK();
-        return 0;
-    }
-    if (sdf_out)
-        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<1>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
-                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta);
-    else
-        hipLaunchKernelGGL(ffn_layer_f16x3_kernel<0>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, X, X, rows, img,
-                           w, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta);
     S3D_LAUNCH_CHECK();
     return 0;
 }
 
+// training forward: y = LN2(u), u = x + dropout(FFN(x)); y -> Yout, u -> Uout, activity bits -> Mout
 int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
                                  const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
                                  hipStream_t stream) {
     if (rows <= 0) return 0;
     S3D_CHECK_ARG(w.wf16 != nullptr, "ffn train f16x3: no packed f16 image");
-    const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
-    FfnTrainArgs ta = {Uout, drop_hidden, drop_out, nullptr, Mout, 0};
-    hipLaunchKernelGGL(ffn_layer_f16x3_kernel<2>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, Xin, Yout, rows,
-                       reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L,
-                       nullptr, ta);
-    S3D_LAUNCH_CHECK();
-    return 0;
-}
-
-int launch_ffn_hidden_f16x3(const float* Xin, float* Hout, long rows, long row_base, const LayerPtrs& w,
-                            const DropCfg& drop_hidden, hipStream_t stream) {
-    if (rows <= 0) return 0;
-    S3D_CHECK_ARG(w.wf16 != nullptr, "ffn hidden f16x3: no packed f16 image");
-    const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
-    FfnTrainArgs ta = {nullptr, drop_hidden, make_drop(0, 0.f, 0), Hout, nullptr, row_base};
-    hipLaunchKernelGGL(ffn_layer_f16x3_kernel<3>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, Xin, nullptr, rows,
-                       reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L,
-                       nullptr, ta);
+    const FfnTrainArgs ta = {Uout, drop_hidden, drop_out, Mout};
+    const FfnBwdArgs ba = {};
+    const dim3 grid((unsigned)((rows + PIPE_ROWS_PER_WG - 1) / PIPE_ROWS_PER_WG)), block(PIPE_THREADS);
+    S3D_CHECK_ARG((drop_hidden.p > 0.f) == (drop_out.p > 0.f), "ffn train f16x3: hidden / output dropout must be on or off together");
+    if (drop_hidden.p > 0.f)
+        hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<2, false>), grid, block, 0, stream, Xin, Yout, rows,
+                           reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr,
+                           ta, ba);
+    else
+        hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<3, false>), grid, block, 0, stream, Xin, Yout, rows,
+                           reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr,
+                           ta, ba);
     S3D_LAUNCH_CHECK();
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// FFN backward, data path:  given dY (gradient w.r.t. the lin2 output) and the activity bits M of the
-// hidden units (forward kernel, FfnTrainArgs::Mout),
+// FFN backward, data path (MODE 4 of the pipelined kernel):  given dY (gradient w.r.t. the lin2 output) and the
+// activity bits M of the hidden units (forward kernel, FfnTrainArgs::Mout),
 //   dA = (dY W2) * (bit ? gate_scale : 0)        [rows][2048], registers only
 //   dX = dA W1 + Dres                             [rows][128]
-// Same tiling as the forward kernel: dY rows live in registers as f16 hi/lo B fragments, the transposed
-// weights (W2^T chunk as GEMM-1-shaped fragments, W1^T chunk as GEMM-2-shaped fragments; packed by
-// pack_ffn_f16x3_kernel with swapped strides) stream through LDS, dA never re-enters registers from memory.
+// dY rows live in registers as f16 hi/lo B fragments, the transposed weights (W2^T chunk as GEMM-1-shaped fragments,
+// W1^T chunk as GEMM-2-shaped fragments; packed by pack_ffn_f16x3_kernel with swapped strides) stream through LDS.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(F16_THREADS, 2) void ffn_bwd_dx_f16x3_kernel(const float* __restrict__ DY,
-                                                               const float* __restrict__ Dres,
-                                                               const unsigned* __restrict__ M,
-                                                               float* __restrict__ DX, long rows,
-                                                               const _Float16* __restrict__ timg, float gate_scale) {
-    __shared__ __attribute__((aligned(16))) _Float16 s_w[2][F16_CHUNK_HALFS];  // 64 KiB
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = lane & 15, g = lane >> 4;
-    const long row0 = ((long)blockIdx.x * F16_WAVES + wave) * (F16_R * 16);
-
-    half8 yh[F16_R][4], yl[F16_R][4];
-    f32x4 acc[F16_R][8];
-#pragma unroll
-    for (int r = 0; r < F16_R; ++r) {
-        long row = row0 + r * 16 + m;
-        if (row >= rows) row = rows - 1;
-        const float* p = DY + row * 128 + 8 * g;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
-            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-            split8(v, yh[r][u], yl[r][u]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
-    }
-    dma_chunk32k(timg, s_w[0], wave, lane, F16_WAVES);
-    dma_publish_barrier();
-
-    unsigned mw[F16_R] = {};
-#pragma unroll 1
-    for (int c = 0; c < S3D_FFN_NCHUNK; ++c) {
-        const _Float16* sw = s_w[c & 1];
-        if (c + 1 < S3D_FFN_NCHUNK)
-            dma_chunk32k(timg + (size_t)(c + 1) * F16_CHUNK_HALFS, s_w[(c + 1) & 1], wave, lane, F16_WAVES);
-        // gate: activity bits of this chunk's hidden units (written by the forward kernel), one dword per 4 chunks
-        if ((c & 3) == 0) {
-#pragma unroll
-            for (int r = 0; r < F16_R; ++r) {
-                long row = row0 + r * 16 + m;
-                if (row >= rows) row = rows - 1;
-                mw[r] = M[row * 64 + g * 16 + (c >> 2)];
-            }
-        }
-        // GEMM1': dh^T[32 hidden][16 rows] = W2_c^T dy^T, K = 128
-        float dav[F16_R][8];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            f32x4 dd[F16_R];
-#pragma unroll
-            for (int r = 0; r < F16_R; ++r) dd[r] = zero4();
-            half8 wh[4], wl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                wh[u] = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8);
-                wl[u] = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) dd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], yl[r][u], dd[r], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) dd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], yh[r][u], dd[r], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) dd[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], yh[r][u], dd[r], 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < F16_R; ++r)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    dav[r][4 * a + i] = ((mw[r] >> (8 * (c & 3) + 4 * a + i)) & 1u) ? dd[r][i] * gate_scale : 0.f;
-        }
-        half8 dh_[F16_R], dl_[F16_R];
-#pragma unroll
-        for (int r = 0; r < F16_R; ++r) split8(dav[r], dh_[r], dl_[r]);
-        // GEMM2': dx^T[128][16 rows] += W1_c^T da^T, K = 32
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh) {
-            half8 w2h[4], w2l[4];
-#pragma unroll
-            for (int jq = 0; jq < 4; ++jq) {
-                w2h[jq] = ldh8(sw + 8192 + ((4 * jh + jq) * 64 + lane) * 8);
-                w2l[jq] = ldh8(sw + 12288 + ((4 * jh + jq) * 64 + lane) * 8);
-            }
-#pragma unroll
-            for (int jq = 0; jq < 4; ++jq) {
-                const int j = 4 * jh + jq;
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], dl_[r], acc[r][j], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[jq], dh_[r], acc[r][j], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < F16_R; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[jq], dh_[r], acc[r][j], 0, 0, 0);
-            }
-        }
-        dma_publish_barrier();   // chunk c+1 has landed; everyone is done with buffer c & 1
-    }
-    // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i
-#pragma unroll
-    for (int r = 0; r < F16_R; ++r) {
-        const long row = row0 + r * 16 + m;
-        if (row >= rows) continue;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
-            st4(DX + row * 128 + col, acc[r][j] + ld4(Dres + row * 128 + col));
-        }
-    }
-}
-
 int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
                             const float* timg, float gate_scale, hipStream_t stream) {
     if (rows <= 0) return 0;
-    const long blocks = (rows + F16_WAVES * F16_R * 16 - 1) / (F16_WAVES * F16_R * 16);
-    hipLaunchKernelGGL(ffn_bwd_dx_f16x3_kernel, dim3((unsigned)blocks), dim3(F16_THREADS), 0, stream, DY, Dres, M, DX,
-                       rows, reinterpret_cast<const _Float16*>(timg), gate_scale);
+    const FfnTrainArgs ta = {};
+    const FfnBwdArgs ba = {Dres, M, gate_scale};
+    const LayerPtrs w = {};
+    const dim3 grid((unsigned)((rows + PIPE_ROWS_PER_WG - 1) / PIPE_ROWS_PER_WG)), block(PIPE_THREADS);
+    hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<4, false>), grid, block, 0, stream, DY, DX, rows,
+                       reinterpret_cast<const _Float16*>(timg), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr, ta,
+                       ba);
     S3D_LAUNCH_CHECK();
     return 0;
 }

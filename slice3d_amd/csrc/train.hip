@@ -244,20 +244,22 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int nchun
 
 // ---------------------------------------------------------------------------------------------
 // FFN weight gradients with recomputation (see train.h).  Workgroup = 128 (q) x 128 (hidden) output tile of
-// hidden block blockIdx.x, rows split over blockIdx.y; 4 waves.  Per 32-row step:
-//   1. stage  D^T  (gathered, [q][row]) and  R  (row-major) as f16 hi/lo in LDS, the step's mask dwords too;
-//   2. every wave recomputes 2 hidden tiles x 2 row tiles of Z = R W^T on the MFMA (its 16 W fragments stay in
-//      registers for the whole kernel), applies bias / mask / scale and writes Z^T ([hidden][row], hi/lo) to LDS
-//      — the D registers hold 4 consecutive rows of one hidden unit, i.e. one 8-byte LDS word;
-//   3. the 64 x 64 wave tiles of  out += D^T Z  run from LDS as in wgrad_lin_f16x3_kernel.
+// hidden block hb, rows split over the grid; 4 waves, wave w owns hidden units 32w .. 32w+31 of the block against
+// ALL 128 q.  Per 32-row step (ONE barrier; the LDS tiles are double buffered):
+//   1. stage  D^T  (gathered, [q][row slot]) and  R  (row-major) as f16 hi/lo in LDS, the step's mask dwords too;
+//   2. the wave recomputes its 2 hidden tiles x 2 row tiles of Z = R W^T on the MFMA (its 16 W fragments stay in
+//      registers for the whole kernel) and applies bias / mask / scale.  The D registers ARE the B operand of the
+//      contraction: lane (hidden m, g) holds rows {4g..4g+3} of row tile 0 and of row tile 1, and the D^T tile is
+//      staged with exactly that row order in its k-slots (slot 8g+t <-> row 4g+t, t < 4; row 16+4g+t-4 otherwise) —
+//      Z never goes through LDS;
+//   3. out[:, own hidden] += D^T Z: the 8 q-tile A fragments come from LDS, 48 MFMAs.
 // ---------------------------------------------------------------------------------------------
 #define FWR_XLD 136   // halfs per row of the row-major R tile (128 + 8 pad)
 template <int COLSUM>
 __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArgs a, int steps_per_split, int nsplit) {
-    __shared__ __attribute__((aligned(16))) _Float16 s_d[2][128 * WL_LD];    // D^T hi|lo       20 KiB
-    __shared__ __attribute__((aligned(16))) _Float16 s_z[2][128 * WZ_LD];    // Z^T hi|lo       20 KiB
-    __shared__ __attribute__((aligned(16))) _Float16 s_r[2][32 * FWR_XLD];   // R row-major     17 KiB
-    __shared__ unsigned s_m[128];                                            // [row][g] mask dwords of this block
+    __shared__ __attribute__((aligned(16))) _Float16 s_d[2][2][128 * WL_LD];    // [buffer][hi|lo] D^T      40 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 s_r[2][2][32 * FWR_XLD];   // [buffer][hi|lo] R        34 KiB
+    __shared__ __attribute__((aligned(16))) unsigned s_m[2][128];               // [buffer][g'][row] mask dwords of hb
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
     // 1-D grid of 16 hidden blocks x nsplit row ranges.  Workgroups are dealt to the 8 XCDs round-robin; remap so
@@ -275,9 +277,8 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
             split = L / nb;
         }
     }
-    const int ch = tid & 127, rg = tid >> 7;      // gather role: channel, row group
+    const int ch = tid & 127, rg = tid >> 7;      // gather role: channel, k-slot groups g = 2 rg + {0, 1}
     const int rrow = tid >> 3, rcq = tid & 7;     // row-major role: row, channel quad
-    const int wn = wave & 1, wc = wave >> 1;
     const long P = a.P;
 
     // this wave's W fragments: hidden tiles 2*wave + e of the block, K = 128 = 4 x 32
@@ -297,164 +298,242 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
             bv[e] = a.bias ? a.bias[tile * 16 + m] : 0.f;
         }
     }
-    f32x4 acc[4][4];
+    f32x4 acc[8][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = zero4();
+        for (int e = 0; e < 2; ++e) acc[i][e] = zero4();
     float csum[2] = {0.f, 0.f};
+    const unsigned bitsel[2] = {1u << (8 * wave + (m & 3)), 1u << (8 * wave + 4 + (m & 3))};
 
     float pd[2][8];
     f32x4 pr[4];
     unsigned pm = 0;
-    auto gload = [&](long pbase) {
+    // row of k-slot (gs, t) of a 32-row step
+    auto slot_row = [](int gs, int t) { return t < 4 ? 4 * gs + t : 16 + 4 * gs + (t - 4); };
+    // addresses as 32-bit offsets from the split's first row (uniform base + lane offset: no 64-bit VALU address math,
+    // which cost this kernel its register budget); rows past P are clamped here and zeroed when staged
+    const long p_begin = (long)split * steps_per_split * 32;
+    const float* Dbase = a.D + p_begin * 128;
+    const float* Rbase = a.R + p_begin * 128;
+    const unsigned* Mbase = a.mask + p_begin * 64;
+    const int nrel = (int)(P - p_begin < (long)steps_per_split * 32 ? P - p_begin : (long)steps_per_split * 32);   // >= 1
+    const unsigned voff_d = (unsigned)(8 * rg * 128 + ch), voff_r = (unsigned)(rrow * 128 + 4 * rcq),
+                   voff_m = (unsigned)((tid & 31) * 64 + ((tid >> 5) & 3) * 16 + hb);
+    auto gload = [&](int rbase) {
+        if (rbase + 32 <= nrel) {   // whole step inside the range (all but the last step of the last split): uniform
+                                    // step base + loop-invariant lane offset + immediate
+            // two lane addresses 16 rows apart; the 8 rows around each are immediate offsets (< 4 KiB)
+            const float* d0 = Dbase + (size_t)rbase * 128 + voff_d;
+            const float* d1 = d0 + 16 * 128;
+            const float* r0 = Rbase + (size_t)rbase * 128 + voff_r;
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) pd[ps][t] = (t < 4 ? d0 : d1)[(4 * ps + (t & 3)) * 128];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pr[k] = ld4(r0 + 32 * k);
+            pm = (Mbase + (size_t)rbase * 64)[voff_m];
+            return;
+        }
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                long row = pbase + 16 * ps + 8 * rg + t;
-                row = row < P ? row : P - 1;
-                pd[ps][t] = a.D[row * 128 + ch];
+                int r = rbase + slot_row(2 * rg + ps, t);
+                r = r < nrel ? r : nrel - 1;
+                pd[ps][t] = Dbase[(unsigned)(r * 128 + ch)];
             }
-        long row = pbase + rrow;
-        row = row < P ? row : P - 1;
+        int r = rbase + rrow;
+        r = r < nrel ? r : nrel - 1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pr[k] = ld4(a.R + row * 128 + 32 * k + 4 * rcq);
-        if (tid < 128) {
-            long mr = pbase + (tid >> 2);
-            mr = mr < P ? mr : P - 1;
-            pm = a.mask[mr * 64 + (tid & 3) * 16 + hb];
+        for (int k = 0; k < 4; ++k) pr[k] = ld4(Rbase + (unsigned)(r * 128 + 32 * k + 4 * rcq));
+        int mr = rbase + (tid & 31);
+        mr = mr < nrel ? mr : nrel - 1;
+        pm = Mbase[(unsigned)(mr * 64 + ((tid >> 5) & 3) * 16 + hb)];
+    };
+    // registers -> LDS buffer `bf`, in pieces that are issued between the MFMA groups of the contraction:
+    // mask_tail zeroes the rows past the end of a partial last step (uniform, rare), piece_d / piece_r split and store
+    auto mask_tail = [&](int rbase) {
+        if (rbase + 32 > nrel) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) pd[ps][t] *= rbase + slot_row(2 * rg + ps, t) < nrel ? 1.f : 0.f;
+            if (rbase + (tid & 31) >= nrel) pm = 0u;
         }
     };
-    const long p_begin = (long)split * steps_per_split * 32;
-    gload(p_begin);
+    auto piece_d = [&](int bf, int ps) {
+        wl_half8 hi, lo;
+        s3d_split8(pd[ps], hi, lo);
+        *reinterpret_cast<wl_half8*>(&s_d[bf][0][ch * WL_LD + 8 * (2 * rg + ps)]) = hi;
+        *reinterpret_cast<wl_half8*>(&s_d[bf][1][ch * WL_LD + 8 * (2 * rg + ps)]) = lo;
+    };
+    auto piece_r = [&](int bf, int k) {
+        s3d_half4 hi, lo;
+        s3d_split4(pr[k], hi, lo);
+        *reinterpret_cast<s3d_half4*>(&s_r[bf][0][rrow * FWR_XLD + 32 * k + 4 * rcq]) = hi;
+        *reinterpret_cast<s3d_half4*>(&s_r[bf][1][rrow * FWR_XLD + 32 * k + 4 * rcq]) = lo;
+    };
+    auto piece_m = [&](int bf) {
+        if (tid < 128) s_m[bf][tid] = pm;
+    };
+    auto stage = [&](int bf, int rbase) {
+        mask_tail(rbase);
+        piece_d(bf, 0);
+        piece_d(bf, 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) piece_r(bf, k);
+        piece_m(bf);
+    };
+    gload(0);
+    stage(0, 0);
+    __syncthreads();
     for (int it = 0; it < steps_per_split; ++it) {
-        const long pb = p_begin + (long)it * 32;
-        // ---- 1. stage D^T, R, mask ----
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            wl_half8 hi, lo;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float v = pd[ps][t] * (pb + 16 * ps + 8 * rg + t < P ? 1.f : 0.f);
-                const _Float16 h = (_Float16)v;
-                hi[t] = h;
-                lo[t] = (_Float16)(v - (float)h);
-            }
-            *reinterpret_cast<wl_half8*>(&s_d[0][ch * WL_LD + 16 * ps + 8 * rg]) = hi;
-            *reinterpret_cast<wl_half8*>(&s_d[1][ch * WL_LD + 16 * ps + 8 * rg]) = lo;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-            half4_t hi, lo;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const _Float16 h = (_Float16)pr[k][t];
-                hi[t] = h;
-                lo[t] = (_Float16)(pr[k][t] - (float)h);
-            }
-            *reinterpret_cast<half4_t*>(&s_r[0][rrow * FWR_XLD + 32 * k + 4 * rcq]) = hi;
-            *reinterpret_cast<half4_t*>(&s_r[1][rrow * FWR_XLD + 32 * k + 4 * rcq]) = lo;
-        }
-        if (tid < 128) s_m[tid] = (pb + (tid >> 2) < P) ? pm : 0u;
-        __syncthreads();
-        if (it + 1 < steps_per_split) gload(pb + 32);
+        const int cur = it & 1;
+        const bool more = it + 1 < steps_per_split;
+#ifndef FWR_ABL_NOLOAD
+        if (more) gload((it + 1) * 32);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
         // ---- 2. recompute Z tiles (rt, e): D[row 4g+i of tile rt][hidden m of tile e] ----
         f32x4 z[2][2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) z[rt][e] = zero4();
+            for (int e = 0; e < 2; ++e) z[rt][e] = f32x4{bv[e], bv[e], bv[e], bv[e]};   // D[row 4g+i][hidden m]: one unit per lane
+#ifndef FWR_ABL_NOREC
+        {
+            // R fragments of K step u+1 are requested before the MFMAs of step u (two register sets)
+            wl_half8 xh[2][2], xl[2][2];
+            auto rd_x = [&](int set, int u) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            wl_half8 xh[2], xl[2];
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int o = (rt * 16 + m) * FWR_XLD + 32 * u + 8 * g;
+                    xh[set][rt] = *reinterpret_cast<const wl_half8*>(&s_r[cur][0][o]);
+                    xl[set][rt] = *reinterpret_cast<const wl_half8*>(&s_r[cur][1][o]);
+                }
+            };
+            rd_x(0, 0);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const int o = (rt * 16 + m) * FWR_XLD + 32 * u + 8 * g;
-                xh[rt] = *reinterpret_cast<const wl_half8*>(&s_r[0][o]);
-                xl[rt] = *reinterpret_cast<const wl_half8*>(&s_r[1][o]);
+            for (int u = 0; u < 4; ++u) {
+                const int cs = u & 1;
+                if (u < 3) rd_x(cs ^ 1, u + 1);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wlo[e][u], z[rt][e], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next step's 4 fragment reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);  // ... then this step's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], wlo[e][u], z[rt][e], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], wh[e][u], z[rt][e], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], wh[e][u], z[rt][e], 0, 0, 0);
         }
+#endif
+        // activity bit, split (the dropout scale is applied once, to the finished sums): hidden unit (block-local)
+        // 32*wave + 16e + m -> mask byte `wave`, bit 4e + (m & 3) of dword g' = m >> 2 of the row; this lane's rows are
+        // 4g..4g+3 (tile 0) and 16+4g.. (tile 1)
+        wl_half8 zh[2], zl[2];
+#ifdef FWR_ABL_NOZ
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int e = 0; e < 2; ++e) {
+            zh[e] = __builtin_bit_cast(wl_half8, f32x4{z[0][e][0], z[0][e][1], z[1][e][0], z[1][e][1]});
+            zl[e] = __builtin_bit_cast(wl_half8, f32x4{z[0][e][2], z[0][e][3], z[1][e][2], z[1][e][3]});
+        }
+#else
+        {
+            const uint4 mw0 = *reinterpret_cast<const uint4*>(&s_m[cur][(m >> 2) * 32 + 4 * g]);
+            const uint4 mw1 = *reinterpret_cast<const uint4*>(&s_m[cur][(m >> 2) * 32 + 16 + 4 * g]);
+            const unsigned mw[8] = {mw0.x, mw0.y, mw0.z, mw0.w, mw1.x, mw1.y, mw1.z, mw1.w};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-                half4_t hi, lo;
-                // hidden unit (block-local) = 32*wave + 16*e + m  ->  mask byte `wave`, bit 4e + (m & 3), dword g' = m >> 2
+                float v[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned mw = s_m[(rt * 16 + 4 * g + i) * 4 + (m >> 2)];
-                    const bool on = (mw >> (8 * wave + 4 * e + (m & 3))) & 1u;
-                    const float v = on ? (z[rt][e][i] + bv[e]) * a.scale : 0.f;
-                    if (COLSUM) csum[e] += v;
-                    const _Float16 h = (_Float16)v;
-                    hi[i] = h;
-                    lo[i] = (_Float16)(v - (float)h);
+                for (int t = 0; t < 8; ++t) {
+                    v[t] = (mw[t] & bitsel[e]) ? z[t >> 2][e][t & 3] : 0.f;
+                    if (COLSUM) csum[e] += v[t];
                 }
-                const int o = ((2 * wave + e) * 16 + m) * WZ_LD + rt * 16 + 4 * g;
-                *reinterpret_cast<half4_t*>(&s_z[0][o]) = hi;
-                *reinterpret_cast<half4_t*>(&s_z[1][o]) = lo;
+                s3d_split8(v, zh[e], zl[e]);
             }
-        __syncthreads();
-        // ---- 3. out tile += D^T Z ----
-        wl_half8 ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = (64 * wn + 16 * i + m) * WL_LD + 8 * g;
-            ah[i] = *reinterpret_cast<const wl_half8*>(&s_d[0][o]);
-            al[i] = *reinterpret_cast<const wl_half8*>(&s_d[1][o]);
         }
+#endif
+        S3D_SPLIT_SETTLE();   // partial-register split results feed the MFMAs below straight from registers
+        // ---- 3. out[q tile i][own hidden tile e] += D^T Z, one q tile (6 MFMAs) per group; the A fragments of tile
+        //      i+1 are requested before the MFMAs of tile i, and the NEXT step's staging (split + LDS stores of the rows
+        //      requested at the top of this step, into the other buffer) is issued in pieces between the groups: it
+        //      used to follow the MFMAs as a block — 39 % of the kernel's time (FWR_ABL_NOSTAGE) ----
+#ifndef FWR_ABL_NOSTAGE
+        mask_tail((it + 1) * 32);
+#endif
+#ifndef FWR_ABL_NOCON
+        {
+            wl_half8 ah[2], al[2];
+            auto rd_a = [&](int set, int i) {
+                const int o = (16 * i + m) * WL_LD + 8 * g;
+                ah[set] = *reinterpret_cast<const wl_half8*>(&s_d[cur][0][o]);
+                al[set] = *reinterpret_cast<const wl_half8*>(&s_d[cur][1][o]);
+            };
+            rd_a(0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = (64 * wc + 16 * j + m) * WZ_LD + 8 * g;
-            bh[j] = *reinterpret_cast<const wl_half8*>(&s_z[0][o]);
-            bl[j] = *reinterpret_cast<const wl_half8*>(&s_z[1][o]);
+            for (int i = 0; i < 8; ++i) {
+                const int cs = i & 1;
+                if (i < 7) rd_a(cs ^ 1, i + 1);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zl[e], acc[i][e], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cs], zh[e], acc[i][e], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zh[e], acc[i][e], 0, 0, 0);
+#ifndef FWR_ABL_NOSTAGE
+                // the last step stages stale registers into the buffer nobody reads again: harmless, and branch-free
+                if (i == 1) piece_d(cur ^ 1, 0);
+                if (i == 2) piece_d(cur ^ 1, 1);
+                if (i == 3) { piece_r(cur ^ 1, 0); piece_r(cur ^ 1, 1); }
+                if (i == 4) { piece_r(cur ^ 1, 2); piece_r(cur ^ 1, 3); }
+                if (i == 5) piece_m(cur ^ 1);
+#endif
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+#else
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int e = 0; e < 2; ++e) asm volatile("" :: "v"(zh[e]), "v"(zl[e]));
+#ifndef FWR_ABL_NOSTAGE
+        stage(cur ^ 1, (it + 1) * 32);
+#endif
+#endif
         __syncthreads();
     }
-    // partial[split][q][hidden]
+    // partial[split][q][hidden]: D[row = q 4g+reg][col = hidden m]
     float* part = a.partial + (size_t)split * 128 * S3D_FFN;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int q = 64 * wn + 16 * i + 4 * g + reg;
-                const int hid = hb * 128 + 64 * wc + 16 * j + m;
-                part[(size_t)q * S3D_FFN + hid] = acc[i][j][reg];
+                const int q = 16 * i + 4 * g + reg;
+                const int hid = hb * 128 + 32 * wave + 16 * e + m;
+                part[(size_t)q * S3D_FFN + hid] = acc[i][e][reg] * a.scale;
             }
     if (COLSUM) {
         float* cp = a.partial + (size_t)nsplit * 128 * S3D_FFN + (size_t)split * S3D_FFN;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            float v = csum[e];
+            float v = csum[e] * a.scale;
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             if (g == 0) cp[hb * 128 + (2 * wave + e) * 16 + m] = v;

@@ -478,7 +478,7 @@ def test_smooth_output_gradients_match_oracle_autograd_tightly(b, s, q, ns, prec
     out = m({k: v.cuda() for k, v in fd.items()})
     assert (out["sdf_pred"].detach().cpu() - sdf_ref).abs().max() < 1e-4
     ((out["sdf_pred"] * w_sdf.cuda()).sum() + (out["slices_rec"] * w_rec.cuda()).sum() + w_vgg * out["vgg_loss"]).backward()
-    worst, worst_k, n = 0.0, None, 0
+    worst, worst_k, n, rels = 0.0, None, 0, []
     for k, p in m.named_parameters():
         if p.grad is None or k not in grads:
             continue
@@ -486,7 +486,9 @@ def test_smooth_output_gradients_match_oracle_autograd_tightly(b, s, q, ns, prec
             continue
         rel = float((p.grad.cpu() - grads[k]).norm() / grads[k].norm())
         n += 1
+        rels.append((rel, k))
         if rel > worst:
             worst, worst_k = rel, k
+    print("  largest:", ", ".join("%s %.1e" % (k, r) for r, k in sorted(rels, reverse=True)[:8]))
     print("smooth-gradient parity %s (%s): worst per-tensor relative L2 error %.2e (%s), %d tensors" % (key, prec, worst, worst_k, n))
     assert n > 100 and worst < 1e-3, (worst_k, worst)
