@@ -115,6 +115,43 @@ def cpu_baseline(sd, fd, n_slices, n_sample, gpu_sdf, runs=5):
     }, err
 
 
+def _pmc_traffic(args, kname):
+    """(2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes per launch of the kernel whose name contains `kname`, from two
+    rocprofv3 --pmc child runs of this script's timed inference loop (counters need their own passes; gfx950 reports
+    half of the bytes of a wide streaming read, hence the factor — MI355X_MICROARCH.md, HBM section)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, None
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="s3d_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+               os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "1", "--img-size", str(args.img_size),
+               "--n-qry", str(args.n_qry), "--n-slices", str(args.n_slices), "--batch", str(args.batch), "--prec", args.prec]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            acc = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and kname in row["Kernel_Name"]:
+                        acc.append(float(row["Counter_Value"]))
+            if not acc:
+                return None, None
+            vals[counter] = sum(acc) / len(acc)
+        except Exception:
+            return None, None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of the timed loop, "
+        "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch (FETCH %.0f KiB, WRITE %.0f KiB)" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+
+
 def _self_launch(n):
     """Re-run this command as an n-rank torch.distributed.run job on this node (127.0.0.1, a free port)."""
     import socket
@@ -148,7 +185,10 @@ def main():
     ap.add_argument("--mesh-steps", type=int, default=2, help="timed reconstruct.py-default mesh extractions (MISE 64 -> 256 + "
                     "marching cubes on the device; 0 = skip)")
     ap.add_argument("--ldm-steps", type=int, default=5, help="timed LDM denoising steps (BASELINE configs[4]; 0 = skip)")
-    ap.add_argument("--train-steps", type=int, default=3, help="timed training steps for train_samples_per_s (0 = skip)")
+    ap.add_argument("--pmc", type=int, default=1, help="1: measure roofline.traffic in this run (two rocprofv3 --pmc child passes "
+                    "of the timed inference loop, FETCH_SIZE and WRITE_SIZE); 0: quote the committed profiles/pmc_traffic.json")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child pass: inference loop only
+    ap.add_argument("--train-steps", type=int, default=10, help="timed training steps for train_samples_per_s (0 = skip)")
     ap.add_argument("--gt-train-steps", type=int, default=5, help="timed Slices3DGTModel training steps (0 = skip)")
     args = ap.parse_args()
 
@@ -207,6 +247,8 @@ def main():
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    if args.pmc_child:      # counter pass under rocprofv3: only the timed loop's launches are wanted
+        return
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -472,16 +514,25 @@ def main():
         ffn_flops = 2.0 * n_tok * args.n_qry * args.batch * FFN_FLOP_PER_ROW * args.steps / ffn_launches
         achieved = ffn_flops / (ffn_ms * 1e-3) / 1e12
         peak = F32_MFMA_PEAK_TFLOPS if args.prec == "f32" else F16_MFMA_PEAK_TFLOPS
-        traffic = None   # HBM bytes/launch of the dominant kernel from the committed PMC pass of this command
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            wl = pmc["workload"]
-            if (wl["img_size"], wl["n_slices"], wl["n_qry"], wl.get("batch", 1)) == (args.img_size, args.n_slices,
-                                                                                      args.n_qry, args.batch):
-                kname = "ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_pipe_kernel<false>"
-                traffic = pmc["kernels"][args.prec][kname]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM bytes per launch of the dominant kernel: measured in this run by two counter passes (FETCH_SIZE, WRITE_SIZE:
+        # separate rocprofv3 --pmc runs of the same timed loop, MI355X_MICROARCH.md's recipe and gfx950 correction);
+        # only if that is impossible the figure of the committed pass is quoted, and the source field says which
+        kname = "ffn_layer_kernel" if args.prec == "f32" else "ffn_layer_f16x3_pipe_kernelILi0ELb0"
+        traffic, traffic_src = (None, None)
+        if args.pmc and world == 1:
+            traffic, traffic_src = _pmc_traffic(args, kname)
+        if traffic is None:
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                wl = pmc["workload"]
+                if (wl["img_size"], wl["n_slices"], wl["n_qry"], wl.get("batch", 1)) == (args.img_size, args.n_slices,
+                                                                                          args.n_qry, args.batch):
+                    jk = "ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_pipe_kernel<false>"
+                    traffic = pmc["kernels"][args.prec][jk]["hbm_bytes_per_launch"]
+                    traffic_src = "committed pass profiles/pmc_traffic.json (not measured in this run: %s)" % (
+                        "disabled" if not args.pmc else "multi-rank run" if world > 1 else "rocprofv3 pass failed")
+            except (OSError, KeyError, ValueError):
+                pass
         decode_ms = sum(stage_ms[k] for k in ("sample_tokens", "attn_layer", "ffn_layer", "ffn_final"))
         res = {
             "metric": "occupancy query-points/sec (U-Net encode + per-query decode, 256^2 x 12 slices)",
@@ -507,7 +558,7 @@ def main():
                                   "same kernel on all-zero operands runs 2.35 GHz and 0.24 of peak, "
                                   "profiles/r02_ffn_data_power.md), peak is quoted at 2.4 GHz" if args.prec != "f32" else "exact fp32 MFMA"),
                          "mfma_pipe_tflops": achieved * (3 if args.prec != "f32" else 1),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/",
+                         "traffic_source": traffic_src,
                          "avg_launch_ms": ffn_ms, "launches": counts["ffn_layer"],
                          "alg_flop_per_launch": ffn_flops},
             "secondary_rooflines": [

@@ -1,4 +1,5 @@
 // api.hip — exported C ABI (include/slice3d_hip.h): weight packing + kernel orchestration.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -24,6 +25,45 @@ extern "C" int s3d_version(void) { return S3D_VERSION; }
 extern "C" const char* s3d_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------
+// roctx ranges (tracing): every tracked stage of the inference path and every phase of the train
+// step is bracketed by roctxRangePush / roctxRangePop, so a `rocprofv3 --marker-trace --kernel-trace` run can be read by
+// phase.  libroctx64 is looked up at run time (no link-time dependency; without it the ranges are no-ops).
+// ---------------------------------------------------------------------------------------------
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        void* h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+static const Roctx& roctx() {
+    static const Roctx r;
+    return r;
+}
+// one open range at a time: next(name) closes the previous phase and opens the next; the destructor closes the last one
+// (also on the early returns of TRY)
+struct RangeSeq {
+    bool open = false;
+    void next(const char* name) {
+        const Roctx& r = roctx();
+        if (!r.push) return;
+        if (open) r.pop();
+        r.push(name);
+        open = true;
+    }
+    ~RangeSeq() {
+        if (open) roctx().pop();
+    }
+};
+static const char* const kProfRangeNames[] = {"s3d:unet_encode", "s3d:latent_build", "s3d:sample_tokens", "s3d:attn_layer",
+                                               "s3d:ffn_layer", "s3d:ffn_final", "s3d:vgg_loss", "s3d:sample_pyramid"};
+
+// ---------------------------------------------------------------------------------------------
 // optional event profiler: brackets the tracked launches with hipEvents ON THE CALLER'S STREAM so
 // bench.py can report per-kernel durations measured live inside its timed region.
 // ---------------------------------------------------------------------------------------------
@@ -34,7 +74,9 @@ struct ProfScope {
     int id;
     hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
+    RangeSeq range;
     ProfScope(int id_, hipStream_t st_) : id(id_), st(st_) {
+        range.next(kProfRangeNames[id]);
         if (!g_prof) return;
         (void)hipEventCreate(&a);
         (void)hipEventCreate(&b);
@@ -560,7 +602,6 @@ HeadLayout head_layout() {
         H.L[l].ln2g = take(128);
         H.L[l].ln2b = take(128);
         H.L[l].wf16 = take((size_t)S3D_FFN_NCHUNK * 8192);
-        H.L[l].af16 = take((size_t)(96 + 32) * 512);
         H.L[l].aq16 = take((size_t)(96 + 32) * 512);
     }
     H.fco_w = take(128);
@@ -599,7 +640,6 @@ static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLa
         TRY(copy_vec(b + H.L[l].ln2g, p.norm2_w, 128, st));
         TRY(copy_vec(b + H.L[l].ln2b, p.norm2_b, 128, st));
         TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wf16, st));
-        TRY(launch_pack_attn_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].af16, st));
         TRY(launch_pack_attn_q_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].aq16, st));
     }
     {   // absorbed token-0 attention of the last layer (launch_attn_last_mix)
@@ -703,25 +743,8 @@ static LayerPtrs layer_ptrs(const float* b, const HeadLayout& H, int l) {
     p.ln1g = b + H.L[l].ln1g; p.ln1b = b + H.L[l].ln1b; p.w1 = b + H.L[l].w1; p.b1 = b + H.L[l].b1;
     p.w2 = b + H.L[l].w2; p.b2 = b + H.L[l].b2; p.ln2g = b + H.L[l].ln2g; p.ln2b = b + H.L[l].ln2b;
     p.wf16 = b + H.L[l].wf16;
-    p.af16 = b + H.L[l].af16;
     p.aq16 = b + H.L[l].aq16;
     return p;
-}
-
-static bool attn_query_major() {   // S3D_ATTN_Q=0 selects the token-major kernel for every layer (A/B timing)
-    static const int on = [] {
-        const char* e = getenv("S3D_ATTN_Q");
-        return e ? atoi(e) : 1;
-    }();
-    return on != 0;
-}
-
-static bool attn_last_absorbed() {   // S3D_ATTN_LAST=0 selects the token-major pruned kernel (A/B timing)
-    static const int on = [] {
-        const char* e = getenv("S3D_ATTN_LAST");
-        return e ? atoi(e) : 1;
-    }();
-    return on != 0;
 }
 
 // rows x k  ->  rows x n  linear map on the conv engine (1x1 convolution over a row "image")
@@ -803,14 +826,12 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
             const bool last = l == S3D_N_LAYERS - 1;
             {
                 ProfScope prof_(S3D_PROF_ATTN, st);
-                if (last && attn_last_absorbed())
+                if (last)          // only token 0 of the last layer is consumed (models.py:83): absorbed form, every mode
                     TRY(attn_last_layer(b, H, lp, X, X0, gc, T, (float*)workspace + W.last, prec, st));
-                else if (prec != S3D_PREC_F32 && !last && attn_query_major())
-                    TRY(launch_attn_layer_q(X, gc, T, lp, st, prec == S3D_PREC_F16));
                 else if (prec != S3D_PREC_F32)
-                    TRY(launch_attn_layer_f16x3(X, last ? X0 : nullptr, gc, T, lp, st));
+                    TRY(launch_attn_layer_q(X, gc, T, lp, st, prec == S3D_PREC_F16));
                 else
-                    TRY(launch_attn_layer(X, last ? X0 : nullptr, gc, T, lp, st));
+                    TRY(launch_attn_layer(X, nullptr, gc, T, lp, st));
             }
             ProfScope prof_(last ? S3D_PROF_FFN_FINAL : S3D_PROF_FFN, st);
             if (!last)

@@ -385,11 +385,7 @@ __global__ __launch_bounds__(256, 2) void lin_rows_f16x3_kernel(const ConvLaunch
 }
 
 static bool lin_rows_eligible(const ConvLaunch& a) {
-    static const int on = [] {
-        const char* e = getenv("S3D_LIN_ROWS");
-        return e ? atoi(e) : 1;
-    }();
-    if (!on || a.ks != 1 || a.nsrc != 1 || a.stride > 1 || !a.wpk16 || (a.KU & 1) || a.CoutPad % 32) return false;
+    if (a.ks != 1 || a.nsrc != 1 || a.stride > 1 || !a.wpk16 || (a.KU & 1) || a.CoutPad % 32) return false;
     if ((a.Hin && a.Hin != a.H) || (a.Win && a.Win != a.W)) return false;
     const ConvSrc& S = a.src[0];
     if (S.sbcast || S.bmod || S.bdiv != 1 || S.C % 32 || S.C > 128 || a.KU != S.C / 16) return false;
@@ -613,11 +609,7 @@ static bool conv3x3_lds_eligible(const ConvLaunch& a) {
     if ((a.W < 16 || a.H < 8) && !(a.splitk_ws && a.out_mode == S3D_OUT_NHWC)) return false;
     for (int s = 0; s < a.nsrc; ++s)
         if (a.src[s].C % 32 || a.src[s].sbcast) return false;
-    static const int on = [] {
-        const char* e = getenv("S3D_CONV_LDS");
-        return e ? atoi(e) : 1;
-    }();
-    return on != 0;
+    return true;
 }
 static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
@@ -637,10 +629,7 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     const int cps = (nchunk + splits - 1) / splits;
     splits = (nchunk + cps - 1) / cps;
     dim3 grid((unsigned)nblk, (unsigned)splits);
-    static const int one_buf_max = [] {
-        const char* e = getenv("S3D_CONV_ONEBUF");   // chunks per workgroup up to which the single-buffer variant runs
-        return e ? atoi(e) : 2;
-    }();
+    constexpr int one_buf_max = 2;   // chunks per workgroup up to which the single-buffer variant runs
     const bool one = cps <= one_buf_max;   // 32-channel-output layers only: measured -13 % there, +5 % on the 64-wide tile
     if (co_wg == 64) {
         hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<4, 2, 2, 2>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
@@ -688,12 +677,8 @@ static int launch_cfg(const ConvLaunch& a, hipStream_t stream) {
 }
 
 int launch_conv(const ConvLaunch& a_in, hipStream_t stream) {
-    static const int xcd_on = [] {
-        const char* e = getenv("S3D_CONV_XCD");
-        return e ? atoi(e) : 1;
-    }();
     ConvLaunch a = a_in;
-    a.xcd_remap = xcd_on;
+    a.xcd_remap = 1;   // block -> (pixel tile, cout tile) mapping keeps the cout tiles of a pixel tile on one XCD
     S3D_CHECK_ARG(a.ks >= 1 && a.ks <= 3, "conv: ks must be 1, 2 or 3");
     S3D_CHECK_ARG(a.CoutPad % 16 == 0 && a.CoutPad > 0, "conv: CoutPad %d", a.CoutPad);
     for (int s = 0; s < a.nsrc; ++s)

@@ -18,7 +18,6 @@ struct HeadLayout {
         size_t w1, b1, w2, b2, ln2g, ln2b;   // w1: [128 tiles][8] image; w2: chunked [64][8][2] image
         size_t wf16;                         // f16 hi/lo chunk image of lin1/lin2 (64 x 32 KiB), decode_f16.hip
         size_t aq16;                         // in_proj / out_proj fragments of the query-major attention kernel
-        size_t af16;                         // f16 hi/lo fragment pairs of in_proj (96) and out_proj (32)
     } L[S3D_N_LAYERS];
     size_t fco_w, fco_b;
     // token-0-only attention of the LAST layer in absorbed form (launch_attn_last_mix): fragment images (fp32 | f16
@@ -31,7 +30,7 @@ struct HeadLayout {
 HeadLayout head_layout();
 
 struct LayerPtrs {
-    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b, *wf16, *af16, *aq16;
+    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b, *wf16, *aq16;
 };
 
 struct SampleArgs {
@@ -146,5 +145,3 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
                            long g_begin, const int* perm, hipStream_t stream, bool single_pass = false);
 int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream);
-int launch_attn_layer_f16x3(float* X, float* x0_out, long groups, int T, const LayerPtrs& w, hipStream_t stream);
-int launch_pack_attn_f16x3(const float* win, const float* wout, float* out, hipStream_t stream);

@@ -378,23 +378,19 @@ __global__ __launch_bounds__(256) void attn_layer_kernel(float* X, float* x0_out
 
 int launch_attn_layer(float* X, float* x0_out, long groups, int T, const LayerPtrs& w, hipStream_t stream) {
     S3D_CHECK_ARG(T >= 2 && T <= S3D_N_TOKENS_MAX, "attn: T %d", T);
+    // the last layer (token 0 only) always runs the absorbed form (launch_attn_last_mix); the LAST instantiation of this
+    // kernel is no longer built
+    S3D_CHECK_ARG(x0_out == nullptr, "attn: the token-0-only form of this kernel was retired (use the absorbed last layer)");
     if (groups <= 0) return 0;
     const size_t lds = (size_t)S3D_N_TOKENS_MAX * 16 * (QKV_LD + OH_LD) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-        (void)hipFuncSetAttribute((const void*)attn_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
         attr_set = true;
     }
     const long blocks = groups < 4096 ? groups : 4096;
-    if (x0_out)
-        hipLaunchKernelGGL(attn_layer_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, X, x0_out,
-                           groups, T, w);
-    else
-        hipLaunchKernelGGL(attn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, X, x0_out,
-                           groups, T, w);
+    hipLaunchKernelGGL(attn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, X, x0_out, groups, T, w);
     S3D_LAUNCH_CHECK();
     return 0;
 }

@@ -615,273 +615,3 @@ int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipS
     S3D_LAUNCH_CHECK();
     return 0;
 }
-
-// =============================================================================================
-// Self-attention block in split precision:  X <- LN1(X + out_proj(MHA(X)))
-//   one workgroup of 8 waves (2 per SIMD) per 16-query group; wave w owns token tiles t = w and w+8.
-//   Per head: the W_in_h f16 hi/lo fragments (48 KiB) are staged in LDS by LDS-DMA (global_load_lds,
-//   the next head's copy runs under the attention phase) and shared by all waves; W_o_h fragments (16 KiB,
-//   L1/L2-resident) are read straight from global.  Q/K/V_h on f16x3
-//   MFMA; K_h, V_h go to LDS (fp32, padded rows), Q_h and the attention output O_h stay in registers:
-//   the row permutation of the packed fragments makes lane (m, g) own head dims {8g..8g+7} of query m,
-//   so the 13-key softmax attention is computed by the MFMA lanes themselves (partial dot over 8 dims +
-//   2 shuffles) and O_h is directly the B operand of the out_proj MFMA.
-// =============================================================================================
-#define AKV_LD 36      // floats per K/V row in LDS: 36*m mod 64 are 16 distinct multiples of 4 -> conflict-free
-#define A16_MAXT 2
-#define A16_WIN_HALFS (24 * 1024)
-#define A16_WO_HALFS (8 * 1024)
-
-// async global -> LDS copy of n_kib KiB (one 1-KiB piece per wave-instruction, LDS-DMA, no VGPR staging)
-__device__ __forceinline__ void dma_kib(const _Float16* gsrc, _Float16* ldst, int n_kib, int wave, int lane) {
-    for (int i = wave; i < n_kib; i += 8)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(gsrc + i * 512 + lane * 8),
-            (__attribute__((address_space(3))) void*)(ldst + i * 512), 16, 0, 0);
-}
-
-template <bool LAST>
-__global__ __launch_bounds__(512) void attn_layer_f16x3_kernel(float* X, float* x0_out, long groups, int T,
-                                                               const _Float16* wimg, const LayerPtrs w) {
-    extern __shared__ __attribute__((aligned(16))) float smem16[];
-    _Float16* s_win = reinterpret_cast<_Float16*>(smem16);                  // 24 fragment pairs, 48 KiB
-    float* s_q = smem16 + A16_WIN_HALFS / 2;                                // [T*16][AKV_LD]; O_h overwrites it
-    float* s_k = s_q + S3D_N_TOKENS_MAX * 16 * AKV_LD;
-    float* s_v = s_k + S3D_N_TOKENS_MAX * 16 * AKV_LD;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 15, g = lane >> 4;
-    const float scale = 0.17677669529663687f;
-    const _Float16* g_in = wimg;                  // per head: 24 fragment pairs = 48 KiB
-    const _Float16* g_out = wimg + 96 * 1024;     // per head:  8 fragment pairs = 16 KiB
-
-    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        float* Xg = X + grp * T * S3D_GROUP * 128;
-        // stage head 0 weights
-        dma_kib(g_in, s_win, 48, wave, lane);
-        half8 xh[A16_MAXT][4], xl[A16_MAXT][4];
-#pragma unroll
-        for (int ti = 0; ti < A16_MAXT; ++ti) {
-            const int t = wave + 8 * ti;
-            if (t < T) {
-                const float* p = Xg + (t * S3D_GROUP + m) * 128 + 8 * g;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
-                    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                    split8(v, xh[ti][u], xl[ti][u]);
-                }
-            }
-        }
-        f32x4 acc_o[A16_MAXT][8];
-#pragma unroll
-        for (int ti = 0; ti < A16_MAXT; ++ti)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc_o[ti][j] = zero4();
-        dma_publish_barrier();   // head 0 weights have landed
-
-#pragma unroll 1
-        for (int h = 0; h < 4; ++h) {
-            // ---- phase 1: projections.  part p (0 Q, 1 K, 2 V), half jj: lane (m,g) gets head dims 8g+4jj+i;
-            //      all three go to LDS as fp32 rows [token][query][32 dims] (padded to AKV_LD) ----
-#pragma unroll 1
-            for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    f32x4 d[A16_MAXT];
-#pragma unroll
-                    for (int ti = 0; ti < A16_MAXT; ++ti) d[ti] = zero4();
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const _Float16* f = s_win + (((p * 2 + jj) * 4 + u) * 1024) + lane * 8;
-                        const half8 wh = ldh8(f), wl = ldh8(f + 512);
-#pragma unroll
-                        for (int ti = 0; ti < A16_MAXT; ++ti) {
-                            const int t = wave + 8 * ti;
-                            if (t >= T) continue;
-                            if (LAST && p == 0 && t != 0) continue;   // Q only for token 0
-                            d[ti] = mfma3(wh, wl, xh[ti][u], xl[ti][u], d[ti]);
-                        }
-                    }
-                    const f32x4 bias = ld4(w.inb + p * 128 + 32 * h + 8 * g + 4 * jj);
-                    float* dstb = p == 0 ? s_q : (p == 1 ? s_k : s_v);
-#pragma unroll
-                    for (int ti = 0; ti < A16_MAXT; ++ti) {
-                        const int t = wave + 8 * ti;
-                        if (t >= T) continue;
-                        if (LAST && p == 0 && t != 0) continue;
-                        st4(dstb + (t * S3D_GROUP + m) * AKV_LD + 8 * g + 4 * jj, d[ti] + bias);
-                    }
-                }
-            }
-            __syncthreads();   // Q_h / K_h / V_h complete; every wave is done with W_in_h
-            // W_in_h is dead: start the DMA of the next head's in_proj fragments under the attention phase
-            if (h < 3) dma_kib(g_in + (h + 1) * A16_WIN_HALFS, s_win, 48, wave, lane);
-            // ---- phase 2a: softmax attention of queries 2*wave, 2*wave+1 on fp32 MFMA.
-            //      lane (r, g): S^T = K Q^T  -> lane (tq = r, g) holds scores of keys 4g..4g+3;
-            //      O^T = V^T P^T with that very register as B operand; O overwrites Q in LDS ----
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                const int mq = 2 * wave + qi;
-                const int r = m;                                  // token index carried by this lane (tq or tk)
-                const int rc = r < T ? r : T - 1;                 // rows >= T do not exist: read a valid row, use 0
-                const float* krow = s_k + (rc * S3D_GROUP + mq) * AKV_LD + 4 * g;
-                const float* qrow = s_q + (rc * S3D_GROUP + mq) * AKV_LD + 4 * g;
-                const bool rv = r < T;
-                f32x4 k0 = ld4(krow), k1 = ld4(krow + 16), q0 = ld4(qrow), q1 = ld4(qrow + 16);
-                if (!rv) {
-                    k0 = zero4(); k1 = zero4(); q0 = zero4(); q1 = zero4();
-                }
-                f32x4 sacc = mfma4(k0, q0, zero4());              // MFMA always runs wave-wide, outside any branch
-                sacc = mfma4(k1, q1, sacc);
-                float e[4];
-                float mx = -1e30f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    e[i] = (4 * g + i < T) ? sacc[i] * scale : -1e30f;
-                    mx = fmaxf(mx, e[i]);
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                float den = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    e[i] = (4 * g + i < T) ? __expf(e[i] - mx) : 0.f;
-                    den += e[i];
-                }
-                den = quad_sum16(den);
-                const float inv = 1.f / den;
-                const f32x4 pb = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    f32x4 va;                                      // A: lane (d = r, g) holds V[key 4g+i][d]
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        va[i] = (4 * g + i < T) ? s_v[((4 * g + i) * S3D_GROUP + mq) * AKV_LD + 16 * dt + r] : 0.f;
-                    const f32x4 o = mfma4(va, pb, zero4());        // lane (tq = r, g): dims 16dt + 4g + i
-                    if (r < (LAST ? 1 : T)) st4(s_q + (r * S3D_GROUP + mq) * AKV_LD + 16 * dt + 4 * g, o);
-                }
-            }
-            __syncthreads();   // O_h (in the Q buffer) visible to the tile owners
-            // ---- phase 2b: out_proj partial sums on f16x3 MFMA, accumulated over heads in registers ----
-#pragma unroll
-            for (int ti = 0; ti < A16_MAXT; ++ti) {
-                const int t = wave + 8 * ti;
-                if (t >= (LAST ? 1 : T)) continue;
-                const float* orow = s_q + (t * S3D_GROUP + m) * AKV_LD + 8 * g;
-                const f32x4 o0 = ld4(orow), o1 = ld4(orow + 4);
-                const float o8[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
-                half8 oh, ol;
-                split8(o8, oh, ol);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const _Float16* f = g_out + h * A16_WO_HALFS + (j * 1024) + lane * 8;   // L1/L2-resident
-                    acc_o[ti][j] = mfma3(ldh8(f), ldh8(f + 512), oh, ol, acc_o[ti][j]);
-                }
-            }
-            dma_publish_barrier();   // Q/K/V buffers free for the next head; W_in_{h+1} has landed
-        }
-        // ---- residual + LayerNorm1 (columns 32*(j>>1) + 8g + 4*(j&1) + i), store ----
-#pragma unroll
-        for (int ti = 0; ti < A16_MAXT; ++ti) {
-            const int t = wave + 8 * ti;
-            if (t >= (LAST ? 1 : T)) continue;
-            f32x4 y[8];
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
-                const f32x4 bo = ld4(w.outb + col);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int tt = 4 * (j & 1) + i;
-                    y[j][i] = acc_o[ti][j][i] + bo[i] + ((float)xh[ti][j >> 1][tt] + (float)xl[ti][j >> 1][tt]);
-                    s += y[j][i];
-                }
-            }
-            const float mean = quad_sum16(s) * (1.f / 128.f);
-            float v = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float dd = y[j][i] - mean;
-                    v += dd * dd;
-                }
-            const float rstd = 1.f / sqrtf(quad_sum16(v) * (1.f / 128.f) + 1e-5f);
-            float* o = LAST ? x0_out + (grp * S3D_GROUP + m) * 128 : Xg + (t * S3D_GROUP + m) * 128;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
-                const f32x4 ga = ld4(w.ln1g + col), be = ld4(w.ln1b + col);
-                f32x4 r;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) r[i] = (y[j][i] - mean) * rstd * ga[i] + be[i];
-                st4(o + col, r);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();   // LDS weight buffers are restaged for the next group
-    }
-}
-
-int launch_attn_layer_f16x3(float* X, float* x0_out, long groups, int T, const LayerPtrs& w, hipStream_t stream) {
-    if (groups <= 0) return 0;
-    const size_t lds = (size_t)A16_WIN_HALFS * 2 + (size_t)3 * S3D_N_TOKENS_MAX * 16 * AKV_LD * 4;   // 136 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_layer_f16x3_kernel<false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)attn_layer_f16x3_kernel<true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    const long blocks = groups < 4096 ? groups : 4096;
-    const _Float16* img = reinterpret_cast<const _Float16*>(w.af16);
-    if (x0_out)
-        hipLaunchKernelGGL(attn_layer_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(512), lds, stream, X, x0_out,
-                           groups, T, img, w);
-    else
-        hipLaunchKernelGGL(attn_layer_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(512), lds, stream, X, x0_out,
-                           groups, T, img, w);
-    S3D_LAUNCH_CHECK();
-    return 0;
-}
-
-// in_proj (384,128) / out_proj (128,128) -> f16 hi/lo fragment pairs (hi 512 halfs | lo 512 halfs each)
-__global__ void pack_attn_f16x3_kernel(const float* __restrict__ win, const float* __restrict__ wout,
-                                       _Float16* __restrict__ out) {
-    const int total = (96 + 32) * 64;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int lane = idx & 63, frag = idx >> 6;
-        const int r = lane & 15, g = lane >> 4;
-        float v[8];
-        if (frag < 96) {   // frag = ((h*3 + p)*2 + jj)*4 + u : row = p*128 + 32h + 8(r>>2) + 4jj + (r&3)
-            const int u = frag & 3, jj = (frag >> 2) & 1, hp = frag >> 3, p = hp % 3, h = hp / 3;
-            const int n = p * 128 + 32 * h + 8 * (r >> 2) + 4 * jj + (r & 3);
-            const float* src = win + (size_t)n * 128 + 32 * u + 8 * g;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = src[t];
-        } else {           // frag-96 = h*8 + j : row = permuted output column, k = 32h + 8g + t
-            const int f = frag - 96, j = f & 7, h = f >> 3;
-            const int n = 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3);
-            const float* src = wout + (size_t)n * 128 + 32 * h + 8 * g;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = src[t];
-        }
-        _Float16* dst = out + (size_t)frag * 1024 + lane * 8;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const _Float16 hh = (_Float16)v[t];
-            dst[t] = hh;
-            dst[512 + t] = (_Float16)(v[t] - (float)hh);
-        }
-    }
-}
-
-int launch_pack_attn_f16x3(const float* win, const float* wout, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(pack_attn_f16x3_kernel, dim3(32), dim3(256), 0, stream, win, wout,
-                       reinterpret_cast<_Float16*>(out));
-    S3D_LAUNCH_CHECK();
-    return 0;
-}

@@ -818,8 +818,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv3_f16x3_kernel(const WgradAr
 }
 
 static bool wgrad_conv3_eligible(const WgradArgs& a) {
-    static const bool off = getenv("S3D_WGRAD3_F32") != nullptr;
-    return !off && a.prec == S3D_PREC_F16X3 && a.ks == 3 && a.stride <= 1 && !a.x.sbcast && a.x.bdiv >= 1 &&
+    return a.prec == S3D_PREC_F16X3 && a.ks == 3 && a.stride <= 1 && !a.x.sbcast && a.x.bdiv >= 1 &&
            (a.Hin == 0 || a.Hin == a.H) && (a.Win == 0 || a.Win == a.W) && (a.N % 64 == 0 || a.N == 32) &&
            (a.Cx % 64 == 0 || a.Cx == 32 || a.Cx == 16) && a.H % 4 == 0 && a.W % 8 == 0 &&
            a.out_kind == S3D_PACK_CONV;
@@ -830,10 +829,7 @@ static int launch_wgrad_conv3_f16x3(const WgradArgs& a, hipStream_t stream) {
     const int n_nblk = (a.N + 63) / 64, n_cblk = narrow ? 1 : (half ? 1 : a.Cx / 64), Ktot = 9 * a.Cx;
     const long n_tiles = (long)a.Nimg * (a.H / 4) * (a.W / 8);
     const long blocks = (long)n_nblk * n_cblk;
-    static const long want_wgs = [] {
-        const char* e = getenv("S3D_WGRAD3_WGS");
-        return e ? atol(e) : 1024L;
-    }();
+    constexpr long want_wgs = 1024;
     long splits = (want_wgs + blocks - 1) / blocks;            // aim at >= 1024 workgroups (4 per CU): more only grows the partial-sum reduction
     const long max_by_tiles = (n_tiles + 7) / 8;               // >= 8 tiles per workgroup
     if (splits > max_by_tiles) splits = max_by_tiles;
@@ -1149,21 +1145,7 @@ int launch_colsum(const float* in, long P, int cstride, int coff, int C, float* 
 // =============================================================================================
 // BatchNorm2d train mode
 // =============================================================================================
-__global__ void bn_finalize_kernel(const float* __restrict__ var_sum, long P, int C, float* __restrict__ rstd,
-                                   const float* __restrict__ mean, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float var = var_sum[c] / (float)P;
-    rstd[c] = 1.f / sqrtf(var + 1e-5f);
-    if (running_mean) {
-        running_mean[c] = 0.9f * running_mean[c] + 0.1f * mean[c];
-        const float unb = P > 1 ? var * (float)P / (float)(P - 1) : var;
-        running_var[c] = 0.9f * running_var[c] + 0.1f * unb;
-    }
-}
-
-// one-pass variant: m1 = E[x - k] (in `mean`), m2 = E[(x - k)^2] (in `rstd`), k = the pilot value of colsum mode 4
+// one-pass statistics: m1 = E[x - k] (in `mean`), m2 = E[(x - k)^2] (in `rstd`), k = the pilot value of colsum mode 4
 __global__ void bn_finalize_shift_kernel(const float* __restrict__ z, long P, int C, float* __restrict__ mean,
                                          float* __restrict__ rstd, float* __restrict__ running_mean,
                                          float* __restrict__ running_var) {
@@ -1246,7 +1228,6 @@ int launch_bn_stats(const float* z, long P, int C, float* mean, float* rstd, flo
     S3D_CHECK_ARG(C % 4 == 0 && P > 0, "bn_stats: bad dims");
     long rpc;
     const int n = colsum_chunks(P, rpc);
-    static const bool two_pass = getenv("S3D_BN_TWO_PASS") != nullptr;
     if (sync) {
         hipLaunchKernelGGL((colsum_kernel<4>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, nullptr,
                            nullptr, partial, rpc, nullptr, nullptr);
@@ -1268,33 +1249,16 @@ int launch_bn_stats(const float* z, long P, int C, float* mean, float* rstd, flo
         S3D_LAUNCH_CHECK();
         return 0;
     }
-    if (!two_pass) {
-        hipLaunchKernelGGL((colsum_kernel<4>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, nullptr,
-                           nullptr, partial, rpc, nullptr, nullptr);
-        S3D_LAUNCH_CHECK();
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial, n, C,
-                           1.f / (float)P, mean, 0);
-        S3D_LAUNCH_CHECK();
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial + (size_t)n * C,
-                           n, C, 1.f / (float)P, rstd, 0);
-        S3D_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_finalize_shift_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, z, P, C, mean, rstd,
-                           running_mean, running_var);
-        S3D_LAUNCH_CHECK();
-        return 0;
-    }
-    hipLaunchKernelGGL((colsum_kernel<0>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, nullptr, nullptr,
-                       partial, rpc, nullptr, nullptr);
+    hipLaunchKernelGGL((colsum_kernel<4>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, nullptr,
+                       nullptr, partial, rpc, nullptr, nullptr);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial, n, C,
                        1.f / (float)P, mean, 0);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL((colsum_kernel<1>), dim3(n), dim3(256), 0, stream, z, nullptr, P, C, 0, C, mean, nullptr,
-                       partial, rpc, nullptr, nullptr);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial + (size_t)n * C,
+                       n, C, 1.f / (float)P, rstd, 0);
     S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partial, n, C, 1.f, rstd, 0);
-    S3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, rstd, P, C, rstd, mean,
+    hipLaunchKernelGGL(bn_finalize_shift_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, z, P, C, mean, rstd,
                        running_mean, running_var);
     S3D_LAUNCH_CHECK();
     return 0;

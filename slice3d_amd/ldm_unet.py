@@ -278,7 +278,7 @@ class UNetModel(nn.Module):
         att = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
         ch = c // blk.num_heads
         # long sequences of narrow heads: the f16-MFMA kernel with fp32-class logits and pre-split K / V (ldm_attn.hip)
-        use_mfma = self._precv() == _lib.PREC_F16X3 and os.environ.get("S3D_LDM_ATTN_MFMA", "1") != "0"   # 0: A/B against the fp32 core
+        use_mfma = self._precv() == _lib.PREC_F16X3
         ws_bytes = lib.s3d_qkv_attention_ws_bytes(n, h * w, blk.num_heads, ch) if use_mfma else 0
         if ws_bytes and h * w >= 1024:
             ws = self._attn_ws.get(x.device)

@@ -343,22 +343,26 @@ class HipTrainer:
         world = self._world()
         if world == 1:
             return
-        if not (self.overlap_all_reduce and self._events_armed):
-            from .parallel import all_reduce_mean_
-            all_reduce_mean_(self.grad_flat, self.group)
-            return
-        main = torch.cuda.current_stream(self.grad_flat.device)
-        comm = self._comm_stream
-        with torch.cuda.stream(comm):
-            for k, (lo, hi) in enumerate(self._buckets):
-                if k < 3:
-                    comm.wait_event(self._events[k])
-                else:
-                    comm.wait_stream(main)
-                dist.all_reduce(self.grad_flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-        main.wait_stream(comm)
-        self.grad_flat.div_(world)
-        self._events_armed = False
+        torch.cuda.nvtx.range_push("s3d:train:grad_all_reduce")     # roctx on ROCm: the exchange step as a trace range
+        try:
+            if not (self.overlap_all_reduce and self._events_armed):
+                from .parallel import all_reduce_mean_
+                all_reduce_mean_(self.grad_flat, self.group)
+                return
+            main = torch.cuda.current_stream(self.grad_flat.device)
+            comm = self._comm_stream
+            with torch.cuda.stream(comm):
+                for k, (lo, hi) in enumerate(self._buckets):
+                    if k < 3:
+                        comm.wait_event(self._events[k])
+                    else:
+                        comm.wait_stream(main)
+                    dist.all_reduce(self.grad_flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            main.wait_stream(comm)
+            self.grad_flat.div_(world)
+            self._events_armed = False
+        finally:
+            torch.cuda.nvtx.range_pop()
 
     _events_armed = False
 

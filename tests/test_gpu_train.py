@@ -439,6 +439,7 @@ def test_shard_gradients_match_ddp_golden():
 
 
 _smooth_oracle = {}
+GATE_FREE = ("att_decoder.layers.2.linear2.", "att_decoder.layers.2.norm2.", "fc_out.")
 
 
 def _smooth_output_grads(b, s, q, ns, seed):
@@ -449,14 +450,32 @@ def _smooth_output_grads(b, s, q, ns, seed):
     return w_sdf, w_rec, 1.0
 
 
+def _oracle_smooth_grads(fd, ns, w_sdf, w_rec, w_vgg, dtype):
+    from oracle import ref_cpu
+    sd = seeded_sd_from_shapes(_shapes(ns), dtype=dtype)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and not k.startswith("vggptlossfunc"):
+            v.requires_grad_(True)
+    f = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in fd.items()}
+    _, _, out, _ = ref_cpu.forward_train(sd, f, ns, 0.0)
+    ((out["sdf_pred"] * w_sdf.to(dtype)).sum() + (out["slices_rec"] * w_rec.to(dtype)).sum() + w_vgg * out["vgg_loss"]).backward()
+    return out["sdf_pred"].detach(), {k: v.grad for k, v in sd.items() if v.grad is not None}
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("b,s,q,ns", [(2, 32, 128, 12), (1, 128, 16384, 12)])
-def test_smooth_output_gradients_match_oracle_autograd_tightly(b, s, q, ns, prec):
+def test_smooth_output_gradients_sit_at_the_fp32_floor_of_the_reference(b, s, q, ns, prec):
     """Gradient parity WITHOUT the L1 losses' sign noise: the same fixed, smooth output gradients (seeded normals on
     sdf_pred and slices_rec, 1 on vgg_loss) are pushed through the autograd path of the HIP model (s3d_train_fwd /
-    s3d_train_bwd behind _TrainForward) and through CPU autograd of the oracle, dropout 0.  Per-tensor relative L2
-    error <= 1e-3 (the L1 tests keep their 2e-2: there two fp32 evaluations disagree on signs of near-zero residuals)."""
-    from oracle import ref_cpu
+    s3d_train_bwd behind _TrainForward) and through CPU autograd of the oracle, dropout 0.
+
+    What the first version of this test found: the ORACLE ITSELF, evaluated in fp32 and in fp64, differs by 2e-3 relative
+    L2 in every tensor upstream of the first full-width ReLU (layer 1's FFN: 6.8 M hidden units at 32^2 / 128 queries, a
+    handful of which have pre-activations within fp32 rounding of zero — their gates flip between two fp32 evaluations,
+    each flip moves one unit's whole contribution), and by 1e-6 .. 3e-4 downstream of it.  The HIP gradients show the same
+    pattern against the fp32 oracle (4e-6 in layer 2 / fc_out, 2e-3 upstream).  So the gate is stated against the exact
+    gradient: per tensor  rel(hip, ref_fp64) <= 3 * max(rel(ref_fp32, ref_fp64), its median) + 3e-4, and the medians within
+    a factor 1.5 — the HIP path is no farther from the fp64 gradient than an fp32 evaluation of the reference is."""
     from slice3d_amd.models import Slices3DRegModel
     from slice3d_amd.synth import make_feed_dict
     from slice3d_amd.weights import load_seeded
@@ -464,31 +483,35 @@ def test_smooth_output_gradients_match_oracle_autograd_tightly(b, s, q, ns, prec
     w_sdf, w_rec, w_vgg = _smooth_output_grads(b, s, q, ns, seed=q)
     key = (b, s, q, ns)
     if key not in _smooth_oracle:
-        sd = seeded_sd_from_shapes(_shapes(ns))
-        for k, v in sd.items():
-            if v.is_floating_point() and "running" not in k and not k.startswith("vggptlossfunc"):
-                v.requires_grad_(True)
-        _, _, out, _ = ref_cpu.forward_train(sd, fd, ns, 0.0)
-        ((out["sdf_pred"] * w_sdf).sum() + (out["slices_rec"] * w_rec).sum() + w_vgg * out["vgg_loss"]).backward()
-        _smooth_oracle[key] = (out["sdf_pred"].detach(), {k: v.grad for k, v in sd.items() if v.grad is not None})
-        del out
-    sdf_ref, grads = _smooth_oracle[key]
+        sdf32, g32 = _oracle_smooth_grads(fd, ns, w_sdf, w_rec, w_vgg, torch.float32)
+        _, g64 = _oracle_smooth_grads(fd, ns, w_sdf, w_rec, w_vgg, torch.float64)
+        _smooth_oracle[key] = (sdf32, g32, g64)
+    sdf_ref, g32, g64 = _smooth_oracle[key]
     m = load_seeded(Slices3DRegModel(n_slices=ns, mode="train", prec=prec), 0).cuda().train()
     m.train_dropout = 0.0
     out = m({k: v.cuda() for k, v in fd.items()})
     assert (out["sdf_pred"].detach().cpu() - sdf_ref).abs().max() < 1e-4
     ((out["sdf_pred"] * w_sdf.cuda()).sum() + (out["slices_rec"] * w_rec.cuda()).sum() + w_vgg * out["vgg_loss"]).backward()
-    worst, worst_k, n, rels = 0.0, None, 0, []
+    rows = []
     for k, p in m.named_parameters():
-        if p.grad is None or k not in grads:
+        if p.grad is None or k not in g64 or k in PRE_BN_BIASES:   # pre-BN biases: exact gradient 0, rounding noise on both sides
             continue
-        if k in PRE_BN_BIASES:      # exact gradient 0 (train-mode BN removes the mean): rounding noise on both sides
-            continue
-        rel = float((p.grad.cpu() - grads[k]).norm() / grads[k].norm())
-        n += 1
-        rels.append((rel, k))
-        if rel > worst:
-            worst, worst_k = rel, k
-    print("  largest:", ", ".join("%s %.1e" % (k, r) for r, k in sorted(rels, reverse=True)[:8]))
-    print("smooth-gradient parity %s (%s): worst per-tensor relative L2 error %.2e (%s), %d tensors" % (key, prec, worst, worst_k, n))
-    assert n > 100 and worst < 1e-3, (worst_k, worst)
+        n64 = g64[k].norm()
+        rows.append((k, float((p.grad.cpu().double() - g64[k]).norm() / n64), float((g32[k].double() - g64[k]).norm() / n64),
+                     float((p.grad.cpu() - g32[k]).norm() / g32[k].norm())))
+    assert len(rows) > 100
+    med_hip = sorted(r[1] for r in rows)[len(rows) // 2]
+    med_ref = sorted(r[2] for r in rows)[len(rows) // 2]
+    worst = max(rows, key=lambda r: r[1] / (3 * max(r[2], med_ref) + 3e-4))
+    print("smooth-gradient parity %s (%s): median rel-L2 vs fp64  hip %.2e / fp32 oracle %.2e;  worst tensor %s: hip %.2e, "
+          "fp32 oracle %.2e;  tensors with no ReLU gate behind them (hip vs fp32 oracle): max %.2e"
+          % (key, prec, med_hip, med_ref, worst[0], worst[1], worst[2], max(r[3] for r in rows if r[0].startswith(GATE_FREE))))
+    for k, e_hip, e_ref, _ in rows:
+        assert e_hip <= 3 * max(e_ref, med_ref) + 3e-4, (k, e_hip, e_ref, med_ref)
+    assert med_hip <= 1.5 * med_ref + 1e-4, (med_hip, med_ref)
+    # the tensors no ReLU gate sits behind (last layer's lin2 / norm2, fc_out): tight against the fp32 oracle itself.  (In
+    # f16x3 mode the last layer's own gate already flips a unit now and then — its pre-activations are 22-bit — which
+    # moves that layer's linear1 / attention gradients by 1e-3, the fp32 oracle's own distance from fp64 there is 3e-4.)
+    for k, _, _, e32 in rows:
+        if k.startswith(GATE_FREE):
+            assert e32 < 2e-5, (k, e32)
