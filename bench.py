@@ -184,7 +184,7 @@ def main():
     ap.add_argument("--c4-res", type=int, default=256)
     ap.add_argument("--mesh-steps", type=int, default=2, help="timed reconstruct.py-default mesh extractions (MISE 64 -> 256 + "
                     "marching cubes on the device; 0 = skip)")
-    ap.add_argument("--ldm-steps", type=int, default=5, help="timed LDM denoising steps (BASELINE configs[4]; 0 = skip)")
+    ap.add_argument("--ldm-steps", type=int, default=20, help="timed LDM denoising steps (BASELINE configs[4]; 0 = skip)")
     ap.add_argument("--pmc", type=int, default=1, help="1: measure roofline.traffic in this run (two rocprofv3 --pmc child passes "
                     "of the timed inference loop, FETCH_SIZE and WRITE_SIZE); 0: quote the committed profiles/pmc_traffic.json")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child pass: inference loop only
@@ -404,32 +404,21 @@ def main():
         lc = {k: (torch.randn(1, c, r, r, generator=g) * 0.5).cuda()
               for k, (c, r) in (("f1", (192, 64)), ("f2", (384, 32)), ("f3", (384, 16)), ("f4", (768, 8)), ("f5", (768, 4)))}
         def time_ldm(x, t, cf):
-            """ms per step: the step's ~480 launches captured once into a HIP graph and replayed, as a sampler loop over
-            fixed shapes would run it (eager launches from Python are CPU-bound on some hosts: 4.7 vs 5.7 ms here)."""
-            for _ in range(2):
-                um(x, t, c_fmaps=cf)
-            torch.cuda.synchronize()
-            mode = "hip-graph replay"
-            try:
-                gr = torch.cuda.CUDAGraph()
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    um(x, t, c_fmaps=cf)
-                torch.cuda.current_stream().wait_stream(side)
-                with torch.cuda.graph(gr):
-                    um(x, t, c_fmaps=cf)
-                run = gr.replay
-                run()
-            except Exception:
-                mode = "eager launches"
-                run = lambda: um(x, t, c_fmaps=cf)
+            """ms per DDIM step of slice3d_amd.ldm_sampler.DDIMSampler (ddim.py:56-203: 200-step schedule, eta = 1, the
+            conditioning concatenated on the channel axis): the loop captures the step's ~480 launches once into a HIP
+            graph and replays it per step, then does the x_{t-1} update — what is timed is that loop itself, `ldm_steps`
+            consecutive steps from x_T after a 3-step warm-up run (which includes the capture)."""
+            from slice3d_amd.ldm_sampler import DDIMSampler
+            smp = DDIMSampler(um)
+            x_T, cc = x[:, :4].contiguous(), x[:, 4:].contiguous()
+            gen = torch.Generator(device="cuda").manual_seed(rank)
+            smp.sample(200, x_T, cc, cf, eta=1.0, generator=gen, n_steps=3)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(args.ldm_steps):
-                run()
+            smp.sample(200, x_T, cc, cf, eta=1.0, generator=gen, n_steps=args.ldm_steps)
             torch.cuda.synchronize()
-            return (time.perf_counter() - t1) / args.ldm_steps * 1e3, mode
+            return (time.perf_counter() - t1) / args.ldm_steps * 1e3, ("DDIM sampler loop, hip-graph replay" if smp._graph
+                                                                        else "DDIM sampler loop, eager launches")
 
         lms, lmode = time_ldm(lx, lt, lc)
         ldm = {"workload": "gen_slices LDM UNetModel denoise step, objaverse-ldm-kl-8.yaml, batch 1 (222 GFLOP)",

@@ -245,6 +245,11 @@ int s3d_conv_fwd(const void* packed, const float* x0, const float* x1, const flo
  * stats: N*groups*50 floats of scratch (mean / rstd per group, then the per-slice partial moments). */
 int s3d_group_norm_fwd(const float* x, const float* gamma, const float* beta, const float* film, float* y,
                        float* stats, int N, int HW, int C, int groups, float eps, int silu, void* stream);
+/* the same with film rows read in place from a wider tensor: image n's (scale | shift) at film + n * film_stride floats
+ * (replaces ResBlock.emb_layers + the chunk of openaimodel.py:262-270 for a block whose emb_layers output is a column
+ * range of one stacked GEMV over all blocks) */
+int s3d_group_norm_film_fwd(const float* x, const float* gamma, const float* beta, const float* film, long film_stride,
+                            float* y, float* stats, int N, int HW, int C, int groups, float eps, int silu, void* stream);
 /* the same on th.cat([x0, x1], dim=1) (openaimodel.py:750, the skip connections of the output blocks) without
  * materialising the concatenation: x0 (N,HW,c0), x1 (N,HW,c1) -> y (N,HW,c0+c1); c0, c1 multiples of 4 */
 int s3d_group_norm2_fwd(const float* x0, int c0, const float* x1, int c1, const float* gamma, const float* beta,

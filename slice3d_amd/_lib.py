@@ -120,6 +120,7 @@ SYMBOLS = {
     "s3d_conv_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "s3d_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "s3d_group_norm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "s3d_group_norm_film_fwd": (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "s3d_group_norm2_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "s3d_qkv_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "s3d_qkv_attention_ws_bytes": (_sz, [_i, _i, _i, _i]),

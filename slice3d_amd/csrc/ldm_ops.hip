@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnSrc src, int HW, 
 // with film = [N][2C] (scale | shift) ; optional SiLU.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnSrc src, const float* __restrict__ part,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ film, float* __restrict__ y, int N,
-                                                       int HW, int C, int groups, float eps, int silu) {
+                                                       const float* __restrict__ film, long film_ld, float* __restrict__ y,
+                                                       int N, int HW, int C, int groups, float eps, int silu) {
     // every block first merges the slice moments of all (image, group) pairs (Chan's parallel-variance formula)
     extern __shared__ float s_stats[];   // [N*groups][2] = mean, rstd
     for (int i = threadIdx.x; i < N * groups; i += 256) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnSrc src, const fl
             const int g = (c + i) / cpg;
             const float m = s_stats[2 * (n * groups + g)], r = s_stats[2 * (n * groups + g) + 1];
             float t = (v[i] - m) * r * ga[i] + be[i];
-            if (film) t = t * (1.f + film[(long)n * 2 * C + c + i]) + film[(long)n * 2 * C + C + c + i];
+            if (film) t = t * (1.f + film[(long)n * film_ld + c + i]) + film[(long)n * film_ld + C + c + i];
             if (silu) t = t / (1.f + expf(-t));
             o[i] = t;
         }
@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnSrc src, const fl
 template <int EPT>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ film,
-                                                        float* __restrict__ y, int HW, int C, int groups, float eps,
-                                                        int silu) {
+                                                        long film_ld, float* __restrict__ y, int HW, int C, int groups,
+                                                        float eps, int silu) {
     __shared__ float red[16];
     const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
     const int cpg = C / groups;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const f
         if (i < total) {
             const int c = gidx * cpg + (int)(i % cpg);
             float t = (v[k] - mean) * rstd * gamma[c] + beta[c];
-            if (film) t = t * (1.f + film[(long)n * 2 * C + c]) + film[(long)n * 2 * C + C + c];
+            if (film) t = t * (1.f + film[(long)n * film_ld + c]) + film[(long)n * film_ld + C + c];
             if (silu) t = t / (1.f + expf(-t));
             obase[(i / cpg) * C + i % cpg] = t;
         }
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const f
 
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
                       int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream, const float* x1,
-                      int C0) {
+                      int C0, long film_ld) {
+    if (film_ld <= 0) film_ld = 2L * C;   // rows of a dense (N, 2C) film tensor
     S3D_CHECK_ARG(C % groups == 0 && C % 4 == 0 && N >= 1 && HW >= 1, "group_norm: C=%d groups=%d", C, groups);
     if (!x1) C0 = C;
     S3D_CHECK_ARG(C0 >= 4 && C0 <= C && C0 % 4 == 0 && (C - C0) % 4 == 0, "group_norm: source split %d | %d", C0, C - C0);
@@ -167,7 +168,7 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
             const dim3 grid((unsigned)(N * groups));
 #define GN_CASE(e)                                                                                                     \
     if (per_thread <= e) {                                                                                             \
-        hipLaunchKernelGGL((gn_fused_kernel<e>), grid, dim3(1024), 0, stream, src, gamma, beta, film, y, HW, C, groups, eps, \
+        hipLaunchKernelGGL((gn_fused_kernel<e>), grid, dim3(1024), 0, stream, src, gamma, beta, film, film_ld, y, HW, C, groups, eps, \
                            silu);                                                                                      \
         S3D_LAUNCH_CHECK();                                                                                            \
         return 0;                                                                                                      \
@@ -182,7 +183,7 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
     const long total = (long)N * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), (size_t)N * groups * 2 * sizeof(float), stream, src, stats,
-                       gamma, beta, film, y, N, HW, C, groups, eps, silu);
+                       gamma, beta, film, film_ld, y, N, HW, C, groups, eps, silu);
     S3D_LAUNCH_CHECK();
     return 0;
 }

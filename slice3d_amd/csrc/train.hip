@@ -243,28 +243,189 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int nchun
                                     float* __restrict__ out, int accumulate);
 
 // ---------------------------------------------------------------------------------------------
-// FFN weight gradients with recomputation (see train.h).  Workgroup = 128 (q) x 128 (hidden) output tile of
-// hidden block hb, rows split over the grid; 4 waves, wave w owns hidden units 32w .. 32w+31 of the block against
-// ALL 128 q.  Per 32-row step (ONE barrier; the LDS tiles are double buffered):
-//   1. stage  D^T  (gathered, [q][row slot]) and  R  (row-major) as f16 hi/lo in LDS, the step's mask dwords too;
-//   2. the wave recomputes its 2 hidden tiles x 2 row tiles of Z = R W^T on the MFMA (its 16 W fragments stay in
-//      registers for the whole kernel) and applies bias / mask / scale.  The D registers ARE the B operand of the
-//      contraction: lane (hidden m, g) holds rows {4g..4g+3} of row tile 0 and of row tile 1, and the D^T tile is
-//      staged with exactly that row order in its k-slots (slot 8g+t <-> row 4g+t, t < 4; row 16+4g+t-4 otherwise) —
-//      Z never goes through LDS;
-//   3. out[:, own hidden] += D^T Z: the 8 q-tile A fragments come from LDS, 48 MFMAs.
+// FFN weight gradients with recomputation (see train.h).
+//
+// Operand images.  Both contraction operands of a 32-row step are needed by the 16 hidden-block workgroups that share the
+// rows, as f16 hi/lo, one of them transposed: splitting and transposing them inside the weight-gradient kernel cost it
+// 39 % of its time (16x redundant VALU work, 33 prefetch registers, a global-load wait in the middle of every step —
+// profiles/r03_ffn_wgrad_ablation.md).  ffn_rec_images_kernel does it ONCE per tensor and writes, per 32-row block,
+// the two LDS images byte for byte (16 KiB each), so that the consumer stages a step with 32 LDS-DMA instructions:
+//   R image  [hi|lo][32 rows][128 ch] halfs: the 16-byte chunk s (channels 8s..8s+7) of row r sits at chunk s ^ (r & 15)
+//            (b128 fragment reads of lane (row m, k-group g) at chunk (4u+g) ^ m: conflict-free, no padding)
+//   D^T image [hi|lo][128 ch][32 slots] halfs: slot 8g+t <-> row 4g+t (t < 4) / 16+4g+t-4 — the order the recomputed Z
+//            tile has in the MFMA D registers — and chunk g of channel q sits at chunk g ^ perm[(q >> 2) & 3],
+//            perm = {0, 2, 3, 1} (conflict-free for the A-fragment reads of lane (q & 15, g))
+// Rows past the end are zero in both images.
 // ---------------------------------------------------------------------------------------------
-#define FWR_XLD 136   // halfs per row of the row-major R tile (128 + 8 pad)
+#define FWR_BLK_HALFS 8192   // one image of one 32-row block: hi 4096 halfs | lo 4096 halfs = 16 KiB
+__device__ __forceinline__ int fwr_dperm(int q) { return (0x1320 >> (4 * ((q >> 2) & 3))) & 3; }   // {0,2,3,1}
+__global__ __launch_bounds__(256) void ffn_rec_images_kernel(const float* __restrict__ x, long P, _Float16* __restrict__ dimg,
+                                                             _Float16* __restrict__ rimg) {
+    __shared__ float s_t[32][129];
+    const int tid = threadIdx.x;
+    const long blk = blockIdx.x, row0 = blk * 32;
+    _Float16* rb = rimg + blk * FWR_BLK_HALFS;
+    _Float16* db = dimg + blk * FWR_BLK_HALFS;
+    {   // row-major role: thread (row, channel quad); R image straight from the registers
+        const int row = tid >> 3, cq = tid & 7;
+        const bool ok = row0 + row < P;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 32 * k + 4 * cq;
+            const f32x4 v = ok ? ld4(x + (row0 + row) * 128 + c) : zero4();
+            s_t[row][c] = v[0]; s_t[row][c + 1] = v[1]; s_t[row][c + 2] = v[2]; s_t[row][c + 3] = v[3];
+            s3d_half4 hi, lo;
+            s3d_split4(v, hi, lo);
+            const int o = row * 128 + (((c >> 3) ^ (row & 15)) << 3) + (c & 4);
+            *reinterpret_cast<s3d_half4*>(rb + o) = hi;
+            *reinterpret_cast<s3d_half4*>(rb + 4096 + o) = lo;
+        }
+    }
+    __syncthreads();
+    {   // transposed role: thread (channel q, two k-groups)
+        const int q = tid & 127, gg = tid >> 7;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int g = 2 * gg + ps;
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = s_t[t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)][q];
+            s3d_half8 hi, lo;
+            s3d_split8(v, hi, lo);
+            const int o = q * 32 + ((g ^ fwr_dperm(q)) << 3);
+            *reinterpret_cast<s3d_half8*>(db + o) = hi;
+            *reinterpret_cast<s3d_half8*>(db + 4096 + o) = lo;
+        }
+    }
+}
+int launch_ffn_rec_images(const float* x, long P, float* dimg, float* rimg, hipStream_t stream) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(ffn_rec_images_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, stream, x, P,
+                       reinterpret_cast<_Float16*>(dimg), reinterpret_cast<_Float16*>(rimg));
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The contraction.  Workgroup = 128 (q) x 128 (hidden) output tile of hidden block hb, rows split over the grid; 4 waves,
+// wave w owns hidden units 32w .. 32w+31 of the block against ALL 128 q.  Per 32-row step (one barrier; two LDS buffers
+// per operand, each its own object so that a fragment read is never guarded against the other buffer's refill):
+//   1. the NEXT step's D^T and R images are requested by LDS-DMA (8 KiB per wave, no registers, no VALU);
+//   2. the wave recomputes its 2 hidden tiles x 2 row tiles of Z = R W^T on the MFMA (its 16 W fragments stay in
+//      registers for the whole kernel; lin1's bias opens the accumulators) and applies the activity bits.  The D
+//      registers ARE the B operand of the contraction (see the D^T image's slot order): Z never goes through LDS;
+//   3. out[:, own hidden] += D^T Z: the 8 q-tile A fragments come from LDS one tile ahead, 48 MFMAs.
+// The dropout scale multiplies the finished sums.
+// ---------------------------------------------------------------------------------------------
+template <int COLSUM>
+__device__ __forceinline__ void fwr_step(const _Float16 (&sd)[FWR_BLK_HALFS], const _Float16 (&sr)[FWR_BLK_HALFS],
+                                         const unsigned (&sm)[128], const wl_half8 (&wh)[2][4], const wl_half8 (&wlo)[2][4],
+                                         const float (&bv)[2], const unsigned (&bitsel)[2], f32x4 (&acc)[8][2],
+                                         float (&csum)[2], int m, int g) {
+    // ---- 2. recompute Z tiles (rt, e): D[row 4g+i of tile rt][hidden m of tile e]; fragments of K step u+1 are read
+    //      before the MFMAs of step u ----
+    f32x4 z[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) z[rt][e] = f32x4{bv[e], bv[e], bv[e], bv[e]};
+    wl_half8 ah[2], al[2];
+    auto rd_a = [&](int set, int i) {
+        const int o = (16 * i + m) * 32 + ((g ^ fwr_dperm(m)) << 3);
+        ah[set] = *reinterpret_cast<const wl_half8*>(&sd[o]);
+        al[set] = *reinterpret_cast<const wl_half8*>(&sd[4096 + o]);
+    };
+    {
+        wl_half8 xh[2][2], xl[2][2];
+        auto rd_x = [&](int set, int u) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int o = (rt * 16 + m) * 128 + (((4 * u + g) ^ m) << 3);
+                xh[set][rt] = *reinterpret_cast<const wl_half8*>(&sr[o]);
+                xl[set][rt] = *reinterpret_cast<const wl_half8*>(&sr[4096 + o]);
+            }
+        };
+        rd_x(0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cs = u & 1;
+            if (u < 3) rd_x(cs ^ 1, u + 1);
+            else rd_a(0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wlo[e][u], z[rt][e], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
+            if (u < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next fragments first ...
+            else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);            // ... then this step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // activity bit, split: hidden unit (block-local) 32*wave + 16e + m -> mask byte `wave`, bit 4e + (m & 3) of dword
+    // g' = m >> 2 of the row; this lane's rows are 4g..4g+3 (tile 0) and 16+4g.. (tile 1)
+    wl_half8 zh[2], zl[2];
+    {
+        const uint4 mw0 = *reinterpret_cast<const uint4*>(&sm[(m >> 2) * 32 + 4 * g]);
+        const uint4 mw1 = *reinterpret_cast<const uint4*>(&sm[(m >> 2) * 32 + 16 + 4 * g]);
+        const unsigned mw[8] = {mw0.x, mw0.y, mw0.z, mw0.w, mw1.x, mw1.y, mw1.z, mw1.w};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                v[t] = (mw[t] & bitsel[e]) ? z[t >> 2][e][t & 3] : 0.f;
+                if (COLSUM) csum[e] += v[t];
+            }
+            s3d_split8(v, zh[e], zl[e]);
+        }
+    }
+    S3D_SPLIT_SETTLE();   // partial-register split results feed the MFMAs below straight from registers
+    // ---- 3. out[q tile i][own hidden tile e] += D^T Z ----
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int cs = i & 1;
+        if (i < 7) rd_a(cs ^ 1, i + 1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zl[e], acc[i][e], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cs], zh[e], acc[i][e], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zh[e], acc[i][e], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// one block image (16 KiB) -> an LDS buffer: wave w copies the 4 KiB at offset 4096 w as four 1-KiB LDS-DMA
+// instructions that differ only in their immediate offset (one lane address, one M0 value per image)
+__device__ __forceinline__ void fwr_dma(const _Float16* gblk, _Float16* lbuf, int wave, int lane) {
+    const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(gblk + wave * 2048 + lane * 8);
+    __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(lbuf + wave * 2048);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+}
+
 template <int COLSUM>
 __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArgs a, int steps_per_split, int nsplit) {
-    __shared__ __attribute__((aligned(16))) _Float16 s_d[2][2][128 * WL_LD];    // [buffer][hi|lo] D^T      40 KiB
-    __shared__ __attribute__((aligned(16))) _Float16 s_r[2][2][32 * FWR_XLD];   // [buffer][hi|lo] R        34 KiB
-    __shared__ __attribute__((aligned(16))) unsigned s_m[2][128];               // [buffer][g'][row] mask dwords of hb
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) _Float16 s_d0[FWR_BLK_HALFS], s_d1[FWR_BLK_HALFS];   // D^T hi|lo, 2 x 16 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 s_r0[FWR_BLK_HALFS], s_r1[FWR_BLK_HALFS];   // R   hi|lo, 2 x 16 KiB
+    __shared__ __attribute__((aligned(16))) unsigned s_m0[128], s_m1[128];                       // [g'][row] mask dwords of hb
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, g = lane >> 4;
     // 1-D grid of 16 hidden blocks x nsplit row ranges.  Workgroups are dealt to the 8 XCDs round-robin; remap so
-    // that the 16 hidden blocks of one row range run on ONE XCD back to back: they read the same D / R rows, which
-    // then come from that XCD's L2 once instead of from the fabric 16 times (21 GB -> 1.3 GB per launch).
+    // that the 16 hidden blocks of one row range run on ONE XCD back to back: they read the same images, which
+    // then come from that XCD's L2 once instead of from the fabric 16 times.
     int hb, split;
     {
         const int L = blockIdx.x, nb = S3D_FFN / 128;
@@ -277,9 +438,12 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
             split = L / nb;
         }
     }
-    const int ch = tid & 127, rg = tid >> 7;      // gather role: channel, k-slot groups g = 2 rg + {0, 1}
-    const int rrow = tid >> 3, rcq = tid & 7;     // row-major role: row, channel quad
     const long P = a.P;
+    const long blk0 = (long)split * steps_per_split;                 // first 32-row block of this range
+    const long nblk_all = (P + 31) / 32;
+    const int steps = (int)(nblk_all - blk0 < steps_per_split ? nblk_all - blk0 : steps_per_split);   // >= 1
+    const _Float16* dimg = reinterpret_cast<const _Float16*>(a.Dimg) + blk0 * FWR_BLK_HALFS;
+    const _Float16* rimg = reinterpret_cast<const _Float16*>(a.Rimg) + blk0 * FWR_BLK_HALFS;
 
     // this wave's W fragments: hidden tiles 2*wave + e of the block, K = 128 = 4 x 32
     wl_half8 wh[2][4], wlo[2][4];
@@ -306,216 +470,45 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
     float csum[2] = {0.f, 0.f};
     const unsigned bitsel[2] = {1u << (8 * wave + (m & 3)), 1u << (8 * wave + 4 + (m & 3))};
 
-    float pd[2][8];
-    f32x4 pr[4];
-    unsigned pm = 0;
-    // row of k-slot (gs, t) of a 32-row step
-    auto slot_row = [](int gs, int t) { return t < 4 ? 4 * gs + t : 16 + 4 * gs + (t - 4); };
-    // addresses as 32-bit offsets from the split's first row (uniform base + lane offset: no 64-bit VALU address math,
-    // which cost this kernel its register budget); rows past P are clamped here and zeroed when staged
-    const long p_begin = (long)split * steps_per_split * 32;
-    const float* Dbase = a.D + p_begin * 128;
-    const float* Rbase = a.R + p_begin * 128;
-    const unsigned* Mbase = a.mask + p_begin * 64;
-    const int nrel = (int)(P - p_begin < (long)steps_per_split * 32 ? P - p_begin : (long)steps_per_split * 32);   // >= 1
-    const unsigned voff_d = (unsigned)(8 * rg * 128 + ch), voff_r = (unsigned)(rrow * 128 + 4 * rcq),
-                   voff_m = (unsigned)((tid & 31) * 64 + ((tid >> 5) & 3) * 16 + hb);
-    auto gload = [&](int rbase) {
-        if (rbase + 32 <= nrel) {   // whole step inside the range (all but the last step of the last split): uniform
-                                    // step base + loop-invariant lane offset + immediate
-            // two lane addresses 16 rows apart; the 8 rows around each are immediate offsets (< 4 KiB)
-            const float* d0 = Dbase + (size_t)rbase * 128 + voff_d;
-            const float* d1 = d0 + 16 * 128;
-            const float* r0 = Rbase + (size_t)rbase * 128 + voff_r;
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) pd[ps][t] = (t < 4 ? d0 : d1)[(4 * ps + (t & 3)) * 128];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pr[k] = ld4(r0 + 32 * k);
-            pm = (Mbase + (size_t)rbase * 64)[voff_m];
-            return;
-        }
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                int r = rbase + slot_row(2 * rg + ps, t);
-                r = r < nrel ? r : nrel - 1;
-                pd[ps][t] = Dbase[(unsigned)(r * 128 + ch)];
+    // the step's mask dwords: thread (g' = tid >> 5, row = tid & 31) of the first 128 threads; rows past the end carry 0
+    const unsigned* mbase = a.mask + blk0 * 32 * 64;                                           // uniform
+    const unsigned moff = (unsigned)((tid & 31) * 64 + ((tid >> 5) & 3) * 16 + hb);             // lane offset
+    const int rows_left = (int)(P - blk0 * 32 < (long)steps_per_split * 32 ? P - blk0 * 32 : (long)steps_per_split * 32);
+    auto mask_of = [&](int step) -> unsigned {
+        return step * 32 + (tid & 31) < rows_left ? (mbase + (size_t)step * 32 * 64)[moff] : 0u;
+    };
+    fwr_dma(dimg, s_d0, wave, lane);
+    fwr_dma(rimg, s_r0, wave, lane);
+    if (tid < 128) s_m0[tid] = mask_of(0);
+    dma_publish_barrier();
+    for (int it = 0; it < steps; it += 2) {
+        {   // even step: buffers 0, refill of buffers 1
+            const bool more = it + 1 < steps;
+            unsigned pm = 0;
+            if (more) {
+                fwr_dma(dimg + (size_t)(it + 1) * FWR_BLK_HALFS, s_d1, wave, lane);
+                fwr_dma(rimg + (size_t)(it + 1) * FWR_BLK_HALFS, s_r1, wave, lane);
+                pm = mask_of(it + 1);
             }
-        int r = rbase + rrow;
-        r = r < nrel ? r : nrel - 1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pr[k] = ld4(Rbase + (unsigned)(r * 128 + 32 * k + 4 * rcq));
-        int mr = rbase + (tid & 31);
-        mr = mr < nrel ? mr : nrel - 1;
-        pm = Mbase[(unsigned)(mr * 64 + ((tid >> 5) & 3) * 16 + hb)];
-    };
-    // registers -> LDS buffer `bf`, in pieces that are issued between the MFMA groups of the contraction:
-    // mask_tail zeroes the rows past the end of a partial last step (uniform, rare), piece_d / piece_r split and store
-    auto mask_tail = [&](int rbase) {
-        if (rbase + 32 > nrel) {
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) pd[ps][t] *= rbase + slot_row(2 * rg + ps, t) < nrel ? 1.f : 0.f;
-            if (rbase + (tid & 31) >= nrel) pm = 0u;
+            __builtin_amdgcn_sched_barrier(0);
+            fwr_step<COLSUM>(s_d0, s_r0, s_m0, wh, wlo, bv, bitsel, acc, csum, m, g);
+            if (tid < 128) s_m1[tid] = pm;
+            dma_publish_barrier();
+            if (!more) break;
         }
-    };
-    auto piece_d = [&](int bf, int ps) {
-        wl_half8 hi, lo;
-        s3d_split8(pd[ps], hi, lo);
-        *reinterpret_cast<wl_half8*>(&s_d[bf][0][ch * WL_LD + 8 * (2 * rg + ps)]) = hi;
-        *reinterpret_cast<wl_half8*>(&s_d[bf][1][ch * WL_LD + 8 * (2 * rg + ps)]) = lo;
-    };
-    auto piece_r = [&](int bf, int k) {
-        s3d_half4 hi, lo;
-        s3d_split4(pr[k], hi, lo);
-        *reinterpret_cast<s3d_half4*>(&s_r[bf][0][rrow * FWR_XLD + 32 * k + 4 * rcq]) = hi;
-        *reinterpret_cast<s3d_half4*>(&s_r[bf][1][rrow * FWR_XLD + 32 * k + 4 * rcq]) = lo;
-    };
-    auto piece_m = [&](int bf) {
-        if (tid < 128) s_m[bf][tid] = pm;
-    };
-    auto stage = [&](int bf, int rbase) {
-        mask_tail(rbase);
-        piece_d(bf, 0);
-        piece_d(bf, 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) piece_r(bf, k);
-        piece_m(bf);
-    };
-    gload(0);
-    stage(0, 0);
-    __syncthreads();
-    for (int it = 0; it < steps_per_split; ++it) {
-        const int cur = it & 1;
-        const bool more = it + 1 < steps_per_split;
-#ifndef FWR_ABL_NOLOAD
-        if (more) gload((it + 1) * 32);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- 2. recompute Z tiles (rt, e): D[row 4g+i of tile rt][hidden m of tile e] ----
-        f32x4 z[2][2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) z[rt][e] = f32x4{bv[e], bv[e], bv[e], bv[e]};   // D[row 4g+i][hidden m]: one unit per lane
-#ifndef FWR_ABL_NOREC
-        {
-            // R fragments of K step u+1 are requested before the MFMAs of step u (two register sets)
-            wl_half8 xh[2][2], xl[2][2];
-            auto rd_x = [&](int set, int u) {
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    const int o = (rt * 16 + m) * FWR_XLD + 32 * u + 8 * g;
-                    xh[set][rt] = *reinterpret_cast<const wl_half8*>(&s_r[cur][0][o]);
-                    xl[set][rt] = *reinterpret_cast<const wl_half8*>(&s_r[cur][1][o]);
-                }
-            };
-            rd_x(0, 0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int cs = u & 1;
-                if (u < 3) rd_x(cs ^ 1, u + 1);
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wlo[e][u], z[rt][e], 0, 0, 0);
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next step's 4 fragment reads first ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);  // ... then this step's MFMAs
-                __builtin_amdgcn_sched_barrier(0);
+        {   // odd step: buffers 1, refill of buffers 0
+            const bool more = it + 2 < steps;
+            unsigned pm = 0;
+            if (more) {
+                fwr_dma(dimg + (size_t)(it + 2) * FWR_BLK_HALFS, s_d0, wave, lane);
+                fwr_dma(rimg + (size_t)(it + 2) * FWR_BLK_HALFS, s_r0, wave, lane);
+                pm = mask_of(it + 2);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            fwr_step<COLSUM>(s_d1, s_r1, s_m1, wh, wlo, bv, bitsel, acc, csum, m, g);
+            if (tid < 128) s_m0[tid] = pm;
+            dma_publish_barrier();
         }
-#endif
-        // activity bit, split (the dropout scale is applied once, to the finished sums): hidden unit (block-local)
-        // 32*wave + 16e + m -> mask byte `wave`, bit 4e + (m & 3) of dword g' = m >> 2 of the row; this lane's rows are
-        // 4g..4g+3 (tile 0) and 16+4g.. (tile 1)
-        wl_half8 zh[2], zl[2];
-#ifdef FWR_ABL_NOZ
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            zh[e] = __builtin_bit_cast(wl_half8, f32x4{z[0][e][0], z[0][e][1], z[1][e][0], z[1][e][1]});
-            zl[e] = __builtin_bit_cast(wl_half8, f32x4{z[0][e][2], z[0][e][3], z[1][e][2], z[1][e][3]});
-        }
-#else
-        {
-            const uint4 mw0 = *reinterpret_cast<const uint4*>(&s_m[cur][(m >> 2) * 32 + 4 * g]);
-            const uint4 mw1 = *reinterpret_cast<const uint4*>(&s_m[cur][(m >> 2) * 32 + 16 + 4 * g]);
-            const unsigned mw[8] = {mw0.x, mw0.y, mw0.z, mw0.w, mw1.x, mw1.y, mw1.z, mw1.w};
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float v[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    v[t] = (mw[t] & bitsel[e]) ? z[t >> 2][e][t & 3] : 0.f;
-                    if (COLSUM) csum[e] += v[t];
-                }
-                s3d_split8(v, zh[e], zl[e]);
-            }
-        }
-#endif
-        S3D_SPLIT_SETTLE();   // partial-register split results feed the MFMAs below straight from registers
-        // ---- 3. out[q tile i][own hidden tile e] += D^T Z, one q tile (6 MFMAs) per group; the A fragments of tile
-        //      i+1 are requested before the MFMAs of tile i, and the NEXT step's staging (split + LDS stores of the rows
-        //      requested at the top of this step, into the other buffer) is issued in pieces between the groups: it
-        //      used to follow the MFMAs as a block — 39 % of the kernel's time (FWR_ABL_NOSTAGE) ----
-#ifndef FWR_ABL_NOSTAGE
-        mask_tail((it + 1) * 32);
-#endif
-#ifndef FWR_ABL_NOCON
-        {
-            wl_half8 ah[2], al[2];
-            auto rd_a = [&](int set, int i) {
-                const int o = (16 * i + m) * WL_LD + 8 * g;
-                ah[set] = *reinterpret_cast<const wl_half8*>(&s_d[cur][0][o]);
-                al[set] = *reinterpret_cast<const wl_half8*>(&s_d[cur][1][o]);
-            };
-            rd_a(0, 0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int cs = i & 1;
-                if (i < 7) rd_a(cs ^ 1, i + 1);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zl[e], acc[i][e], 0, 0, 0);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cs], zh[e], acc[i][e], 0, 0, 0);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zh[e], acc[i][e], 0, 0, 0);
-#ifndef FWR_ABL_NOSTAGE
-                // the last step stages stale registers into the buffer nobody reads again: harmless, and branch-free
-                if (i == 1) piece_d(cur ^ 1, 0);
-                if (i == 2) piece_d(cur ^ 1, 1);
-                if (i == 3) { piece_r(cur ^ 1, 0); piece_r(cur ^ 1, 1); }
-                if (i == 4) { piece_r(cur ^ 1, 2); piece_r(cur ^ 1, 3); }
-                if (i == 5) piece_m(cur ^ 1);
-#endif
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#else
-#pragma unroll
-        for (int e = 0; e < 2; ++e) asm volatile("" :: "v"(zh[e]), "v"(zl[e]));
-#ifndef FWR_ABL_NOSTAGE
-        stage(cur ^ 1, (it + 1) * 32);
-#endif
-#endif
-        __syncthreads();
     }
     // partial[split][q][hidden]: D[row = q 4g+reg][col = hidden m]
     float* part = a.partial + (size_t)split * 128 * S3D_FFN;
@@ -563,7 +556,7 @@ __global__ void ffn_wgrad_rec_reduce_kernel(const float* __restrict__ partial, i
 
 int launch_ffn_wgrad_rec(const FfnWgradArgs& a, hipStream_t stream) {
     if (a.P <= 0) return 0;
-    S3D_CHECK_ARG(a.D && a.R && a.wimg && a.mask && a.out && a.partial, "ffn_wgrad_rec: null argument");
+    S3D_CHECK_ARG(a.Dimg && a.Rimg && a.wimg && a.mask && a.out && a.partial, "ffn_wgrad_rec: null argument");
     const long total_steps = (a.P + 31) / 32;
     long splits = 64;                                          // 16 hidden blocks x 64 = 1024 workgroups
     const long max_by_steps = (total_steps + 7) / 8;

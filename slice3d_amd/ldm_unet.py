@@ -202,6 +202,13 @@ class UNetModel(nn.Module):
                        "s3d_group_norm2_fwd")
             return y
         y = torch.empty_like(x)
+        if isinstance(film, tuple):     # (stacked film tensor, first column)
+            ft, off = film
+            _lib.check(lib.s3d_group_norm_film_fwd(x.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(),
+                                                   ft.data_ptr() + 4 * off, ft.shape[1], y.data_ptr(), stats.data_ptr(), n, h * w, c,
+                                                   gn.num_groups, C.c_float(gn.eps), 1 if silu else 0, self._stream()),
+                       "s3d_group_norm_film_fwd")
+            return y
         _lib.check(lib.s3d_group_norm_fwd(x.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(),
                                           film.data_ptr() if film is not None else None, y.data_ptr(), stats.data_ptr(),
                                           n, h * w, c, gn.num_groups, C.c_float(gn.eps), 1 if silu else 0,
@@ -257,10 +264,10 @@ class UNetModel(nn.Module):
             xs = self._resample(x, blk.up)
         h = self._conv(blk.in_layers[2], h)
         off, rows = self._film_off[id(blk)]
-        film = self._film_all[:, off:off + rows].contiguous()               # (N, 2*Cout) = scale | shift
         if not blk.use_scale_shift_norm:
             raise NotImplementedError("ResBlock without use_scale_shift_norm is not built")
-        h = self._group_norm(blk.out_layers[0], h, film=film, silu=True)
+        # (N, 2*Cout) = scale | shift: columns [off, off + rows) of the stacked emb_layers output, read in place
+        h = self._group_norm(blk.out_layers[0], h, film=(self._film_all, off), silu=True)
         if isinstance(blk.skip_connection, nn.Conv2d):
             res = self._conv(blk.skip_connection, xs, x1=skip)
         elif skip is not None:

@@ -77,6 +77,50 @@ def test_ldm_full_config_at_128_latent_matches_reference():
     assert err < 2e-4 * max(1.0, float(np.abs(y).max()))
 
 
+def test_ddim_schedule_matches_the_reference_sampler():
+    """ldm_sampler's schedule (beta schedule of the yaml -> alphas_cumprod -> 200 uniform DDIM steps, eta = 1) against the
+    arrays the REAL reference DDIMSampler.make_schedule produced (tests/golden/make_golden_ldm_ddim.py)."""
+    from slice3d_amd.ldm_sampler import DDIMSampler
+    z = np.load(os.path.join(GOLDEN, "ldm_ddim_small_b2.npz"))
+    s = DDIMSampler(unet=None)
+    s.make_schedule(200, 1.0)
+    assert np.array_equal(s.ddim_timesteps, z["timesteps200"])
+    for got, key in ((s.ddim_sigmas, "sigmas200"), (s.ddim_alphas, "alphas200"), (s.ddim_alphas_prev, "alphas_prev200")):
+        assert np.abs(np.asarray(got, np.float64) - z[key]).max() <= 1e-7 * np.abs(z[key]).max(), key
+    s.make_schedule(4, 1.0)
+    assert np.array_equal(s.ddim_timesteps, z["timesteps4"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_ddim_sampler_reproduces_the_reference_run(prec, graph):
+    """A complete 4-step DDIM run (eta = 1; ddim.py:56-203 — the reference's own loop, schedule and x_{t-1} update around
+    the real UNetModel, golden from the imported reference) against slice3d_amd.ldm_sampler around the HIP UNet, fed the
+    noise the reference drew: every intermediate latent and x0 prediction, replayed as a HIP graph and launched eagerly."""
+    from slice3d_amd.ldm_sampler import DDIMSampler
+    from slice3d_amd.ldm_unet import UNetModel
+    from slice3d_amd.weights import load_seeded
+    z = np.load(os.path.join(GOLDEN, "ldm_ddim_small_b2.npz"))
+    batch, seed = int(z["meta"][0]), int(z["meta"][1])
+    x8, _, cf = ldm_inputs(LDM_SMALL, batch, seed)
+    m = load_seeded(UNetModel(prec=prec, **LDM_SMALL), 0).cuda().eval()
+    smp = DDIMSampler(m, use_graph=graph)
+    x_T, c_concat = x8[:, :4].contiguous().cuda(), x8[:, 4:].contiguous().cuda()
+    samples, inter = smp.sample(4, x_T, c_concat, {k: v.cuda() for k, v in cf.items()}, eta=1.0,
+                                noises=[torch.from_numpy(n) for n in z["noises"]])
+    assert bool(smp._graph) == graph
+    worst = 0.0
+    for i in range(1, 5):
+        for key in ("x_inter", "pred_x0"):
+            ref = z[key][i]
+            err = float(np.abs(inter[key][i].cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max()))
+            worst = max(worst, err)
+            assert err < 5e-4, (key, i, err)
+    assert float(np.abs(samples.cpu().numpy() - z["samples"]).max()) < 5e-4 * max(1.0, float(np.abs(z["samples"]).max()))
+    print("ddim 4-step run (%s, graph=%s): worst relative deviation %.2e" % (prec, graph, worst))
+
+
 @pytest.mark.gpu
 def test_group_norm_of_two_sources_equals_group_norm_of_the_concatenation():
     """s3d_group_norm2_fwd (the th.cat([h, hs.pop()]) of openaimodel.py:750, never materialised) == s3d_group_norm_fwd on
