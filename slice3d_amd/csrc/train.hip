@@ -308,8 +308,8 @@ int launch_ffn_rec_images(const float* x, long P, float* dimg, float* rimg, hipS
 
 // ---------------------------------------------------------------------------------------------
 // The contraction.  Workgroup = 128 (q) x 128 (hidden) output tile of hidden block hb, rows split over the grid; 4 waves,
-// wave w owns hidden units 32w .. 32w+31 of the block against ALL 128 q.  Per 32-row step (one barrier; two LDS buffers
-// per operand, each its own object so that a fragment read is never guarded against the other buffer's refill):
+// wave w owns hidden units 32w .. 32w+31 of the block against ALL 128 q.  Per 32-row step (one barrier; the images are
+// double buffered in LDS):
 //   1. the NEXT step's D^T and R images are requested by LDS-DMA (8 KiB per wave, no registers, no VALU);
 //   2. the wave recomputes its 2 hidden tiles x 2 row tiles of Z = R W^T on the MFMA (its 16 W fragments stay in
 //      registers for the whole kernel; lin1's bias opens the accumulators) and applies the activity bits.  The D
@@ -317,96 +317,17 @@ int launch_ffn_rec_images(const float* x, long P, float* dimg, float* rimg, hipS
 //   3. out[:, own hidden] += D^T Z: the 8 q-tile A fragments come from LDS one tile ahead, 48 MFMAs.
 // The dropout scale multiplies the finished sums.
 // ---------------------------------------------------------------------------------------------
-template <int COLSUM>
-__device__ __forceinline__ void fwr_step(const _Float16 (&sd)[FWR_BLK_HALFS], const _Float16 (&sr)[FWR_BLK_HALFS],
-                                         const unsigned (&sm)[128], const wl_half8 (&wh)[2][4], const wl_half8 (&wlo)[2][4],
-                                         const float (&bv)[2], const unsigned (&bitsel)[2], f32x4 (&acc)[8][2],
-                                         float (&csum)[2], int m, int g) {
-    // ---- 2. recompute Z tiles (rt, e): D[row 4g+i of tile rt][hidden m of tile e]; fragments of K step u+1 are read
-    //      before the MFMAs of step u ----
-    f32x4 z[2][2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) z[rt][e] = f32x4{bv[e], bv[e], bv[e], bv[e]};
-    wl_half8 ah[2], al[2];
-    auto rd_a = [&](int set, int i) {
-        const int o = (16 * i + m) * 32 + ((g ^ fwr_dperm(m)) << 3);
-        ah[set] = *reinterpret_cast<const wl_half8*>(&sd[o]);
-        al[set] = *reinterpret_cast<const wl_half8*>(&sd[4096 + o]);
-    };
-    {
-        wl_half8 xh[2][2], xl[2][2];
-        auto rd_x = [&](int set, int u) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const int o = (rt * 16 + m) * 128 + (((4 * u + g) ^ m) << 3);
-                xh[set][rt] = *reinterpret_cast<const wl_half8*>(&sr[o]);
-                xl[set][rt] = *reinterpret_cast<const wl_half8*>(&sr[4096 + o]);
-            }
-        };
-        rd_x(0, 0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int cs = u & 1;
-            if (u < 3) rd_x(cs ^ 1, u + 1);
-            else rd_a(0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wlo[e][u], z[rt][e], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
-            if (u < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next fragments first ...
-            else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);            // ... then this step's MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // activity bit, split: hidden unit (block-local) 32*wave + 16e + m -> mask byte `wave`, bit 4e + (m & 3) of dword
-    // g' = m >> 2 of the row; this lane's rows are 4g..4g+3 (tile 0) and 16+4g.. (tile 1)
-    wl_half8 zh[2], zl[2];
-    {
-        const uint4 mw0 = *reinterpret_cast<const uint4*>(&sm[(m >> 2) * 32 + 4 * g]);
-        const uint4 mw1 = *reinterpret_cast<const uint4*>(&sm[(m >> 2) * 32 + 16 + 4 * g]);
-        const unsigned mw[8] = {mw0.x, mw0.y, mw0.z, mw0.w, mw1.x, mw1.y, mw1.z, mw1.w};
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float v[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                v[t] = (mw[t] & bitsel[e]) ? z[t >> 2][e][t & 3] : 0.f;
-                if (COLSUM) csum[e] += v[t];
-            }
-            s3d_split8(v, zh[e], zl[e]);
-        }
-    }
-    S3D_SPLIT_SETTLE();   // partial-register split results feed the MFMAs below straight from registers
-    // ---- 3. out[q tile i][own hidden tile e] += D^T Z ----
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int cs = i & 1;
-        if (i < 7) rd_a(cs ^ 1, i + 1);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zl[e], acc[i][e], 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cs], zh[e], acc[i][e], 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zh[e], acc[i][e], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
+// LDS fragment reads and their waits are issued by hand (as in ffn_layer_f16x3_pipe_kernel): with an LDS-DMA refill of
+// the other buffer in flight hipcc guards compiler-generated ds_reads of the same object with s_waitcnt vmcnt(0) — the
+// wait the double buffer exists to avoid — and splitting the buffers into separate objects (an unrolled two-step loop)
+// made it shuffle and spill the accumulators.  LDS returns in order: lgkmcnt(n) leaves exactly the n youngest reads out.
+#define FWR_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define FWR_WAIT4(n, r0, r1, r2, r3) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(n))
+#define FWR_WAIT2(n, r0, r1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(n))
+#define FWR_BUF_BYTES (4 * FWR_BLK_HALFS)   // one buffer: D^T image (16 KiB) | R image (16 KiB)
 
-// one block image (16 KiB) -> an LDS buffer: wave w copies the 4 KiB at offset 4096 w as four 1-KiB LDS-DMA
-// instructions that differ only in their immediate offset (one lane address, one M0 value per image)
+// one block image (16 KiB) -> LDS: wave w copies the 4 KiB at offset 4096 w as four 1-KiB LDS-DMA instructions that
+// differ only in their immediate offset (one lane address, one M0 value per image)
 __device__ __forceinline__ void fwr_dma(const _Float16* gblk, _Float16* lbuf, int wave, int lane) {
     const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(gblk + wave * 2048 + lane * 8);
     __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(lbuf + wave * 2048);
@@ -418,9 +339,8 @@ __device__ __forceinline__ void fwr_dma(const _Float16* gblk, _Float16* lbuf, in
 
 template <int COLSUM>
 __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArgs a, int steps_per_split, int nsplit) {
-    __shared__ __attribute__((aligned(16))) _Float16 s_d0[FWR_BLK_HALFS], s_d1[FWR_BLK_HALFS];   // D^T hi|lo, 2 x 16 KiB
-    __shared__ __attribute__((aligned(16))) _Float16 s_r0[FWR_BLK_HALFS], s_r1[FWR_BLK_HALFS];   // R   hi|lo, 2 x 16 KiB
-    __shared__ __attribute__((aligned(16))) unsigned s_m0[128], s_m1[128];                       // [g'][row] mask dwords of hb
+    __shared__ __attribute__((aligned(16))) _Float16 s_t[2][2][FWR_BLK_HALFS];   // [buffer][D^T | R] hi|lo images, 64 KiB
+    __shared__ __attribute__((aligned(16))) unsigned s_m[2][128];                 // [buffer][g'][row] mask dwords of hb
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, g = lane >> 4;
     // 1-D grid of 16 hidden blocks x nsplit row ranges.  Workgroups are dealt to the 8 XCDs round-robin; remap so
@@ -468,7 +388,15 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
 #pragma unroll
         for (int e = 0; e < 2; ++e) acc[i][e] = zero4();
     float csum[2] = {0.f, 0.f};
-    const unsigned bitsel[2] = {1u << (8 * wave + (m & 3)), 1u << (8 * wave + 4 + (m & 3))};
+    const unsigned bitsel0 = 1u << (8 * wave + (m & 3));
+
+    // lane byte addresses inside buffer 0: A fragment of q tile 0 (tile i at +1024 i, lo half at +8192), R fragment of K
+    // step u, row tile 0 (row tile 1 at +4096, lo half at +8192; the R image follows the D^T image)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&s_t[0][0][0];
+    const unsigned a_addr0 = lds0 + 2u * (unsigned)(m * 32 + ((g ^ fwr_dperm(m)) << 3));
+    unsigned x_addr0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x_addr0[u] = lds0 + 2u * FWR_BLK_HALFS + 2u * (unsigned)(m * 128 + (((4 * u + g) ^ m) << 3));
 
     // the step's mask dwords: thread (g' = tid >> 5, row = tid & 31) of the first 128 threads; rows past the end carry 0
     const unsigned* mbase = a.mask + blk0 * 32 * 64;                                           // uniform
@@ -477,38 +405,102 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
     auto mask_of = [&](int step) -> unsigned {
         return step * 32 + (tid & 31) < rows_left ? (mbase + (size_t)step * 32 * 64)[moff] : 0u;
     };
-    fwr_dma(dimg, s_d0, wave, lane);
-    fwr_dma(rimg, s_r0, wave, lane);
-    if (tid < 128) s_m0[tid] = mask_of(0);
+    fwr_dma(dimg, s_t[0][0], wave, lane);
+    fwr_dma(rimg, s_t[0][1], wave, lane);
+    if (tid < 128) s_m[0][tid] = mask_of(0);
     dma_publish_barrier();
-    for (int it = 0; it < steps; it += 2) {
-        {   // even step: buffers 0, refill of buffers 1
-            const bool more = it + 1 < steps;
-            unsigned pm = 0;
-            if (more) {
-                fwr_dma(dimg + (size_t)(it + 1) * FWR_BLK_HALFS, s_d1, wave, lane);
-                fwr_dma(rimg + (size_t)(it + 1) * FWR_BLK_HALFS, s_r1, wave, lane);
-                pm = mask_of(it + 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            fwr_step<COLSUM>(s_d0, s_r0, s_m0, wh, wlo, bv, bitsel, acc, csum, m, g);
-            if (tid < 128) s_m1[tid] = pm;
-            dma_publish_barrier();
-            if (!more) break;
+#pragma unroll 1
+    for (int it = 0; it < steps; ++it) {
+        const int cur = it & 1;
+        const bool more = it + 1 < steps;
+        unsigned pm = 0;
+        if (more) {   // ---- 1. next step's images by LDS-DMA into the other buffer ----
+            fwr_dma(dimg + (size_t)(it + 1) * FWR_BLK_HALFS, s_t[cur ^ 1][0], wave, lane);
+            fwr_dma(rimg + (size_t)(it + 1) * FWR_BLK_HALFS, s_t[cur ^ 1][1], wave, lane);
+            pm = mask_of(it + 1);
         }
-        {   // odd step: buffers 1, refill of buffers 0
-            const bool more = it + 2 < steps;
-            unsigned pm = 0;
-            if (more) {
-                fwr_dma(dimg + (size_t)(it + 2) * FWR_BLK_HALFS, s_d0, wave, lane);
-                fwr_dma(rimg + (size_t)(it + 2) * FWR_BLK_HALFS, s_r0, wave, lane);
-                pm = mask_of(it + 2);
+        const unsigned boff = (unsigned)cur * FWR_BUF_BYTES;
+        const unsigned aa = a_addr0 + boff;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 2. recompute Z tiles (rt, e): D[row 4g+i of tile rt][hidden m of tile e]; the fragments of K step u+1
+        //      are requested before the MFMAs of step u ----
+        f32x4 z[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) z[rt][e] = f32x4{bv[e], bv[e], bv[e], bv[e]};
+        wl_half8 ah[2], al[2];
+        {
+            wl_half8 xh[2][2], xl[2][2];
+            {
+                const unsigned xa = x_addr0[0] + boff;
+                FWR_READ(xh[0][0], xa, 0); FWR_READ(xl[0][0], xa, 8192); FWR_READ(xh[0][1], xa, 4096); FWR_READ(xl[0][1], xa, 12288);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            fwr_step<COLSUM>(s_d1, s_r1, s_m1, wh, wlo, bv, bitsel, acc, csum, m, g);
-            if (tid < 128) s_m0[tid] = pm;
-            dma_publish_barrier();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cs = u & 1, ns = cs ^ 1;
+                if (u < 3) {
+                    const unsigned xa = x_addr0[u + 1] + boff;
+                    FWR_READ(xh[ns][0], xa, 0); FWR_READ(xl[ns][0], xa, 8192); FWR_READ(xh[ns][1], xa, 4096); FWR_READ(xl[ns][1], xa, 12288);
+                    FWR_WAIT4(4, xh[cs][0], xl[cs][0], xh[cs][1], xl[cs][1]);
+                } else {
+                    FWR_READ(ah[0], aa, 0); FWR_READ(al[0], aa, 8192);
+                    FWR_WAIT4(2, xh[cs][0], xl[cs][0], xh[cs][1], xl[cs][1]);
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wlo[e][u], z[rt][e], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        // activity bit, split: hidden unit (block-local) 32*wave + 16e + m -> mask byte `wave`, bit 4e + (m & 3) of dword
+        // g' = m >> 2 of the row; this lane's rows are 4g..4g+3 (tile 0) and 16+4g.. (tile 1)
+        wl_half8 zh[2], zl[2];
+        {
+            const uint4 mw0 = *reinterpret_cast<const uint4*>(&s_m[cur][(m >> 2) * 32 + 4 * g]);
+            const uint4 mw1 = *reinterpret_cast<const uint4*>(&s_m[cur][(m >> 2) * 32 + 16 + 4 * g]);
+            const unsigned mw[8] = {mw0.x, mw0.y, mw0.z, mw0.w, mw1.x, mw1.y, mw1.z, mw1.w};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    v[t] = (mw[t] & (bitsel0 << (4 * e))) ? z[t >> 2][e][t & 3] : 0.f;
+                    if (COLSUM) csum[e] += v[t];
+                }
+                s3d_split8(v, zh[e], zl[e]);
+            }
+        }
+        S3D_SPLIT_SETTLE();   // partial-register split results feed the MFMAs below straight from registers
+        // ---- 3. out[q tile i][own hidden tile e] += D^T Z, the A fragments one tile ahead ----
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cs = i & 1, ns = cs ^ 1;
+            if (i < 7) {
+                FWR_READ(ah[ns], aa, (i + 1) * 1024); FWR_READ(al[ns], aa, (i + 1) * 1024 + 8192);
+                FWR_WAIT2(2, ah[cs], al[cs]);
+            } else {
+                FWR_WAIT2(0, ah[cs], al[cs]);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zl[e], acc[i][e], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cs], zh[e], acc[i][e], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zh[e], acc[i][e], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tid < 128) s_m[cur ^ 1][tid] = pm;
+        dma_publish_barrier();   // the other buffer's images have landed; everyone is done with this one
     }
     // partial[split][q][hidden]: D[row = q 4g+reg][col = hidden m]
     float* part = a.partial + (size_t)split * 128 * S3D_FFN;
