@@ -82,14 +82,18 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #define SG_DSRD 0x100
 #define SG_VMEM 0x020
 
-// pieces [p0, p1) (1 KiB each) of one chunk image -> the same pieces of an LDS buffer, spread over the waves
+// pieces [p0, p1) (1 KiB each, p1 - p0 == 16) of one chunk image -> the same pieces of an LDS buffer: wave w copies
+// 16 / PIPE_WAVES consecutive pieces as LDS-DMA instructions that differ only in their immediate offset (one lane
+// address and one M0 value per call instead of a 64-bit add per piece)
 __device__ __forceinline__ void dma_pieces(const _Float16* gchunk, _Float16* lbuf, int p0, int p1, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 16 / PIPE_WAVES; ++i) {   // p1 - p0 == 16 pieces, wave-uniform LDS address (M0)
-        const int piece = p0 + wave + i * PIPE_WAVES;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gchunk + piece * 512 + lane * 8),
-                                         (__attribute__((address_space(3))) void*)(lbuf + piece * 512), 16, 0, 0);
-    }
+    constexpr int PER = 16 / PIPE_WAVES;
+    const int first = p0 + wave * PER;
+    const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(gchunk + first * 512 + lane * 8);
+    __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(lbuf + first * 512);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    if (PER > 1) __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+    if (PER > 2) __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+    if (PER > 3) __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
 }
 __device__ __forceinline__ half8 cat4(half2v a, half2v b, half2v c, half2v d) {
     typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -130,7 +134,8 @@ struct FfnBwdArgs {     // MODE 4
 struct FfnActState {
     unsigned mw[PIPE_R];               // MODE 2: bits of the 4-chunk group being produced; MODE 4: of the group being consumed
     unsigned mw_next[PIPE_R];          // MODE 4: next group's dword (requested one group ahead)
-    unsigned long long ctr[PIPE_R];    // MODE 2: dropout counter of (row, hidden unit 4g)
+    unsigned rm[PIPE_R];               // MODE 2: folded dropout counter of (row, hidden units 4g..4g+3) >> 2, see ffn_act4
+    unsigned key;                      // MODE 2: stream key of the hidden-dropout site
 };
 // D tile (a2, r2) of chunk c: pre-activation -> f16 hi/lo halves of GEMM2's B operand
 template <int MODE>
@@ -140,20 +145,34 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
         const float inf = __builtin_inff();
         float a[4] = {__builtin_amdgcn_fmed3f(v[0], 0.f, inf), __builtin_amdgcn_fmed3f(v[1], 0.f, inf),
                       __builtin_amdgcn_fmed3f(v[2], 0.f, inf), __builtin_amdgcn_fmed3f(v[3], 0.f, inf)};
-        if (MODE == 2) {   // hidden-unit dropout, counter = row*2048 + unit (a template mode, not a run-time branch: the
-                           // activation must stay in the MFMA group's basic block to be interleaved with it).  Drawing
-                           // the factors one phase earlier, under GEMM2, measured 2 % slower: the hashes (~550 VALU issue
-                           // slots per two chunks, 32-bit multiplies at quarter rate) exceed the 576 slots the 192 MFMAs
-                           // leave wherever they are placed — this mode is VALU-issue bound (MFMA pipe 53 % busy)
-            float mk4[4];
-            s3d_drop4(ta.dh, as.ctr[r2] + (unsigned)(c * S3D_FFN_CHUNK + 16 * a2), mk4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] *= mk4[i];
+        if (MODE == 2) {   // hidden-unit dropout (a template mode, not a run-time branch: the activation must stay in the
+                           // MFMA group's basic block to be interleaved with it).  This mode is VALU-issue bound (the
+                           // 192 MFMAs of two chunks leave 576 issue slots, 32-bit multiplies take four), so:
+                           //  * the counter (row*2048 + unit) >> 2 = row*512 | (8c + 4a + g) never carries into the row
+                           //    part: its fold is rm ^ (8c + 4a), one v_xad_u32 with the key instead of 64-bit adds and
+                           //    the high word's multiply — the same hash value s3d_drop4 computes;
+                           //  * a kept unit keeps its value here, the factor 1/(1-p) multiplies the finished sums in
+                           //    the epilogue (GEMM2 is linear in h);
+            const unsigned h = s3d_hash32_rounds((as.rm[r2] ^ (unsigned)(8 * c + 4 * a2)) + as.key), h2 = s3d_drop_remix(h);
+            a[0] = (h & 0xFFFFu) >= ta.dh.thresh ? a[0] : 0.f;
+            a[1] = (h >> 16) >= ta.dh.thresh ? a[1] : 0.f;
+            a[2] = (h2 & 0xFFFFu) >= ta.dh.thresh ? a[2] : 0.f;
+            a[3] = (h2 >> 16) >= ta.dh.thresh ? a[3] : 0.f;
         }
-        unsigned bits = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bits |= (a[i] > 0.f ? 1u : 0u) << i;
-        as.mw[r2] |= bits << (8 * (c & 3) + 4 * a2);
+        // activity bits of the four a >= 0: min(bits(a), 1) each, gathered into a nibble and deposited with one shift-or
+        // (asm: hipcc turns the min into a float class test + select + shift)
+        {
+            unsigned b0, b1, b2, b3;
+            asm("v_min_u32 %0, 1, %1" : "=v"(b0) : "v"(a[0]));
+            asm("v_min_u32 %0, 1, %1" : "=v"(b1) : "v"(a[1]));
+            asm("v_min_u32 %0, 1, %1" : "=v"(b2) : "v"(a[2]));
+            asm("v_min_u32 %0, 1, %1" : "=v"(b3) : "v"(a[3]));
+            asm("v_lshl_or_b32 %0, %1, 1, %0" : "+v"(b0) : "v"(b1));
+            asm("v_lshl_or_b32 %0, %1, 1, %0" : "+v"(b2) : "v"(b3));
+            asm("v_lshl_or_b32 %0, %1, 2, %0" : "+v"(b0) : "v"(b2));
+            const unsigned sh = (unsigned)(8 * (c & 3) + 4 * a2);
+            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(as.mw[r2]) : "v"(b0), "s"(sh));
+        }
         h0 = __builtin_convertvector(float2v{a[0], a[1]}, half2v);
         h1 = __builtin_convertvector(float2v{a[2], a[3]}, half2v);
         l0 = __builtin_convertvector(float2v{a[0] - (float)h0[0], a[1] - (float)h0[1]}, half2v);
@@ -226,7 +245,7 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
         if (!LAST) {                                                                                                 \
             _Pragma("unroll") for (int i = 0; i < (SINGLE ? 1 : 3) * PIPE_R; ++i) {                                  \
                 SGB(SG_MFMA, 1);                                                                                     \
-                SGB(SG_VALU, SINGLE ? 9 : (MODE == 2 ? 5 : 3));                                                      \
+                SGB(SG_VALU, SINGLE ? 9 : (MODE == 2 ? 4 : 3));                                                      \
             }                                                                                                        \
         }                                                                                                            \
         SB();                                                                                                        \
@@ -331,8 +350,12 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
         as.mw[r] = as.mw_next[r] = 0u;
-        as.ctr[r] = 0ull;
-        if (MODE == 2) as.ctr[r] = (unsigned long long)(row0 + r * 16 + m) * S3D_FFN + 4 * g;
+        as.rm[r] = 0u;
+        as.key = 0u;
+        if (MODE == 2) {
+            as.rm[r] = s3d_hash32_fold((unsigned long long)(row0 + r * 16 + m) * (S3D_FFN / 4)) ^ (unsigned)g;
+            as.key = s3d_stream_key(ta.dh.seed, ta.dh.site);
+        }
         if (MODE == 4) {   // activity bits: one dword per 4 chunks, the next group's requested one group ahead
             as.mw[r] = ba.M[row * 64 + g * 16];
             as.mw_next[r] = ba.M[row * 64 + g * 16 + 1];
@@ -455,7 +478,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int t = 4 * (j & 1) + i;
-                float f = acc[r][j][i] + b2[i];
+                float f = MODE == 2 ? acc[r][j][i] * ta.dh.scale + b2[i] : acc[r][j][i] + b2[i];   // hidden-dropout factor, see ffn_act4
                 if (MODE == 2) f *= mq4[i];
                 y[j][i] = f + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
                 s += y[j][i];

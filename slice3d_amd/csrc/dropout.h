@@ -33,8 +33,7 @@ __host__ __device__ inline unsigned s3d_stream_key(unsigned long long seed, int 
 // 32-bit mixing only (three multiply / xor-shift rounds of the murmur3 finaliser on the keyed counter; the key is
 // ADDED, the high index word multiplied in): the FFN forward draws 2 176 masks per token row, 64-bit multiplies there
 // cost a millisecond per layer.
-__host__ __device__ inline unsigned s3d_hash32(unsigned long long seed, int site, unsigned long long idx) {
-    unsigned x = ((unsigned)idx ^ ((unsigned)(idx >> 32) * 0x9E3779B1u)) + s3d_stream_key(seed, site);
+__host__ __device__ inline unsigned s3d_hash32_rounds(unsigned x) {
     x ^= x >> 16;
     x *= 0x85EBCA6Bu;
     x ^= x >> 13;
@@ -43,6 +42,14 @@ __host__ __device__ inline unsigned s3d_hash32(unsigned long long seed, int site
     x *= 0x9E3779B1u;
     x ^= x >> 15;
     return x;
+}
+// the keyed counter the rounds start from; a kernel that walks counters of the form base | small (no carry into base) can
+// precompute (unsigned)base ^ hi(base) * K once and XOR the small part in: s3d_hash32_rounds((that ^ small) + key)
+__host__ __device__ inline unsigned s3d_hash32_fold(unsigned long long idx) {
+    return (unsigned)idx ^ ((unsigned)(idx >> 32) * 0x9E3779B1u);
+}
+__host__ __device__ inline unsigned s3d_hash32(unsigned long long seed, int site, unsigned long long idx) {
+    return s3d_hash32_rounds(s3d_hash32_fold(idx) + s3d_stream_key(seed, site));
 }
 // One full hash serves FOUR consecutive elements (idx >> 2): two 16-bit fields of the hash word and two of a cheap
 // remix of it.  keep iff field >= thresh (thresh = round(p * 65536): p = 0.1 -> 6554 / 65536).  s3d_drop4 draws the four
