@@ -128,8 +128,10 @@ int launch_adam_table(const AdamTable& t, const float* g, float* m, float* v, fl
 
 // ---- decoder backward pieces ----
 // LayerNorm backward over rows of 128: du = LN'(u; gamma) dy ; dgamma/dbeta (+)= column sums
+// optional third output: dum = du * dropout mask (drop; dum == du allowed when drop->p == 0) and dsum[128] = its column sums
 int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du, long rows, float* dgamma,
-                  float* dbeta, int accumulate, float* partial, hipStream_t stream);
+                  float* dbeta, int accumulate, float* partial, hipStream_t stream, const DropCfg* drop = nullptr,
+                  float* dum = nullptr, float* dsum = nullptr);
 int launch_ln_fwd(const float* u, const float* gamma, const float* beta, float* y, long rows, hipStream_t stream);
 // attention core on stored QKV [groups][T][16][384] (q | k | v, 4 heads x 32): O [groups][T][16][128]
 int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, const DropCfg& drop, hipStream_t stream);

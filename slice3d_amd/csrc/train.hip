@@ -1873,13 +1873,19 @@ int launch_ln_fwd(const float* u, const float* gamma, const float* beta, float* 
 }
 
 #define LN_BLOCKS 1024
+// DUM: also writes dum = du * dropout mask of (row, channel) (the gradient w.r.t. the pre-dropout branch output that
+// the layer's GEMMs consume; dum == du without dropout, then only its column sums are new) and the column sums of dum
+// (the bias gradient of the linear layer in front of the dropout) — one pass instead of ln_bwd + dropout_apply + colsum
+template <bool DUM>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gamma,
                                                      const float* __restrict__ dy, float* __restrict__ du, long rows,
-                                                     float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float s_g[8][128], s_b[8][128];
+                                                     float* __restrict__ partial, const DropCfg drop,
+                                                     float* __restrict__ dum) {
+    constexpr int NP = DUM ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float s_p[NP][8][128];
     const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
     const f32x4 ga = ld4(gamma + 4 * l);
-    f32x4 dg = zero4(), db = zero4();
+    f32x4 dg = zero4(), db = zero4(), dm = zero4();
     for (long row = (long)blockIdx.x * 8 + sub; row < rows; row += (long)gridDim.x * 8) {
         const f32x4 v = ld4(u + row * 128 + 4 * l);
         const f32x4 g = ld4(dy + row * 128 + 4 * l);
@@ -1891,34 +1897,55 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ u
         const f32x4 gx = g * ga;
         const float m1 = half_sum((gx[0] + gx[1]) + (gx[2] + gx[3])) * (1.f / 128.f);
         const float m2 = half_sum(gx[0] * xh[0] + gx[1] * xh[1] + gx[2] * xh[2] + gx[3] * xh[3]) * (1.f / 128.f);
-        st4(du + row * 128 + 4 * l, (gx - m1 - xh * m2) * rstd);
+        const f32x4 r = (gx - m1 - xh * m2) * rstd;
+        st4(du + row * 128 + 4 * l, r);
         dg += g * xh;
         db += g;
+        if (DUM) {
+            f32x4 rm = r;
+            if (drop.p > 0.f) {
+                float mk[4];
+                s3d_drop4(drop, (unsigned long long)row * 128 + 4 * l, mk);
+                rm = f32x4{r[0] * mk[0], r[1] * mk[1], r[2] * mk[2], r[3] * mk[3]};
+                st4(dum + row * 128 + 4 * l, rm);
+            }
+            dm += rm;
+        }
     }
-    st4(&s_g[sub][4 * l], dg);
-    st4(&s_b[sub][4 * l], db);
+    st4(&s_p[0][sub][4 * l], dg);
+    st4(&s_p[1][sub][4 * l], db);
+    if (DUM) st4(&s_p[NP - 1][sub][4 * l], dm);
     __syncthreads();
     if (threadIdx.x < 128) {
-        float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            a += s_g[k][threadIdx.x];
-            b += s_b[k][threadIdx.x];
+        for (int q = 0; q < NP; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += s_p[q][k][threadIdx.x];
+            partial[(size_t)blockIdx.x * (128 * NP) + 128 * q + threadIdx.x] = acc;
         }
-        partial[(size_t)blockIdx.x * 256 + threadIdx.x] = a;
-        partial[(size_t)blockIdx.x * 256 + 128 + threadIdx.x] = b;
     }
 }
+// dum / dsum: optional third output (see the kernel): dum may equal du when drop.p == 0; dsum[128] = column sums of dum
 int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du, long rows, float* dgamma,
-                  float* dbeta, int accumulate, float* partial, hipStream_t stream) {
+                  float* dbeta, int accumulate, float* partial, hipStream_t stream, const DropCfg* drop, float* dum,
+                  float* dsum) {
     if (rows <= 0) return 0;
     const int nb = (int)((rows + 7) / 8 < LN_BLOCKS ? (rows + 7) / 8 : LN_BLOCKS);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, u, gamma, dy, du, rows, partial);
+    const bool third = dsum != nullptr;
+    S3D_CHECK_ARG(!third || (drop && (drop->p <= 0.f || (dum && dum != du))), "ln_bwd: dropped output needs its own buffer");
+    const int np = third ? 3 : 2;
+    if (third)
+        hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nb), dim3(256), 0, stream, u, gamma, dy, du, rows, partial, *drop, dum);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nb), dim3(256), 0, stream, u, gamma, dy, du, rows, partial,
+                           make_drop(0, 0.f, 0), nullptr);
     S3D_LAUNCH_CHECK();
-    // partial rows are [block][256] = dgamma(128) | dbeta(128)
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(4), dim3(1024), 0, stream, partial, nb, 256, 1.f, partial + (size_t)nb * 256, 0);
+    // partial rows are [block][128 np] = dgamma(128) | dbeta(128) [| dsum(128)]
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((128 * np + 63) / 64), dim3(1024), 0, stream, partial, nb, 128 * np, 1.f,
+                       partial + (size_t)nb * 128 * np, 0);
     S3D_LAUNCH_CHECK();
-    float* fin = partial + (size_t)nb * 256;
+    float* fin = partial + (size_t)nb * 128 * np;
     if (accumulate) {
         TRY_RET(launch_axpy(dgamma, fin, 1.f, 128, stream));
         TRY_RET(launch_axpy(dbeta, fin + 128, 1.f, 128, stream));
@@ -1928,6 +1955,10 @@ int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du
             s3d_set_error("ln_bwd: memcpy failed");
             return (int)hipErrorUnknown;
         }
+    }
+    if (third && hipMemcpyAsync(dsum, fin + 256, 128 * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+        s3d_set_error("ln_bwd: memcpy failed");
+        return (int)hipErrorUnknown;
     }
     return 0;
 }
