@@ -1973,6 +1973,24 @@ int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du
 #define ATT_LD 36
 #define ATT_THREADS 256
 
+// the same copy in two halves — global -> registers (issued a phase early, so that its latency runs under the compute of
+// the phase in between), registers -> LDS: T*16*8 16-byte pieces over 256 threads = up to 7 per thread
+#define ATT_PF 7
+__device__ __forceinline__ void att_fetch(const float* __restrict__ src, int src_ld, int coff, int T, f32x4 (&r)[ATT_PF]) {
+#pragma unroll
+    for (int k = 0; k < ATT_PF; ++k) {
+        const int i = threadIdx.x + ATT_THREADS * k;
+        const int ic = i < T * 128 ? i : T * 128 - 1;
+        r[k] = ld4(src + (long)(ic >> 3) * src_ld + coff + 4 * (ic & 7));
+    }
+}
+__device__ __forceinline__ void att_put(const f32x4 (&r)[ATT_PF], int T, float* dst) {
+#pragma unroll
+    for (int k = 0; k < ATT_PF; ++k) {
+        const int i = threadIdx.x + ATT_THREADS * k;
+        if (i < T * 128) st4(dst + (i >> 3) * ATT_LD + 4 * (i & 7), r[k]);
+    }
+}
 // rows [T*16][32] of one head (column offset coff in the 384/128-wide source) -> LDS [row][ATT_LD]
 __device__ __forceinline__ void att_stage(const float* __restrict__ src, int src_ld, int coff, int T, float* dst) {
     for (int i = threadIdx.x; i < T * 16 * 8; i += ATT_THREADS) {
@@ -1981,25 +1999,42 @@ __device__ __forceinline__ void att_stage(const float* __restrict__ src, int src
     }
 }
 
-__global__ __launch_bounds__(ATT_THREADS) void attn_core_fwd_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_core_fwd_kernel(const float* __restrict__ qkv,
                                                                     float* __restrict__ o, long groups, int T,
                                                                     const DropCfg drop) {
     __shared__ __attribute__((aligned(16))) float sK[S3D_N_TOKENS_MAX * 16 * ATT_LD], sV[S3D_N_TOKENS_MAX * 16 * ATT_LD];
     const int tid = threadIdx.x;
     const int ql = tid & 15, tq = tid >> 4;
+    // the next task's K / V pieces are requested before this task's compute and parked in LDS after it (the kernel moves
+    // 10.7 GB per call and used to expose every load: stage -> barrier -> compute -> barrier)
+    f32x4 pk[ATT_PF], pv[ATT_PF];
+    if ((long)blockIdx.x < groups * 4) {
+        const float* b0 = qkv + ((long)blockIdx.x >> 2) * T * 16 * 384;
+        att_fetch(b0, 384, 128 + 32 * (int)(blockIdx.x & 3), T, pk);
+        att_fetch(b0, 384, 256 + 32 * (int)(blockIdx.x & 3), T, pv);
+    }
     for (long task = blockIdx.x; task < groups * 4; task += gridDim.x) {
         const long grp = task >> 2;
         const int h = (int)(task & 3);
         const float* base = qkv + grp * T * 16 * 384;
         __syncthreads();
-        att_stage(base, 384, 128 + 32 * h, T, sK);
-        att_stage(base, 384, 256 + 32 * h, T, sV);
-        __syncthreads();
-        if (tq >= T) continue;
-        const float* qrow = base + (tq * 16 + ql) * 384 + 32 * h;
+        att_put(pk, T, sK);
+        att_put(pv, T, sV);
+        const bool on = tq < T;
+        const float* qrow = base + ((on ? tq : 0) * 16 + ql) * 384 + 32 * h;
         f32x4 qv[8];
 #pragma unroll
         for (int d = 0; d < 8; ++d) qv[d] = ld4(qrow + 4 * d);
+        {
+            const long nt = task + gridDim.x;
+            if (nt < groups * 4) {
+                const float* nb = qkv + (nt >> 2) * T * 16 * 384;
+                att_fetch(nb, 384, 128 + 32 * (int)(nt & 3), T, pk);
+                att_fetch(nb, 384, 256 + 32 * (int)(nt & 3), T, pv);
+            }
+        }
+        __syncthreads();
+        if (!on) continue;
         float sc[S3D_N_TOKENS_MAX];
         float mx = -1e30f;
 #pragma unroll
@@ -2054,7 +2089,7 @@ int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, const D
 // backward: phase A (thread = (ql, tq), K/V of the head in LDS): P row, dS row -> LDS, dQ row -> global;
 //           phase B (thread = (ql, tk), Q/dO of the head restaged into the same LDS):
 //           dK[tk] = sum_tq dS[tq][tk] Q[tq] * scale,  dV[tk] = sum_tq P[tq][tk] dO[tq]
-__global__ __launch_bounds__(ATT_THREADS) void attn_core_bwd_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_core_bwd_kernel(const float* __restrict__ qkv,
                                                                     const float* __restrict__ d_o,
                                                                     float* __restrict__ dqkv, long groups, int T,
                                                                     const DropCfg drop) {
@@ -2063,6 +2098,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_core_bwd_kernel(const float*
     const int tid = threadIdx.x;
     const int ql = tid & 15, tt = tid >> 4;
     const bool act = tt < T;
+    // K / V of the NEXT task are requested before phase B and parked in LDS at the top of the next trip (their latency runs
+    // under phase B; prefetching Q / dO under phase A as well needs 56 more registers there and spilled): the kernel moves
+    // 18.7 GB per call and used to expose every load
+    f32x4 pa[ATT_PF];
+    if ((long)blockIdx.x < groups * 4)
+        att_fetch(qkv + ((long)blockIdx.x >> 2) * T * 16 * 384, 384, 128 + 32 * (int)(blockIdx.x & 3), T, pa);
     for (long task = blockIdx.x; task < groups * 4; task += gridDim.x) {
         const long grp = task >> 2;
         const int h = (int)(task & 3);
@@ -2070,7 +2111,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_core_bwd_kernel(const float*
         const float* dob = d_o + grp * T * 16 * 128;
         float* dbase = dqkv + grp * T * 16 * 384;
         __syncthreads();
-        att_stage(base, 384, 128 + 32 * h, T, sA);   // K
+        att_put(pa, T, sA);                          // K (requested one task ahead)
         att_stage(base, 384, 256 + 32 * h, T, sB);   // V
         __syncthreads();
         if (act) {  // phase A, tq = tt
@@ -2143,6 +2184,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_core_bwd_kernel(const float*
         __syncthreads();
         att_stage(base, 384, 32 * h, T, sA);   // Q
         att_stage(dob, 128, 32 * h, T, sB);    // dO
+        {
+            const long nt = task + gridDim.x;
+            if (nt < groups * 4) {
+                att_fetch(qkv + (nt >> 2) * T * 16 * 384, 384, 128 + 32 * (int)(nt & 3), T, pa);
+            }
+        }
         __syncthreads();
         if (act) {  // phase B, tk = tt
             f32x4 dk[8], dv[8];
