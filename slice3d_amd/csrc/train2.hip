@@ -324,8 +324,10 @@ __device__ __forceinline__ TapL make_taps_l(float gx, float gy, int W, int ox, i
     return t;
 }
 
+#define SBT_THREADS 512    // 8 waves share one tile's LDS accumulators (147 KiB: one workgroup per CU); 1024 threads measured the
+                           // same 15.4 ms: the kernel is bound by its LDS float adds, not by latency
 template <int GT>
-__global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdArgs a, const SbtGeom G) {
+__global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const SampleBwdArgs a, const SbtGeom G) {
     using LV = SbLevels<GT>;
     constexpr int NU = LV::NU;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -337,8 +339,8 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
     const int* ends = a.bin_ends + (long)b * 65536;
     const long qs_lo = tile ? ends[256 * tile - 1] : 0, qs_hi = ends[256 * tile + 255];
     if (qs_lo >= qs_hi) return;
-    for (int i = threadIdx.x; i < NU * 8 * 64; i += 512) st4(s_wt + 4 * i, ld4(a.ws34_t + 4 * i));
-    for (int i = threadIdx.x; i < G.total / 4; i += 512) st4(s_acc + 4 * i, zero4());
+    for (int i = threadIdx.x; i < NU * 8 * 64; i += SBT_THREADS) st4(s_wt + 4 * i, ld4(a.ws34_t + 4 * i));
+    for (int i = threadIdx.x; i < G.total / 4; i += SBT_THREADS) st4(s_acc + 4 * i, zero4());
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
     }
     const long img = (long)b * a.n_slices + ts;
     const float* Tm = a.trans + b * 12;
-    for (long gi = qs_lo / 16 + wave; gi * 16 < qs_hi; gi += 8) {
+    for (long gi = qs_lo / 16 + wave; gi * 16 < qs_hi; gi += SBT_THREADS / 64) {
         const long qs = gi * 16 + m;
         const bool qv = qs >= qs_lo && qs < qs_hi;
         // lanes outside the tile's range carry zero gradients; they borrow a valid neighbour's coordinates so
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(512) void sample_bwd_tiled_kernel(const SampleBwdAr
         const int C = G.C[l], fw = G.fw[l], W = G.W[l];
         float* gmap = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + img * (long)W * W * C;
         const int c4 = C >> 2, n4 = fw * fw * c4;
-        for (int i = threadIdx.x; i < n4; i += 512) {
+        for (int i = threadIdx.x; i < n4; i += SBT_THREADS) {
             const f32x4 v = ld4(s_acc + G.off[l] + 4 * i);
             if (v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f) continue;
             const int pix = i / c4, c = (i - pix * c4) * 4;
@@ -494,7 +496,7 @@ static int launch_sample_bwd_t(const SampleBwdArgs& a, hipStream_t stream) {
                 attr_set = true;
             }
             const long batch = a.groups / a.groups_per_batch;
-            hipLaunchKernelGGL(sample_bwd_tiled_kernel<GT>, dim3((unsigned)(batch * a.n_slices * 256)), dim3(512), lds,
+            hipLaunchKernelGGL(sample_bwd_tiled_kernel<GT>, dim3((unsigned)(batch * a.n_slices * 256)), dim3(SBT_THREADS), lds,
                                stream, a, G);
             S3D_LAUNCH_CHECK();
             return 0;
