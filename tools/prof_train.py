@@ -11,3 +11,9 @@ fd = make_feed_dict(int(os.environ.get("S3D_B", "4")), 256, 100000, 12, seed=1, 
 for _ in range(3):
     print(tr.train_step(fd))
 torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(5):
+    tr.train_step(fd)
+torch.cuda.synchronize()
+print("train step wall time: %.1f ms (5 steps)" % ((time.perf_counter() - t0) / 5 * 1e3))
