@@ -93,3 +93,35 @@ def test_seeded_weights_are_deterministic():
     assert (a == b).all() and (a != seeded_array("fc_s.weight", (128, 992), 1)).any()
     m = load_seeded(Slices3DRegModel(n_slices=12, backend="none"))
     assert float(m.vggptlossfunc.mean.flatten()[0]) == pytest.approx(0.485)
+
+
+def test_bench_self_launch_builds_a_torchrun_job(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself as an N-rank torch.distributed.run job on
+    127.0.0.1 with a free port and forwards every argument (the driver's single-command form); with WORLD_SIZE set it
+    does not."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
