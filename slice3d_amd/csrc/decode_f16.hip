@@ -100,16 +100,22 @@ __device__ __forceinline__ half8 cat4(half2v a, half2v b, half2v c, half2v d) {
     const half4v ab = __builtin_shufflevector(a, b, 0, 1, 2, 3), cd = __builtin_shufflevector(c, d, 0, 1, 2, 3);
     return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// hi/lo halves of four values, 1.5 VALU per value (s3d_split2: v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16, bit-identical to
+// convert - subtract - convert).  The partial-register results feed MFMAs a whole phase later: no settle needed here.
+__device__ __forceinline__ void split4_pk(float a0, float a1, float a2, float a3, half2v& h0, half2v& h1, half2v& l0, half2v& l1) {
+    unsigned uh0, ul0, uh1, ul1;
+    s3d_split2(a0, a1, uh0, ul0);
+    s3d_split2(a2, a3, uh1, ul1);
+    h0 = __builtin_bit_cast(half2v, uh0); l0 = __builtin_bit_cast(half2v, ul0);
+    h1 = __builtin_bit_cast(half2v, uh1); l1 = __builtin_bit_cast(half2v, ul1);
+}
 // relu + split of the 4 pre-activations of one D tile: hi = f16(max(v,0)), lo = f16(max(v,0) - hi)
 __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h1, half2v& l0, half2v& l1) {
     // relu as one v_med3_f32 (fmaxf on an MFMA result costs a canonicalising v_max first)
     const float inf = __builtin_inff();
     const float a0 = __builtin_amdgcn_fmed3f(v[0], 0.f, inf), a1 = __builtin_amdgcn_fmed3f(v[1], 0.f, inf),
                 a2 = __builtin_amdgcn_fmed3f(v[2], 0.f, inf), a3 = __builtin_amdgcn_fmed3f(v[3], 0.f, inf);
-    h0 = __builtin_convertvector(float2v{a0, a1}, half2v);
-    h1 = __builtin_convertvector(float2v{a2, a3}, half2v);
-    l0 = __builtin_convertvector(float2v{a0 - (float)h0[0], a1 - (float)h0[1]}, half2v);
-    l1 = __builtin_convertvector(float2v{a2 - (float)h1[0], a3 - (float)h1[1]}, half2v);
+    split4_pk(a0, a1, a2, a3, h0, h1, l0, l1);
 }
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
@@ -173,19 +179,13 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
             const unsigned sh = (unsigned)(8 * (c & 3) + 4 * a2);
             asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(as.mw[r2]) : "v"(b0), "s"(sh));
         }
-        h0 = __builtin_convertvector(float2v{a[0], a[1]}, half2v);
-        h1 = __builtin_convertvector(float2v{a[2], a[3]}, half2v);
-        l0 = __builtin_convertvector(float2v{a[0] - (float)h0[0], a[1] - (float)h0[1]}, half2v);
-        l1 = __builtin_convertvector(float2v{a[2] - (float)h1[0], a[3] - (float)h1[1]}, half2v);
+        split4_pk(a[0], a[1], a[2], a[3], h0, h1, l0, l1);
     } else if (MODE == 4) {
         const unsigned bits = as.mw[r2] >> (8 * (c & 3) + 4 * a2);
         float a[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = ((bits >> i) & 1u) ? v[i] * ba.gate_scale : 0.f;
-        h0 = __builtin_convertvector(float2v{a[0], a[1]}, half2v);
-        h1 = __builtin_convertvector(float2v{a[2], a[3]}, half2v);
-        l0 = __builtin_convertvector(float2v{a[0] - (float)h0[0], a[1] - (float)h0[1]}, half2v);
-        l1 = __builtin_convertvector(float2v{a[2] - (float)h1[0], a[3] - (float)h1[1]}, half2v);
+        split4_pk(a[0], a[1], a[2], a[3], h0, h1, l0, l1);
     } else {
         relu_split4(v, h0, h1, l0, l1);
     }

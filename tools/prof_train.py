@@ -6,7 +6,7 @@ from slice3d_amd.weights import load_seeded
 from slice3d_amd.synth import make_feed_dict
 m = load_seeded(Slices3DRegModel(n_slices=12, mode="train"), 0).cuda()
 tr = HipTrainer(m, prec=os.environ.get('S3D_PREC', 'f16x3'))
-tr.dropout = 0.1
+tr.dropout = float(os.environ.get('S3D_DROPOUT', '0.1'))
 fd = make_feed_dict(int(os.environ.get("S3D_B", "4")), 256, 100000, 12, seed=1, device="cuda")
 for _ in range(3):
     print(tr.train_step(fd))
