@@ -324,15 +324,36 @@ __device__ __forceinline__ TapL make_taps_l(float gx, float gy, int W, int ox, i
     return t;
 }
 
-#define SBT_THREADS 512    // 8 waves share one tile's LDS accumulators (147 KiB: one workgroup per CU); 1024 threads measured the
-                           // same 15.4 ms: the kernel is bound by its LDS float adds, not by latency
+#define SBT_THREADS 512    // 8 waves per (object, slice, tile); 1024 threads measured the same on the LDS-add form of round 2
+#define SBT_CHUNK 64       // queries per MFMA chunk of the folded levels (16 k-steps of 4)
+// M tiles (16 footprint pixels each) of the folded levels at S <= 256: footprint widths 3, 4, 6 (, 10) -> 1, 1, 3 (, 7) tiles
+template <int GT>
+struct SbFold {
+    static constexpr int NF = GT ? 4 : 3;                       // folded 128-channel levels: the MFMA path
+    static constexpr int NMT = GT ? 12 : 5;                     // accumulator tiles per wave
+    __host__ __device__ static constexpr int mt0(int l) { return l == 0 ? 0 : l == 1 ? 1 : l == 2 ? 2 : 5; }
+    __host__ __device__ static constexpr int nmt(int l) { return l < 2 ? 1 : l == 2 ? 3 : 7; }
+};
+
+// Round 3.  The FOLDED levels (three — GT: four — coarse 128-channel maps) no longer go through LDS adds.  All queries of a
+// tile hit the same few pixels there (3 x 3 / 4 x 4 / 6 x 6 at 256^2), so their scatter is a small dense product
+//     dMap[pix][c] = sum_q w[q][pix] * dX[q][c]
+// and runs on the fp32 MFMA (exact products, fp32 accumulate): wave j owns channels 16j..16j+15 of every folded level, a
+// k-step is four queries (A[pix m][query g] = the query's bilinear weight on footprint pixel m — built from the four
+// (pixel, weight) taps a cooperative pass parks in LDS per 64-query chunk; B[query g][channel m] straight from dX), the
+// accumulators (5 / 12 tiles of 16 pixels) stay in registers for the whole tile and are flushed with one global atomic per
+// element.  That form cost 1 536 ds_add_f32 per (query, slice) row before — 3/4 of the kernel's 15.5 ms.  The RAW levels
+// (64 / 32 channels at S/2 and S: every query has its own pixels) keep the run-reduced LDS adds below.
 template <int GT>
 __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const SampleBwdArgs a, const SbtGeom G) {
     using LV = SbLevels<GT>;
-    constexpr int NU = LV::NU;
+    using FD = SbFold<GT>;
+    constexpr int NU = LV::NU, NF = FD::NF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_wt = smem;                  // W_raw^T fragment image [NU][8]
-    float* s_acc = smem + NU * 8 * 256;  // per-level footprint accumulators
+    float* s_acc = smem + NU * 8 * 256;  // footprint accumulators of the RAW levels
+    int* s_tidx = reinterpret_cast<int*>(s_acc + G.total);          // [NF][SBT_CHUNK][4] footprint pixel of each tap, or -1
+    float* s_tw = reinterpret_cast<float*>(s_tidx + NF * SBT_CHUNK * 4);   // [NF][SBT_CHUNK][4] its weight
     const int tile = blockIdx.x & 255;
     const int ts = (blockIdx.x >> 8) % a.n_slices;
     const int b = (blockIdx.x >> 8) / a.n_slices;
@@ -354,13 +375,9 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
     }
     const long img = (long)b * a.n_slices + ts;
     const float* Tm = a.trans + b * 12;
-    for (long gi = qs_lo / 16 + wave; gi * 16 < qs_hi; gi += SBT_THREADS / 64) {
-        const long qs = gi * 16 + m;
-        const bool qv = qs >= qs_lo && qs < qs_hi;
-        // lanes outside the tile's range carry zero gradients; they borrow a valid neighbour's coordinates so
-        // that they do not break the row-uniformity test below
-        const long qsc = qs < qs_lo ? qs_lo : (qs >= qs_hi ? qs_hi - 1 : qs);
-        const long q = a.perm[(long)b * a.n_qry + qsc];
+    // image coordinates of sorted slot qs of this object (clamped into the tile's range by the caller)
+    auto project_slot = [&](long qs, float& gx, float& gy) {
+        const long q = a.perm[(long)b * a.n_qry + qs];
         const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
         float x = p[0], y = p[1], z = p[2];
         if (a.flip_yz) {
@@ -375,8 +392,20 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
         const float X = x * Tm[0] + y * Tm[3] + z * Tm[6] + Tm[9];
         const float Y = x * Tm[1] + y * Tm[4] + z * Tm[7] + Tm[10];
         const float Z = x * Tm[2] + y * Tm[5] + z * Tm[8] + Tm[11];
-        const float gx = fminf(fmaxf(2.f * (X / Z - 0.5f), -1.f), 1.f);
-        const float gy = fminf(fmaxf(2.f * (Y / Z - 0.5f), -1.f), 1.f);
+        gx = fminf(fmaxf(2.f * (X / Z - 0.5f), -1.f), 1.f);
+        gy = fminf(fmaxf(2.f * (Y / Z - 0.5f), -1.f), 1.f);
+    };
+    auto row_of = [&](long qs) { return ((((long)b * a.groups_per_batch + (qs >> 4)) * T + t) * S3D_GROUP + (qs & 15)) * 128; };
+
+    // ================= raw levels: W_raw^T product + run-reduced LDS adds, one 16-query group per wave =================
+    for (long gi = qs_lo / 16 + wave; gi * 16 < qs_hi; gi += SBT_THREADS / 64) {
+        const long qs = gi * 16 + m;
+        const bool qv = qs >= qs_lo && qs < qs_hi;
+        // lanes outside the tile's range carry zero gradients; they borrow a valid neighbour's coordinates so
+        // that they do not break the row-uniformity test below
+        const long qsc = qs < qs_lo ? qs_lo : (qs >= qs_hi ? qs_hi - 1 : qs);
+        float gx, gy;
+        project_slot(qsc, gx, gy);
         const float* dp = a.dX + ((((long)b * a.groups_per_batch + gi) * T + t) * S3D_GROUP + m) * 128 + 4 * g;
         f32x4 dt[8];
 #pragma unroll
@@ -390,7 +419,7 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
             draw[u] = c;
         }
 #pragma unroll
-        for (int l = 0; l < 5; ++l) {
+        for (int l = NF; l < 5; ++l) {
             const int C = LV::C(l);
             const int nv = C / 16;
             const TapL tp = make_taps_l(gx, gy, G.W[l], ox[l], oy[l], G.fw[l]);
@@ -424,7 +453,7 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
                     const bool wr = tail && tp.ok[k];
 #pragma unroll
                     for (int j = 0; j < nv; ++j) {
-                        f32x4 v = (LV::folded(l) ? dt[j] : draw[LV::draw0(l) + j]) * tp.w[k];
+                        f32x4 v = draw[LV::draw0(l) + j] * tp.w[k];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             float x = v[i];
@@ -444,22 +473,94 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
                     if (tp.lofs[k] >= 0) {
                         float* o = lbase + tp.lofs[k] * C;
 #pragma unroll
-                        for (int j = 0; j < nv; ++j)
-                            atomic_add4(o + 16 * j, (LV::folded(l) ? dt[j] : draw[LV::draw0(l) + j]) * tp.w[k]);
+                        for (int j = 0; j < nv; ++j) atomic_add4(o + 16 * j, draw[LV::draw0(l) + j] * tp.w[k]);
                     } else {   // rounding put the tap one pixel outside the footprint: global atomic
                         float* o = gbase + (long)tp.gofs[k] * C;
 #pragma unroll
-                        for (int j = 0; j < nv; ++j)
-                            atomic_add4(o + 16 * j, (LV::folded(l) ? dt[j] : draw[LV::draw0(l) + j]) * tp.w[k]);
+                        for (int j = 0; j < nv; ++j) atomic_add4(o + 16 * j, draw[LV::draw0(l) + j] * tp.w[k]);
                     }
                 }
             }
         }
     }
-    __syncthreads();
-    // flush the footprints (skip untouched entries)
+
+    // ================= folded levels: dMap[pix][c] = sum_q w[q][pix] dX[q][c] on the fp32 MFMA =================
+    f32x4 accm[FD::NMT];
 #pragma unroll
-    for (int l = 0; l < 5; ++l) {
+    for (int i = 0; i < FD::NMT; ++i) accm[i] = zero4();
+    for (long c0 = qs_lo; c0 < qs_hi; c0 += SBT_CHUNK) {
+        __syncthreads();   // the previous chunk's taps have been consumed
+        if (threadIdx.x < NF * SBT_CHUNK) {   // thread = (level, query of the chunk): its four taps -> LDS
+            const int l = threadIdx.x / SBT_CHUNK, qq = threadIdx.x % SBT_CHUNK;
+            const long qs = c0 + qq;
+            int ti[4] = {-1, -1, -1, -1};
+            float tw[4] = {0.f, 0.f, 0.f, 0.f};
+            if (qs < qs_hi) {
+                float gx, gy;
+                project_slot(qs, gx, gy);
+                const TapL tp = make_taps_l(gx, gy, G.W[l], ox[l], oy[l], G.fw[l]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!tp.ok[k] || tp.w[k] == 0.f) continue;
+                    if (tp.lofs[k] >= 0) {
+                        ti[k] = tp.lofs[k];
+                        tw[k] = tp.w[k];
+                    } else {   // rounding put the tap one pixel outside the footprint (rare): this thread adds the row itself
+                        float* o = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + (img * (long)G.W[l] * G.W[l] + tp.gofs[k]) * 128;
+                        const float* xr = a.dX + row_of(qs);
+                        for (int c = 0; c < 128; ++c) unsafeAtomicAdd(o + c, xr[c] * tp.w[k]);
+                    }
+                }
+            }
+            *reinterpret_cast<int4*>(s_tidx + (l * SBT_CHUNK + qq) * 4) = int4{ti[0], ti[1], ti[2], ti[3]};
+            st4(s_tw + (l * SBT_CHUNK + qq) * 4, f32x4{tw[0], tw[1], tw[2], tw[3]});
+        }
+        // B operands of the chunk's 16 k-steps: dX[query 4 step + g][channel 16 wave + m]
+        float bfr[SBT_CHUNK / 4];
+#pragma unroll
+        for (int st = 0; st < SBT_CHUNK / 4; ++st) {
+            long qs = c0 + 4 * st + g;
+            qs = qs < qs_hi ? qs : qs_hi - 1;      // weights of slots past the end are zero
+            bfr[st] = a.dX[row_of(qs) + 16 * wave + m];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < SBT_CHUNK / 4; ++st) {
+#pragma unroll
+            for (int l = 0; l < NF; ++l) {
+                const int4 ti = *reinterpret_cast<const int4*>(s_tidx + (l * SBT_CHUNK + 4 * st + g) * 4);
+                const f32x4 tw = ld4(s_tw + (l * SBT_CHUNK + 4 * st + g) * 4);
+#pragma unroll
+                for (int k = 0; k < FD::nmt(l); ++k) {
+                    const int pm = m + 16 * k;
+                    const float wa = (ti.x == pm ? tw[0] : 0.f) + (ti.y == pm ? tw[1] : 0.f) + (ti.z == pm ? tw[2] : 0.f) +
+                                     (ti.w == pm ? tw[3] : 0.f);
+                    accm[FD::mt0(l) + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, bfr[st], accm[FD::mt0(l) + k], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D[row = pixel 16k + 4g + i][col = channel 16 wave + m] -> one global atomic per touched element
+#pragma unroll
+    for (int l = 0; l < NF; ++l) {
+        const int W = G.W[l], fw = G.fw[l];
+        float* gmap = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + img * (long)W * W * 128 + 16 * wave + m;
+#pragma unroll
+        for (int k = 0; k < FD::nmt(l); ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pix = 16 * k + 4 * g + i;
+                const float v = accm[FD::mt0(l) + k][i];
+                if (pix < fw * fw && v != 0.f) {
+                    const int y = oy[l] + pix / fw, x = ox[l] + pix % fw;
+                    if (x < W && y < W) unsafeAtomicAdd(gmap + ((long)y * W + x) * 128, v);
+                }
+            }
+    }
+    __syncthreads();
+    // flush the raw levels' footprints (skip untouched entries)
+#pragma unroll
+    for (int l = NF; l < 5; ++l) {
         const int C = G.C[l], fw = G.fw[l], W = G.W[l];
         float* gmap = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + img * (long)W * W * C;
         const int c4 = C >> 2, n4 = fw * fw * c4;
@@ -476,19 +577,22 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
 template <int GT>
 static int launch_sample_bwd_t(const SampleBwdArgs& a, hipStream_t stream) {
     using LV = SbLevels<GT>;
+    using FD = SbFold<GT>;
     if (a.perm && a.bin_ends) {
         SbtGeom G;
         int off = 0;
+        bool fits = true;
         for (int l = 0; l < 5; ++l) {
             G.W[l] = a.size >> (4 - l);
             G.C[l] = LV::C(l);
             G.fw[l] = (16 * (G.W[l] - 1) + 254) / 255 + 2;
             G.off[l] = off;
-            off += G.fw[l] * G.fw[l] * G.C[l];
+            if (l >= FD::NF) off += G.fw[l] * G.fw[l] * G.C[l];                   // raw levels: LDS accumulators
+            else fits = fits && G.fw[l] * G.fw[l] <= 16 * FD::nmt(l);             // folded levels: register tiles
         }
         G.total = off;
-        const size_t lds = (size_t)(LV::NU * 8 * 256 + off) * sizeof(float);
-        if (lds <= 160 * 1024) {
+        const size_t lds = (size_t)(LV::NU * 8 * 256 + off + 2 * FD::NF * SBT_CHUNK * 4) * sizeof(float);
+        if (fits && lds <= 160 * 1024) {
             static bool attr_set = false;
             if (!attr_set) {
                 (void)hipFuncSetAttribute((const void*)sample_bwd_tiled_kernel<GT>,
