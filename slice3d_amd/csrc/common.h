@@ -111,6 +111,43 @@ __device__ __forceinline__ void s3d_split4(const f32x4 a, s3d_half4& hi, s3d_hal
     asm volatile("s_nop 15" ::: "memory");          \
     __builtin_amdgcn_sched_barrier(0);
 
+// Full-line stores out of the swapped-form accumulator layout.  Lane (m = row, g) of a D tile holds 4 consecutive output
+// channels, so one store instruction writes 64-byte runs of 16 rows, and the two tiles nt = 0, 1 that complete a row's
+// 128-byte line go out in different instructions.  Exchanging the tiles between lanes m and m ^ 8 (a rotation by 8 inside
+// the 16-lane DPP row) gives instruction A rows 0-7 and instruction B rows 8-15 of the tile pair, each row as one full
+// line: lanes m < 8 carry channels 0-15, lanes m >= 8 channels 16-31 of row m & 7 (+ 8).  Measured on the 128 -> 384
+// row-linear layer: 3.10 -> 2.59 ms (tools/lin_abl.sh).
+// (issued as asm: with __builtin_amdgcn_update_dpp on the four elements hipcc emitted ONE v_mov_b32_dpp and used its result
+// for all four — seen in the ISA and as scrambled rows on the GPU; s_nop 1 = the VALU-write -> DPP-read wait states the
+// compiler would have added)
+__device__ __forceinline__ f32x4 s3d_row_ror8(const f32x4 v) {
+    float r0, r1, r2, r3;
+    asm volatile("s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %2, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    return f32x4{r0, r1, r2, r3};
+}
+__device__ __forceinline__ unsigned s3d_row_ror8_u32(unsigned v) {
+    unsigned r;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(v));
+    return r;
+}
+// (v0, v1) = tiles nt = 0, 1 of row m  ->  (a, b) = this lane's 16 bytes of row (m & 7) and of row (m & 7) + 8, both at
+// channel offset 16 (m >> 3) + 4 g of the 32-channel pair
+__device__ __forceinline__ void s3d_full_line_pair(const f32x4 v0, const f32x4 v1, int m, f32x4& a, f32x4& b) {
+    const f32x4 t0 = s3d_row_ror8(v0), t1 = s3d_row_ror8(v1);
+    const bool lo = m < 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = lo ? v0[i] : t1[i];
+        b[i] = lo ? t0[i] : v1[i];
+    }
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Workgroup barrier that publishes LDS-DMA (global_load_lds) data: a wave must see ITS OWN requests land before it

@@ -20,6 +20,61 @@ __device__ __forceinline__ void conv_epilogue(const ConvLaunch& a, f32x4 (&acc)[
                                               const int (&py)[MT], const int (&px)[MT], const bool (&pv)[MT],
                                               int jt0, int g) {
     // epilogue: lane owns channels co..co+3 of pixel (pn,py,px)
+    if (NT % 2 == 0 && a.out_mode == S3D_OUT_NHWC) {
+        // NHWC rows leave as full 128-byte lines (s3d_full_line_pair, common.h): the accumulator pair (nt, nt + 1) of pixel m
+        // is exchanged with lane m ^ 8 FIRST; the lane then owns channels cpair .. cpair + 3 of pixel m & 7 and of pixel
+        // (m & 7) + 8 of the tile and runs the same per-element epilogue as below on them (every step of it — affine,
+        // activation, dropout, gate, residual — is a function of the output index alone, so the stored bits do not
+        // change).  One instruction writes 32 channels of 8 pixels as whole lines; the plain form writes 64-byte runs of
+        // 16 pixels (3.10 -> 2.59 ms on the 128 -> 384 row-linear layer, tools/lin_abl.sh).
+        const int m = threadIdx.x & 15;
+        const bool lo = m < 8;
+#pragma unroll
+        for (int np = 0; np < NT / 2; ++np) {
+            const int co = (jt0 + 2 * np) * 16 + 16 * (m >> 3) + 4 * g;
+            const f32x4 sc = a.scale ? ld4(a.scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+            const f32x4 sh = a.shift ? ld4(a.shift + co) : zero4();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 val[2];
+                s3d_full_line_pair(acc[mt][2 * np], acc[mt][2 * np + 1], m, val[0], val[1]);
+                // the partner lane's pixel: its output offset and validity travel the same way
+                const long ob = ((long)(pn[mt] * a.H + py[mt]) * a.W + px[mt]) * a.out_cstride;
+                const unsigned ob_lo = s3d_row_ror8_u32((unsigned)ob), ob_hi = s3d_row_ror8_u32((unsigned)((unsigned long long)ob >> 32));
+                const bool pvp = s3d_row_ror8_u32(pv[mt] ? 1u : 0u) != 0u;
+                const long obp = (long)(((unsigned long long)ob_hi << 32) | ob_lo);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {   // k = 0: pixel m & 7, k = 1: pixel (m & 7) + 8
+                    const bool own = (k == 0) == lo;
+                    if (!(own ? pv[mt] : pvp) || co >= a.cout_store) continue;
+                    const long oi = (own ? ob : obp) + co;
+                    f32x4 v = val[k] * sc + sh;
+                    if (a.act == S3D_ACT_RELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    } else if (a.act == S3D_ACT_TANH) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = tanhf(v[i]);
+                    }
+                    if (a.drop.p > 0.f) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] *= s3d_drop(a.drop, a.drop_base + (unsigned long long)(oi + i));
+                    }
+                    if (a.gate) {
+                        const f32x4 gt = ld4(a.gate + oi);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = gt[i] > 0.f ? v[i] * a.gate_scale : 0.f;
+                    }
+                    if (a.residual) v += ld4(a.residual + oi);
+                    if (a.out_accumulate) v += ld4(a.out + oi);
+                    // streaming store: activations are far larger than L2, keeping them out of it measured faster
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + oi));
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one pixel tile at a time
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (jt0 + nt) * 16 + 4 * g;
@@ -401,6 +456,270 @@ static int launch_lin_rows(const ConvLaunch& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row-linear layers on the long row sets of the training step (K and Cout multiples of 128: the attention block's in_proj
+// 128 -> 384, its data gradient 384 -> 128, out_proj, the last layer's K|V gradient 256 -> 128), streaming form.
+// lin_rows above re-requests all weight fragments from L2 for every 48 rows of every wave (196 KB per 48 rows for in_proj:
+// 21 GB of L2 traffic per call) and its MFMA phases wait on them: with the stores removed the 128 -> 384 call still took
+// 2.3 ms for 2.7 GB of input (tools/lin_abl.sh).  Here a persistent workgroup (4 waves x 48 rows; 32 for K > 128) streams the weight image
+// through a three-slot LDS ring of 16 KiB slots (slot = 128 input channels x 32 output channels, hi | lo fragments) with
+// LDS-DMA two phases ahead, so a weight byte leaves L2 once per 192 rows and the fragments of a phase come out of LDS.
+// A wave keeps the 128 input channels of its rows in registers as f16 hi / lo (requested all at once); for K > 128 the
+// accumulators of all 128 outputs stay live across the K chunks.  One s_barrier per phase (72 MFMAs per wave).
+//
+// vmcnt bookkeeping: a phase issues [DMA of phase + 2][MFMAs][s_waitcnt vmcnt(4)][stores of this phase].  The wait leaves
+// only the four DMA instructions just issued outstanding, i.e. the DMA of phase + 1 (a phase old) has landed and the
+// stores of the phase before have retired — whatever their number (tail rows store nothing) — before the wave arrives
+// at the next barrier; the stores of this phase get a whole phase to retire.  LDS is read by hand-issued ds_read_b128
+// with counted lgkmcnt waits only (no compiler-visible LDS access: nothing makes hipcc guard them with vmcnt(0)).
+// Per accumulator the products are added in the order of lin_rows / conv_igemm_f16x3 (k ascending; hi*lo, lo*hi, hi*hi):
+// the same bits.
+// ---------------------------------------------------------------------------------------------
+#define LS_SLOT_HALFS 8192
+#define LS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define LS_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
+#define LS_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+// the epilogue of conv_epilogue restricted to what these calls use (bias, ReLU, output dropout, residual; NHWC rows:
+// the output index is the flat row index times the channel stride) — the general one costs 50 registers more
+template <int MT, bool DROP, bool AFFINE>
+__device__ __forceinline__ void lin_stream_epilogue(const ConvLaunch& a, const f32x4 (&acc)[MT][2], const f32x4 (&res)[MT][2],
+                                                    const f32x4 (&sh)[2], const long (&p)[MT], long tile0, long P, int jt0,
+                                                    int m, int g) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 v[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            v[nt] = AFFINE ? acc[mt][nt] + sh[nt] : acc[mt][nt];
+            if (a.act == S3D_ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[nt][i] = fmaxf(v[nt][i], 0.f);
+            }
+            if (DROP && a.drop.p > 0.f) {
+                const long oi = p[mt] * a.out_cstride + (jt0 + nt) * 16 + 4 * g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[nt][i] *= s3d_drop(a.drop, a.drop_base + (unsigned long long)(oi + i));
+            }
+            if (a.residual) v[nt] += res[mt][nt];
+        }
+        // full 128-byte lines: rows 0-7 of the tile in one instruction, rows 8-15 in the next (s3d_full_line_pair)
+        f32x4 oa, ob;
+        s3d_full_line_pair(v[0], v[1], m, oa, ob);
+        const long ra = tile0 + 16 * mt + (m & 7);
+        const int co = jt0 * 16 + 16 * (m >> 3) + 4 * g;
+        if (co < a.cout_store) {
+            if (ra < P) __builtin_nontemporal_store(oa, reinterpret_cast<f32x4*>(a.out + ra * a.out_cstride + co));
+            if (ra + 8 < P) __builtin_nontemporal_store(ob, reinterpret_cast<f32x4*>(a.out + (ra + 8) * a.out_cstride + co));
+        }
+    }
+}
+
+template <int KC>
+__global__ __launch_bounds__(256, 2) void lin_stream_f16x3_kernel(const ConvLaunch a, long n_tasks) {
+    __shared__ __attribute__((aligned(16))) _Float16 s_w[3 * LS_SLOT_HALFS];
+    constexpr int NSL = KC > 1 ? 4 : 1;   // output slots whose accumulators stay live across the K chunks
+    constexpr int LS_MT = KC > 1 ? 2 : 3;  // row tiles per wave: 128 live accumulator registers at most
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const long P = (long)a.N * a.H * a.W;
+    const ConvSrc S = a.src[0];
+    const int KU32 = S.C >> 5;
+    const int n_slots = KC > 1 ? 4 : a.CoutPad >> 5;
+    const int ppt = KC * n_slots;   // phases per task
+    const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wpk16);
+    const unsigned lw0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_w) + lane * 16;
+    // a wave's share of a slot: fragments (nt = wave >> 1, u = 2 (wave & 1) + {0, 1}), hi | lo each = 4 KiB contiguous in the
+    // image and in the slot (fragment f = 4 nt + u at f * 2 KiB)
+    auto dma_slot = [&](int q, int slot) {   // q = kc * n_slots + ns: phase within a task
+        const int kc = KC > 1 ? q >> 2 : 0, ns = KC > 1 ? q & 3 : q;
+        const __attribute__((address_space(1))) void* gp = (const __attribute__((address_space(1))) void*)(
+            wimg + ((size_t)(2 * ns + (wave >> 1)) * KU32 + 4 * kc + 2 * (wave & 1)) * 1024 + lane * 8);
+        __attribute__((address_space(3))) void* lp =
+            (__attribute__((address_space(3))) void*)(s_w + slot * LS_SLOT_HALFS + wave * 2048);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+    };
+    int slot = 0, q = 0;   // ring slot and task phase of the NEXT phase to run
+    dma_slot(0, 0);
+    dma_slot(1 % ppt, 1);
+    bool first = true;
+#pragma unroll 1
+    for (long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        long prow[LS_MT];
+        bool pv[LS_MT];
+        const float* row[LS_MT];
+#pragma unroll
+        for (int mt = 0; mt < LS_MT; ++mt) {
+            const long p = (task * 4 + wave) * (16 * LS_MT) + 16 * mt + m;
+            pv[mt] = p < P;
+            prow[mt] = pv[mt] ? p : 0;
+            row[mt] = S.p + prow[mt] * S.C + 8 * g;
+        }
+        f32x4 acc[NSL][LS_MT][2];
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int mt = 0; mt < LS_MT; ++mt) acc[sl][mt][0] = acc[sl][mt][1] = zero4();
+#pragma unroll 1
+        for (int kc = 0; kc < KC; ++kc) {
+            // the rows' 128 channels of this K chunk: all 24 requests out, then split in place (v0 -> hi, v1 -> lo)
+            f32x4 v0[LS_MT][4], v1[LS_MT][4];
+#pragma unroll
+            for (int mt = 0; mt < LS_MT; ++mt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v0[mt][u] = ld4(row[mt] + 128 * kc + 32 * u);   // rows past the end read row 0 and store nothing
+                    v1[mt][u] = ld4(row[mt] + 128 * kc + 32 * u + 4);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < LS_MT; ++mt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float x[8] = {v0[mt][u][0], v0[mt][u][1], v0[mt][u][2], v0[mt][u][3],
+                                        v1[mt][u][0], v1[mt][u][1], v1[mt][u][2], v1[mt][u][3]};
+                    s3d_half8 h, l;
+                    s3d_split8(x, h, l);
+                    v0[mt][u] = __builtin_bit_cast(f32x4, h);
+                    v1[mt][u] = __builtin_bit_cast(f32x4, l);
+                }
+#define LS_XH(mt, u) __builtin_bit_cast(chalf8, v0[mt][u])
+#define LS_XL(mt, u) __builtin_bit_cast(chalf8, v1[mt][u])
+            if (first) {   // the two prologue slots
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                first = false;
+            }
+#pragma unroll
+            for (int sl = 0; sl < (KC > 1 ? 4 : 1); ++sl) {
+#pragma unroll 1
+                for (int ns = (KC > 1 ? sl : 0); ns < (KC > 1 ? sl + 1 : n_slots); ++ns) {
+                    // ---- one phase: slot `slot` holds (kc, ns) ----
+                    asm volatile("s_barrier" ::: "memory");   // every wave's share of this slot has landed; slot + 2 is free
+                    // residual rows of this phase's outputs: requested BEFORE the DMA (the vmcnt(4) below then covers them)
+                    // residual rows and bias of this phase's outputs: requested BEFORE the DMA so that the vmcnt(4)
+                    // below covers them, and by hand — hipcc waits with vmcnt(0) for a load of its own that has LDS-DMA
+                    // requests behind it, i.e. for the weights of phase + 2
+                    f32x4 res[LS_MT][2], sh[2];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        sh[nt] = zero4();
+#pragma unroll
+                        for (int mt = 0; mt < LS_MT; ++mt) res[mt][nt] = zero4();
+                    }
+                    if (KC == 1) {   // K > 128 serves plain products (no bias: see lin_stream_eligible)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int co = (2 * ns + nt) * 16 + 4 * g;
+                            if (a.shift) LS_GLOAD(sh[nt], a.shift + co);
+                        }
+                    }
+                    if (kc == KC - 1 && a.residual) {
+#pragma unroll
+                        for (int mt = 0; mt < LS_MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                LS_GLOAD(res[mt][nt], a.residual + prow[mt] * a.out_cstride + (2 * ns + nt) * 16 + 4 * g);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        int q2 = q + 2;
+                        if (q2 >= ppt) q2 -= ppt;
+                        if (q2 >= ppt) q2 -= ppt;   // ppt = 1: a single 32-channel output slot
+                        int s2 = slot + 2;
+                        if (s2 >= 3) s2 -= 3;
+                        dma_slot(q2, s2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned lwa = lw0 + (unsigned)slot * (LS_SLOT_HALFS * 2);
+                    chalf8 wh[2][2], wl[2][2];   // [buffer][nt]
+#define LS_READS(B, U)                                  \
+    LS_READ(wh[B][0], lwa, (U) * 2048);                 \
+    LS_READ(wl[B][0], lwa, (U) * 2048 + 1024);          \
+    LS_READ(wh[B][1], lwa, (4 + (U)) * 2048);           \
+    LS_READ(wl[B][1], lwa, (4 + (U)) * 2048 + 1024);
+#define LS_MFMA(B, U)                                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                 \
+        if (!a.single_pass) {                                                                                          \
+            _Pragma("unroll") for (int mt = 0; mt < LS_MT; ++mt) acc[sl][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16( \
+                wh[B][nt], LS_XL(mt, U), (KC == 1 && (U) == 0) ? zero4() : acc[sl][mt][nt], 0, 0, 0);                  \
+            _Pragma("unroll") for (int mt = 0; mt < LS_MT; ++mt) acc[sl][mt][nt] =                                     \
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[B][nt], LS_XH(mt, U), acc[sl][mt][nt], 0, 0, 0);             \
+            _Pragma("unroll") for (int mt = 0; mt < LS_MT; ++mt) acc[sl][mt][nt] =                                     \
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[B][nt], LS_XH(mt, U), acc[sl][mt][nt], 0, 0, 0);             \
+        } else {                                                                                                       \
+            _Pragma("unroll") for (int mt = 0; mt < LS_MT; ++mt) acc[sl][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16( \
+                wh[B][nt], LS_XH(mt, U), (KC == 1 && (U) == 0) ? zero4() : acc[sl][mt][nt], 0, 0, 0);                  \
+        }                                                                                                              \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+                    LS_READS(0, 0)
+                    LS_READS(1, 1)
+                    LS_WAIT4(4, wh[0][0], wl[0][0], wh[0][1], wl[0][1]);
+                    LS_MFMA(0, 0)
+                    LS_READS(0, 2)
+                    LS_WAIT4(4, wh[1][0], wl[1][0], wh[1][1], wl[1][1]);
+                    LS_MFMA(1, 1)
+                    LS_READS(1, 3)
+                    LS_WAIT4(4, wh[0][0], wl[0][0], wh[0][1], wl[0][1]);
+                    LS_MFMA(0, 2)
+                    LS_WAIT4(0, wh[1][0], wl[1][0], wh[1][1], wl[1][1]);
+                    LS_MFMA(1, 3)
+#undef LS_READS
+#undef LS_MFMA
+                    // DMA of the next phase landed, stores of the previous phase retired (see the header)
+                    if (KC == 1)
+                        asm volatile("s_waitcnt vmcnt(4)"
+                                     : "+v"(res[0][0]), "+v"(res[0][1]), "+v"(res[1][0]), "+v"(res[1][1]), "+v"(res[LS_MT - 1][0]),
+                                       "+v"(res[LS_MT - 1][1]), "+v"(sh[0]), "+v"(sh[1])
+                                     :
+                                     : "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(4)"
+                                     : "+v"(res[0][0]), "+v"(res[0][1]), "+v"(res[1][0]), "+v"(res[1][1])
+                                     :
+                                     : "memory");
+                    if (kc == KC - 1) lin_stream_epilogue<LS_MT, KC == 1, KC == 1>(a, acc[sl], res, sh, prow, (task * 4 + wave) * (16 * LS_MT), P,
+                                                                         2 * ns, m, g);
+                    if (++q == ppt) q = 0;
+                    if (++slot == 3) slot = 0;
+                }
+            }
+#undef LS_XH
+#undef LS_XL
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last prefetches must not outlive the workgroup's LDS
+}
+
+static bool lin_stream_eligible(const ConvLaunch& a) {
+    if (a.ks != 1 || a.nsrc != 1 || a.stride > 1 || !a.wpk16 || a.CoutPad % 32) return false;
+    if ((a.Hin && a.Hin != a.H) || (a.Win && a.Win != a.W)) return false;
+    const ConvSrc& S = a.src[0];
+    if (S.sbcast || S.bmod || S.bdiv != 1 || S.C % 128 || S.C > 384 || a.KU != S.C / 16) return false;
+    // K > 128: all 128 outputs live; plain products only (no scale / bias / output dropout)
+    if (S.C > 128 && (a.CoutPad != 128 || a.drop.p > 0.f || a.scale || a.shift)) return false;
+    if (a.out_mode != S3D_OUT_NHWC || a.gate || a.out_accumulate || a.cout_store % 4 || a.scale) return false;
+    if (a.act != S3D_ACT_NONE && a.act != S3D_ACT_RELU) return false;
+    return (long)a.N * a.H * a.W >= (1L << 17);   // long row sets (the decoder token rows); short ones keep lin_rows (more, smaller workgroups)
+}
+static int launch_lin_stream(const ConvLaunch& a, hipStream_t stream) {
+    const long P = (long)a.N * a.H * a.W;
+    const int kc = a.src[0].C / 128;
+    const int rows_wg = kc > 1 ? 128 : 192;   // 4 waves x 2 or 3 row tiles
+    const long n_tasks = (P + rows_wg - 1) / rows_wg;
+    const unsigned grid = (unsigned)(n_tasks < 512 ? n_tasks : 512);   // two workgroups per CU
+    if (kc == 1)
+        hipLaunchKernelGGL(lin_stream_f16x3_kernel<1>, dim3(grid), dim3(256), 0, stream, a, n_tasks);
+    else if (kc == 2)
+        hipLaunchKernelGGL(lin_stream_f16x3_kernel<2>, dim3(grid), dim3(256), 0, stream, a, n_tasks);
+    else
+        hipLaunchKernelGGL(lin_stream_f16x3_kernel<3>, dim3(grid), dim3(256), 0, stream, a, n_tasks);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS-staged 3x3 convolution (stride 1, "same"), split precision.
 // A workgroup (4 waves) owns an 8-row x 16-column pixel tile of one image and CO_WG output channels.  Per
 // 32-channel K chunk the (8+2) x (16+2) input halo is fetched ONCE (coalesced 16 B/lane), split into f16 hi/lo
@@ -684,6 +1003,7 @@ int launch_conv(const ConvLaunch& a_in, hipStream_t stream) {
     for (int s = 0; s < a.nsrc; ++s)
         S3D_CHECK_ARG(a.src[s].C % 16 == 0 && a.src[s].bdiv >= 1, "conv: bad source %d", s);
     if (conv3x3_lds_eligible(a)) return launch_conv3x3_lds(a, stream);
+    if (lin_stream_eligible(a)) return launch_lin_stream(a, stream);
     if (lin_rows_eligible(a)) return launch_lin_rows(a, stream);
     const long P = (long)a.N * a.H * a.W;
     // Tile menu: (pixels x couts) per workgroup of 4 waves.  Prefer the largest tile that still

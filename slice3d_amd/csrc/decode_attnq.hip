@@ -416,19 +416,29 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 v4 += acc_o[r][j] * acc_o[r][j];
             }
             const float rstd = __builtin_amdgcn_rsqf(colsum16((v4[0] + v4[1]) + (v4[2] + v4[3])) * (1.f / 128.f) + 1e-5f);
-            float* o = Xg + (mt * S3D_GROUP + q0 + r) * 128;
             if (r == 0)
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]), "+v"(ga[4]), "+v"(ga[5]), "+v"(ga[6]), "+v"(ga[7]),
                                "+v"(be[0]), "+v"(be[1]), "+v"(be[2]), "+v"(be[3]), "+v"(be[4]), "+v"(be[5]), "+v"(be[6]), "+v"(be[7]));
+            // Full-line stores (s3d_full_line_pair): a lane's tiles j = 2J, 2J + 1 are columns 32J + 8g + {0..3} and {4..7} of
+            // token m, so a plain store writes 16-byte pieces at a 32-byte stride.  After the exchange with lane m ^ 8
+            // one instruction writes tokens 0-7, the next tokens 8-15, each token's 128-byte line whole (lanes m < 8 the
+            // low, lanes m >= 8 the high 16 bytes of every 32).
+            float* oa = Xg + ((m & 7) * S3D_GROUP + q0 + r) * 128 + 8 * g + 4 * (m >> 3);
+            const bool ok_b = (m & 7) + 8 < T;   // tokens 0-7 always exist (T >= 8 is not required: see ok_a)
+            const bool ok_a = (m & 7) < T;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int col = 32 * (j >> 1) + 8 * g + 4 * (j & 1);
-                const f32x4 rr = acc_o[r][j] * (ga[j] * rstd) + be[j];
+            for (int J = 0; J < 4; ++J) {
+                const f32x4 r0 = acc_o[r][2 * J] * (ga[2 * J] * rstd) + be[2 * J];
+                const f32x4 r1 = acc_o[r][2 * J + 1] * (ga[2 * J + 1] * rstd) + be[2 * J + 1];
+                f32x4 va, vb;
+                s3d_full_line_pair(r0, r1, m, va, vb);
 #ifdef AQ_ABL_NOROWS
-                if (row_ok && rr[0] == 1234.5f) st4(o + col, rr);
+                if (ok_a && va[0] == 1234.5f) st4(oa + 32 * J, va);
+                if (ok_b && vb[0] == 1234.5f) st4(oa + 8 * S3D_GROUP * 128 + 32 * J, vb);
 #else
-                if (row_ok) st4(o + col, rr);
+                if (ok_a) st4(oa + 32 * J, va);
+                if (ok_b) st4(oa + 8 * S3D_GROUP * 128 + 32 * J, vb);
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);   // one row tile at a time

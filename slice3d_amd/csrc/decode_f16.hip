@@ -445,15 +445,27 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
     // and read back by every wave: +0.4 GB of HBM writes per launch in the PMC pass)
     int ge = g, me = m;
     asm volatile("" : "+v"(ge), "+v"(me));
+    // Stores go out as full 128-byte lines (s3d_full_line_pair, common.h): a lane's tiles 2J, 2J + 1 are 32 contiguous
+    // bytes of row m, a plain store writes 16-byte pieces at a 32-byte stride; after the exchange with lane m ^ 8 one
+    // instruction covers rows 0-7 of the tile and the next rows 8-15, every row's line whole.
+    auto store_pair = [&](float* base, int r, int J, const f32x4 v0, const f32x4 v1) {
+        f32x4 va, vb;
+        s3d_full_line_pair(v0, v1, me, va, vb);
+        const long ra = row0 + r * 16 + (me & 7);
+        float* o = base + ra * 128 + 32 * J + 8 * ge + 4 * (me >> 3);
+        if (ra < rows) st4(o, va);
+        if (ra + 8 < rows) st4(o + 8 * 128, vb);
+    };
     if (MODE == 4) {   // dX = dA W1 + Dres
 #pragma unroll
         for (int r = 0; r < PIPE_R; ++r) {
-            const long row = row0 + r * 16 + me;
-            if (row >= rows) continue;
+            long row = row0 + r * 16 + me;
+            if (row >= rows) row = rows - 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int col = 32 * (j >> 1) + 8 * ge + 4 * (j & 1);
-                st4(Yout + row * 128 + col, acc[r][j] + ld4(ba.Dres + row * 128 + col));
+            for (int J = 0; J < 4; ++J) {
+                const int col = 32 * J + 8 * ge;
+                store_pair(Yout, r, J, acc[r][2 * J] + ld4(ba.Dres + row * 128 + col),
+                           acc[r][2 * J + 1] + ld4(ba.Dres + row * 128 + col + 4));
             }
         }
         return;
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
                 y[j][i] = f + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
                 s += y[j][i];
             }
-            if ((MODE == 2 || MODE == 3) && row < rows) st4(ta.Uout + row * 128 + col, y[j]);
+            if ((MODE == 2 || MODE == 3) && (j & 1)) store_pair(ta.Uout, r, j >> 1, y[j - 1], y[j]);
         }
         const float mean = quad_sum16(s) * (1.f / 128.f);
         float v = 0.f;
@@ -505,8 +517,8 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
             if (FINAL) {
                 const f32x4 wo = ld4(fco_w + col);
                 dot += y[j][0] * wo[0] + y[j][1] * wo[1] + y[j][2] * wo[2] + y[j][3] * wo[3];
-            } else if (row < rows) {
-                st4(Yout + row * 128 + col, y[j]);
+            } else if (j & 1) {
+                store_pair(Yout, r, j >> 1, y[j - 1], y[j]);
             }
         }
         if (FINAL) {

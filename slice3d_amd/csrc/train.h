@@ -25,6 +25,10 @@ struct WgradArgs {
     int prec;             // S3D_PREC_F16X3: plain 1x1 contractions run on split-precision f16 MFMA (else fp32 MFMA)
     float* partial;       // workspace
     size_t partial_floats;
+    float* bias_out;      // null, or [N]: column sums of dY (the layer's bias gradient; `accumulate` applies).  The
+                          // split-precision linear kernel adds them up while it converts dY (no second pass over dY);
+                          // the other kernels run launch_colsum with `bias_partial` as its workspace
+    float* bias_partial;
 };
 int launch_wgrad(const WgradArgs& a, hipStream_t stream);
 

@@ -92,10 +92,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, int n_cbl
             }
 }
 
+template <bool BIAS>   // BIAS: the split-precision linear kernel left nsplit x N bias partials behind the weight partials
 __global__ void wgrad_reduce_kernel(const WgradArgs a, int nsplit, int Ktot) {
     const long total = (long)a.N * Ktot;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total + (BIAS ? a.N : 0);
          idx += (long)gridDim.x * blockDim.x) {
+        if (BIAS && idx >= total) {
+            const float* bp = a.partial + (size_t)nsplit * total + (idx - total);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int sp = 0;
+            for (; sp + 4 <= nsplit; sp += 4) {
+                s0 += bp[(size_t)sp * a.N];
+                s1 += bp[(size_t)(sp + 1) * a.N];
+                s2 += bp[(size_t)(sp + 2) * a.N];
+                s3 += bp[(size_t)(sp + 3) * a.N];
+            }
+            for (; sp < nsplit; ++sp) s0 += bp[(size_t)sp * a.N];
+            const float s = (s0 + s1) + (s2 + s3);
+            float* o = a.bias_out + (idx - total);
+            *o = a.accumulate ? *o + s : s;
+            continue;
+        }
         float s = 0.f;
         int sp = 0;
         for (; sp + 8 <= nsplit; sp += 8) {
@@ -170,6 +187,7 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
     };
     const float nf = n_ok ? 1.f : 0.f, cf = c_ok ? 1.f : 0.f;
     const long p_begin = (long)blockIdx.y * steps_per_split * 32;
+    float csum = 0.f;   // this thread's rows of dY channel ch (bias gradient)
     gload(p_begin);
     for (int it = 0; it < steps_per_split; ++it) {
         const long pb = p_begin + (long)it * 32;
@@ -179,6 +197,7 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const float v = pd[ps][t] * (pb + 16 * ps + 8 * rg + t < P ? nf : 0.f);
+                csum += v;
                 const _Float16 h = (_Float16)v;
                 hi[t] = h;
                 lo[t] = (_Float16)(v - (float)h);
@@ -237,6 +256,13 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
                 const int c = c0 + 64 * wc + 16 * j + m;
                 if (n < a.N && c < a.Cx) part[(size_t)n * a.Cx + c] = acc[i][j][reg];
             }
+    if (a.bias_out != nullptr && cb == 0) {   // the two row groups of a channel meet in LDS (free after the loop's last barrier)
+        float* s_c = reinterpret_cast<float*>(&s_t[0][0][0]);
+        s_c[tid] = csum;
+        __syncthreads();
+        if (tid < 128 && n_ok)
+            a.partial[(size_t)gridDim.y * a.N * a.Cx + (size_t)blockIdx.y * a.N + n0 + tid] = s_c[tid] + s_c[tid + 128];
+    }
 }
 
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int nchunks, int C, float scale,
@@ -839,7 +865,7 @@ static int launch_wgrad_conv3_f16x3(const WgradArgs& a, hipStream_t stream) {
     S3D_LAUNCH_CHECK();
     const long total = (long)a.N * Ktot;
     const int rb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, a, (int)splits, Ktot);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(rb), dim3(256), 0, stream, a, (int)splits, Ktot);
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -856,7 +882,7 @@ static int launch_wgrad_lin_f16x3(const WgradArgs& a, long P, hipStream_t stream
     long splits = (1024 + tiles - 1) / tiles;                 // aim at >= 1024 workgroups
     const long max_by_steps = (total_steps + 7) / 8;          // >= 8 K-steps per workgroup
     if (splits > max_by_steps) splits = max_by_steps;
-    const long cap = (long)(a.partial_floats / ((size_t)a.N * a.Cx));
+    const long cap = (long)(a.partial_floats / ((size_t)a.N * a.Cx + (a.bias_out ? a.N : 0)));
     if (splits > cap) splits = cap;
     if (splits < 1) {
         s3d_set_error("wgrad: partial workspace too small for %d x %d", a.N, a.Cx);
@@ -869,7 +895,10 @@ static int launch_wgrad_lin_f16x3(const WgradArgs& a, long P, hipStream_t stream
     S3D_LAUNCH_CHECK();
     const long total = (long)a.N * a.Cx;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a, (int)splits, a.Cx);
+    if (a.bias_out)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream, a, (int)splits, a.Cx);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream, a, (int)splits, a.Cx);
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -905,6 +934,11 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
                   "wgrad: channel strides/offsets must be multiples of 4");
     const long P = (long)a.Nimg * a.H * a.W;
     if (wgrad_lin_eligible(a, P)) return launch_wgrad_lin_f16x3(a, P, stream);
+    if (a.bias_out != nullptr) {
+        S3D_CHECK_ARG(a.bias_partial != nullptr, "wgrad: bias_out needs bias_partial");
+        const int rc = launch_colsum(a.dy, P, a.dy_cstride, a.dy_coff, a.N, a.bias_out, a.accumulate, a.bias_partial, stream);
+        if (rc) return rc;
+    }
     if (wgrad_conv3_eligible(a)) return launch_wgrad_conv3_f16x3(a, stream);
     const int taps = a.ks * a.ks;
     int TN, TK, n_nblk, n_cblk, sy, spw;
@@ -924,7 +958,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     S3D_LAUNCH_CHECK();
     const long total = (long)a.N * Ktot;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a, sy * 4, Ktot);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream, a, sy * 4, Ktot);
     S3D_LAUNCH_CHECK();
     return 0;
 }
