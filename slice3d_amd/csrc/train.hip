@@ -2010,24 +2010,26 @@ int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du
 // the same copy in two halves — global -> registers (issued a phase early, so that its latency runs under the compute of
 // the phase in between), registers -> LDS: T*16*8 16-byte pieces over 256 threads = up to 7 per thread
 #define ATT_PF 7
-__device__ __forceinline__ void att_fetch(const float* __restrict__ src, int src_ld, int coff, int T, f32x4 (&r)[ATT_PF]) {
+__device__ __forceinline__ void att_fetch(const float* __restrict__ src, int src_ld, int coff, int T, f32x4 (&r)[ATT_PF],
+                                          int tid = threadIdx.x) {
 #pragma unroll
     for (int k = 0; k < ATT_PF; ++k) {
-        const int i = threadIdx.x + ATT_THREADS * k;
+        const int i = tid + ATT_THREADS * k;
         const int ic = i < T * 128 ? i : T * 128 - 1;
         r[k] = ld4(src + (long)(ic >> 3) * src_ld + coff + 4 * (ic & 7));
     }
 }
-__device__ __forceinline__ void att_put(const f32x4 (&r)[ATT_PF], int T, float* dst) {
+__device__ __forceinline__ void att_put(const f32x4 (&r)[ATT_PF], int T, float* dst, int tid = threadIdx.x) {
 #pragma unroll
     for (int k = 0; k < ATT_PF; ++k) {
-        const int i = threadIdx.x + ATT_THREADS * k;
+        const int i = tid + ATT_THREADS * k;
         if (i < T * 128) st4(dst + (i >> 3) * ATT_LD + 4 * (i & 7), r[k]);
     }
 }
 // rows [T*16][32] of one head (column offset coff in the 384/128-wide source) -> LDS [row][ATT_LD]
-__device__ __forceinline__ void att_stage(const float* __restrict__ src, int src_ld, int coff, int T, float* dst) {
-    for (int i = threadIdx.x; i < T * 16 * 8; i += ATT_THREADS) {
+__device__ __forceinline__ void att_stage(const float* __restrict__ src, int src_ld, int coff, int T, float* dst,
+                                          int tid = threadIdx.x) {
+    for (int i = tid; i < T * 16 * 8; i += ATT_THREADS) {
         const int row = i >> 3, q4 = i & 7;
         st4(dst + row * ATT_LD + 4 * q4, ld4(src + (long)row * src_ld + coff + 4 * q4));
     }
@@ -2120,43 +2122,68 @@ int launch_attn_core_fwd(const float* qkv, float* o, long groups, int T, const D
     return 0;
 }
 
-// backward: phase A (thread = (ql, tq), K/V of the head in LDS): P row, dS row -> LDS, dQ row -> global;
-//           phase B (thread = (ql, tk), Q/dO of the head restaged into the same LDS):
+// backward: phase A (thread = (ql, tq), K/V of the head in LDS): P row, dS row -> LDS, dQ row;
+//           phase B (thread = (ql, tk), Q/dO of the head in the same LDS):
 //           dK[tk] = sum_tq dS[tq][tk] Q[tq] * scale,  dV[tk] = sum_tq P[tq][tk] dO[tq]
+// Every global access is row-coalesced (8 lanes x 16 B = one head row of 128 B; att_fetch / att_put / att_flush): a thread
+// that walks its own row — Q / dO in, dQ / dK / dV out, 13 of the kernel's 19 GB — touches 64 different lines with every
+// instruction, which held the kernel at 2.6 TB/s.  Rows now change hands in LDS: Q / dO are parked first and each thread
+// picks its row up from there, gradient rows are parked by their owners and flushed by all threads (the K / V tiles are
+// dead by then).  Ten barriers per task instead of four; Q / dO of the next task are requested under phase B, K / V of
+// this one while the Q / dO rows are being picked up.
+__device__ __forceinline__ void att_flush(const float* src, int T, float* __restrict__ dst, int dst_ld, int coff, int tid) {
+    for (int i = tid; i < T * 16 * 8; i += ATT_THREADS) {
+        const int row = i >> 3, q4 = i & 7;
+        st4(dst + (long)row * dst_ld + coff + 4 * q4, ld4(src + row * ATT_LD + 4 * q4));
+    }
+}
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_core_bwd_kernel(const float* __restrict__ qkv,
                                                                     const float* __restrict__ d_o,
                                                                     float* __restrict__ dqkv, long groups, int T,
                                                                     const DropCfg drop) {
     __shared__ __attribute__((aligned(16))) float sA[S3D_N_TOKENS_MAX * 16 * ATT_LD], sB[S3D_N_TOKENS_MAX * 16 * ATT_LD];
     __shared__ float sP[16 * S3D_N_TOKENS_MAX * S3D_N_TOKENS_MAX], sS[16 * S3D_N_TOKENS_MAX * S3D_N_TOKENS_MAX];
-    const int tid = threadIdx.x;
-    const int ql = tid & 15, tt = tid >> 4;
-    const bool act = tt < T;
-    // K / V of the NEXT task are requested before phase B and parked in LDS at the top of the next trip (their latency runs
-    // under phase B; prefetching Q / dO under phase A as well needs 56 more registers there and spilled): the kernel moves
-    // 18.7 GB per call and used to expose every load
-    f32x4 pa[ATT_PF];
-    if ((long)blockIdx.x < groups * 4)
-        att_fetch(qkv + ((long)blockIdx.x >> 2) * T * 16 * 384, 384, 128 + 32 * (int)(blockIdx.x & 3), T, pa);
+    f32x4 pa[ATT_PF], pb[ATT_PF];   // coalesced pieces in flight: Q / dO of the next task, K / V of this one
+    if ((long)blockIdx.x < groups * 4) {
+        const long g0 = (long)blockIdx.x >> 2;
+        const int h0 = (int)(blockIdx.x & 3);
+        att_fetch(qkv + g0 * T * 16 * 384, 384, 32 * h0, T, pa);
+        att_fetch(d_o + g0 * T * 16 * 128, 128, 32 * h0, T, pb);
+    }
     for (long task = blockIdx.x; task < groups * 4; task += gridDim.x) {
+        // the thread index is made opaque per task: otherwise every piece offset of the copies below (loop-invariant 64-bit
+        // values, ~60 of them) is computed before the loop, kept live through it and spilled (176 dwords per lane)
+        int tid = threadIdx.x;
+#define ATT_OPAQUE() asm volatile("" : "+v"(tid))   /* re-derive the copy offsets here instead of keeping them live */
+        ATT_OPAQUE();
+        const int ql = tid & 15, tt = tid >> 4;
+        const bool act = tt < T;
+        const int my_row = ((act ? tt : 0) * 16 + ql) * ATT_LD;
         const long grp = task >> 2;
         const int h = (int)(task & 3);
         const float* base = qkv + grp * T * 16 * 384;
         const float* dob = d_o + grp * T * 16 * 128;
         float* dbase = dqkv + grp * T * 16 * 384;
+        __syncthreads();                // the previous task's dK / dV rows have been flushed
+        att_put(pa, T, sA, tid);             // Q
+        att_put(pb, T, sB, tid);             // dO
+        ATT_OPAQUE();
+        att_fetch(base, 384, 128 + 32 * h, T, pa, tid);   // K, V: in flight while the rows are picked up
+        att_fetch(base, 384, 256 + 32 * h, T, pb, tid);
         __syncthreads();
-        att_put(pa, T, sA);                          // K (requested one task ahead)
-        att_stage(base, 384, 256 + 32 * h, T, sB);   // V
-        __syncthreads();
-        if (act) {  // phase A, tq = tt
-            const float* qrow = base + (tt * 16 + ql) * 384 + 32 * h;
-            const float* dorow = dob + (tt * 16 + ql) * 128 + 32 * h;
-            f32x4 qv[8], dov[8];
+        f32x4 qv[8], dov[8];
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                qv[d] = ld4(qrow + 4 * d);
-                dov[d] = ld4(dorow + 4 * d);
-            }
+        for (int d = 0; d < 8; ++d) {
+            qv[d] = ld4(sA + my_row + 4 * d);
+            dov[d] = ld4(sB + my_row + 4 * d);
+        }
+        __syncthreads();
+        ATT_OPAQUE();
+        att_put(pa, T, sA, tid);             // K
+        att_put(pb, T, sB, tid);             // V
+        __syncthreads();
+        f32x4 dq[8];
+        if (act) {  // phase A, tq = tt
             float sc[S3D_N_TOKENS_MAX], dp[S3D_N_TOKENS_MAX];
             float mx = -1e30f;
 #pragma unroll
@@ -2174,6 +2201,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_core_bwd_kernel(const flo
                     sc[tk] = s * ATT_SCALE;
                     dp[tk] = e;
                     mx = fmaxf(mx, sc[tk]);
+                    // one key at a time: left alone, the scheduler hoists the LDS reads of all 13 unrolled keys and spills
+                    if (tk & 1) __builtin_amdgcn_sched_barrier(0);
                 }
             float den = 0.f;
 #pragma unroll
@@ -2184,49 +2213,57 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_core_bwd_kernel(const flo
                 }
             const float inv = 1.f / den;
             float dot = 0.f;
-            float mk[S3D_N_TOKENS_MAX];
-#pragma unroll
-            for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
-                if (tk < T) {
-                    sc[tk] *= inv;
-                    mk[tk] = drop.p > 0.f
-                                 ? s3d_drop(drop, ((unsigned long long)((grp * T + tt) * 16 + ql) * 4 + h) * 16 + tk)
-                                 : 1.f;
-                    dp[tk] *= mk[tk];        // d/dP of sum_k (P*mask)[k] V[k]
-                    dot += sc[tk] * dp[tk];
-                }
-            f32x4 dq[8];
-#pragma unroll
-            for (int d = 0; d < 8; ++d) dq[d] = zero4();
             float* pP = sP + (ql * T + tt) * T;
             float* pS = sS + (ql * T + tt) * T;
 #pragma unroll
             for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
                 if (tk < T) {
+                    sc[tk] *= inv;
+                    const float mk = drop.p > 0.f
+                                         ? s3d_drop(drop, ((unsigned long long)((grp * T + tt) * 16 + ql) * 4 + h) * 16 + tk)
+                                         : 1.f;
+                    pP[tk] = sc[tk] * mk;    // dropped probabilities multiply dO in dV
+                    dp[tk] *= mk;            // d/dP of sum_k (P*mask)[k] V[k]
+                    dot += sc[tk] * dp[tk];
+                }
+#pragma unroll
+            for (int d = 0; d < 8; ++d) dq[d] = zero4();
+#pragma unroll
+            for (int tk = 0; tk < S3D_N_TOKENS_MAX; ++tk)
+                if (tk < T) {
                     const float ds = sc[tk] * (dp[tk] - dot);
-                    pP[tk] = sc[tk] * mk[tk];   // dropped probabilities multiply dO in dV
                     pS[tk] = ds * ATT_SCALE;
                     const float* krow = sA + (tk * 16 + ql) * ATT_LD;
                     const float w = ds * ATT_SCALE;
 #pragma unroll
                     for (int d = 0; d < 8; ++d) dq[d] += ld4(krow + 4 * d) * w;
+                    if (tk & 1) __builtin_amdgcn_sched_barrier(0);
                 }
-            float* dqrow = dbase + (tt * 16 + ql) * 384 + 32 * h;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) st4(dqrow + 4 * d, dq[d]);
         }
+        __syncthreads();                // K / V are dead
+        if (act) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) st4(sB + my_row + 4 * d, dq[d]);
+        }
+        ATT_OPAQUE();
+        att_fetch(base, 384, 32 * h, T, pa, tid);   // Q again (L2), parked for phase B while the dQ rows leave
         __syncthreads();
-        att_stage(base, 384, 32 * h, T, sA);   // Q
-        att_stage(dob, 128, 32 * h, T, sB);    // dO
+        ATT_OPAQUE();
+        att_flush(sB, T, dbase, 384, 32 * h, tid);  // dQ
+        att_put(pa, T, sA, tid);                    // Q
+        __syncthreads();
+        ATT_OPAQUE();
+        att_stage(dob, 128, 32 * h, T, sB, tid);    // dO (L2)
         {
             const long nt = task + gridDim.x;
-            if (nt < groups * 4) {
-                att_fetch(qkv + (nt >> 2) * T * 16 * 384, 384, 128 + 32 * (int)(nt & 3), T, pa);
+            if (nt < groups * 4) {             // the next task's Q / dO: requested under phase B
+                att_fetch(qkv + (nt >> 2) * T * 16 * 384, 384, 32 * (int)(nt & 3), T, pa, tid);
+                att_fetch(d_o + (nt >> 2) * T * 16 * 128, 128, 32 * (int)(nt & 3), T, pb, tid);
             }
         }
         __syncthreads();
+        f32x4 dk[8], dv[8];
         if (act) {  // phase B, tk = tt
-            f32x4 dk[8], dv[8];
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
                 dk[d] = zero4();
@@ -2243,13 +2280,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_core_bwd_kernel(const flo
                     dv[d] += ld4(dorow + 4 * d) * p;
                 }
             }
-            float* dkrow = dbase + (tt * 16 + ql) * 384 + 128 + 32 * h;
+        }
+        __syncthreads();                // Q / dO are dead
+        if (act) {
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
-                st4(dkrow + 4 * d, dk[d]);
-                st4(dkrow + 128 + 4 * d, dv[d]);
+                st4(sA + my_row + 4 * d, dk[d]);
+                st4(sB + my_row + 4 * d, dv[d]);
             }
         }
+        __syncthreads();
+        ATT_OPAQUE();
+        att_flush(sA, T, dbase, 384, 128 + 32 * h, tid);   // dK
+        att_flush(sB, T, dbase, 384, 256 + 32 * h, tid);   // dV
+#undef ATT_OPAQUE
     }
 }
 
