@@ -20,7 +20,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvLaunch& a, f32x4 (&acc)[
                                               const int (&py)[MT], const int (&px)[MT], const bool (&pv)[MT],
                                               int jt0, int g) {
     // epilogue: lane owns channels co..co+3 of pixel (pn,py,px)
-    if (NT % 2 == 0 && a.out_mode == S3D_OUT_NHWC) {
+    const bool convt32 = a.out_mode == S3D_OUT_CONVT && a.cout_store % 32 == 0;   // a 32-channel pair stays inside one quadrant
+    if (NT % 2 == 0 && (a.out_mode == S3D_OUT_NHWC || convt32)) {
         // NHWC rows leave as full 128-byte lines (s3d_full_line_pair, common.h): the accumulator pair (nt, nt + 1) of pixel m
         // is exchanged with lane m ^ 8 FIRST; the lane then owns channels cpair .. cpair + 3 of pixel m & 7 and of pixel
         // (m & 7) + 8 of the tile and runs the same per-element epilogue as below on them (every step of it — affine,
@@ -34,20 +35,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvLaunch& a, f32x4 (&acc)[
             const int co = (jt0 + 2 * np) * 16 + 16 * (m >> 3) + 4 * g;
             const f32x4 sc = a.scale ? ld4(a.scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
             const f32x4 sh = a.shift ? ld4(a.shift + co) : zero4();
+            // ConvTranspose2d(2, stride 2): packed channel co = quadrant q * ct + c lands at output pixel (2y + q/2, 2x + q%2)
+            const int ct = a.cout_store, cq = convt32 ? co / ct : 0, ccol = convt32 ? co - cq * ct : co;
+            const bool col_ok = convt32 ? cq < 4 : co < a.cout_store;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 f32x4 val[2];
                 s3d_full_line_pair(acc[mt][2 * np], acc[mt][2 * np + 1], m, val[0], val[1]);
                 // the partner lane's pixel: its output offset and validity travel the same way
-                const long ob = ((long)(pn[mt] * a.H + py[mt]) * a.W + px[mt]) * a.out_cstride;
+                const long ob = convt32 ? ((long)(pn[mt] * 2 * a.H + 2 * py[mt] + (cq >> 1)) * (2 * a.W) + 2 * px[mt] + (cq & 1)) * ct
+                                        : ((long)(pn[mt] * a.H + py[mt]) * a.W + px[mt]) * a.out_cstride;
                 const unsigned ob_lo = s3d_row_ror8_u32((unsigned)ob), ob_hi = s3d_row_ror8_u32((unsigned)((unsigned long long)ob >> 32));
                 const bool pvp = s3d_row_ror8_u32(pv[mt] ? 1u : 0u) != 0u;
                 const long obp = (long)(((unsigned long long)ob_hi << 32) | ob_lo);
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {   // k = 0: pixel m & 7, k = 1: pixel (m & 7) + 8
                     const bool own = (k == 0) == lo;
-                    if (!(own ? pv[mt] : pvp) || co >= a.cout_store) continue;
-                    const long oi = (own ? ob : obp) + co;
+                    if (!(own ? pv[mt] : pvp) || !col_ok) continue;
+                    const long oi = (own ? ob : obp) + ccol;
                     f32x4 v = val[k] * sc + sh;
                     if (a.act == S3D_ACT_RELU) {
 #pragma unroll

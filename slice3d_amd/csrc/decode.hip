@@ -211,9 +211,16 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
                     for (int u = 0; u < 6; ++u) st4(ro + 16 * u, braw[u]);
                 }
             }
-            float* o = a.X + ((gi * T + t) * S3D_GROUP + m) * 128 + 4 * g;
+            // full 128-byte lines per query row (s3d_full_line_pair, common.h): tiles 2J, 2J + 1 of query m are exchanged
+            // with lane m ^ 8; one instruction then writes queries 0-7, the next queries 8-15
+            float* o = a.X + ((gi * T + t) * S3D_GROUP + (m & 7)) * 128 + 16 * (m >> 3) + 4 * g;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) st4(o + 16 * j, acc[j]);
+            for (int J = 0; J < 4; ++J) {
+                f32x4 va, vb;
+                s3d_full_line_pair(acc[2 * J], acc[2 * J + 1], m, va, vb);
+                st4(o + 32 * J, va);
+                st4(o + 8 * 128 + 32 * J, vb);
+            }
             if (a.raw_out && t == 0) {
                 float* ro = a.raw_out + ((gi * T) * S3D_GROUP + m) * 96 + 4 * g;
 #pragma unroll
@@ -1114,9 +1121,16 @@ __global__ __launch_bounds__(256) void sample_tokens_gt_kernel(const SampleGtArg
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[j][i] = fmaxf(acc[j][i], 0.f);
             }
-            float* o = a.X + ((gi * T + t) * S3D_GROUP + m) * 128 + 4 * g;
+            // full 128-byte lines per query row (s3d_full_line_pair, common.h): tiles 2J, 2J + 1 of query m are exchanged
+            // with lane m ^ 8; one instruction then writes queries 0-7, the next queries 8-15
+            float* o = a.X + ((gi * T + t) * S3D_GROUP + (m & 7)) * 128 + 16 * (m >> 3) + 4 * g;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) st4(o + 16 * j, acc[j]);
+            for (int J = 0; J < 4; ++J) {
+                f32x4 va, vb;
+                s3d_full_line_pair(acc[2 * J], acc[2 * J + 1], m, va, vb);
+                st4(o + 32 * J, va);
+                st4(o + 8 * 128 + 32 * J, vb);
+            }
             if (a.raw_out) {
                 float* ro = a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 64 + 4 * g;
 #pragma unroll

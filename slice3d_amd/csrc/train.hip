@@ -157,7 +157,25 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int ch = tid & 127, rg = tid >> 7;
-    const int cb = blockIdx.x % n_cblk, nb = blockIdx.x / n_cblk;
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id.  The tiles of one row split read the same rows of dY / X:
+    // XCD x owns the splits x, x + 8, ... and runs all tiles of a split back to back, so the second and third tile find the
+    // operand they share in that XCD's L2 (in_proj: three 128-row blocks of dQKV x one X — X came from HBM three times).
+    int tile, split;
+    {
+        const int n_tiles = gridDim.x, n_split = gridDim.y;
+        const long L = (long)blockIdx.y * n_tiles + blockIdx.x;
+        const long full = (long)(n_split & ~7) * n_tiles;
+        if (L < full) {
+            const long k = L >> 3;
+            tile = (int)(k % n_tiles);
+            split = (int)(k / n_tiles) * 8 + (int)(L & 7);
+        } else {
+            const long r = L - full;
+            tile = (int)(r % n_tiles);
+            split = (n_split & ~7) + (int)(r / n_tiles);
+        }
+    }
+    const int cb = tile % n_cblk, nb = tile / n_cblk;
     const int n0 = nb * 128, c0 = cb * 128;
     const int wn = wave & 1, wc = wave >> 1;
     const bool n_ok = n0 + ch < a.N, c_ok = c0 + ch < a.Cx;
@@ -186,7 +204,7 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
             }
     };
     const float nf = n_ok ? 1.f : 0.f, cf = c_ok ? 1.f : 0.f;
-    const long p_begin = (long)blockIdx.y * steps_per_split * 32;
+    const long p_begin = (long)split * steps_per_split * 32;
     float csum = 0.f;   // this thread's rows of dY channel ch (bias gradient)
     gload(p_begin);
     for (int it = 0; it < steps_per_split; ++it) {
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
         __syncthreads();
     }
     // D[row = 4g+reg <-> n][col = l&15 <-> c]
-    float* part = a.partial + (size_t)blockIdx.y * a.N * a.Cx;
+    float* part = a.partial + (size_t)split * a.N * a.Cx;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -261,7 +279,7 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
         s_c[tid] = csum;
         __syncthreads();
         if (tid < 128 && n_ok)
-            a.partial[(size_t)gridDim.y * a.N * a.Cx + (size_t)blockIdx.y * a.N + n0 + tid] = s_c[tid] + s_c[tid + 128];
+            a.partial[(size_t)gridDim.y * a.N * a.Cx + (size_t)split * a.N + n0 + tid] = s_c[tid] + s_c[tid + 128];
     }
 }
 
