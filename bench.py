@@ -545,7 +545,7 @@ def main():
                                   "sustains ~1.96-2.0 GHz under its 1400 W power cap (1.24 kW averaged over the step, "
                                   "profiles/r02_clock_power_under_load.md; the "
                                   "same kernel on all-zero operands runs 2.35 GHz and 0.24 of peak, "
-                                  "profiles/r02_ffn_data_power.md), peak is quoted at 2.4 GHz" if args.prec != "f32" else "exact fp32 MFMA"),
+                                  "profiles/r02_ffn_data_power.md), peak is quoted at 2.4 GHz; a register-resident loop of nothing but this MFMA on random f16 operands sustains 1.65 PFLOP/s at the cap (profiles/r03_mfma_power_ceiling.md), so the kernel's 3x matrix work is ~0.87 of what the socket can power" if args.prec != "f32" else "exact fp32 MFMA"),
                          "mfma_pipe_tflops": achieved * (3 if args.prec != "f32" else 1),
                          "traffic_source": traffic_src,
                          "avg_launch_ms": ffn_ms, "launches": counts["ffn_layer"],
