@@ -13,8 +13,7 @@
 //                 (token, g) holds dims 4g+i
 //   out_proj      f16x3 MFMA: O^T registers are its B operand (k-slot 8g+t <-> dim 16(t>>2) + 4g + (t&3), folded
 //                 into the packed W_o columns), accumulated over heads
-// No Q/K/V/O ever touches LDS; LDS holds weight fragments (LDS-DMA ring of quarter-head slots) and the high halves of
-// the rows (see the kernel).  13 of 16 tile rows are useful (19 % padding);
+// No Q/K/V/O ever touches LDS; LDS holds only weight fragments (LDS-DMA ring of quarter-head slots, see the kernel).  13 of 16 tile rows are useful (19 % padding);
 // the token-0-pruned last layer keeps the token-major kernel (decode_f16.hip), where pruning skips whole tiles.
 #include "decode.h"
 
@@ -98,11 +97,13 @@ __device__ __forceinline__ float colmax16(float v) {
 // ---------------------------------------------------------------------------------------------
 // Four waves per workgroup, TWO workgroups per CU (one computes while the other sits at a barrier); a workgroup owns
 // half a group (8 queries), a wave two of them.  The rows of the wave's two queries are loaded and split ONCE per
-// item: the low halves stay in registers, the high halves in a wave-private 8 KiB LDS region, so the four heads do
-// not re-read (and re-split) them from L2.  The weight ring holds QUARTER-head slots of 16 KiB (q | k | v | out_proj
-// fragments) filled by LDS-DMA one phase ahead, four barriers per head; LDS = 2 x 16 KiB ring + 4 x 8 KiB rows.
+// item and stay in registers as f16 hi / lo fragments for the four heads (round 3: the high halves used to be parked in a
+// wave-private LDS region and re-read with every k-step — 2 of 6 fragment reads).  The weight ring holds QUARTER-head
+// slots of 16 KiB (q | k | v | out_proj fragments), FOUR of them, filled by LDS-DMA three phases ahead; four barriers per
+// head; LDS = 4 x 16 KiB ring + 3 KiB of small vectors.
 // (Earlier versions: eight waves / whole-head slots / rows re-read per head: 1.16 ms per layer; four waves / half-head
-// slots: 1.13 ms; this one 0.94 ms.)
+// slots: 1.13 ms; quarter-head slots, two-slot ring: 0.94 ms.  Bench stage, 4 launches + the last layer: 7.41 ms with the
+// two-slot ring, 6.9 with full-line stores, 6.86 with the rows in registers, 6.74 with the four-slot ring.)
 // ---------------------------------------------------------------------------------------------
 // LDS reads and their counted waits are issued by hand (same finding as in decode_f16.hip's pipelined FFN): with an
 // LDS-DMA refill in flight hipcc turns every LDS wait of this single-LDS-object kernel into lgkmcnt(0), i.e. it waits
@@ -111,34 +112,40 @@ __device__ __forceinline__ float colmax16(float v) {
 #define AQ_WAIT6(n, a, b, c, d, e, f) \
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(n))
 #define AQ_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
+#define AQ_READ32(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 #ifdef AQ_ABL_NOBAR   // timing ablations (tools/attn_abl.sh): wrong results, never shipped
 #define AQ_BARRIER() ((void)0)
 #else
-#define AQ_BARRIER() dma_publish_barrier()
+// Four-slot ring, DMA three phases ahead: at a barrier the slot of the phase that starts must have landed, and at most two
+// newer DMA sets (2 x 4 instructions per wave) have been issued since — whatever else is in flight (row loads, stores of
+// the previous item) is older or only makes the wait stricter.  vmcnt retires in order.  Raw s_barrier: the kernel has no
+// compiler-visible LDS access after its prologue, so nothing needs the fence __syncthreads() carries (which would drain vmcnt).
+#define AQ_BARRIER()                                       \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       \
+    asm volatile("s_barrier" ::: "memory")
 #endif
 #define AQ3_SLOT_HALFS (8 * 1024)    // 8 fragment pairs = 16 KiB
-#define AQ3_XROW_HALFS (4 * 1024)    // per wave: 2 tiles x 4 k-steps x 64 lanes x 8 halfs
 template <bool SINGLE>   // SINGLE: S3D_PREC_F16, one f16 MFMA per projection product (the 13x13 core stays on the fp32 MFMA)
 __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long groups, int T, const _Float16* wimg,
                                                                const LayerPtrs w) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // ring 2 x 16 KiB, then the rows 4 x 8 KiB
+    extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // ring 4 x 16 KiB, then the small vectors
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: no waterfall around M0
     const int m = lane & 15, g = lane >> 4;
     const float scale = 0.17677669529663687f * 1.4426950408889634f;   // log2(e) / sqrt(32)
     const _Float16* g_in = wimg;
     const _Float16* g_out = wimg + 4 * AQ_WIN_HALFS;
-    _Float16* s_x = s_win + 2 * AQ3_SLOT_HALFS + wave * AQ3_XROW_HALFS;
-    // in_proj bias | out_proj bias | LayerNorm1 gamma | beta: 768 floats behind the rows (published by the first barrier)
-    float* s_par = reinterpret_cast<float*>(s_win + 2 * AQ3_SLOT_HALFS + 4 * AQ3_XROW_HALFS);
+    // in_proj bias | out_proj bias | LayerNorm1 gamma | beta: 768 floats behind the ring (published by the first barrier)
+    float* s_par = reinterpret_cast<float*>(s_win + 4 * AQ3_SLOT_HALFS);
     for (int i = tid; i < 192; i += 256) {
         const float* src = i < 96 ? w.inb + 4 * i : i < 128 ? w.outb + 4 * (i - 96) : i < 160 ? w.ln1g + 4 * (i - 128) : w.ln1b + 4 * (i - 160);
         st4(s_par + 4 * i, ld4(src));
     }
     __syncthreads();   // the first item's accumulators read the out_proj bias before the first ring barrier
     const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_win + lane * 8);
-    const unsigned lxa = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_x + lane * 8);
     const unsigned lpar = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_par + 8 * g);
+    const unsigned lpar4 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_par + 4 * g);
+    const unsigned lparm = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_par + m);
     // phase ph = 4*h + {0 q, 1 k, 2 v, 3 out_proj}: 16 chunks of 1 KiB, four per wave.  A wave issues its four one at a
     // time BETWEEN the MFMA groups of the phase before (dma_piece(ph, buf, k) after the first half of k-step k): issued
     // back to back at the top of the phase, with the matrix pipe empty, they cost the wave ~60 issue cycles each
@@ -159,8 +166,12 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
         for (int k = 0; k < 4; ++k) dma_piece(ph, buf, k);
     };
     const long items = 2 * groups;
-    long ps = 0;   // running phase count: slot = ps & 1
-    if ((long)blockIdx.x < items) dma_phase(0, 0);
+    long ps = 0;   // running phase count: slot = ps & 3
+    if ((long)blockIdx.x < items) {
+        dma_phase(0, 0);
+        dma_phase(1, 1);
+        dma_phase(2, 2);
+    }
     const bool row_ok = m < T;
     const int mt = row_ok ? m : T - 1;
 
@@ -193,26 +204,24 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
         // out_proj accumulators open with residual row + out_proj bias (exact fp32 rows: tile j of the accumulator is
         // columns 32(j>>1) + 8g + 4(j&1) + i, i.e. xf[r][j>>1][j&1]), so the epilogue is LayerNorm only
         f32x4 acc_o[2][8];
-        {
-            unsigned par_off = 0;
-            asm volatile("" : "+v"(par_off));   // opaque: re-read per item instead of 32 pinned VGPRs
+        {   // hand-issued reads (a compiler-visible LDS read is guarded with vmcnt(0) against the ring's DMA in flight)
+            f32x4 bo[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const f32x4 bo = *reinterpret_cast<const f32x4*>(s_par + par_off + 384 + 32 * (j >> 1) + 8 * g + 4 * (j & 1));
+            for (int j = 0; j < 8; ++j) AQ_READ(bo[j], lpar, (384 + 32 * (j >> 1) + 4 * (j & 1)) * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(bo[0]), "+v"(bo[1]), "+v"(bo[2]), "+v"(bo[3]), "+v"(bo[4]), "+v"(bo[5]), "+v"(bo[6]), "+v"(bo[7]));
 #pragma unroll
-                for (int r = 0; r < 2; ++r) acc_o[r][j] = xf[r][j >> 1][j & 1] + bo;
-            }
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc_o[r][j] = xf[r][j >> 1][j & 1] + bo[j];
         }
-        // rows of the item: low halves in registers for the whole item, high halves parked in LDS
-        half8q xl[2][4];
+        // rows of the item: both halves in registers for the whole item (the high halves used to be parked in LDS and re-read
+        // with every k-step: 2 of 6 fragment reads)
+        half8q xl[2][4], xh[2][4];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                half8q hi;
-                split8pk(xf[r][u][0], xf[r][u][1], hi, xl[r][u]);
-                *reinterpret_cast<half8q*>(s_x + ((r * 4 + u) * 64 + lane) * 8) = hi;
-            }
+            for (int u = 0; u < 4; ++u) split8pk(xf[r][u][0], xf[r][u][1], xh[r][u], xl[r][u]);
         const bool more_items = item + gridDim.x < items;
 #pragma unroll 1
         for (int h = 0; h < 4; ++h) {
@@ -225,29 +234,26 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 if (part == 0) {   // the head's biases (LDS copy) open the accumulations below; read BEFORE the barrier, whose
                                    // LDS fence the compiler knows about (a later read would be waited for with lgkmcnt(0)
                                    // at the first MFMA, i.e. behind the hand-issued fragment reads of two k-steps)
+                    const unsigned lq = lpar4 + (unsigned)h * 128u, lv = lparm + (unsigned)h * 128u;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        bq[j] = *reinterpret_cast<const f32x4*>(s_par + 32 * h + 16 * j + 4 * g);
-                        bk[j] = *reinterpret_cast<const f32x4*>(s_par + 128 + 32 * h + 16 * j + 4 * g);
-                        bv[j] = s_par[256 + 32 * h + 16 * j + m];
+                        AQ_READ(bq[j], lq, 64 * j);
+                        AQ_READ(bk[j], lq, 512 + 64 * j);
+                        AQ_READ32(bv[j], lv, 1024 + 64 * j);
                     }
                 }
                 AQ_BARRIER();   // this phase's fragments have landed; the other slot is free
-                const int nph = 4 * h + part + 1, nbuf = (int)((ps + 1) & 1);
-                const unsigned lwa = lds_ring + (unsigned)(ps & 1) * (AQ3_SLOT_HALFS * 2);
+                const int nph = (4 * h + part + 3) & 15, nbuf = (int)((ps + 3) & 3);
+                const unsigned lwa = lds_ring + (unsigned)(ps & 3) * (AQ3_SLOT_HALFS * 2);
                 f32x4 d[2][2], c0[2];   // c0: the bias opens both row tiles' accumulations (C operand of k-step 0, no copies)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) c0[j] = part == 0 ? bq[j] : part == 1 ? bk[j] : f32x4{bv[j], bv[j], bv[j], bv[j]};
                 // fragment pairs (hi | lo) of the two 16-row tiles j and the high halves of the wave's two row tiles for
                 // k-step U, all read one k-step ahead (6 reads in flight under the 12 MFMAs of the current step)
-                half8q fh[2][2], fl[2][2], xq[2][2];
+                half8q fh[2][2], fl[2][2];
 #define AQ_STEP_READS(B, U)                                          \
     AQ_READ(fh[B][0], lwa, (U) * 2048);                              \
     AQ_READ(fl[B][0], lwa, (U) * 2048 + 1024);                       \
     AQ_READ(fh[B][1], lwa, (4 + (U)) * 2048);                        \
-    AQ_READ(fl[B][1], lwa, (4 + (U)) * 2048 + 1024);                 \
-    AQ_READ(xq[B][0], lxa, (U) * 1024);                              \
-    AQ_READ(xq[B][1], lxa, (4 + (U)) * 1024);
+    AQ_READ(fl[B][1], lwa, (4 + (U)) * 2048 + 1024);
 #define AQ_STEP_MFMA(B, U)                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
         if (j == 1) {                                                                                        \
@@ -256,25 +262,29 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
         if (part < 2) { /* D^T = W X^T */                                                                    \
-            d[0][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xq[B][0], xl[0][U], (U) == 0 ? c0[j] : d[0][j]);    \
-            d[1][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xq[B][1], xl[1][U], (U) == 0 ? c0[j] : d[1][j]);    \
+            d[0][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xh[0][U], xl[0][U], (U) == 0 ? c0[j] : d[0][j]);    \
+            d[1][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xh[1][U], xl[1][U], (U) == 0 ? c0[j] : d[1][j]);    \
         } else { /* D = X W^T */                                                                             \
-            d[0][j] = mfma3q<SINGLE>(xq[B][0], xl[0][U], fh[B][j], fl[B][j], (U) == 0 ? c0[j] : d[0][j]);    \
-            d[1][j] = mfma3q<SINGLE>(xq[B][1], xl[1][U], fh[B][j], fl[B][j], (U) == 0 ? c0[j] : d[1][j]);    \
+            d[0][j] = mfma3q<SINGLE>(xh[0][U], xl[0][U], fh[B][j], fl[B][j], (U) == 0 ? c0[j] : d[0][j]);    \
+            d[1][j] = mfma3q<SINGLE>(xh[1][U], xl[1][U], fh[B][j], fl[B][j], (U) == 0 ? c0[j] : d[1][j]);    \
         }                                                                                                    \
     }                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);
                 AQ_STEP_READS(0, 0)
                 AQ_STEP_READS(1, 1)
-                AQ_WAIT6(6, fh[0][0], fl[0][0], fh[0][1], fl[0][1], xq[0][0], xq[0][1]);
+                AQ_WAIT4(4, fh[0][0], fl[0][0], fh[0][1], fl[0][1]);
+                if (part == 0)   // the head's bias reads are older than the fragment reads: landed with this wait
+                    asm volatile("" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) c0[j] = part == 0 ? bq[j] : part == 1 ? bk[j] : f32x4{bv[j], bv[j], bv[j], bv[j]};
                 AQ_STEP_MFMA(0, 0)
                 AQ_STEP_READS(0, 2)
-                AQ_WAIT6(6, fh[1][0], fl[1][0], fh[1][1], fl[1][1], xq[1][0], xq[1][1]);
+                AQ_WAIT4(4, fh[1][0], fl[1][0], fh[1][1], fl[1][1]);
                 AQ_STEP_MFMA(1, 1)
                 AQ_STEP_READS(1, 3)
-                AQ_WAIT6(6, fh[0][0], fl[0][0], fh[0][1], fl[0][1], xq[0][0], xq[0][1]);
+                AQ_WAIT4(4, fh[0][0], fl[0][0], fh[0][1], fl[0][1]);
                 AQ_STEP_MFMA(0, 2)
-                AQ_WAIT6(0, fh[1][0], fl[1][0], fh[1][1], fl[1][1], xq[1][0], xq[1][1]);
+                AQ_WAIT4(0, fh[1][0], fl[1][0], fh[1][1], fl[1][1]);
                 AQ_STEP_MFMA(1, 3)
 #undef AQ_STEP_READS
 #undef AQ_STEP_MFMA
@@ -353,9 +363,9 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             AQ_BARRIER();   // out_proj fragments have landed; the v slot is free
             // the next phase is the next head's q, or phase 0 of the next item (issued even after the last item: no
             // branch in the MFMA stream; the kernel drains vmcnt before it ends)
-            const int oph = h < 3 ? 4 * (h + 1) : 0, obuf = (int)((ps + 1) & 1);
+            const int oph = (4 * h + 3 + 3) & 15, obuf = (int)((ps + 3) & 3);
             {
-                const unsigned lwa = lds_ring + (unsigned)(ps & 1) * (AQ3_SLOT_HALFS * 2);
+                const unsigned lwa = lds_ring + (unsigned)(ps & 3) * (AQ3_SLOT_HALFS * 2);
                 half8q wh[2][2], wl[2][2];   // [buffer][tile of the pair]
 #define AQ_O_READS(B, G)                                             \
     AQ_READ(wh[B][0], lwa, (2 * (G)) * 2048);                        \
@@ -450,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
 int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass) {
     if (groups <= 0) return 0;
     S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr, "attn_q: T %d", T);
-    const size_t lds = (size_t)(2 * AQ3_SLOT_HALFS + 4 * AQ3_XROW_HALFS) * 2 + 768 * 4;   // 64 KiB + the small vectors
+    const size_t lds = (size_t)(4 * AQ3_SLOT_HALFS) * 2 + 768 * 4;   // 64 KiB ring + the small vectors
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
