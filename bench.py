@@ -135,15 +135,18 @@ def _pmc_traffic(args, kname):
                "--n-qry", str(args.n_qry), "--n-slices", str(args.n_slices), "--batch", str(args.batch), "--prec", args.prec]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
-            acc = []
+            per_inst = {}   # every instantiation of the kernel template (mangled or demangled name) -> its launches' values
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     if row["Counter_Name"] == counter and kname in row["Kernel_Name"]:
-                        acc.append(float(row["Counter_Value"]))
-            if not acc:
+                        per_inst.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not per_inst:
+                print("bench: no '%s' rows in the rocprofv3 %s pass" % (kname, counter), file=sys.stderr)
                 return None, None
+            acc = max(per_inst.values(), key=sum)    # the dominant instantiation (the non-final layers' kernel)
             vals[counter] = sum(acc) / len(acc)
-        except Exception:
+        except Exception as e:
+            print("bench: rocprofv3 --pmc %s pass failed (%s)" % (counter, e), file=sys.stderr)
             return None, None
         finally:
             shutil.rmtree(d, ignore_errors=True)
@@ -506,7 +509,7 @@ def main():
         # HBM bytes per launch of the dominant kernel: measured in this run by two counter passes (FETCH_SIZE, WRITE_SIZE:
         # separate rocprofv3 --pmc runs of the same timed loop, MI355X_MICROARCH.md's recipe and gfx950 correction);
         # only if that is impossible the figure of the committed pass is quoted, and the source field says which
-        kname = "ffn_layer_kernel" if args.prec == "f32" else "ffn_layer_f16x3_pipe_kernelILi0ELb0"
+        kname = "ffn_layer_kernel" if args.prec == "f32" else "ffn_layer_f16x3_pipe_kernel"   # base name: any template arguments
         traffic, traffic_src = (None, None)
         if args.pmc and world == 1:
             traffic, traffic_src = _pmc_traffic(args, kname)
@@ -520,6 +523,8 @@ def main():
                     traffic = pmc["kernels"][args.prec][jk]["hbm_bytes_per_launch"]
                     traffic_src = "committed pass profiles/pmc_traffic.json (not measured in this run: %s)" % (
                         "disabled" if not args.pmc else "multi-rank run" if world > 1 else "rocprofv3 pass failed")
+                    if args.pmc and world == 1:
+                        print("bench: roofline.traffic falls back to the committed figure", file=sys.stderr)
             except (OSError, KeyError, ValueError):
                 pass
         decode_ms = sum(stage_ms[k] for k in ("sample_tokens", "attn_layer", "ffn_layer", "ffn_final"))

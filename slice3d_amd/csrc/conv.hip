@@ -704,7 +704,9 @@ static bool lin_stream_eligible(const ConvLaunch& a) {
     if (S.sbcast || S.bmod || S.bdiv != 1 || S.C % 128 || S.C > 384 || a.KU != S.C / 16) return false;
     // K > 128: all 128 outputs live; plain products only (no scale / bias / output dropout)
     if (S.C > 128 && (a.CoutPad != 128 || a.drop.p > 0.f || a.scale || a.shift)) return false;
-    if (a.out_mode != S3D_OUT_NHWC || a.gate || a.out_accumulate || a.cout_store % 4 || a.scale) return false;
+    // cout_store == CoutPad: the residual rows of a 32-channel output slot are requested without a per-channel guard
+    // (hand-issued loads), so every slot must lie inside the output / residual row
+    if (a.out_mode != S3D_OUT_NHWC || a.gate || a.out_accumulate || a.cout_store != a.CoutPad || a.scale) return false;
     if (a.act != S3D_ACT_NONE && a.act != S3D_ACT_RELU) return false;
     return (long)a.N * a.H * a.W >= (1L << 17);   // long row sets (the decoder token rows); short ones keep lin_rows (more, smaller workgroups)
 }
@@ -1007,6 +1009,11 @@ int launch_conv(const ConvLaunch& a_in, hipStream_t stream) {
     S3D_CHECK_ARG(a.CoutPad % 16 == 0 && a.CoutPad > 0, "conv: CoutPad %d", a.CoutPad);
     for (int s = 0; s < a.nsrc; ++s)
         S3D_CHECK_ARG(a.src[s].C % 16 == 0 && a.src[s].bdiv >= 1, "conv: bad source %d", s);
+    // ConvTranspose output: the quadrant-scatter store carries affine + activation only.  Its full-line form (32-channel
+    // pairs, conv_epilogue) pairs accumulator tiles (jt0 + 2 np, jt0 + 2 np + 1) with jt0 = a multiple of NT — even for
+    // every tile shape of the menu below — and would index dropout / gate / residual by the SCATTERED offset.
+    S3D_CHECK_ARG(a.out_mode != S3D_OUT_CONVT || (a.drop.p <= 0.f && !a.gate && !a.residual && !a.out_accumulate),
+                  "conv: ConvTranspose output takes no dropout / gate / residual / accumulate");
     if (conv3x3_lds_eligible(a)) return launch_conv3x3_lds(a, stream);
     if (lin_stream_eligible(a)) return launch_lin_stream(a, stream);
     if (lin_rows_eligible(a)) return launch_lin_rows(a, stream);

@@ -1969,8 +1969,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ u
                 float mk[4];
                 s3d_drop4(drop, (unsigned long long)row * 128 + 4 * l, mk);
                 rm = f32x4{r[0] * mk[0], r[1] * mk[1], r[2] * mk[2], r[3] * mk[3]};
-                st4(dum + row * 128 + 4 * l, rm);
             }
+            if (dum != du) st4(dum + row * 128 + 4 * l, rm);   // a separate buffer is always written (== du at p = 0)
             dm += rm;
         }
     }
@@ -1996,6 +1996,7 @@ int launch_ln_bwd(const float* u, const float* gamma, const float* dy, float* du
     const int nb = (int)((rows + 7) / 8 < LN_BLOCKS ? (rows + 7) / 8 : LN_BLOCKS);
     const bool third = dsum != nullptr;
     S3D_CHECK_ARG(!third || (drop && (drop->p <= 0.f || (dum && dum != du))), "ln_bwd: dropped output needs its own buffer");
+    if (third && !dum) dum = du;
     const int np = third ? 3 : 2;
     if (third)
         hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nb), dim3(256), 0, stream, u, gamma, dy, du, rows, partial, *drop, dum);

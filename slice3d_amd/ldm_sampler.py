@@ -51,12 +51,15 @@ class DDIMSampler:
         self.ddim_sqrt_one_minus_alphas = np.sqrt(1.0 - a)
 
     # -- one UNet evaluation on static buffers (graph replay when possible) --------------------------------------
-    def _eps(self, x, c_concat, t_int, c_fmaps):
+    def _prepare(self, x, c_concat, c_fmaps):
+        """Static input buffers + (when possible) the captured graph for these shapes and c_fmaps buffers, then the
+        conditioning latent of THIS call: c_concat is copied on every sample() — the graph reads the static copy, so a
+        caller that refills its tensor in place (or whose new tensor lands on a recycled address) must not meet the
+        previous batch's condition.  c_fmaps are read by address and always show their current contents."""
         if self._graph is None:
             dev = x.device
-            self._xc = torch.empty((x.shape[0], x.shape[1] + c_concat.shape[1]) + tuple(x.shape[2:]), device=dev)
+            self._xc = torch.zeros((x.shape[0], x.shape[1] + c_concat.shape[1]) + tuple(x.shape[2:]), device=dev)
             self._t = torch.zeros((x.shape[0],), dtype=torch.long, device=dev)
-            self._xc[:, x.shape[1]:].copy_(c_concat)
             self._graph = False
             if self.use_graph and x.is_cuda:
                 try:
@@ -69,6 +72,9 @@ class DDIMSampler:
                     self._graph = g
                 except Exception:      # capture unsupported: eager launches
                     self._graph = False
+        self._xc[:, x.shape[1]:].copy_(c_concat)
+
+    def _eps(self, x, t_int, c_fmaps):
         self._xc[:, :x.shape[1]].copy_(x)
         self._t.fill_(int(t_int))
         if self._graph:
@@ -82,10 +88,11 @@ class DDIMSampler:
         x_T (N,4,H,W) start latent, c_concat (N,4,H,W), c_fmaps dict.  Returns (x_0 estimate after the last step,
         {'x_inter': [...], 'pred_x0': [...]}) like the reference; n_steps stops early (timing runs)."""
         self.make_schedule(S, eta)
-        key = (tuple(x_T.shape), tuple(c_concat.shape), x_T.device, c_concat.data_ptr(),
+        key = (tuple(x_T.shape), tuple(c_concat.shape), x_T.device,
                tuple((k, v.data_ptr(), tuple(v.shape)) for k, v in sorted(c_fmaps.items())))
-        if key != self._key:      # the captured graph reads these very buffers: new conditioning -> new capture
+        if key != self._key:      # the captured graph reads the c_fmaps buffers by address: new buffers -> new capture
             self._graph, self._key = None, key
+        self._prepare(x_T, c_concat, c_fmaps)
         img = x_T
         total = self.ddim_timesteps.shape[0]
         inter = {"x_inter": [img], "pred_x0": [img]}
@@ -93,7 +100,7 @@ class DDIMSampler:
             if n_steps is not None and i >= n_steps:
                 break
             index = total - i - 1
-            e_t = self._eps(img, c_concat, step, c_fmaps)
+            e_t = self._eps(img, step, c_fmaps)
             if noises is not None:
                 nz = noises[i].to(img.device)
             else:

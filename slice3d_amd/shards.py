@@ -149,11 +149,10 @@ class ShardLoader:
             self._dev_perm = torch.from_numpy(np.array(self.perm)).to(self.device)
         self._pin = None
         self._pin_done = None   # event after the last H2D copy out of _pin: the next batch must not overwrite it earlier
-        self._batch_no = 0
+        self._gen = None        # one device generator, re-seeded per (epoch, rank, batch, item)
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
-        self._batch_no = 0
 
     def _order(self):
         idx = np.arange(self.n)
@@ -173,10 +172,12 @@ class ShardLoader:
         for b in range(nb):
             ids = order[b * self.bs:(b + 1) * self.bs]
             views = rng.integers(0, self.nv, len(ids)) if self.split == "train" else np.full(len(ids), min(4, self.nv - 1))
-            yield self.make_batch(ids, views)
+            yield self.make_batch(ids, views, batch_no=b)
 
-    def make_batch(self, ids, views):
-        """The batch of shapes `ids` seen from `views` (both 1-D integer arrays)."""
+    def make_batch(self, ids, views, batch_no=0):
+        """The batch of shapes `ids` seen from `views` (both 1-D integer arrays).  batch_no = its index inside the epoch
+        (the iterator passes it): with (seed, epoch, rank, item) it keys the train split's query subsets, so iterating an
+        epoch twice — or resuming in its middle — replays the same subsets."""
         from . import _lib
         if self._lib is None:
             self._lib = _lib.load()
@@ -215,12 +216,13 @@ class ShardLoader:
             else:
                 pts = torch.from_numpy(np.array(self.pts[lo:hi])).to(dev, non_blocking=True)
             if self.split == "train":      # np.random.seed(); permutation[:n_qry]  ->  a uniform subset, drawn on the device
-                # from the loader's own stream: a function of (seed, epoch, rank, batch, item), so ranks draw different
-                # subsets and a resumed epoch replays its own
-                gen = torch.Generator(device=dev)
-                gen.manual_seed(int(np.random.SeedSequence((self.seed, self.epoch, self.rank, self._batch_no, k))
-                                    .generate_state(1, dtype=np.uint64)[0] >> 1))
-                idx = torch.randperm(n, device=dev, generator=gen)[:self.n_qry].int()
+                # from the loader's own stream: a function of (seed, epoch, rank, batch index, item), so ranks draw
+                # different subsets and an epoch iterated twice / resumed replays its own
+                if self._gen is None:
+                    self._gen = torch.Generator(device=dev)
+                self._gen.manual_seed(int(np.random.SeedSequence((self.seed, self.epoch, self.rank, int(batch_no), k))
+                                          .generate_state(1, dtype=np.uint64)[0] >> 1))
+                idx = torch.randperm(n, device=dev, generator=self._gen)[:self.n_qry].int()
             elif self._dev_perm is not None:
                 idx = self._dev_perm[lo:lo + self.n_qry]
             else:
@@ -229,7 +231,6 @@ class ShardLoader:
                                                   qry[k].data_ptr(), sdf[k].data_ptr(),
                                                   occ[k].data_ptr() if occ is not None else None, st),
                        "s3d_dataset_points_fwd")
-        self._batch_no += 1
         batch = {"img_input": img_input, "qry_norot": qry, "obj_rot_mat": cam[:, :9].reshape(b, 3, 3).contiguous(),
                  "trans_mat_wo_rot_tp": cam[:, 9:].reshape(b, 4, 3).contiguous(), "sdf": sdf, "img_slices": img_slices}
         if occ is not None:

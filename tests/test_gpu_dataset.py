@@ -47,6 +47,12 @@ def test_device_batches_equal_the_host_dataset(tmp_path, white, in_hbm):
         assert float(batch["img_input"].abs().max()) <= 1.0
         seen.append(batch["qry_norot"].cpu())
     assert len(seen) == 1                                                # 3 shapes, batch 2, drop_last
+    # iterating the same epoch again replays its query subsets (keyed on the batch index inside the epoch, not on a
+    # running counter); another epoch draws others
+    again = [b["qry_norot"].cpu() for b in lt]
+    assert torch.equal(again[0], seen[0])
+    lt.set_epoch(2)
+    assert not torch.equal(next(iter(lt))["qry_norot"].cpu(), seen[0])
     pts_all = torch.from_numpy(np.load(os.path.join(out, "train", "pts.npy")))
     rows = {tuple(r) for r in pts_all[:, :3].numpy().round(6).tolist()}
     q = seen[0][0].numpy().round(6)

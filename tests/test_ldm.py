@@ -122,6 +122,32 @@ def test_ddim_sampler_reproduces_the_reference_run(prec, graph):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("graph", [True, False])
+def test_ddim_sampler_sees_a_conditioning_latent_refilled_in_place(graph):
+    """The captured graph reads a STATIC copy of c_concat: a caller that refills its conditioning tensor in place between
+    two sample() calls (same address, same shapes — no re-capture) must get the second condition's result, i.e. the same
+    latents a fresh sampler produces for it."""
+    from slice3d_amd.ldm_sampler import DDIMSampler
+    from slice3d_amd.ldm_unet import UNetModel
+    from slice3d_amd.weights import load_seeded
+    x8, _, cf = ldm_inputs(LDM_SMALL, 1, 11)
+    m = load_seeded(UNetModel(prec="f16x3", **LDM_SMALL), 0).cuda().eval()
+    cfd = {k: v.cuda() for k, v in cf.items()}
+    x_T, c_a = x8[:, :4].contiguous().cuda(), x8[:, 4:].contiguous().cuda()
+    c_b = torch.flip(c_a, dims=(-1,)).contiguous() * 0.5
+    noises = [torch.randn(x_T.shape, generator=torch.Generator().manual_seed(5 + i)) for i in range(2)]
+    smp = DDIMSampler(m, use_graph=graph)
+    cond = c_a.clone()
+    out_a, _ = smp.sample(2, x_T, cond, cfd, noises=noises)
+    out_a = out_a.clone()
+    cond.copy_(c_b)                                # in place: same data_ptr, no new capture
+    out_b, _ = smp.sample(2, x_T, cond, cfd, noises=noises)
+    fresh, _ = DDIMSampler(m, use_graph=False).sample(2, x_T, c_b, cfd, noises=noises)
+    assert float((out_b - fresh).abs().max()) < 1e-5
+    assert float((out_b - out_a).abs().max()) > 1e-3      # and the condition really matters
+
+
+@pytest.mark.gpu
 def test_group_norm_of_two_sources_equals_group_norm_of_the_concatenation():
     """s3d_group_norm2_fwd (the th.cat([h, hs.pop()]) of openaimodel.py:750, never materialised) == s3d_group_norm_fwd on
     torch.cat, bit for bit, on the fused one-launch path and on the sliced two-pass path (large map)."""
