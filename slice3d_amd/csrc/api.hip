@@ -602,7 +602,6 @@ HeadLayout head_layout() {
         H.L[l].ln2g = take(128);
         H.L[l].ln2b = take(128);
         H.L[l].wf16 = take((size_t)S3D_FFN_NCHUNK * 8192);
-        H.L[l].wf8 = take((size_t)S3D_FFN_NCHUNK * 2048);
         H.L[l].aq16 = take((size_t)(96 + 32) * 512);
     }
     H.fco_w = take(128);
@@ -641,7 +640,6 @@ static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLa
         TRY(copy_vec(b + H.L[l].ln2g, p.norm2_w, 128, st));
         TRY(copy_vec(b + H.L[l].ln2b, p.norm2_b, 128, st));
         TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wf16, st));
-        TRY(launch_pack_ffn_fp8(p.lin1_w, b + H.L[l].wf8, st));
         TRY(launch_pack_attn_q_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].aq16, st));
     }
     {   // absorbed token-0 attention of the last layer (launch_attn_last_mix)
@@ -745,7 +743,6 @@ static LayerPtrs layer_ptrs(const float* b, const HeadLayout& H, int l) {
     p.ln1g = b + H.L[l].ln1g; p.ln1b = b + H.L[l].ln1b; p.w1 = b + H.L[l].w1; p.b1 = b + H.L[l].b1;
     p.w2 = b + H.L[l].w2; p.b2 = b + H.L[l].b2; p.ln2g = b + H.L[l].ln2g; p.ln2b = b + H.L[l].ln2b;
     p.wf16 = b + H.L[l].wf16;
-    p.wf8 = b + H.L[l].wf8;
     p.aq16 = b + H.L[l].aq16;
     return p;
 }

@@ -17,8 +17,6 @@ struct HeadLayout {
         size_t inw, inb, outw, outb, ln1g, ln1b;
         size_t w1, b1, w2, b2, ln2g, ln2b;   // w1: [128 tiles][8] image; w2: chunked [64][8][2] image
         size_t wf16;                         // f16 hi/lo chunk image of lin1/lin2 (64 x 32 KiB), decode_f16.hip
-        size_t wf8;                          // fp8 (e4m3) images of lin1's f16 hi and scaled lo parts (64 x 8 KiB): the cross
-                                             // terms of the inference FFN's first GEMM, decode_f16.hip
         size_t aq16;                         // in_proj / out_proj fragments of the query-major attention kernel
     } L[S3D_N_LAYERS];
     size_t fco_w, fco_b;
@@ -32,7 +30,7 @@ struct HeadLayout {
 HeadLayout head_layout();
 
 struct LayerPtrs {
-    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b, *wf16, *aq16, *wf8;
+    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b, *wf16, *aq16;
 };
 
 struct SampleArgs {
@@ -147,4 +145,3 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
                            long g_begin, const int* perm, hipStream_t stream, bool single_pass = false);
 int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream);
-int launch_pack_ffn_fp8(const float* w1, float* out8, hipStream_t stream);   // lin1 (2048,128) -> S3D_FFN_NCHUNK x 8 KiB

@@ -113,9 +113,6 @@ __device__ __forceinline__ float colmax16(float v) {
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(n))
 #define AQ_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
 #define AQ_READ32(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#ifdef AQ_ABL_NOBAR   // timing ablations (tools/attn_abl.sh): wrong results, never shipped
-#define AQ_BARRIER() ((void)0)
-#else
 // Four-slot ring, DMA three phases ahead: at a barrier the slot of the phase that starts must have landed, and at most two
 // newer DMA sets (2 x 4 instructions per wave) have been issued since — whatever else is in flight (row loads, stores of
 // the previous item) is older or only makes the wait stricter.  vmcnt retires in order.  Raw s_barrier: the kernel has no
@@ -123,7 +120,6 @@ __device__ __forceinline__ float colmax16(float v) {
 #define AQ_BARRIER()                                       \
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       \
     asm volatile("s_barrier" ::: "memory")
-#endif
 #define AQ3_SLOT_HALFS (8 * 1024)    // 8 fragment pairs = 16 KiB
 template <bool SINGLE>   // SINGLE: S3D_PREC_F16, one f16 MFMA per projection product (the 13x13 core stays on the fp32 MFMA)
 __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long groups, int T, const _Float16* wimg,
@@ -150,9 +146,6 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
     // time BETWEEN the MFMA groups of the phase before (dma_piece(ph, buf, k) after the first half of k-step k): issued
     // back to back at the top of the phase, with the matrix pipe empty, they cost the wave ~60 issue cycles each
     auto dma_piece = [&](int ph, int buf, int k) {
-#ifdef AQ_ABL_NODMA
-        return;
-#endif
         const int h = ph >> 2, part = ph & 3;
         const _Float16* src0 = part < 3 ? g_in + (size_t)h * AQ_WIN_HALFS + part * AQ3_SLOT_HALFS
                                         : g_out + (size_t)h * AQ_WO_HALFS;
@@ -185,13 +178,8 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             const float* p = Xn + (mt * S3D_GROUP + qn + r) * 128 + 8 * g;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-#ifdef AQ_ABL_NOROWS
-                xf[r][u][0] = f32x4{0.1f * g, 0.2f * m, 0.3f, (float)it};
-                xf[r][u][1] = f32x4{0.5f * u, 0.25f, 0.125f * r, 1.f};
-#else
                 xf[r][u][0] = ld4(p + 32 * u);
                 xf[r][u][1] = ld4(p + 32 * u + 4);
-#endif
             }
         }
     };
@@ -312,10 +300,6 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
     asm volatile("s_nop 15" ::: "memory");          \
     __builtin_amdgcn_sched_barrier(0);
             half8q oh[2], ol[2];
-#ifdef AQ_ABL_NOCORE
-#pragma unroll
-            for (int r = 0; r < 2; ++r) split8pk(qd[r][0] + kd[r][0] + vd[r][0], qd[r][1] + kd[r][1] + vd[r][1], oh[r], ol[r]);
-#else
             {
                 half8q kh[2], kl[2], qh[2], ql[2];
 #pragma unroll
@@ -358,7 +342,6 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
 #pragma unroll
                 for (int r = 0; r < 2; ++r) split8pk(od[r][0], od[r][1], oh[r], ol[r]);
             }
-#endif
 #undef AQ_SETTLE
             AQ_BARRIER();   // out_proj fragments have landed; the v slot is free
             // the next phase is the next head's q, or phase 0 of the next item (issued even after the last item: no
@@ -443,13 +426,8 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 const f32x4 r1 = acc_o[r][2 * J + 1] * (ga[2 * J + 1] * rstd) + be[2 * J + 1];
                 f32x4 va, vb;
                 s3d_full_line_pair(r0, r1, m, va, vb);
-#ifdef AQ_ABL_NOROWS
-                if (ok_a && va[0] == 1234.5f) st4(oa + 32 * J, va);
-                if (ok_b && vb[0] == 1234.5f) st4(oa + 8 * S3D_GROUP * 128 + 32 * J, vb);
-#else
                 if (ok_a) st4(oa + 32 * J, va);
                 if (ok_b) st4(oa + 8 * S3D_GROUP * 128 + 32 * J, vb);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);   // one row tile at a time
         }

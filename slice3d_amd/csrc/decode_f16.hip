@@ -119,60 +119,6 @@ __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h
 }
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
-// EXPERIMENT switch (never set in the product build; result in profiles/r03_ffn_two_product_gemm2.md): GEMM2 of the
-// inference modes with two of the three split products — 1 drops W2_lo * h_hi, 2 drops W2_hi * h_lo
-#ifndef FFN_G2_TWO
-#define FFN_G2_TWO 0
-#endif
-
-// The cross terms of GEMM1 (x_hi * W1_lo + x_lo * W1_hi, each 2^-11 of the product) on the block-scaled fp8 MFMA of gfx950
-// (v_mfma_scale_f32_16x16x128_f8f6f4, twice the f16 rate, one instruction per 128-deep product): their operands are the
-// e4m3 roundings of the f16 hi parts and of the lo parts times 2^13 (the instruction's E8M0 scale takes the 2^13 back
-// out), i.e. the CORRECTION carries a relative error of ~2^-5 and the product one of ~2^-16 — the hi * hi term stays on
-// the f16 MFMA, exact.  Inference modes only (0 / 1); 12 f16 MFMAs per (hidden tile, row tile) become 4 + 2 fp8 ones
-// (= 0.63 of the matrix-pipe time of GEMM1).  tools/emu_fp8_corr.py is the numerical model, tools/unit/t_mfma_fp8.hip
-// the operand-layout / scale check of the instruction.
-// EXPERIMENT, off in the product build (profiles/r03_ffn_g1_fp8.md): the FFN stage went 22.7 -> 21.6 ms only (the chip is
-// power-capped: fewer matrix-pipe cycles, not proportionally less energy), the error against the oracle rose from 4.3e-5 to
-// 7.0e-5 of the 1e-4 gate, the f16x3-vs-fp32 tests at 1e-5 fail, and one chunking bit-exactness test failed (unexplained).
-#ifndef FFN_G1_FP8
-#define FFN_G1_FP8 0
-#endif
-#define FP8_LO_SCALE_LOG2 13
-typedef int int8v __attribute__((ext_vector_type(8)));
-typedef int int4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ int8v cat8(const int4v a, const int4v b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
-// 4 fp32 values -> e4m3 bytes of f16(x) and of f16(x - f16(x)) * 2^13, k order = byte order
-__device__ __forceinline__ void split4_fp8(const f32x4 v, int& hi8, int& lo8) {
-    float h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const _Float16 hh = (_Float16)v[i];
-        h[i] = (float)hh;
-        l[i] = (float)(_Float16)(v[i] - h[i]) * (float)(1 << FP8_LO_SCALE_LOG2);
-    }
-    hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(h[0], h[1], 0, false);
-    hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(h[2], h[3], hi8, true);
-    lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(l[0], l[1], 0, false);
-    lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(l[2], l[3], lo8, true);
-}
-#define MFMA_F8(A, B, C, SA, SB_) __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, C, 0, 0, 0, SA, 0, SB_)
-#define F8_ONE 127
-#define F8_DOWN (127 - FP8_LO_SCALE_LOG2)
-// the W1 half of a weight buffer in that mode: pieces 0-7 = the f16 hi fragments (chunk image), pieces 8-15 = the fp8
-// image's chunk (hi tiles 0, 1 | scaled lo tiles 0, 1; a tile = 64 lanes x 32 bytes as two 1 KiB halves)
-__device__ __forceinline__ void dma_w1_fp8(const _Float16* gchunk16, const _Float16* gchunk8, _Float16* lbuf, int wave, int lane) {
-    static_assert(PIPE_WAVES == 4, "two waves copy the f16 pieces, two the fp8 pieces");
-    const int first = wave * 4;
-    const _Float16* src = wave < 2 ? gchunk16 + first * 512 : gchunk8 + (first - 8) * 512;
-    const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(src + lane * 8);
-    __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(lbuf + first * 512);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
-}
-
 struct FfnTrainArgs {   // MODE 2
     float* Uout;     // pre-LayerNorm output u = x + dropout(FFN(x)), saved for the backward
     DropCfg dh, dq;  // hidden-unit / output dropout
@@ -253,70 +199,6 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
 #define DS_WAIT5(n, r0, r1, r2, r3, r4) \
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : "n"(n))
 
-// phase A group K with GEMM1's cross terms on the fp8 MFMA (FFN_G1_FP8): the f16 hi * hi MFMAs of (u, a) = (K >> 1, K & 1) and
-// ONE 128-deep fp8 MFMA — hidden tile a8 = (K & 1) ^ 1 (never an accumulator of this group's f16 MFMAs), row tile
-// (K >> 1) & 1, W1_hi8 * x_lo8 for K < 4 and W1_lo8 * x_hi8 after.  wa / wb hold tile 1 / tile 0 of the fp8 image (hi
-// first, reloaded with the lo tiles at K = 3 / 4, a group after their last reader).  Reads in flight are counted as in
-// FFN_GROUP_A: see the table in the comments of each wait.
-#define FFN_GROUP_A8(K)                                                                                              \
-    {                                                                                                                \
-        constexpr int u = (K) >> 1, a = (K) & 1, s = (K) & 1;                                                        \
-        constexpr int a8 = ((K) & 1) ^ 1, r8 = ((K) >> 1) & 1, t8 = (K) >> 2;                                        \
-        if (!LAST) {                                                                                                 \
-            if ((K) < 7) {                                                                                           \
-                DS_READ(fh[s ^ 1], lw, ((((K) + 1) & 1) * 4 + (((K) + 1) >> 1)) * 1024);                             \
-            } else {                                                                                                 \
-                DS_READ(vh[0], lw, 16384);                                                                           \
-                DS_READ(vl[0], lw, 24576);                                                                           \
-            }                                                                                                        \
-            if ((K) == 0) { DS_READ(wb0, lw, 8192); DS_READ(wb1, lw, 8192 + 1024); }                 /* (0, hi) */   \
-            if ((K) == 3) { DS_READ(wa0, lw, 8192 + 4096 + 2048); DS_READ(wa1, lw, 8192 + 4096 + 3072); } /* (1, lo) */ \
-            if ((K) == 4) { DS_READ(wb0, lw, 8192 + 4096); DS_READ(wb1, lw, 8192 + 4096 + 1024); }   /* (0, lo) */   \
-            if ((K) == 0) {        /* top: bq0 bq1 fh0 wa0 wa1 | fh1 wb0 wb1 */                                      \
-                DS_WAIT5(3, bq[0], bq[1], fh[0], wa0, wa1);                                                          \
-                _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r) { hn[0][r] = bq[0]; hn[1][r] = bq[1]; }            \
-            } else if ((K) == 1) { /* fh1 wb0 wb1 | fh0 */                                                           \
-                DS_WAIT3(1, fh[1], wb0, wb1);                                                                        \
-            } else if ((K) == 2) { /* fh0 | fh1 */                                                                   \
-                DS_WAIT1(1, fh[0]);                                                                                  \
-            } else if ((K) == 3) { /* fh1 | fh0 wa0 wa1 */                                                           \
-                DS_WAIT1(3, fh[1]);                                                                                  \
-            } else if ((K) == 4) { /* fh0 wa0 wa1 | fh1 wb0 wb1 */                                                   \
-                DS_WAIT3(3, fh[0], wa0, wa1);                                                                        \
-            } else if ((K) == 5) { /* fh1 wb0 wb1 | fh0 */                                                           \
-                DS_WAIT3(1, fh[1], wb0, wb1);                                                                        \
-            } else if ((K) == 6) { /* fh0 | fh1 */                                                                   \
-                DS_WAIT1(1, fh[0]);                                                                                  \
-            } else {               /* fh1 | vh0 vl0 */                                                               \
-                DS_WAIT1(2, fh[1]);                                                                                  \
-            }                                                                                                        \
-            /* issue order: f16 (row tile rf), fp8, f16 (the other row tile) — no MFMA follows one that writes the */ \
-            /* accumulator it reads within two slots (rf = the row tile the PREVIOUS group's fp8 MFMA did not touch) */ \
-            static_assert(PIPE_R == 2, "issue order below");                                                         \
-            constexpr int rf = (K) == 0 ? 0 : ((((K) - 1) >> 1) & 1) ^ 1;                                            \
-            hn[a][rf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xh[rf][u], hn[a][rf], 0, 0, 0);                \
-            hn[a8][r8] = MFMA_F8(a8 ? cat8(wa0, wa1) : cat8(wb0, wb1), t8 ? xh8[r8] : xl8[r8], hn[a8][r8],            \
-                                 t8 ? F8_DOWN : F8_ONE, t8 ? F8_ONE : F8_DOWN);                                      \
-            hn[a][rf ^ 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xh[rf ^ 1][u], hn[a][rf ^ 1], 0, 0, 0);    \
-        } else if ((K) == 7) {                                                                                       \
-            DS_READ(vh[0], lw, 16384);                                                                               \
-            DS_READ(vl[0], lw, 24576);                                                                               \
-        }                                                                                                            \
-        if ((K) % (4 / PIPE_R) == 0) {   /* 2 * PIPE_R D tiles over the 8 groups */                                   \
-            constexpr int tile = (K) / (4 / PIPE_R), a2 = tile / PIPE_R, r2 = tile % PIPE_R;                         \
-            ffn_act4<MODE>(hd[a2][r2], hh2[r2][2 * a2], hh2[r2][2 * a2 + 1], hl2[r2][2 * a2], hl2[r2][2 * a2 + 1], as, ta, ba, c, a2, r2); \
-            asm volatile("" : "+v"(hl2[r2][2 * a2]), "+v"(hl2[r2][2 * a2 + 1]), "+v"(hh2[r2][2 * a2]),               \
-                         "+v"(hh2[r2][2 * a2 + 1]));                                                                 \
-        }                                                                                                            \
-        if (!LAST) {                                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < 1 + PIPE_R; ++i) {                                                 \
-                SGB(SG_MFMA, 1);                                                                                     \
-                SGB(SG_VALU, 6);                                                                                     \
-            }                                                                                                        \
-        }                                                                                                            \
-        SB();                                                                                                        \
-    }
-
 // phase A group K = (u, a): reads of group K+1 (or of phase B's first tile), 6 MFMAs, VALU slice on even K
 #define FFN_GROUP_A(K)                                                                                               \
     {                                                                                                                \
@@ -377,11 +259,9 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
         } else {                                                                                                     \
             DS_WAIT2(0, vh[s], vl[s]);                                                                               \
         }                                                                                                            \
-        if (!SINGLE && FFN_G2_TWO != 2) {                                                                            \
+        if (!SINGLE) {                                                                                               \
             _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
                 acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[s], hl[r], acc[r][J], 0, 0, 0);                \
-        }                                                                                                            \
-        if (!SINGLE && FFN_G2_TWO != 1) {                                                                            \
             _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
                 acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[s], hh[r], acc[r][J], 0, 0, 0);                \
         }                                                                                                            \
@@ -398,12 +278,9 @@ template <int MODE, bool LAST, bool SINGLE>
 __device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned lb, const half8 (&xh)[PIPE_R][4],
                                               const half8 (&xl)[PIPE_R][4], f32x4 (&acc)[PIPE_R][8],
                                               const f32x4 (&hd)[2][PIPE_R], f32x4 (&hn)[2][PIPE_R], FfnActState& as,
-                                              const FfnTrainArgs& ta, const FfnBwdArgs& ba, const int c,
-                                              const int8v (&xh8)[PIPE_R], const int8v (&xl8)[PIPE_R]) {
-    constexpr bool G1FP8 = FFN_G1_FP8 && !SINGLE && (MODE == 0 || MODE == 1);
+                                              const FfnTrainArgs& ta, const FfnBwdArgs& ba, const int c) {
     half2v hh2[PIPE_R][4], hl2[PIPE_R][4];
     half8 fh[2], fl[2], vh[2], vl[2];
-    int4v wa0, wa1, wb0, wb1;   // G1FP8: fp8 fragments of hidden tile 1 / tile 0 (two 16-byte halves each)
     f32x4 bq[2];
     if (!LAST) {
         if (MODE != 4) {
@@ -411,20 +288,11 @@ __device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned 
             DS_READ(bq[1], lb, 64);
         }
         DS_READ(fh[0], lw, 0);
-        if (G1FP8) {
-            DS_READ(wa0, lw, 8192 + 2048);   // (tile 1, hi)
-            DS_READ(wa1, lw, 8192 + 3072);
-        } else {
-            DS_READ(fl[0], lw, 8192);
-        }
+        DS_READ(fl[0], lw, 8192);
     }
     SB();
     // ---- phase A: hn = W1(c+1) x^T + b1(c+1)   beside   relu / split of hd (chunk c)
-    if (G1FP8) {
-        FFN_GROUP_A8(0) FFN_GROUP_A8(1) FFN_GROUP_A8(2) FFN_GROUP_A8(3) FFN_GROUP_A8(4) FFN_GROUP_A8(5) FFN_GROUP_A8(6) FFN_GROUP_A8(7)
-    } else {
-        FFN_GROUP_A(0) FFN_GROUP_A(1) FFN_GROUP_A(2) FFN_GROUP_A(3) FFN_GROUP_A(4) FFN_GROUP_A(5) FFN_GROUP_A(6) FFN_GROUP_A(7)
-    }
+    FFN_GROUP_A(0) FFN_GROUP_A(1) FFN_GROUP_A(2) FFN_GROUP_A(3) FFN_GROUP_A(4) FFN_GROUP_A(5) FFN_GROUP_A(6) FFN_GROUP_A(7)
     // ---- phase B: acc += W2(c) h(c)
     half8 hh[PIPE_R], hl[PIPE_R];
 #pragma unroll
@@ -445,7 +313,6 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
                                                                    const FfnTrainArgs ta, const FfnBwdArgs ba) {
     constexpr bool FINAL = MODE == 1;
     constexpr int NC = S3D_FFN_NCHUNK;
-    constexpr bool G1FP8 = FFN_G1_FP8 && !SINGLE && (MODE == 0 || MODE == 1);
     // THREE distinct LDS objects: hipcc tags their accesses with alias scopes, so a ds_read of one weight buffer is not
     // guarded (s_waitcnt vmcnt(0)) against the LDS-DMA refill of the OTHER buffer in flight — with one two-buffer array
     // it is, or, when the array is the kernel's only LDS object, every LDS wait degrades to lgkmcnt(0)
@@ -454,13 +321,9 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, g = lane >> 4;
     const long row0 = ((long)blockIdx.x * PIPE_WAVES + wave) * (PIPE_R * 16);
-    const _Float16* w8img = reinterpret_cast<const _Float16*>(w.wf8);   // 4096 halfs (8 KiB) per chunk
     // the W1 half (pieces 0-15) of chunk ch -> LDS buffer
     auto dma_w1 = [&](int ch, _Float16* lbuf) {
-        if (G1FP8)
-            dma_w1_fp8(wimg + (size_t)ch * F16_CHUNK_HALFS, w8img + (size_t)ch * 4096, lbuf, wave, lane);
-        else
-            dma_pieces(wimg + (size_t)ch * F16_CHUNK_HALFS, lbuf, 0, 16, wave, lane);
+        dma_pieces(wimg + (size_t)ch * F16_CHUNK_HALFS, lbuf, 0, 16, wave, lane);
     };
 
     // prologue DMA: W1(0) -> buffer 1 (W1 half);  buffer 0 <- W1(1) | W2(0)
@@ -471,26 +334,12 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
         for (int i = threadIdx.x; i < S3D_FFN / 4; i += PIPE_THREADS) st4(s_b1 + 4 * i, ld4(w.b1 + 4 * i));
 
     half8 xh[PIPE_R][4], xl[PIPE_R][4];
-    int8v xh8[PIPE_R], xl8[PIPE_R];   // G1FP8: the row's channels 32g .. 32g+31 as e4m3 (f16 hi part | lo part * 2^13)
     f32x4 acc[PIPE_R][8];
     FfnActState as;
 #pragma unroll
     for (int r = 0; r < PIPE_R; ++r) {
         long row = row0 + r * 16 + m;
         if (row >= rows) row = rows - 1;
-        if (G1FP8) {
-            const float* p8 = X + row * 128 + 32 * g;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int h8, l8;
-                split4_fp8(ld4(p8 + 4 * i), h8, l8);
-                xh8[r][i] = h8;
-                xl8[r][i] = l8;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xh8[r][i] = xl8[r][i] = 0;
-        }
         const float* p = X + row * 128 + 8 * g;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -524,24 +373,12 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = MODE == 4 ? zero4() : *reinterpret_cast<const f32x4*>(sb + 16 * a);
-        if (G1FP8) {   // the cross terms of chunk 0: same operands and order of accumulation kinds as in FFN_GROUP_A8
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int4v* f8 = reinterpret_cast<const int4v*>(sw + 4096) + lane;   // bytes 8192 ..: 64 lanes x 16 B per half tile
-                const int8v whi = cat8(f8[(2 * a) * 64], f8[(2 * a + 1) * 64]), wlo = cat8(f8[(4 + 2 * a) * 64], f8[(5 + 2 * a) * 64]);
-#pragma unroll
-                for (int r = 0; r < PIPE_R; ++r) {
-                    hdA[a][r] = MFMA_F8(whi, xl8[r], hdA[a][r], F8_ONE, F8_DOWN);
-                    hdA[a][r] = MFMA_F8(wlo, xh8[r], hdA[a][r], F8_DOWN, F8_ONE);
-                }
-            }
-        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const half8 fh = ldh8(sw + ((a * 4 + u) * 64 + lane) * 8);
-                if (!SINGLE && !G1FP8) {
+                if (!SINGLE) {
                     const half8 fl = ldh8(sw + 4096 + ((a * 4 + u) * 64 + lane) * 8);
 #pragma unroll
                     for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xl[r][u], hdA[a][r], 0, 0, 0);
@@ -585,12 +422,12 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
         dma_w1(c + 2, s_w1);
         dma_pieces(wimg + (size_t)(c + 1) * F16_CHUNK_HALFS, s_w1, 16, 32, wave, lane);
         SB();
-        ffn_pipe_iter<MODE, false, SINGLE>(lw0, lb0 + (c + 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB, as, ta, ba, c, xh8, xl8);
+        ffn_pipe_iter<MODE, false, SINGLE>(lw0, lb0 + (c + 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB, as, ta, ba, c);
         dma_publish_barrier();
         dma_w1(c + 3, s_w0);
         dma_pieces(wimg + (size_t)(c + 2) * F16_CHUNK_HALFS, s_w0, 16, 32, wave, lane);
         SB();
-        ffn_pipe_iter<MODE, false, SINGLE>(lw1, lb0 + (c + 2) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdB, hdA, as, ta, ba, c + 1, xh8, xl8);
+        ffn_pipe_iter<MODE, false, SINGLE>(lw1, lb0 + (c + 2) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdB, hdA, as, ta, ba, c + 1);
         if ((MODE == 2 || MODE == 3 || MODE == 4) && (c & 2)) group_done(c + 1);
         dma_publish_barrier();
     }
@@ -598,9 +435,9 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
     dma_w1(NC - 1, s_w1);
     dma_pieces(wimg + (size_t)(NC - 1) * F16_CHUNK_HALFS, s_w1, 16, 32, wave, lane);
     SB();
-    ffn_pipe_iter<MODE, false, SINGLE>(lw0, lb0 + (NC - 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB, as, ta, ba, NC - 2, xh8, xl8);
+    ffn_pipe_iter<MODE, false, SINGLE>(lw0, lb0 + (NC - 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB, as, ta, ba, NC - 2);
     dma_publish_barrier();
-    ffn_pipe_iter<MODE, true, SINGLE>(lw1, lb0, xh, xl, acc, hdB, hdA, as, ta, ba, NC - 1, xh8, xl8);
+    ffn_pipe_iter<MODE, true, SINGLE>(lw1, lb0, xh, xl, acc, hdB, hdA, as, ta, ba, NC - 1);
     if (MODE == 2 || MODE == 3) group_done(NC - 1);
 
     // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i.
@@ -636,23 +473,13 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
     }
     // ... and the rows' halves are made opaque here: left alone, the residual f32(hi) + f32(lo) of all 64 values is
     // formed BEFORE the loop (it is loop-invariant), held in registers through it and partly spilled
-    if (!G1FP8) {
 #pragma unroll
-        for (int r = 0; r < PIPE_R; ++r)
-            asm volatile("" : "+v"(xh[r][0]), "+v"(xh[r][1]), "+v"(xh[r][2]), "+v"(xh[r][3]), "+v"(xl[r][0]), "+v"(xl[r][1]),
-                         "+v"(xl[r][2]), "+v"(xl[r][3]));
-    }
+    for (int r = 0; r < PIPE_R; ++r)
+        asm volatile("" : "+v"(xh[r][0]), "+v"(xh[r][1]), "+v"(xh[r][2]), "+v"(xh[r][3]), "+v"(xl[r][0]), "+v"(xl[r][1]),
+                     "+v"(xl[r][2]), "+v"(xl[r][3]));
 #pragma unroll
     for (int r = 0; r < PIPE_R; ++r) {
         const long row = row0 + r * 16 + me;
-        // G1FP8: the f16 lo fragments of the rows are not kept through the loop (32 registers the fp8 operands need); the
-        // residual rows come back from L2 / MALL here, exact instead of the 22-bit hi + lo sum
-        f32x4 xres[8];
-        if (G1FP8) {
-            const float* px = X + (row < rows ? row : rows - 1) * 128 + 8 * ge;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xres[j] = ld4(px + 32 * (j >> 1) + 4 * (j & 1));
-        }
         f32x4 y[8];
         float s = 0.f;
 #pragma unroll
@@ -666,7 +493,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
                 const int t = 4 * (j & 1) + i;
                 float f = MODE == 2 ? acc[r][j][i] * ta.dh.scale + b2[i] : acc[r][j][i] + b2[i];   // hidden-dropout factor, see ffn_act4
                 if (MODE == 2) f *= mq4[i];
-                y[j][i] = f + (G1FP8 ? xres[j][i] : (float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
+                y[j][i] = f + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
                 s += y[j][i];
             }
             if ((MODE == 2 || MODE == 3) && (j & 1)) store_pair(ta.Uout, r, j >> 1, y[j - 1], y[j]);
@@ -810,45 +637,6 @@ __global__ void pack_ffn_f16x3_kernel(const float* __restrict__ w1, const float*
             dst[4096 + t] = (_Float16)(v[t] - (float)h);
         }
     }
-}
-
-// e4m3fn (OCP) encoding of v, round to nearest even, saturating at +-448 (what v_cvt_pk_fp8_f32 produces for finite inputs)
-__device__ __forceinline__ unsigned char enc_e4m3(float v) {
-    const unsigned bits = __builtin_bit_cast(unsigned, v);
-    const unsigned char sgn = (unsigned char)((bits >> 24) & 0x80u);
-    const float x = fabsf(v);
-    if (!(x < 464.f)) return sgn | 0x7Eu;                 // >= halfway to the next step above 448
-    if (x < 0.015625f) {                                  // below 2^-6: multiples of 2^-9
-        const int q = (int)rintf(x * 512.f);              // 0 .. 8 (8 = the smallest normal)
-        return sgn | (unsigned char)q;
-    }
-    int e = (int)((bits >> 23) & 0xFFu) - 127;
-    unsigned man = bits & 0x7FFFFFu, m3 = man >> 20;
-    const unsigned rem = man & 0xFFFFFu;
-    if (rem > 0x80000u || (rem == 0x80000u && (m3 & 1u))) ++m3;
-    if (m3 == 8u) { m3 = 0u; ++e; }
-    return sgn | (unsigned char)(((unsigned)(e + 7) << 3) | m3);
-}
-// lin1 (2048,128) -> per chunk 8 KiB: [hi | lo * 2^13][hidden tile a][half of the lane's 32 k][lane][16 bytes]; lane (m, g)
-// of tile a = hidden unit 32c + 16a + m, k = 32g + 16 half + byte
-__global__ void pack_ffn_fp8_kernel(const float* __restrict__ w1, unsigned char* __restrict__ out) {
-    const int total = S3D_FFN_NCHUNK * 2 * 64 * 32;   // (chunk, tile, lane, k byte)
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int i = idx & 31, lane = (idx >> 5) & 63, a = (idx >> 11) & 1, c = idx >> 12;
-        const int mm = lane & 15, gg = lane >> 4;
-        const float v = w1[(size_t)(32 * c + 16 * a + mm) * 128 + 32 * gg + i];
-        const _Float16 h = (_Float16)v;
-        const float lo = (float)(_Float16)(v - (float)h) * (float)(1 << FP8_LO_SCALE_LOG2);
-        unsigned char* dst = out + (size_t)c * 8192 + a * 2048 + (i >> 4) * 1024 + lane * 16 + (i & 15);
-        dst[0] = enc_e4m3((float)h);
-        dst[4096] = enc_e4m3(lo);
-    }
-}
-int launch_pack_ffn_fp8(const float* w1, float* out8, hipStream_t stream) {
-    if (!FFN_G1_FP8) return 0;   // the image is only read by the experiment build
-    hipLaunchKernelGGL(pack_ffn_fp8_kernel, dim3(512), dim3(256), 0, stream, w1, reinterpret_cast<unsigned char*>(out8));
-    S3D_LAUNCH_CHECK();
-    return 0;
 }
 
 int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream) {

@@ -199,13 +199,8 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
             for (int t = 0; t < 8; ++t) {
                 long row = pbase + 16 * ps + 8 * rg + t;
                 row = row < P ? row : P - 1;
-#ifdef WL_ABL_NOLOAD   // timing ablations (tools/wgrad_abl.sh): wrong results, never shipped
-                pd[ps][t] = 0.25f * (float)(row & 7);
-                px[ps][t] = 0.5f * (float)(t + ps);
-#else
                 pd[ps][t] = dyp[row * dstride];
                 px[ps][t] = xp[row * xstride];
-#endif
             }
     };
     const float nf = n_ok ? 1.f : 0.f, cf = c_ok ? 1.f : 0.f;
@@ -253,11 +248,6 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
             bl[j] = *reinterpret_cast<const wl_half8*>(&s_t[1][1][o]);
         }
         // three product kinds, each swept over the 16 independent accumulators
-#ifdef WL_ABL_NOMFMA
-        acc[0][0] += __builtin_bit_cast(f32x4, ah[0]) + __builtin_bit_cast(f32x4, bl[1]) + __builtin_bit_cast(f32x4, al[2]) + __builtin_bit_cast(f32x4, bh[3]);
-        __syncthreads();
-        continue;
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -1,4 +1,4 @@
-# timing ablations of attn_layer_q_kernel (build/abl/lib_*.so, see the AQ_ABL_* macros): stage time of the bench workload
+# timing ablations of attn_layer_q_kernel (build/abl/lib_*.so built by tools/build_experiment.sh from tools/patches/attn_q_ablations.patch with -DAQ_ABL_NOBAR etc.): stage time of the bench workload
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 B="--cpu-sample 0 --ldm-steps 0 --train-steps 0 --gt-train-steps 0 --c4-steps 0 --f16-steps 0 --mesh-steps 0 --steps 10 --warmup 3"
 for lib in "" $(ls build/abl/lib_*.so); do

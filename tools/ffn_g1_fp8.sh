@@ -1,3 +1,4 @@
+# experiment libraries: tools/build_experiment.sh tools/patches/ffn_fp8_two_product_experiments.patch <out.so> -DFFN_G1_FP8=1 / -DFFN_G2_TWO=1|2
 # A/B of the inference FFN's first GEMM: cross terms on the scaled fp8 MFMA (product build) vs three f16 products
 # (build/abl/lib_g1_f16.so = the same sources with -DFFN_G1_FP8=0): parity tests, stage times, error against the oracle
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp

@@ -1,3 +1,4 @@
+# experiment libraries: tools/build_experiment.sh tools/patches/ffn_fp8_two_product_experiments.patch <out.so> -DFFN_G1_FP8=1 / -DFFN_G2_TWO=1|2
 # EXPERIMENT: GEMM2 of the inference FFN with two of the three split products
 # (build/abl/lib_ffn_two1.so drops W2_lo*h_hi, lib_ffn_two2.so drops W2_hi*h_lo): parity on the 200-shape sweep, the
 # full-size and white-noise tests, then FFN time / clock / power.  Output -> profiles/r03_ffn_two_product_gemm2.md

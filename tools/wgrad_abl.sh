@@ -1,4 +1,4 @@
-# timing ablations of wgrad_lin_f16x3_kernel (build/abl/lib_wl_*.so, WL_ABL_* macros in train.hip): kernel time of the training
+# timing ablations of wgrad_lin_f16x3_kernel (build/abl/lib_wl_*.so: tools/build_experiment.sh tools/patches/wgrad_lin_ablations.patch ... -DWL_ABL_NOLOAD): kernel time of the training
 # step's in_proj weight gradient with the global loads / the MFMAs removed.  Wrong results; only the time is read.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 for lib in "" build/abl/lib_wl_NOLOAD.so build/abl/lib_wl_NOMFMA.so; do
