@@ -212,8 +212,8 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
-        import torch.distributed as dist
+    if world > 1 or "RANK" in os.environ:     # under a launcher even ONE rank forms its process group (RCCL communicator,
+        import torch.distributed as dist      # barriers and the MAX-over-ranks reduction run as they do at N > 1)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:

@@ -390,6 +390,12 @@ int s3d_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
 #define S3D_PROF_N 8
 int s3d_prof_enable(int on);
 int s3d_prof_read(int id, double* total_ms, long* count);
+/* Trace ranges (tracing; no reference counterpart): the library brackets its stages and the phases of
+ * the train step with roctx ranges ("s3d:...") that `rocprofv3 --marker-trace` records; the host side opens its own ranges
+ * (the gradient exchange of trainer.py) through the same roctx library with these two calls.  No-ops (return 0) when no
+ * roctx library can be loaded. */
+int s3d_range_push(const char* name);
+int s3d_range_pop(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Stand-alone ops of the module's helper API

@@ -151,6 +151,8 @@ SYMBOLS = {
     "s3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _i, _vp]),
     "s3d_adam_step_multi": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp]),
     "s3d_prof_enable": (_i, [_i]),
+    "s3d_range_push": (_i, [C.c_char_p]),
+    "s3d_range_pop": (_i, []),
     "s3d_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "s3d_project_coord_fwd": (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     "s3d_query_sort_workspace_bytes": (_sz, [_i, _l]),

@@ -27,13 +27,16 @@ extern "C" const char* s3d_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------------------------
 // roctx ranges (tracing): every tracked stage of the inference path and every phase of the train
 // step is bracketed by roctxRangePush / roctxRangePop, so a `rocprofv3 --marker-trace --kernel-trace` run can be read by
-// phase.  libroctx64 is looked up at run time (no link-time dependency; without it the ranges are no-ops).
+// phase.  The roctx library is looked up at run time (no link-time dependency; without it the ranges are no-ops).
 // ---------------------------------------------------------------------------------------------
 struct Roctx {
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
     Roctx() {
-        void* h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
+        // rocprofv3 (rocprofiler-sdk) records the ranges of ITS roctx library; the roctracer-era libroctx64 is the fallback
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
         if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_GLOBAL);
         if (!h) return;
         push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
@@ -88,6 +91,15 @@ struct ProfScope {
         g_prof_ev[id].push_back({a, b});
     }
 };
+
+extern "C" int s3d_range_push(const char* name) {
+    const Roctx& r = roctx();
+    return r.push && name ? (r.push(name), 1) : 0;
+}
+extern "C" int s3d_range_pop(void) {
+    const Roctx& r = roctx();
+    return r.pop ? (r.pop(), 1) : 0;
+}
 
 extern "C" int s3d_prof_enable(int on) {
     for (int i = 0; i < S3D_PROF_N; ++i) {

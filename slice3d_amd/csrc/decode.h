@@ -126,6 +126,10 @@ int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, uns
                                  const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
                                  hipStream_t stream);
 int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass = false);
+// training forward of the attention block, query-major (decode_attnq.hip): y = LN1(u), u = xin + dropout1(out_proj(MHA(xin)) + b),
+// o = MHA output before out_proj; nothing else is kept (the fused backward of train_attnq.hip recomputes Q / K / V)
+int launch_attn_layer_q_train(const float* xin, float* y, float* u, float* o, long groups, int T, const LayerPtrs& w,
+                              const DropCfg& d0, const DropCfg& d1, hipStream_t stream);
 // Last layer, token 0 only (models.py:83 consumes nothing else), with the projections absorbed.  Per head h, with
 // q = Wq_h x0 + bq_h:   score_h[t] = q . (Wk_h x_t + bk_h) = (M_h x0 + m_h) . x_t + const   (const cancels in the softmax)
 //                       M_h = Wk_h^T Wq_h (128x128),  m_h = Wk_h^T bq_h

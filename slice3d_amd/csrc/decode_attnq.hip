@@ -15,115 +15,23 @@
 //                 into the packed W_o columns), accumulated over heads
 // No Q/K/V/O ever touches LDS; LDS holds only weight fragments (LDS-DMA ring of quarter-head slots, see the kernel).  13 of 16 tile rows are useful (19 % padding);
 // the token-0-pruned last layer keeps the token-major kernel (decode_f16.hip), where pruning skips whole tiles.
-#include "decode.h"
+#include "attnq.h"
 
-typedef _Float16 half8q __attribute__((ext_vector_type(8)));
-
-#define AQ_WIN_HALFS (24 * 1024)   // per head: 24 fragment pairs (q0,q1,k0,k1,v0,v1) x 4 k-steps, hi|lo = 48 KiB
-#define AQ_WO_HALFS (8 * 1024)     // per head: 8 fragment pairs = 16 KiB
-
-__device__ __forceinline__ half8q ldq8(const _Float16* p) { return *reinterpret_cast<const half8q*>(p); }
-template <bool SINGLE>
-__device__ __forceinline__ f32x4 mfma3q(const half8q ah, const half8q al, const half8q bh, const half8q bl, f32x4 c) {
-    if (!SINGLE) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
-    }
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
-    return c;
-}
-// hi/lo split of a pair: one v_cvt_pk_f16_f32 + two v_fma_mix{lo,hi}_f16 (lo = f16(x - f32(hi)), the subtraction is
-// exact, one rounding: the same value a scalar convert - subtract - convert produces)
-typedef _Float16 half2q __attribute__((ext_vector_type(2)));
-typedef float float2q __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2q(float a, float b, unsigned& hi, unsigned& lo) {
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(float2q{a, b}, half2q));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
-}
-typedef unsigned uint4q __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split8pk(const f32x4 a, const f32x4 b, half8q& hi, half8q& lo) {
-    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    split2q(a[0], a[1], h0, l0);
-    split2q(a[2], a[3], h1, l1);
-    split2q(b[0], b[1], h2, l2);
-    split2q(b[2], b[3], h3, l3);
-    hi = __builtin_bit_cast(half8q, uint4q{h0, h1, h2, h3});
-    lo = __builtin_bit_cast(half8q, uint4q{l0, l1, l2, l3});
-}
-// four values -> the A / B operand of the 16-deep MFMA (v_mfma_f32_16x16x16_f16: lane group g carries k = 4g..4g+3)
-typedef _Float16 half4q __attribute__((ext_vector_type(4)));
-typedef unsigned uint2q __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split4pk(const f32x4 a, half4q& hi, half4q& lo) {
-    unsigned h0, h1, l0, l1;
-    split2q(a[0], a[1], h0, l0);
-    split2q(a[2], a[3], h1, l1);
-    hi = __builtin_bit_cast(half4q, uint2q{h0, h1});
-    lo = __builtin_bit_cast(half4q, uint2q{l0, l1});
-}
-template <bool SINGLE>
-__device__ __forceinline__ f32x4 mfma3h(const half4q ah, const half4q al, const half4q bh, const half4q bl, f32x4 c) {
-    if (!SINGLE) {
-        c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
-    }
-    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
-    return c;
-}
-// reductions over the 4 lane groups g of one column (l & 15) with the gfx950 lane-swap instructions (no LDS crossbar):
-// v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second, so two copies
-// of v become {lo, lo} and {hi, hi}; v_permlane16_swap does the same with odd / even rows of 16.  Issued as asm: the
-// __builtin_amdgcn_permlane*_swap builtins of this hipcc return the FIRST result for both elements (checked on the
-// GPU with build/t-style unit kernels); s_nop 1 = the VALU-write -> permlane hazard the compiler would have padded.
-__device__ __forceinline__ void lane_swap32(float& x, float& y) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
-__device__ __forceinline__ void lane_swap16(float& x, float& y) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
-__device__ __forceinline__ float colsum16(float v) {
-    float x = v, y = v;
-    lane_swap32(x, y);
-    x += y;
-    y = x;
-    lane_swap16(x, y);
-    return x + y;
-}
-__device__ __forceinline__ float colmax16(float v) {
-    float x = v, y = v;
-    lane_swap32(x, y);
-    x = fmaxf(x, y);
-    y = x;
-    lane_swap16(x, y);
-    return fmaxf(x, y);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Four waves per workgroup, TWO workgroups per CU (one computes while the other sits at a barrier); a workgroup owns
-// half a group (8 queries), a wave two of them.  The rows of the wave's two queries are loaded and split ONCE per
-// item and stay in registers as f16 hi / lo fragments for the four heads (round 3: the high halves used to be parked in a
-// wave-private LDS region and re-read with every k-step — 2 of 6 fragment reads).  The weight ring holds QUARTER-head
-// slots of 16 KiB (q | k | v | out_proj fragments), FOUR of them, filled by LDS-DMA three phases ahead; four barriers per
-// head; LDS = 4 x 16 KiB ring + 3 KiB of small vectors.
-// (Earlier versions: eight waves / whole-head slots / rows re-read per head: 1.16 ms per layer; four waves / half-head
-// slots: 1.13 ms; quarter-head slots, two-slot ring: 0.94 ms.  Bench stage, 4 launches + the last layer: 7.41 ms with the
-// two-slot ring, 6.9 with full-line stores, 6.86 with the rows in registers, 6.74 with the four-slot ring.)
-// ---------------------------------------------------------------------------------------------
-// LDS reads and their counted waits are issued by hand (same finding as in decode_f16.hip's pipelined FFN): with an
-// LDS-DMA refill in flight hipcc turns every LDS wait of this single-LDS-object kernel into lgkmcnt(0), i.e. it waits
-// for the fragment reads it has just issued for the NEXT k-step (all 42 waits of the previous build were lgkmcnt(0)).
-#define AQ_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#define AQ_WAIT6(n, a, b, c, d, e, f) \
-    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(n))
-#define AQ_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
-#define AQ_READ32(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-// Four-slot ring, DMA three phases ahead: at a barrier the slot of the phase that starts must have landed, and at most two
-// newer DMA sets (2 x 4 instructions per wave) have been issued since — whatever else is in flight (row loads, stores of
-// the previous item) is older or only makes the wait stricter.  vmcnt retires in order.  Raw s_barrier: the kernel has no
-// compiler-visible LDS access after its prologue, so nothing needs the fence __syncthreads() carries (which would drain vmcnt).
-#define AQ_BARRIER()                                       \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       \
-    asm volatile("s_barrier" ::: "memory")
-#define AQ3_SLOT_HALFS (8 * 1024)    // 8 fragment pairs = 16 KiB
-template <bool SINGLE>   // SINGLE: S3D_PREC_F16, one f16 MFMA per projection product (the 13x13 core stays on the fp32 MFMA)
+// TRAIN (the training step's forward of the block, models.py:83 in train mode): reads Xin, writes the LayerNorm output to X,
+// the pre-LayerNorm sum u = x + dropout1(out_proj(attn) + b) to ta.U (the LayerNorm backward's input) and the attention
+// output O (before out_proj; its weight gradient's operand) to ta.O — Q / K / V and the probabilities never leave the
+// chip, the backward recomputes them (train_attnq.hip).  Dropout: counter-based masks (dropout.h) of site ta.d0 on the
+// probabilities (index ((row * 4 + head) * 16 + key)) and ta.d1 on the block output (index row * 128 + channel) — the
+// indices the stored-QKV kernels of train.hip use, so both paths draw the same masks.
+struct AttnTrainArgs {
+    const float* Xin;   // layer input rows (TRAIN; inference works in place on X)
+    float* U;           // pre-LayerNorm rows
+    float* O;           // attention output rows (128 = 4 heads x 32)
+    DropCfg d0, d1;
+};
+template <bool SINGLE, bool TRAIN>   // SINGLE: S3D_PREC_F16, one f16 MFMA per projection product (the 13x13 core stays on the fp32 MFMA)
 __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long groups, int T, const _Float16* wimg,
-                                                               const LayerPtrs w) {
+                                                               const LayerPtrs w, const AttnTrainArgs ta) {
     extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // ring 4 x 16 KiB, then the small vectors
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: no waterfall around M0
@@ -171,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
     // raw fp32 rows of the NEXT item, requested in the epilogue of the current one (the first item's here)
     f32x4 xf[2][4][2];
     auto load_rows = [&](long it) {
-        const float* Xn = X + (it >> 1) * T * S3D_GROUP * 128;
+        const float* Xn = (TRAIN ? ta.Xin : X) + (it >> 1) * T * S3D_GROUP * 128;
         const int qn = 8 * (int)(it & 1) + 2 * wave;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -201,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int r = 0; r < 2; ++r) acc_o[r][j] = xf[r][j >> 1][j & 1] + bo[j];
+                for (int r = 0; r < 2; ++r) acc_o[r][j] = TRAIN ? bo[j] : xf[r][j >> 1][j & 1] + bo[j];   // TRAIN: the residual joins after the output dropout
         }
         // rows of the item: both halves in registers for the whole item (the high halves used to be parked in LDS and re-read
         // with every k-step: 2 of 6 fragment reads)
@@ -329,7 +237,14 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                         den += e[i];
                     }
                     const float inv = __builtin_amdgcn_rcpf(colsum16(den));   // v_rcp_f32, 1 ulp
-                    split4pk(f32x4{e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv}, ph[r], pl[r]);
+                    f32x4 pr = f32x4{e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
+                    if (TRAIN && ta.d0.p > 0.f) {   // lane (query token m, g): keys 4g .. 4g+3 of probability row (row, head)
+                        float mk[4];
+                        const unsigned long long rowq = (unsigned long long)((grp * T + mt) * S3D_GROUP + q0 + r);
+                        s3d_drop4(ta.d0, (rowq * 4 + (unsigned)h) * 16 + 4 * g, mk);
+                        pr = f32x4{pr[0] * mk[0], pr[1] * mk[1], pr[2] * mk[2], pr[3] * mk[3]};
+                    }
+                    split4pk(pr, ph[r], pl[r]);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) split4pk(vd[r][j], vh[r][j], vl[r][j]);
                 }
@@ -341,6 +256,17 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                     for (int j = 0; j < 2; ++j) od[r][j] = mfma3h<SINGLE>(vh[r][j], vl[r][j], ph[r], pl[r], zero4());
 #pragma unroll
                 for (int r = 0; r < 2; ++r) split8pk(od[r][0], od[r][1], oh[r], ol[r]);
+                if (TRAIN) {   // O rows of this head: tiles j = 0, 1 are dims 4g + i and 16 + 4g + i of token m = one 128-byte
+                               // line per token after the lane exchange (s3d_full_line_pair)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        f32x4 va, vb;
+                        s3d_full_line_pair(od[r][0], od[r][1], m, va, vb);
+                        float* oo = ta.O + ((grp * T + (m & 7)) * S3D_GROUP + q0 + r) * 128 + 32 * h + 16 * (m >> 3) + 4 * g;
+                        if ((m & 7) < T) st4(oo, va);
+                        if ((m & 7) + 8 < T) st4(oo + 8 * S3D_GROUP * 128, vb);
+                    }
+                }
             }
 #undef AQ_SETTLE
             AQ_BARRIER();   // out_proj fragments have landed; the v slot is free
@@ -383,6 +309,24 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             }
             ++ps;
         }
+        if (TRAIN) {   // u = x + dropout1(out_proj + bias): tile j, reg i <-> column 32(j>>1) + 8g + 4(j&1) + i of token m
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (ta.d1.p > 0.f) {
+                        float mk[4];
+                        const unsigned long long row = (unsigned long long)((grp * T + mt) * S3D_GROUP + q0 + r);
+                        s3d_drop4(ta.d1, row * 128 + 32 * (j >> 1) + 8 * g + 4 * (j & 1), mk);
+                        acc_o[r][j] = f32x4{acc_o[r][j][0] * mk[0], acc_o[r][j][1] * mk[1], acc_o[r][j][2] * mk[2], acc_o[r][j][3] * mk[3]};
+                    }
+                    // residual = f32(hi) + f32(lo) of the row's split (22 bits, as in the FFN kernel's epilogue): keeping the
+                    // raw fp32 rows live through the four heads costs 64 registers this kernel does not have
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc_o[r][j][i] += (float)xh[r][j >> 1][4 * (j & 1) + i] + (float)xl[r][j >> 1][4 * (j & 1) + i];
+                }
+        }
         // the next item's rows: requested here, where the q / k / v and fragment registers are free; the LayerNorm
         // below covers most of their latency
         load_rows(more_items ? item + gridDim.x : item);   // unconditional: a conditional load keeps the OLD rows live through the heads
@@ -398,6 +342,16 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
+            if (TRAIN) {   // pre-LayerNorm rows, same full-line form as the output below
+                float* ua = ta.U + ((grp * T + (m & 7)) * S3D_GROUP + q0 + r) * 128 + 8 * g + 4 * (m >> 3);
+#pragma unroll
+                for (int J = 0; J < 4; ++J) {
+                    f32x4 va, vb;
+                    s3d_full_line_pair(acc_o[r][2 * J], acc_o[r][2 * J + 1], m, va, vb);
+                    if ((m & 7) < T) st4(ua + 32 * J, va);
+                    if ((m & 7) + 8 < T) st4(ua + 8 * S3D_GROUP * 128 + 32 * J, vb);
+                }
+            }
             f32x4 s4 = acc_o[r][0];
 #pragma unroll
             for (int j = 1; j < 8; ++j) s4 += acc_o[r][j];
@@ -435,25 +389,39 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last phase-0 prefetch must not outlive the workgroup's LDS
 }
 
-int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass) {
+static int launch_attn_q_any(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass,
+                             const AttnTrainArgs* ta) {
     if (groups <= 0) return 0;
     S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr, "attn_q: T %d", T);
     const size_t lds = (size_t)(4 * AQ3_SLOT_HALFS) * 2 + 768 * 4;   // 64 KiB ring + the small vectors
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long blocks = 2 * groups < 4096 ? 2 * groups : 4096;
-    if (single_pass)
-        hipLaunchKernelGGL(attn_layer_q_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T,
-                           reinterpret_cast<const _Float16*>(w.aq16), w);
+    const _Float16* img = reinterpret_cast<const _Float16*>(w.aq16);
+    const AttnTrainArgs none = {};
+    if (ta)
+        hipLaunchKernelGGL((attn_layer_q_kernel<false, true>), dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T, img, w, *ta);
+    else if (single_pass)
+        hipLaunchKernelGGL((attn_layer_q_kernel<true, false>), dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T, img, w, none);
     else
-        hipLaunchKernelGGL(attn_layer_q_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T,
-                           reinterpret_cast<const _Float16*>(w.aq16), w);
+        hipLaunchKernelGGL((attn_layer_q_kernel<false, false>), dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T, img, w, none);
     S3D_LAUNCH_CHECK();
     return 0;
+}
+int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass) {
+    return launch_attn_q_any(X, groups, T, w, stream, single_pass, nullptr);
+}
+// training forward of the block (see the kernel): xin -> y = LN1(u), u = xin + dropout1(out_proj(MHA(xin))), o = MHA output
+int launch_attn_layer_q_train(const float* xin, float* y, float* u, float* o, long groups, int T, const LayerPtrs& w,
+                              const DropCfg& d0, const DropCfg& d1, hipStream_t stream) {
+    S3D_CHECK_ARG(xin && y && u && o, "attn_q train: null buffer");
+    AttnTrainArgs ta = {xin, u, o, d0, d1};
+    return launch_attn_q_any(y, groups, T, w, stream, false, &ta);
 }
 
 // in_proj (384,128) / out_proj (128,128) -> fragment pairs (hi 512 halfs | lo 512 halfs each) of the query-major kernel

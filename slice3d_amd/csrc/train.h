@@ -180,5 +180,9 @@ int launch_attn_core0_fwd(const float* q0, const float* kv, float* o0, long grou
                           hipStream_t stream);
 int launch_attn_core0_bwd(const float* q0, const float* kv, const float* d_o0, float* dq0, float* dkv, long groups, int T,
                           const DropCfg& drop, hipStream_t stream);
+// fused attention-core backward with Q / K / V recomputed on chip (train_attnq.hip): x, dO (rows x 128) -> dQKV (rows x 384)
+struct LayerPtrs;
+int launch_attn_bwd_q(const float* x, const float* d_o, float* dqkv, long groups, int T, const LayerPtrs& w,
+                      const DropCfg& d0, hipStream_t stream);
 int launch_emb_grad(const float* dF0, const float* w, float* demds, int B, int ns, int npix, hipStream_t stream);
 #define CS_CHUNKS_MAX 512

@@ -181,7 +181,7 @@ class HipTrainer:
         tb = _lib.S3dTrainBatch()
         tb.img, tb.img_slices, tb.qry = img.data_ptr(), sl.data_ptr(), qry.data_ptr()
         tb.rot, tb.trans, tb.sdf = rot.data_ptr(), tm.data_ptr(), sdf.data_ptr()
-        if self.overlap_all_reduce and self._world() > 1:
+        if self.overlap_all_reduce and self._exchange_on():
             for k, e in enumerate(self._ddp_events()):
                 tb.ev_grad_ready[k] = e.cuda_event
             self._events_armed = True
@@ -288,7 +288,7 @@ class HipTrainer:
         with torch.distributed on the current stream — 63 small collectives per step (two per BatchNorm layer in the
         forward: means, then merged variances; one in the backward), issued from inside the library
         call between the kernel that produces the per-rank statistics and the one that consumes the global ones."""
-        if not self.sync_bn or self._world() == 1:
+        if not self.sync_bn or not self._exchange_on():
             return None
         if self._sync is None:
             import torch.distributed as dist
@@ -315,6 +315,18 @@ class HipTrainer:
             tb.sync_bn = C.pointer(st)
 
     # -- data-parallel exchange step ------------------------------------------------------------------
+    def _exchange_on(self):
+        """True when the collectives of the step must be issued: more than one rank — or S3D_FORCE_COLLECTIVES=1 inside an
+        initialised process group of ONE rank (test switch: pushes the bucketed gradient all-reduces through the
+        event-ordered side stream and the sync-BN callback's collectives through RCCL on a single GPU; every sum over one
+        rank is the identity, so the step's results do not change)."""
+        if self._world() > 1:
+            return True
+        import os
+        import torch.distributed as dist
+        return (os.environ.get("S3D_FORCE_COLLECTIVES") == "1" and self.group is not False
+                and dist.is_available() and dist.is_initialized())
+
     def _world(self):
         import torch.distributed as dist
         if self.group is False:          # process_group=False: a lone replica inside a distributed job (no exchange)
@@ -341,13 +353,13 @@ class HipTrainer:
         backward; the shallow-encoder bucket follows the last kernel.  Otherwise: one flat all-reduce."""
         import torch.distributed as dist
         world = self._world()
-        if world == 1:
+        if not self._exchange_on():
             return
-        torch.cuda.nvtx.range_push("s3d:train:grad_all_reduce")     # roctx on ROCm: the exchange step as a trace range
+        self.lib.s3d_range_push(b"s3d:train:grad_all_reduce")       # roctx: the exchange step as a trace range
         try:
-            if not (self.overlap_all_reduce and self._events_armed):
-                from .parallel import all_reduce_mean_
-                all_reduce_mean_(self.grad_flat, self.group)
+            if not (self.overlap_all_reduce and self._events_armed):      # one flat all-reduce (parallel.all_reduce_mean_'s body;
+                dist.all_reduce(self.grad_flat, op=dist.ReduceOp.SUM, group=self.group)   # issued at world size 1 too when forced)
+                self.grad_flat.div_(world)
                 return
             main = torch.cuda.current_stream(self.grad_flat.device)
             comm = self._comm_stream
@@ -362,7 +374,7 @@ class HipTrainer:
             self.grad_flat.div_(world)
             self._events_armed = False
         finally:
-            torch.cuda.nvtx.range_pop()
+            self.lib.s3d_range_pop()
 
     _events_armed = False
 
