@@ -108,4 +108,13 @@ __device__ __forceinline__ float colmax16(float v) {
 #define AQ_BARRIER()                                       \
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       \
     asm volatile("s_barrier" ::: "memory")
+// The same barrier with the EXACT number of vector-memory operations a wave has issued after the DMA set it waits for (round
+// 4).  vmcnt(8) is always safe — at least the two newer DMA sets are younger — but it also waits for all but eight of whatever
+// else was issued since: the previous item's row stores and the next rows' loads at the first barriers of an item (32 - 48
+// operations), the per-head stores of the training kernels.  n must not exceed the real count (a larger n lets the barrier
+// pass before the set has landed), so the callers use these counts only where every counted operation is issued
+// unconditionally (T >= 9: both halves of every full-line store pair have active lanes) and fall back to 8 otherwise.
+#define AQ_BARRIER_N(n)                                          \
+    asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");        \
+    asm volatile("s_barrier" ::: "memory")
 #define AQ3_SLOT_HALFS (8 * 1024)    // 8 fragment pairs = 16 KiB

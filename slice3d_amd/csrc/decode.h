@@ -119,12 +119,26 @@ int launch_sample_planes(const float* plane, const float* grid, float* out, int 
                          hipStream_t stream);
 
 // decode_f16.hip
+// Operand images of a row tensor x [P][128] for the FFN weight-gradient kernel (ffn_wgrad_rec_kernel, train.hip): per 32-row
+// block 16 KiB each, f16 hi | lo in the consumer's LDS byte order, rows past the end zero.
+//   R image   [hi|lo][32 rows][128 ch] halfs: the 16-byte chunk s (channels 8s..8s+7) of row r sits at chunk s ^ (r & 15)
+//   D^T image [hi|lo][128 ch][32 slots] halfs: slot 8g+t <-> row 4g+t (t < 4) / 16+4g+t-4, chunk g of channel q at
+//             chunk g ^ perm[(q >> 2) & 3], perm = {0, 2, 3, 1}
+// The pipelined FFN kernel writes them for the rows it holds anyway (the layer input x in the training forward, dY in the
+// backward data pass): a wave's two 16-row tiles ARE one 32-row block, the R chunks are its split fragments as they
+// are, and the D^T chunks come out of the MFMA D layout of a transposing product (x tile times a 0/1 selector).
+#define FWR_BLK_HALFS 8192   // one image of one 32-row block: hi 4096 halfs | lo 4096 halfs = 16 KiB
+__host__ __device__ inline int fwr_dperm(int q) { return (0x1320 >> (4 * ((q >> 2) & 3))) & 3; }   // {0,2,3,1}
+static inline size_t ffn_rec_image_floats(long P) { return (size_t)((P + 31) / 32) * 4096; }
+// imgd / imgr (optional, ffn_rec_image_floats(rows) floats each): D^T / R image of DY
 int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
-                            const float* timg, float gate_scale, hipStream_t stream);
+                            const float* timg, float gate_scale, hipStream_t stream, float* imgd = nullptr,
+                            float* imgr = nullptr);
 int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipStream_t stream);
+// imgd / imgr (optional): D^T / R image of Xin
 int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
                                  const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
-                                 hipStream_t stream);
+                                 hipStream_t stream, float* imgd = nullptr, float* imgr = nullptr);
 int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass = false);
 // training forward of the attention block, query-major (decode_attnq.hip): y = LN1(u), u = xin + dropout1(out_proj(MHA(xin)) + b),
 // o = MHA output before out_proj; nothing else is kept (the fused backward of train_attnq.hip recomputes Q / K / V)

@@ -75,6 +75,28 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
     }
     const bool row_ok = m < T;
     const int mt = row_ok ? m : T - 1;
+    // Ring barrier of phase (h, part) with the exact count of younger vector-memory operations (AQ_BARRIER_N).  Per item a wave
+    // issues: 16 DMA sets of 4 (set p during phase p - 3), after the last head 16 row loads + 16 output stores (TRAIN: + 16
+    // pre-LayerNorm stores), TRAIN: 4 attention-output stores per head between the v phase and the out_proj barrier.
+    //   inference  h > 0: 8 everywhere;  h = 0, parts q / k / v: 8 + 32 = 40 (the epilogue of the previous item is younger)
+    //   TRAIN      q / k: 12, v: 8, out_proj: 12;  h = 0: q / k 12 + 48 = 60, v 8 + 48 = 56
+    // The first item of a workgroup (prologue: three sets, then the row loads) and T < 9 (store halves without active lanes
+    // are skipped) keep vmcnt(8).
+    const bool wide = T >= 9;
+    bool wide_h0 = false;   // set after the first item
+    auto ring_barrier = [&](int h, int part) {
+        if (!wide) {
+            AQ_BARRIER();
+        } else if (h == 0 && part < 3 && wide_h0) {
+            if (!TRAIN) { AQ_BARRIER_N(40); }
+            else if (part == 2) { AQ_BARRIER_N(56); }
+            else { AQ_BARRIER_N(60); }
+        } else if (TRAIN && part != 2) {
+            AQ_BARRIER_N(12);
+        } else {
+            AQ_BARRIER();
+        }
+    };
 
     // raw fp32 rows of the NEXT item, requested in the epilogue of the current one (the first item's here)
     f32x4 xf[2][4][2];
@@ -138,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                         AQ_READ32(bv[j], lv, 1024 + 64 * j);
                     }
                 }
-                AQ_BARRIER();   // this phase's fragments have landed; the other slot is free
+                ring_barrier(h, part);   // this phase's fragments have landed; the other slot is free
                 const int nph = (4 * h + part + 3) & 15, nbuf = (int)((ps + 3) & 3);
                 const unsigned lwa = lds_ring + (unsigned)(ps & 3) * (AQ3_SLOT_HALFS * 2);
                 f32x4 d[2][2], c0[2];   // c0: the bias opens both row tiles' accumulations (C operand of k-step 0, no copies)
@@ -240,8 +262,10 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                     f32x4 pr = f32x4{e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
                     if (TRAIN && ta.d0.p > 0.f) {   // lane (query token m, g): keys 4g .. 4g+3 of probability row (row, head)
                         float mk[4];
-                        const unsigned long long rowq = (unsigned long long)((grp * T + mt) * S3D_GROUP + q0 + r);
-                        s3d_drop4(ta.d0, (rowq * 4 + (unsigned)h) * 16 + 4 * g, mk);
+                        int mto = mt, go = g;   // opaque copies: otherwise the per-lane index parts are formed in the prologue,
+                        asm volatile("" : "+v"(mto), "+v"(go));   // kept live through the item loop and spilled
+                        const unsigned long long rowq = (unsigned long long)((grp * T + mto) * S3D_GROUP + q0 + r);
+                        s3d_drop4(ta.d0, (rowq * 4 + (unsigned)h) * 16 + 4 * go, mk);
                         pr = f32x4{pr[0] * mk[0], pr[1] * mk[1], pr[2] * mk[2], pr[3] * mk[3]};
                     }
                     split4pk(pr, ph[r], pl[r]);
@@ -258,18 +282,20 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 for (int r = 0; r < 2; ++r) split8pk(od[r][0], od[r][1], oh[r], ol[r]);
                 if (TRAIN) {   // O rows of this head: tiles j = 0, 1 are dims 4g + i and 16 + 4g + i of token m = one 128-byte
                                // line per token after the lane exchange (s3d_full_line_pair)
+                    int mo = m, go = g;
+                    asm volatile("" : "+v"(mo), "+v"(go));   // (see the dropout draw above)
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         f32x4 va, vb;
-                        s3d_full_line_pair(od[r][0], od[r][1], m, va, vb);
-                        float* oo = ta.O + ((grp * T + (m & 7)) * S3D_GROUP + q0 + r) * 128 + 32 * h + 16 * (m >> 3) + 4 * g;
-                        if ((m & 7) < T) st4(oo, va);
-                        if ((m & 7) + 8 < T) st4(oo + 8 * S3D_GROUP * 128, vb);
+                        s3d_full_line_pair(od[r][0], od[r][1], mo, va, vb);
+                        float* oo = ta.O + ((grp * T + (mo & 7)) * S3D_GROUP + q0 + r) * 128 + 32 * h + 16 * (mo >> 3) + 4 * go;
+                        if ((mo & 7) < T) st4(oo, va);
+                        if ((mo & 7) + 8 < T) st4(oo + 8 * S3D_GROUP * 128, vb);
                     }
                 }
             }
 #undef AQ_SETTLE
-            AQ_BARRIER();   // out_proj fragments have landed; the v slot is free
+            ring_barrier(h, 3);   // out_proj fragments have landed; the v slot is free
             // the next phase is the next head's q, or phase 0 of the next item (issued even after the last item: no
             // branch in the MFMA stream; the kernel drains vmcnt before it ends)
             const int oph = (4 * h + 3 + 3) & 15, obuf = (int)((ps + 3) & 3);
@@ -310,14 +336,16 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             ++ps;
         }
         if (TRAIN) {   // u = x + dropout1(out_proj + bias): tile j, reg i <-> column 32(j>>1) + 8g + 4(j&1) + i of token m
+            int mto = mt, go = g;
+            asm volatile("" : "+v"(mto), "+v"(go));
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (ta.d1.p > 0.f) {
                         float mk[4];
-                        const unsigned long long row = (unsigned long long)((grp * T + mt) * S3D_GROUP + q0 + r);
-                        s3d_drop4(ta.d1, row * 128 + 32 * (j >> 1) + 8 * g + 4 * (j & 1), mk);
+                        const unsigned long long row = (unsigned long long)((grp * T + mto) * S3D_GROUP + q0 + r);
+                        s3d_drop4(ta.d1, row * 128 + 32 * (j >> 1) + 8 * go + 4 * (j & 1), mk);
                         acc_o[r][j] = f32x4{acc_o[r][j][0] * mk[0], acc_o[r][j][1] * mk[1], acc_o[r][j][2] * mk[2], acc_o[r][j][3] * mk[3]};
                     }
                     // residual = f32(hi) + f32(lo) of the row's split (22 bits, as in the FFN kernel's epilogue): keeping the
@@ -326,6 +354,23 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                     for (int i = 0; i < 4; ++i)
                         acc_o[r][j][i] += (float)xh[r][j >> 1][4 * (j & 1) + i] + (float)xl[r][j >> 1][4 * (j & 1) + i];
                 }
+            // pre-LayerNorm rows, in the full-line form of the output stores below — BEFORE the next rows are requested: with
+            // the exchange temporaries live next to the 64 prefetch registers and the 64 of gamma / beta, hipcc spilled six of
+            // the freshly loaded row registers (a scratch store that has to wait for its load)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                int mo = m, go = g;
+                asm volatile("" : "+v"(mo), "+v"(go));
+                float* ua = ta.U + ((grp * T + (mo & 7)) * S3D_GROUP + q0 + r) * 128 + 8 * go + 4 * (mo >> 3);
+#pragma unroll
+                for (int J = 0; J < 4; ++J) {
+                    f32x4 va, vb;
+                    s3d_full_line_pair(acc_o[r][2 * J], acc_o[r][2 * J + 1], mo, va, vb);
+                    if ((mo & 7) < T) st4(ua + 32 * J, va);
+                    if ((mo & 7) + 8 < T) st4(ua + 8 * S3D_GROUP * 128 + 32 * J, vb);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // the next item's rows: requested here, where the q / k / v and fragment registers are free; the LayerNorm
         // below covers most of their latency
@@ -342,16 +387,6 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            if (TRAIN) {   // pre-LayerNorm rows, same full-line form as the output below
-                float* ua = ta.U + ((grp * T + (m & 7)) * S3D_GROUP + q0 + r) * 128 + 8 * g + 4 * (m >> 3);
-#pragma unroll
-                for (int J = 0; J < 4; ++J) {
-                    f32x4 va, vb;
-                    s3d_full_line_pair(acc_o[r][2 * J], acc_o[r][2 * J + 1], m, va, vb);
-                    if ((m & 7) < T) st4(ua + 32 * J, va);
-                    if ((m & 7) + 8 < T) st4(ua + 8 * S3D_GROUP * 128 + 32 * J, vb);
-                }
-            }
             f32x4 s4 = acc_o[r][0];
 #pragma unroll
             for (int j = 1; j < 8; ++j) s4 += acc_o[r][j];
@@ -385,6 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             }
             __builtin_amdgcn_sched_barrier(0);   // one row tile at a time
         }
+        wide_h0 = wide;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last phase-0 prefetch must not outlive the workgroup's LDS
 }

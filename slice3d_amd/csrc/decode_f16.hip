@@ -124,11 +124,15 @@ struct FfnTrainArgs {   // MODE 2
     DropCfg dh, dq;  // hidden-unit / output dropout
     unsigned* Mout;  // activity bits of the hidden units (post-dropout h > 0): dword [row][g][chunk>>2],
                      // byte chunk&3, bit 4a+i  <->  hidden unit 32*chunk + 16a + 4g + i
+    _Float16* ImgD;  // optional: D^T / R operand images of the INPUT rows for the weight-gradient kernel (decode.h)
+    _Float16* ImgR;
 };
 struct FfnBwdArgs {     // MODE 4
     const float* Dres;     // added to dX (the residual branch's gradient)
     const unsigned* M;     // activity bits written by the forward
     float gate_scale;      // value of a kept unit's dropout factor
+    _Float16* ImgD;        // optional: D^T / R operand images of the dY rows (decode.h)
+    _Float16* ImgR;
 };
 // per-wave state of the activation stage between GEMM1 and GEMM2
 struct FfnActState {
@@ -361,6 +365,55 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
             as.mw_next[r] = ba.M[row * 64 + g * 16 + 1];
         }
     }
+    if (MODE >= 2) {   // operand images of this wave's 32 rows for the weight-gradient kernel (layout: decode.h)
+        _Float16* imgd = MODE == 4 ? ba.ImgD : ta.ImgD;
+        _Float16* imgr = MODE == 4 ? ba.ImgR : ta.ImgR;
+        if (imgd && row0 < rows) {   // (a wave wholly past the end has no block in the images)
+            const long blk = row0 >> 5;
+            _Float16* rb = imgr + blk * FWR_BLK_HALFS;
+            _Float16* db = imgd + blk * FWR_BLK_HALFS;
+            const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            half8 sel[2];   // B operand that picks channels 16c .. 16c+15 of a 32-channel k-step: B[k = 8g + t][n] = (k == 16c + n)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sel[c2][t] = (8 * g + t == 16 * c2 + m) ? (_Float16)1.f : (_Float16)0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                half8 ah[PIPE_R], al[PIPE_R];
+#pragma unroll
+                for (int r = 0; r < PIPE_R; ++r) {   // rows past the end are zero in both images
+                    const bool ok = row0 + r * 16 + m < rows;
+                    ah[r] = ok ? xh[r][u] : z8;
+                    al[r] = ok ? xl[r][u] : z8;
+                    // R image: the fragment as it is — chunk 4u + g of row 16r + m, swizzled by the row
+                    const int o = (16 * r + m) * 128 + (((4 * u + g) ^ m) << 3);
+                    *reinterpret_cast<half8*>(rb + o) = ah[r];
+                    *reinterpret_cast<half8*>(rb + 4096 + o) = al[r];
+                }
+                // D^T image: x tile (A: row m, k-slot = channel) times the selector -> D layout lane (channel n, g) x rows 4g + i:
+                // the slot order of the image (tile 0 rows | tile 1 rows); products with 1.0 are exact
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    static_assert(PIPE_R == 2, "a wave's two row tiles are one 32-row block");
+                    const f32x4 h0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], sel[c2], zero4(), 0, 0, 0);
+                    const f32x4 h1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], sel[c2], zero4(), 0, 0, 0);
+                    const f32x4 l0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], sel[c2], zero4(), 0, 0, 0);
+                    const f32x4 l1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], sel[c2], zero4(), 0, 0, 0);
+                    half8 oh, ol;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        oh[i] = (_Float16)h0[i]; oh[4 + i] = (_Float16)h1[i];
+                        ol[i] = (_Float16)l0[i]; ol[4 + i] = (_Float16)l1[i];
+                    }
+                    const int q = 32 * u + 16 * c2 + m;
+                    const int o = q * 32 + ((g ^ fwr_dperm(q)) << 3);
+                    *reinterpret_cast<half8*>(db + o) = oh;
+                    *reinterpret_cast<half8*>(db + 4096 + o) = ol;
+                }
+            }
+        }
+    }
     dma_publish_barrier();
     const float* sb = s_b1 + 4 * g;     // this lane's bias quad of D tile 0 of chunk 0; tile 1 at +16, chunk c at +32c
     const unsigned lw0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_w0 + lane * 8);
@@ -564,10 +617,11 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
 // training forward: y = LN2(u), u = x + dropout(FFN(x)); y -> Yout, u -> Uout, activity bits -> Mout
 int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
                                  const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, float* imgd, float* imgr) {
     if (rows <= 0) return 0;
     S3D_CHECK_ARG(w.wf16 != nullptr, "ffn train f16x3: no packed f16 image");
-    const FfnTrainArgs ta = {Uout, drop_hidden, drop_out, Mout};
+    S3D_CHECK_ARG((imgd == nullptr) == (imgr == nullptr), "ffn train f16x3: both operand images or none");
+    const FfnTrainArgs ta = {Uout, drop_hidden, drop_out, Mout, reinterpret_cast<_Float16*>(imgd), reinterpret_cast<_Float16*>(imgr)};
     const FfnBwdArgs ba = {};
     const dim3 grid((unsigned)((rows + PIPE_ROWS_PER_WG - 1) / PIPE_ROWS_PER_WG)), block(PIPE_THREADS);
     S3D_CHECK_ARG((drop_hidden.p > 0.f) == (drop_out.p > 0.f), "ffn train f16x3: hidden / output dropout must be on or off together");
@@ -592,10 +646,11 @@ int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, uns
 // W1^T chunk as GEMM-2-shaped fragments; packed by pack_ffn_f16x3_kernel with swapped strides) stream through LDS.
 // ---------------------------------------------------------------------------------------------
 int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
-                            const float* timg, float gate_scale, hipStream_t stream) {
+                            const float* timg, float gate_scale, hipStream_t stream, float* imgd, float* imgr) {
     if (rows <= 0) return 0;
+    S3D_CHECK_ARG((imgd == nullptr) == (imgr == nullptr), "ffn bwd dx: both operand images or none");
     const FfnTrainArgs ta = {};
-    const FfnBwdArgs ba = {Dres, M, gate_scale};
+    const FfnBwdArgs ba = {Dres, M, gate_scale, reinterpret_cast<_Float16*>(imgd), reinterpret_cast<_Float16*>(imgr)};
     const LayerPtrs w = {};
     const dim3 grid((unsigned)((rows + PIPE_ROWS_PER_WG - 1) / PIPE_ROWS_PER_WG)), block(PIPE_THREADS);
     hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<4, false>), grid, block, 0, stream, DY, DX, rows,

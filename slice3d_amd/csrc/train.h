@@ -39,7 +39,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream);
 //              colsum(Z) -> lin1 bias grad
 // bits: activity mask written by the forward FFN kernel.  The [rows][2048] matrices are never materialised.
 struct FfnWgradArgs {
-    const float* Dimg;      // transposed f16 hi/lo image of D [P][128]   (launch_ffn_rec_images)
+    const float* Dimg;      // transposed f16 hi/lo image of D [P][128]   (written by the pipelined FFN kernel, decode.h)
     const float* Rimg;      // row-major  f16 hi/lo image of R [P][128]
     const float* wimg;      // f16 hi|lo fragment image of W [2048][128] (launch_pack_ffn_rec_f16x3)
     const float* bias;      // [2048] or null
@@ -54,10 +54,6 @@ struct FfnWgradArgs {
     size_t partial_floats;
 };
 int launch_ffn_wgrad_rec(const FfnWgradArgs& a, hipStream_t stream);
-// the two operand images of a row tensor x [P][128]: per 32-row block 16 KiB each (f16 hi | lo, LDS byte order), rows past
-// the end zero.  dimg / rimg: ffn_rec_image_floats(P) floats each.
-int launch_ffn_rec_images(const float* x, long P, float* dimg, float* rimg, hipStream_t stream);
-static inline size_t ffn_rec_image_floats(long P) { return (size_t)((P + 31) / 32) * 4096; }
 // W: element (hid, k) at w[hid*sh + k*sk]  ->  image [128 hid tiles][4][64 lanes][8] halfs hi, then lo
 int launch_pack_ffn_rec_f16x3(const float* w, int sh, int sk, float* out, hipStream_t stream);
 #define S3D_FFN_REC_IMG_FLOATS (S3D_FFN * 128)   /* 2 x 2048*128 halfs */

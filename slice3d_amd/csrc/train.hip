@@ -289,67 +289,10 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int nchun
 // ---------------------------------------------------------------------------------------------
 // FFN weight gradients with recomputation (see train.h).
 //
-// Operand images.  Both contraction operands of a 32-row step are needed by the 16 hidden-block workgroups that share the
-// rows, as f16 hi/lo, one of them transposed: splitting and transposing them inside the weight-gradient kernel cost it
-// 39 % of its time (16x redundant VALU work, 33 prefetch registers, a global-load wait in the middle of every step —
-// profiles/r03_ffn_wgrad_ablation.md).  ffn_rec_images_kernel does it ONCE per tensor and writes, per 32-row block,
-// the two LDS images byte for byte (16 KiB each), so that the consumer stages a step with 32 LDS-DMA instructions:
-//   R image  [hi|lo][32 rows][128 ch] halfs: the 16-byte chunk s (channels 8s..8s+7) of row r sits at chunk s ^ (r & 15)
-//            (b128 fragment reads of lane (row m, k-group g) at chunk (4u+g) ^ m: conflict-free, no padding)
-//   D^T image [hi|lo][128 ch][32 slots] halfs: slot 8g+t <-> row 4g+t (t < 4) / 16+4g+t-4 — the order the recomputed Z
-//            tile has in the MFMA D registers — and chunk g of channel q sits at chunk g ^ perm[(q >> 2) & 3],
-//            perm = {0, 2, 3, 1} (conflict-free for the A-fragment reads of lane (q & 15, g))
-// Rows past the end are zero in both images.
-// ---------------------------------------------------------------------------------------------
-#define FWR_BLK_HALFS 8192   // one image of one 32-row block: hi 4096 halfs | lo 4096 halfs = 16 KiB
-__device__ __forceinline__ int fwr_dperm(int q) { return (0x1320 >> (4 * ((q >> 2) & 3))) & 3; }   // {0,2,3,1}
-__global__ __launch_bounds__(256) void ffn_rec_images_kernel(const float* __restrict__ x, long P, _Float16* __restrict__ dimg,
-                                                             _Float16* __restrict__ rimg) {
-    __shared__ float s_t[32][129];
-    const int tid = threadIdx.x;
-    const long blk = blockIdx.x, row0 = blk * 32;
-    _Float16* rb = rimg + blk * FWR_BLK_HALFS;
-    _Float16* db = dimg + blk * FWR_BLK_HALFS;
-    {   // row-major role: thread (row, channel quad); R image straight from the registers
-        const int row = tid >> 3, cq = tid & 7;
-        const bool ok = row0 + row < P;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 32 * k + 4 * cq;
-            const f32x4 v = ok ? ld4(x + (row0 + row) * 128 + c) : zero4();
-            s_t[row][c] = v[0]; s_t[row][c + 1] = v[1]; s_t[row][c + 2] = v[2]; s_t[row][c + 3] = v[3];
-            s3d_half4 hi, lo;
-            s3d_split4(v, hi, lo);
-            const int o = row * 128 + (((c >> 3) ^ (row & 15)) << 3) + (c & 4);
-            *reinterpret_cast<s3d_half4*>(rb + o) = hi;
-            *reinterpret_cast<s3d_half4*>(rb + 4096 + o) = lo;
-        }
-    }
-    __syncthreads();
-    {   // transposed role: thread (channel q, two k-groups)
-        const int q = tid & 127, gg = tid >> 7;
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int g = 2 * gg + ps;
-            float v[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = s_t[t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)][q];
-            s3d_half8 hi, lo;
-            s3d_split8(v, hi, lo);
-            const int o = q * 32 + ((g ^ fwr_dperm(q)) << 3);
-            *reinterpret_cast<s3d_half8*>(db + o) = hi;
-            *reinterpret_cast<s3d_half8*>(db + 4096 + o) = lo;
-        }
-    }
-}
-int launch_ffn_rec_images(const float* x, long P, float* dimg, float* rimg, hipStream_t stream) {
-    if (P <= 0) return 0;
-    hipLaunchKernelGGL(ffn_rec_images_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, stream, x, P,
-                       reinterpret_cast<_Float16*>(dimg), reinterpret_cast<_Float16*>(rimg));
-    S3D_LAUNCH_CHECK();
-    return 0;
-}
-
+// Operand images (layout: decode.h).  Both contraction operands of a 32-row step are needed by the 16 hidden-block workgroups
+// that share the rows, as f16 hi/lo, one of them transposed: splitting and transposing them inside this kernel cost it 39 % of
+// its time (profiles/r03_ffn_wgrad_ablation.md).  Round 3 built them with a pass of its own (ffn_rec_images_kernel, 3x the
+// tensor's bytes per call, 7.6 ms per step); since round 4 the pipelined FFN kernel writes them for the rows it holds anyway.
 // ---------------------------------------------------------------------------------------------
 // The contraction.  Workgroup = 128 (q) x 128 (hidden) output tile of hidden block hb, rows split over the grid; 4 waves,
 // wave w owns hidden units 32w .. 32w+31 of the block against ALL 128 q.  Per 32-row step (one barrier; the images are

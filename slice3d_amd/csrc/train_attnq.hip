@@ -88,6 +88,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdArgs a,
     }
     const bool row_ok = m < T;
     const int mt = row_ok ? m : T - 1;
+    // Ring barrier with the exact count of younger vector-memory operations (AQ_BARRIER_N, attnq.h).  Per head a wave issues
+    // 4 dO loads (before the q barrier), 3 DMA sets of 4, 12 result stores after the core; per item 16 row loads at the end.
+    // Set p is issued during phase p - 3 (the same part of the previous head), so every barrier has 3 x 4 + 12 - 4 + 4 = 24
+    // younger operations, 24 + 16 at the first head of an item that is not the workgroup's first (there: 8 + 16 + 4 = 28).
+    // T < 9: store halves without active lanes are skipped -> vmcnt(8).
+    const bool wide = T >= 9;
+    bool wide_h0 = false;
+    auto ring_barrier = [&](int h) {
+        if (!wide) { AQ_BARRIER(); }
+        else if (h == 0 && wide_h0) { AQ_BARRIER_N(40); }
+        else { AQ_BARRIER_N(24); }
+    };
     // identity B operand of the transposing MFMA: lane (n, g), k-slot 4g + t
     half4q ident;
 #pragma unroll
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdArgs a,
                         AQ_READ(bv[j], lq, 1024 + 64 * j);
                     }
                 }
-                AQ_BARRIER();   // this phase's fragments have landed; the slot of three phases ahead is free
+                ring_barrier(h);   // this phase's fragments have landed; the slot of three phases ahead is free
                 int nph = 3 * h + part + 3;
                 if (nph >= 12) nph -= 12;
                 const int nbuf = (int)((ps + 3) & 3);
@@ -283,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdArgs a,
         }
         load_rows(more_items ? item + gridDim.x : item);   // unconditional (see decode_attnq.hip)
         __builtin_amdgcn_sched_barrier(0);
+        wide_h0 = wide;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last prefetches must not outlive the workgroup's LDS
 }
