@@ -365,55 +365,6 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
             as.mw_next[r] = ba.M[row * 64 + g * 16 + 1];
         }
     }
-    if (MODE >= 2) {   // operand images of this wave's 32 rows for the weight-gradient kernel (layout: decode.h)
-        _Float16* imgd = MODE == 4 ? ba.ImgD : ta.ImgD;
-        _Float16* imgr = MODE == 4 ? ba.ImgR : ta.ImgR;
-        if (imgd && row0 < rows) {   // (a wave wholly past the end has no block in the images)
-            const long blk = row0 >> 5;
-            _Float16* rb = imgr + blk * FWR_BLK_HALFS;
-            _Float16* db = imgd + blk * FWR_BLK_HALFS;
-            const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-            half8 sel[2];   // B operand that picks channels 16c .. 16c+15 of a 32-channel k-step: B[k = 8g + t][n] = (k == 16c + n)
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) sel[c2][t] = (8 * g + t == 16 * c2 + m) ? (_Float16)1.f : (_Float16)0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                half8 ah[PIPE_R], al[PIPE_R];
-#pragma unroll
-                for (int r = 0; r < PIPE_R; ++r) {   // rows past the end are zero in both images
-                    const bool ok = row0 + r * 16 + m < rows;
-                    ah[r] = ok ? xh[r][u] : z8;
-                    al[r] = ok ? xl[r][u] : z8;
-                    // R image: the fragment as it is — chunk 4u + g of row 16r + m, swizzled by the row
-                    const int o = (16 * r + m) * 128 + (((4 * u + g) ^ m) << 3);
-                    *reinterpret_cast<half8*>(rb + o) = ah[r];
-                    *reinterpret_cast<half8*>(rb + 4096 + o) = al[r];
-                }
-                // D^T image: x tile (A: row m, k-slot = channel) times the selector -> D layout lane (channel n, g) x rows 4g + i:
-                // the slot order of the image (tile 0 rows | tile 1 rows); products with 1.0 are exact
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) {
-                    static_assert(PIPE_R == 2, "a wave's two row tiles are one 32-row block");
-                    const f32x4 h0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], sel[c2], zero4(), 0, 0, 0);
-                    const f32x4 h1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], sel[c2], zero4(), 0, 0, 0);
-                    const f32x4 l0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], sel[c2], zero4(), 0, 0, 0);
-                    const f32x4 l1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], sel[c2], zero4(), 0, 0, 0);
-                    half8 oh, ol;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        oh[i] = (_Float16)h0[i]; oh[4 + i] = (_Float16)h1[i];
-                        ol[i] = (_Float16)l0[i]; ol[4 + i] = (_Float16)l1[i];
-                    }
-                    const int q = 32 * u + 16 * c2 + m;
-                    const int o = q * 32 + ((g ^ fwr_dperm(q)) << 3);
-                    *reinterpret_cast<half8*>(db + o) = oh;
-                    *reinterpret_cast<half8*>(db + 4096 + o) = ol;
-                }
-            }
-        }
-    }
     dma_publish_barrier();
     const float* sb = s_b1 + 4 * g;     // this lane's bias quad of D tile 0 of chunk 0; tile 1 at +16, chunk c at +32c
     const unsigned lw0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_w0 + lane * 8);
@@ -492,6 +443,57 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
     dma_publish_barrier();
     ffn_pipe_iter<MODE, true, SINGLE>(lw1, lb0, xh, xl, acc, hdB, hdA, as, ta, ba, NC - 1);
     if (MODE == 2 || MODE == 3) group_done(NC - 1);
+    if (MODE >= 2) {   // operand images of this wave's 32 rows for the weight-gradient kernel (layout: decode.h).  Written HERE, after
+                       // the loop: in the prologue their 32 stores sat in front of the publishing barrier's vmcnt(0)
+                       // (+1 ms per 5.2 M-row call); the row fragments are live to the epilogue anyway
+        _Float16* imgd = MODE == 4 ? ba.ImgD : ta.ImgD;
+        _Float16* imgr = MODE == 4 ? ba.ImgR : ta.ImgR;
+        if (imgd && row0 < rows) {   // (a wave wholly past the end has no block in the images)
+            const long blk = row0 >> 5;
+            _Float16* rb = imgr + blk * FWR_BLK_HALFS;
+            _Float16* db = imgd + blk * FWR_BLK_HALFS;
+            const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            half8 sel[2];   // B operand that picks channels 16c .. 16c+15 of a 32-channel k-step: B[k = 8g + t][n] = (k == 16c + n)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sel[c2][t] = (8 * g + t == 16 * c2 + m) ? (_Float16)1.f : (_Float16)0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                half8 ah[PIPE_R], al[PIPE_R];
+#pragma unroll
+                for (int r = 0; r < PIPE_R; ++r) {   // rows past the end are zero in both images
+                    const bool ok = row0 + r * 16 + m < rows;
+                    ah[r] = ok ? xh[r][u] : z8;
+                    al[r] = ok ? xl[r][u] : z8;
+                    // R image: the fragment as it is — chunk 4u + g of row 16r + m, swizzled by the row
+                    const int o = (16 * r + m) * 128 + (((4 * u + g) ^ m) << 3);
+                    *reinterpret_cast<half8*>(rb + o) = ah[r];
+                    *reinterpret_cast<half8*>(rb + 4096 + o) = al[r];
+                }
+                // D^T image: x tile (A: row m, k-slot = channel) times the selector -> D layout lane (channel n, g) x rows 4g + i:
+                // the slot order of the image (tile 0 rows | tile 1 rows); products with 1.0 are exact
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    static_assert(PIPE_R == 2, "a wave's two row tiles are one 32-row block");
+                    const f32x4 h0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], sel[c2], zero4(), 0, 0, 0);
+                    const f32x4 h1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], sel[c2], zero4(), 0, 0, 0);
+                    const f32x4 l0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], sel[c2], zero4(), 0, 0, 0);
+                    const f32x4 l1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], sel[c2], zero4(), 0, 0, 0);
+                    half8 oh, ol;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        oh[i] = (_Float16)h0[i]; oh[4 + i] = (_Float16)h1[i];
+                        ol[i] = (_Float16)l0[i]; ol[4 + i] = (_Float16)l1[i];
+                    }
+                    const int q = 32 * u + 16 * c2 + m;
+                    const int o = q * 32 + ((g ^ fwr_dperm(q)) << 3);
+                    *reinterpret_cast<half8*>(db + o) = oh;
+                    *reinterpret_cast<half8*>(db + 4096 + o) = ol;
+                }
+            }
+        }
+    }
 
     // epilogue: tile j, reg i  <->  column 32*(j>>1) + 8*g + 4*(j&1) + i.
     // The lane's column offset is re-derived from an opaque copy of g: otherwise the ten loop-invariant 64-bit addresses
