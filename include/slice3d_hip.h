@@ -242,7 +242,7 @@ int s3d_conv_fwd(const void* packed, const float* x0, const float* x1, const flo
                  int H, int W, int cout, int cin0, int cin1, int ks, int prec, void* workspace,
                  size_t workspace_bytes, void* stream);
 /* GroupNorm32 (util.py normalization) [+ FiLM: y*(1+scale)+shift, film = (N, 2C), openaimodel.py:268-270] [+ SiLU].
- * stats: N*groups*50 floats of scratch (mean / rstd per group, then the per-slice partial moments). */
+ * stats: N*groups*200 floats of scratch (mean / rstd per group, then the per-slice partial moments). */
 int s3d_group_norm_fwd(const float* x, const float* gamma, const float* beta, const float* film, float* y,
                        float* stats, int N, int HW, int C, int groups, float eps, int silu, void* stream);
 /* the same with film rows read in place from a wider tensor: image n's (scale | shift) at film + n * film_stride floats

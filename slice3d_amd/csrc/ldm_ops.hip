@@ -10,7 +10,7 @@
 // ---------------------------------------------------------------------------------------------
 // Stage 1: block (image, group, slice) -> (count, mean, M2) of its slice of the HW pixels (two passes over the slice,
 // which stays in L2).  Stage 2 (inside the apply kernel): the slices are merged with Chan's parallel-variance formula.
-#define GN_SLICES 16
+#define GN_SLICES 64
 // Input = channel concatenation of x (C0 channels) and x1 (C - C0 channels; NULL when C0 == C): the th.cat([h, hs.pop()],
 // dim=1) in front of the output blocks' first ResBlock (openaimodel.py:750) is never materialised — the GroupNorm groups
 // straddle the two tensors, so the concatenation happens in this kernel's loads (its OUTPUT is one tensor).
@@ -54,6 +54,80 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnSrc src, int HW, 
         part[3 * blockIdx.x + 2] = m2;
     }
 }
+// Round 4: the same partial moments from ONE coalesced pass.  gn_stats_kernel above walks a group's C/32 channels of every
+// pixel (24-byte runs at a C*4-byte stride) twice; the one-launch gn_fused_kernel below reads the same way with only
+// N*32 workgroups — 15 / 21 us for a 3 MB map.  Here a workgroup owns a slab of pixels of one image with ALL channels:
+// thread = (pixel lane, channel quad), 16-byte loads along the channel axis, shifted sums sum(x - k), sum((x - k)^2) about
+// the slab's first pixel k[c] (the cancellation of E[d^2] - E[d]^2 is then of the size (mean - k)^2 / var of a channel
+// inside one slab), per-channel totals through LDS adds, then one thread per group folds its C/32 channels into
+// (count, mean, M2) — the partial gn_apply_kernel merges with Chan's formula, as before.
+__global__ __launch_bounds__(1024) void gn_stats_rows_kernel(const GnSrc src, int HW, int C, int groups,
+                                                             float* __restrict__ part) {
+    extern __shared__ float s_g[];          // k[C] | sum1[C] | sum2[C] | per-lane partials [lanes][2][C]
+    float* s_k = s_g;
+    float* s_1 = s_g + C;
+    float* s_2 = s_g + 2 * C;
+    float* s_p = s_g + 3 * C;
+    const int sl = blockIdx.x % GN_SLICES, n = blockIdx.x / GN_SLICES;
+    const int p0 = (int)((long)HW * sl / GN_SLICES), p1 = (int)((long)HW * (sl + 1) / GN_SLICES);
+    const int cq = C >> 2, lanes = 1024 / cq;            // pixel lanes per pass (C <= 4096)
+    const int cqi = threadIdx.x % cq, pr = threadIdx.x / cq;
+    const int c = 4 * cqi;
+    auto row = [&](int p) {
+        const long q = (long)n * HW + p;
+        return c < src.C0 ? ld4(src.x + q * src.C0 + c) : ld4(src.x1 + q * (C - src.C0) + (c - src.C0));
+    };
+    if (pr < lanes) {
+        f32x4 a1 = zero4(), a2 = zero4();
+        if (p1 > p0) {
+            const f32x4 k = row(p0);
+            int p = p0 + pr;
+            for (; p + 3 * lanes < p1; p += 4 * lanes) {   // four rows in flight (the loop is latency-bound otherwise)
+                const f32x4 r0 = row(p), r1 = row(p + lanes), r2 = row(p + 2 * lanes), r3 = row(p + 3 * lanes);
+                const f32x4 d0 = r0 - k, d1 = r1 - k, d2 = r2 - k, d3 = r3 - k;
+                a1 += (d0 + d1) + (d2 + d3);
+                a2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            for (; p < p1; p += lanes) {
+                const f32x4 d = row(p) - k;
+                a1 += d;
+                a2 += d * d;
+            }
+            if (pr == 0) st4(s_k + c, k);
+        } else if (pr == 0) {
+            st4(s_k + c, zero4());
+        }
+        st4(s_p + (size_t)(2 * pr) * C + c, a1);
+        st4(s_p + (size_t)(2 * pr + 1) * C + c, a2);
+    }
+    __syncthreads();
+    if (pr == 0) {   // the pixel lanes' partials in a fixed order (no atomics: the result is bit-reproducible)
+        f32x4 t1 = zero4(), t2 = zero4();
+        for (int l = 0; l < lanes; ++l) {
+            t1 += ld4(s_p + (size_t)(2 * l) * C + c);
+            t2 += ld4(s_p + (size_t)(2 * l + 1) * C + c);
+        }
+        st4(s_1 + c, t1);
+        st4(s_2 + c, t2);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+        const int g = threadIdx.x, cpg = C / groups;
+        const float np = (float)(p1 - p0);
+        float mean_g = 0.f;
+        for (int j = 0; j < cpg; ++j) mean_g += s_k[g * cpg + j] + s_1[g * cpg + j] / fmaxf(np, 1.f);
+        mean_g /= (float)cpg;
+        float m2 = 0.f;
+        for (int j = 0; j < cpg; ++j) {
+            const float s1 = s_1[g * cpg + j], mc = s_k[g * cpg + j] + s1 / fmaxf(np, 1.f);
+            m2 += (s_2[g * cpg + j] - s1 * s1 / fmaxf(np, 1.f)) + np * (mc - mean_g) * (mc - mean_g);
+        }
+        float* o = part + 3 * ((size_t)(n * groups + g) * GN_SLICES + sl);
+        o[0] = np * (float)cpg;
+        o[1] = mean_g;
+        o[2] = fmaxf(m2, 0.f);
+    }
+}
 // y = gn(x) * gamma + beta ; optional FiLM (ResBlock use_scale_shift_norm): y = y * (1 + scale[n,c]) + shift[n,c]
 // with film = [N][2C] (scale | shift) ; optional SiLU.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnSrc src, const float* __restrict__ part,
@@ -62,19 +136,42 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnSrc src, const fl
                                                        int N, int HW, int C, int groups, float eps, int silu) {
     // every block first merges the slice moments of all (image, group) pairs (Chan's parallel-variance formula)
     extern __shared__ float s_stats[];   // [N*groups][2] = mean, rstd
-    for (int i = threadIdx.x; i < N * groups; i += 256) {
+    // eight lanes per (image, group): each folds every eighth slice (independent loads), then three pairwise merges
+    for (int i0 = 0; i0 < N * groups; i0 += 32) {
+        const int i = i0 + (threadIdx.x >> 3), j = threadIdx.x & 7;
         float cnt = 0.f, mean = 0.f, m2 = 0.f;
-        for (int s = 0; s < GN_SLICES; ++s) {
-            const float nb = part[3 * (i * GN_SLICES + s)], mb = part[3 * (i * GN_SLICES + s) + 1],
-                        qb = part[3 * (i * GN_SLICES + s) + 2];
-            if (nb == 0.f) continue;
-            const float tot = cnt + nb, d = mb - mean;
-            mean += d * nb / tot;
-            m2 += qb + d * d * cnt * nb / tot;
+        if (i < N * groups) {
+            float nb[GN_SLICES / 8], mb[GN_SLICES / 8], qb[GN_SLICES / 8];
+#pragma unroll
+            for (int k = 0; k < GN_SLICES / 8; ++k) {
+                const float* q = part + 3 * ((size_t)i * GN_SLICES + j + 8 * k);
+                nb[k] = q[0]; mb[k] = q[1]; qb[k] = q[2];
+            }
+#pragma unroll
+            for (int k = 0; k < GN_SLICES / 8; ++k) {
+                if (nb[k] == 0.f) continue;
+                const float tot = cnt + nb[k], d = mb[k] - mean;
+                mean += d * nb[k] / tot;
+                m2 += qb[k] + d * d * cnt * nb[k] / tot;
+                cnt = tot;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {   // Chan's merge with lane j ^ o (same order on both sides of a pair: symmetric formula)
+            const float cb = __shfl_xor(cnt, o, 64), mbb = __shfl_xor(mean, o, 64), qbb = __shfl_xor(m2, o, 64);
+            const float tot = cnt + cb;
+            if (tot > 0.f) {
+                const float d = mbb - mean;
+                const float nm = (cnt * mean + cb * mbb) / tot;
+                m2 = m2 + qbb + d * d * cnt * cb / tot;
+                mean = nm;
+            }
             cnt = tot;
         }
-        s_stats[2 * i] = mean;
-        s_stats[2 * i + 1] = 1.f / sqrtf(m2 / cnt + eps);
+        if (i < N * groups && j == 0) {
+            s_stats[2 * i] = mean;
+            s_stats[2 * i + 1] = 1.f / sqrtf(m2 / cnt + eps);
+        }
     }
     __syncthreads();
     const int c4n = C >> 2, cpg = C / groups;
@@ -164,7 +261,8 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
     const GnSrc src = {x, x1, C0};
     {
         const long per_thread = ((long)HW * (C / groups) + 1023) / 1024;
-        if (per_thread <= 24) {   // 1024 threads leave 128 registers per lane: larger slabs would spill
+        if (per_thread <= 8 || (per_thread <= 24 && N * groups >= 128)) {   // (with >= 128 workgroups the one-launch form wins again)   // small maps: one launch (a (image, group) slab in the registers of one workgroup); larger ones
+                                 // run the two coalesced kernels below — the fused kernel's strided reads took 21 us there
             const dim3 grid((unsigned)(N * groups));
 #define GN_CASE(e)                                                                                                     \
     if (per_thread <= e) {                                                                                             \
@@ -178,7 +276,11 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
         }
     }
     S3D_CHECK_ARG((size_t)N * groups * 2 * sizeof(float) <= 48 * 1024, "group_norm: N*groups %d too large", N * groups);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, src, HW, C, groups, stats);
+    if (C <= 2048 && groups <= 1024)   // (LDS: 7 C floats) coalesced one-pass partial moments (all channels of a pixel slab per workgroup)
+        hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(N * GN_SLICES), dim3(1024),
+                           (size_t)(3 * C + 2 * (1024 / (C / 4)) * C) * sizeof(float), stream, src, HW, C, groups, stats);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, src, HW, C, groups, stats);
     S3D_LAUNCH_CHECK();
     const long total = (long)N * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

@@ -191,7 +191,7 @@ class UNetModel(nn.Module):
         """GroupNorm(+FiLM)(+SiLU) of x, or of the channel concatenation [x, x1] (never materialised)."""
         lib = self._lib
         n, h, w, c = x.shape
-        stats = torch.empty((n, gn.num_groups, 50), dtype=torch.float32, device=x.device)
+        stats = torch.empty((n, gn.num_groups, 200), dtype=torch.float32, device=x.device)
         if x1 is not None:
             c1 = x1.shape[-1]
             y = torch.empty((n, h, w, c + c1), dtype=torch.float32, device=x.device)

@@ -163,7 +163,7 @@ def test_group_norm_of_two_sources_equals_group_norm_of_the_concatenation():
         film = (torch.randn(n, 2 * c, generator=g) * 0.3).cuda()
         cat = torch.cat([x0, x1], -1).contiguous()
         ya, yb = torch.empty_like(cat), torch.empty_like(cat)
-        stats = torch.empty(n, 32, 50, device="cuda")
+        stats = torch.empty(n, 32, 200, device="cuda")
         _lib.check(lib.s3d_group_norm_fwd(cat.data_ptr(), gw.data_ptr(), gb.data_ptr(), film.data_ptr(), ya.data_ptr(),
                                           stats.data_ptr(), n, hw, c, 32, C.c_float(1e-5), 1, None), "gn")
         _lib.check(lib.s3d_group_norm2_fwd(x0.data_ptr(), c0, x1.data_ptr(), c1, gw.data_ptr(), gb.data_ptr(),
@@ -192,7 +192,7 @@ def test_ldm_primitives_match_torch():
     want = F.silu(want).permute(0, 2, 3, 1).contiguous()
     xc = x.permute(0, 2, 3, 1).contiguous().cuda()
     y = torch.empty_like(xc)
-    stats = torch.empty(n, 32, 50, device="cuda")
+    stats = torch.empty(n, 32, 200, device="cuda")
     gw, gb, fc = gn.weight.detach().cuda(), gn.bias.detach().cuda(), film.cuda()   # keep the device copies alive
     _lib.check(lib.s3d_group_norm_fwd(xc.data_ptr(), gw.data_ptr(), gb.data_ptr(), fc.data_ptr(), y.data_ptr(),
                                       stats.data_ptr(), n, h * w, c, 32, C.c_float(1e-5), 1, None), "gn")
