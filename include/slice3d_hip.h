@@ -145,6 +145,15 @@ int s3d_decode_points_fwd(const void* head_packed, const S3dLatent* latent, cons
                           const float* rot, const float* trans, int flip_yz, float* sdf_out,
                           int batch, long n_qry, int n_slices, int prec,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* Debug / test form of s3d_decode_points_fwd that also returns the intermediate rows the reference's stage probes look at
+ * (fc_p / fc_s output models.py:79-82, token 0 after each layer of att_decoder models.py:83): stages holds
+ * s3d_decode_stages_floats() floats = the token tensor [G][n_slices+1][16][128] (G = B*ceil(Q/16); row of query q of
+ * object b: group b*ceil(Q/16) + q/16, lane q%16; token 0 = fc_p, token 1+s = fc_s of slice s), then [3][G*16][128] token-0
+ * rows after layers 0, 1, 2.  One pass in caller order: Q < 4096 per object. */
+size_t s3d_decode_stages_floats(int batch, long n_qry, int n_slices);
+int s3d_decode_points_stages_fwd(const void* head_packed, const S3dLatent* latent, const float* qry, const float* rot,
+                                 const float* trans, int flip_yz, float* sdf_out, float* stages, int batch, long n_qry,
+                                 int n_slices, int prec, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Dense-grid evaluation for Generator3D with upsampling_steps == 0 (reconstruct.py:135-146):
  * query coordinates box*linspace(-.5,.5,nx)^3 (x slowest, z fastest; common.py:145-164) are generated

@@ -103,6 +103,9 @@ SYMBOLS = {
     "s3d_decode_workspace_bytes": (_sz, [_i, _l, _i]),
     "s3d_decode_points_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _vp, _vp, _i, _vp, _i, _l, _i, _i,
                                    _vp, _sz, _vp]),
+    "s3d_decode_stages_floats": (_sz, [_i, _l, _i]),
+    "s3d_decode_points_stages_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _vp, _vp, _i, _vp, _vp, _i, _l, _i, _i,
+                                          _vp, _sz, _vp]),
     "s3d_decode_grid_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _i, _f, _vp, _i, _i, _vp, _sz, _vp]),
     "s3d_decode_grid_slab_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _i, _f, _l, _l, _vp, _i, _i, _vp, _sz, _vp]),
     "s3d_gt_encoder_packed_bytes": (_sz, []),

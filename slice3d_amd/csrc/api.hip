@@ -794,7 +794,7 @@ static int attn_last_layer(const float* b, const HeadLayout& H, const LayerPtrs&
 static int decode_impl(const void* head_packed, const S3dLatent* lat, const float* qry, const float* rot,
                        const float* trans, int flip_yz, int nx, float box, float sign, float* out, int batch,
                        long n_qry, int ns, int prec, void* workspace, size_t workspace_bytes, hipStream_t st,
-                       long q_offset = 0) {
+                       long q_offset = 0, float* stages = nullptr) {
     S3D_CHECK_ARG(head_packed && lat && trans && out && workspace, "decode: null argument");
     S3D_CHECK_ARG(batch >= 1 && n_qry >= 1, "decode: batch=%d n_qry=%ld", batch, n_qry);
     S3D_CHECK_ARG(ns >= 1 && ns <= 12, "decode: n_slices %d", ns);
@@ -819,6 +819,10 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
                               (int*)((float*)workspace + W.sortws), st));
         perm = pm;
     }
+    // stage capture (s3d_decode_points_stages_fwd): one pass, queries in caller order
+    S3D_CHECK_ARG(!stages || (G <= S3D_CHUNK_GROUPS && !perm), "decode stages: at most %d unsorted queries per object",
+                  (int)S3D_SORT_MIN_QUERIES - 1);
+    const size_t rows_all = (size_t)G * T * S3D_GROUP * 128, rows0_all = (size_t)G * S3D_GROUP * 128;
     for (long g0 = 0; g0 < G; g0 += S3D_CHUNK_GROUPS) {
         const long gc = G - g0 < S3D_CHUNK_GROUPS ? G - g0 : S3D_CHUNK_GROUPS;
         SampleArgs sa = {};
@@ -833,6 +837,10 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
             ProfScope prof_(S3D_PROF_SAMPLE, st);
             TRY(launch_sample_tokens(sa, st));
         }
+        if (stages && hipMemcpyAsync(stages, X, rows_all * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            s3d_set_error("decode stages: memcpy failed");
+            return (int)hipErrorUnknown;
+        }
         for (int l = 0; l < S3D_N_LAYERS; ++l) {
             const LayerPtrs lp = layer_ptrs(b, H, l);
             const bool last = l == S3D_N_LAYERS - 1;
@@ -846,12 +854,24 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
                     TRY(launch_attn_layer(X, nullptr, gc, T, lp, st));
             }
             ProfScope prof_(last ? S3D_PROF_FFN_FINAL : S3D_PROF_FFN, st);
-            if (!last)
+            if (!last) {
                 TRY(launch_ffn_layer(X, gc * T * S3D_GROUP, lp, nullptr, nullptr, nullptr, 1.f, gpb, n_qry, g0,
                                      prec, nullptr, st));
-            else
+                if (stages) TRY(launch_tok0_copy(X, stages + rows_all + (size_t)l * rows0_all, gc, T, 0, 128, st));
+            } else {
+                if (stages) {   // the final kernel keeps the layer's output rows in registers (LayerNorm -> fc_out): the capture
+                                // runs the full-row form of the same kernel on a copy of the token-0 rows
+                    float* d = stages + rows_all + (size_t)l * rows0_all;
+                    if (hipMemcpyAsync(d, X0, rows0_all * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                        s3d_set_error("decode stages: memcpy failed");
+                        return (int)hipErrorUnknown;
+                    }
+                    TRY(launch_ffn_layer(d, gc * S3D_GROUP, lp, nullptr, nullptr, nullptr, 1.f, gpb, n_qry, g0, prec,
+                                         nullptr, st));
+                }
                 TRY(launch_ffn_layer(X0, gc * S3D_GROUP, lp, b + H.fco_w, b + H.fco_b, out, sign, gpb, n_qry, g0,
                                      prec, perm, st));
+            }
         }
     }
     return 0;
@@ -864,6 +884,23 @@ extern "C" int s3d_decode_points_fwd(const void* head_packed, const S3dLatent* l
     S3D_CHECK_ARG(qry, "decode_points: qry is NULL");
     return decode_impl(head_packed, latent, qry, rot, trans, flip_yz, 0, 1.f, 1.f, sdf_out, batch, n_qry,
                        n_slices, prec, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// s3d_decode_points_fwd that also hands out the intermediate rows the reference's stage goldens probe (models.py:79-83):
+// stages = [G][T][16][128] token tensor after fc_p / fc_s (token 0 = fc_p(qry_rot), token 1 + s = fc_s of slice s; row of
+// query q of object b: group b * ceil(Q/16) + q / 16, lane q % 16), then [3][G*16][128]: token 0 after each encoder layer.
+// Debug / test entry point: one decode pass, queries in caller order (Q < 4096 per object).
+extern "C" size_t s3d_decode_stages_floats(int batch, long n_qry, int n_slices) {
+    const size_t G = (size_t)((n_qry + S3D_GROUP - 1) / S3D_GROUP) * batch;
+    return G * S3D_GROUP * 128 * (size_t)(n_slices + 1 + S3D_N_LAYERS);
+}
+extern "C" int s3d_decode_points_stages_fwd(const void* head_packed, const S3dLatent* latent, const float* qry,
+                                            const float* rot, const float* trans, int flip_yz, float* sdf_out,
+                                            float* stages, int batch, long n_qry, int n_slices, int prec, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+    S3D_CHECK_ARG(qry && stages, "decode_points_stages: null argument");
+    return decode_impl(head_packed, latent, qry, rot, trans, flip_yz, 0, 1.f, 1.f, sdf_out, batch, n_qry, n_slices, prec,
+                       workspace, workspace_bytes, (hipStream_t)stream, 0, stages);
 }
 
 extern "C" int s3d_decode_grid_fwd(const void* head_packed, const S3dLatent* latent, const float* trans, int nx,

@@ -476,6 +476,40 @@ class Slices3DRegModel(nn.Module):
                    "s3d_decode_points_fwd")
         return out
 
+    def decode_stages(self, p, c, obj_rot_mat=None, trans_mat_wo_rot_tp=None, mode=None):
+        """Debug / test form of decode_sdf that also returns the rows the reference's stage probes look at: a dict with
+        'sdf' (B,Q), 'fc_p' (B,Q,128) = fc_p(qry_rot), 'fc_s' (B,Q,n_slices,128) = fc_s of the sampled pyramid
+        (models.py:79-82) and 'layer0' / 'layer1' / 'layer2' (B,Q,128) = token 0 after each layer of att_decoder
+        (models.py:83).  One decode pass in caller order: Q < 4096 per object."""
+        lib = self._require_lib()
+        self._require_eval()
+        mode = self.mode if mode is None else mode
+        qry = self._f32(p)
+        b, q, _ = qry.shape
+        tm = self._f32(trans_mat_wo_rot_tp) if trans_mat_wo_rot_tp is not None else c.trans_mat_wo_rot_tp
+        rot = None
+        if mode != "test":
+            rot = self._f32(obj_rot_mat) if obj_rot_mat is not None else c.obj_rot_mat
+        ns, t = self.n_slices, self.n_slices + 1
+        gpb = (q + 15) // 16
+        g = gpb * b
+        out = torch.empty((b, q), dtype=torch.float32, device=qry.device)
+        n_st = lib.s3d_decode_stages_floats(b, q, ns)
+        assert n_st == g * 16 * 128 * (t + 3)
+        st = torch.empty(n_st, dtype=torch.float32, device=qry.device)
+        ws = self._workspace("decode", lib.s3d_decode_workspace_bytes(b, q, ns))
+        _lib.check(lib.s3d_decode_points_stages_fwd(self._head_packed.data_ptr(), C.byref(c._latent_struct), qry.data_ptr(),
+                                                    rot.data_ptr() if rot is not None else None, tm.data_ptr(),
+                                                    1 if mode == "test" else 0, out.data_ptr(), st.data_ptr(), b, q, ns,
+                                                    self.prec, ws.data_ptr(), ws.numel(), self._stream()),
+                   "s3d_decode_points_stages_fwd")
+        tok = st[:g * t * 16 * 128].view(b, gpb, t, 16, 128).permute(0, 1, 3, 2, 4).reshape(b, gpb * 16, t, 128)[:, :q]
+        res = {"sdf": out, "fc_p": tok[:, :, 0], "fc_s": tok[:, :, 1:]}
+        lay = st[g * t * 16 * 128:].view(3, b, gpb * 16, 128)[:, :, :q]
+        for i in range(3):
+            res["layer%d" % i] = lay[i]
+        return res
+
     def decode(self, p, c, **kwargs):
         """ConvONet-style decode: `.logits` follows Generator3D's convention (= -sdf, reconstruct.py:97)."""
         sdf = self.decode_sdf(p, c, **kwargs)

@@ -84,6 +84,33 @@ def test_pyramid_matches_reference_golden(name, prec):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("name", ["g2_s64_n12_q2048_test", "g3_s32_n12_q512_b2_train"])
+def test_decoder_stage_rows_match_reference_golden(name, prec):
+    """SURVEY 8(a) a-10 / a-11 stage by stage on the HIP path: fc_p / fc_s rows (models.py:79-82) and token 0 after each of
+    the three encoder layers (models.py:83) of the first 64 queries, captured from the REAL reference by forward hooks
+    (tests/golden/make_golden.py), against s3d_decode_points_stages_fwd (the product kernels; the capture copies rows
+    between them).  The oracle is checked against the same arrays in tests/test_oracle.py."""
+    g = load_golden(name)
+    model = get_model(g["n_slices"], g["mode"], prec)
+    fd = to_gpu(golden_feed(g))
+    code = model.encode(fd)
+    st = model.decode_stages(fd["qry_norot"], code)
+    torch.cuda.synchronize()
+    assert np.abs(st["sdf"].cpu().numpy() - g["sdf_pred"]).max() < TOL
+    assert torch.equal(st["sdf"], model.decode_sdf(fd["qry_norot"], code))        # the capture does not disturb the path
+    n = g["fc_s_rows"].shape[0]
+    tol = 5e-5     # the oracle's own bound (tests/test_oracle.py); measured 1-2e-5 in both modes
+    assert np.abs(st["fc_p"][0, :n].cpu().numpy() - g["fc_p_rows"]).max() < 1e-5
+    assert np.abs(st["fc_s"][0, :n].cpu().numpy() - g["fc_s_rows"]).max() < tol
+    worst = 0.0
+    for i in range(3):
+        e = float(np.abs(st["layer%d" % i][0, :n].cpu().numpy() - g["layer%d_tok0" % i]).max())
+        worst = max(worst, e)
+        assert e < tol, (i, e)
+    print("stage rows %s (%s): worst layer deviation %.2e" % (name, prec, worst))
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_helper_ops_match_golden(prec):
     g = load_golden("g3_s32_n12_q512_b2_train")
     model = get_model(12, "train", prec)
