@@ -600,6 +600,7 @@ HeadLayout head_layout() {
     for (int l = 0; l < 3; ++l) H.wproj[l] = take((size_t)128 * lc[l]);
     for (int l = 0; l < 3; ++l) H.wproj16[l] = take((size_t)128 * lc[l]);
     H.ws34 = take(128 * 96);
+    H.ws34_16 = take(128 * 96);
     for (int l = 0; l < S3D_N_LAYERS; ++l) {
         H.L[l].inw = take(384 * 128);
         H.L[l].inb = take(384);
@@ -684,6 +685,7 @@ extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed
     for (int l = 0; l < 3; ++l) TRY(pack_linear(P->fc_s_w + lo[l], b + H.wproj[l], 128, 128, lc[l], 992, 0, st));
     for (int l = 0; l < 3; ++l) TRY(pack_linear(P->fc_s_w + lo[l], b + H.wproj16[l], 128, 128, lc[l], 992, 0, st, 1));
     TRY(pack_linear(P->fc_s_w + 896, b + H.ws34, 128, 128, 96, 992, 0, st));
+    TRY(pack_linear(P->fc_s_w + 896, b + H.ws34_16, 128, 128, 96, 992, 0, st, 1));
     TRY(pack_head_layers(P->layer, b, H, st));
     TRY(copy_vec(b + H.fco_w, P->fc_out_w, 128, st));
     TRY(copy_vec(b + H.fco_b, P->fc_out_b, 1, st));
@@ -830,6 +832,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
         sa.fine[0] = lat->fine[0]; sa.fine[1] = lat->fine[1];
         sa.size = lat->size; sa.n_slices = ns;
         sa.fcp_w = b + H.fcp_w; sa.fcp_b = b + H.fcp_b; sa.fcs_b = b + H.fcs_b; sa.ws34 = b + H.ws34;
+        sa.ws34_16 = prec != S3D_PREC_F32 ? b + H.ws34_16 : nullptr;
         sa.qry = qry; sa.rot = rot; sa.trans = trans; sa.flip_yz = flip_yz;
         sa.n_qry = n_qry; sa.groups_per_batch = gpb; sa.g_begin = g0; sa.g_count = gc;
         sa.nx = nx; sa.box = box; sa.q_offset = q_offset; sa.X = X; sa.perm = perm;

@@ -13,6 +13,7 @@ struct HeadLayout {
     size_t wproj[3];   // fc_s column blocks of pyramid levels 0..2 as [8][C_l/16] fragment images
     size_t wproj16[3]; // the same blocks as f16 hi/lo fragment pairs (split-precision mode)
     size_t ws34;       // fc_s columns 896..991 (levels 3,4) as an [8][6] fragment image
+    size_t ws34_16;    // the same block as f16 hi/lo fragment pairs ([8][3] tiles of 32-deep k-steps)
     struct {
         size_t inw, inb, outw, outb, ln1g, ln1b;
         size_t w1, b1, w2, b2, ln2g, ln2b;   // w1: [128 tiles][8] image; w2: chunked [64][8][2] image
@@ -41,6 +42,7 @@ struct SampleArgs {
     int n_slices;        // T = n_slices + 1 tokens
     // head
     const float *fcp_w, *fcp_b, *fcs_b, *ws34;
+    const float* ws34_16;   // f16 hi|lo fragment image of the same block: selects the split-precision form of the K = 96 product (NULL: fp32)
     // queries
     const float* qry;    // (B,Q,3) or NULL in grid mode
     const float* rot;    // (B,3,3) or NULL

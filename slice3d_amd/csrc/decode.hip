@@ -87,9 +87,28 @@ __device__ __forceinline__ void layer_norm_row(f32x4 (&y)[8], const float* gamma
 //     levels 0-2: fc_s already folded into 128-channel maps -> pure weighted gather-accumulate
 //     levels 3-4: 96 raw channels sampled straight into MFMA B fragments, times Ws34 (LDS) on MFMA
 // ---------------------------------------------------------------------------------------------
+// F16 (split-precision modes): the K = 96 product with Ws34 runs on the f16x3 MFMA like every other GEMM of the path.  Cycle
+// stamps (round 4, tools/patches/sample_tokens_stamps.patch) showed the fp32 form — 192 dependent-chain v_mfma_f32_16x16x4
+// of 8 passes per (16 queries, slice) task, the matrix pipe's fp32 rate — taking 7 000 of a task's 20 000 cycles; 72 MFMAs
+// of the 32-deep f16 instruction take 1 200.  The fine levels are then read so that a lane owns 8 consecutive channels of
+// each 32-channel block (the k-slots 8g + t of the f16 fragment image, pack_frag f16 form).  The tap rows of the folded
+// levels are requested one round (two taps x 8 loads) AHEAD of their use: the kernel runs one wave per SIMD (its staging
+// arrays need the registers), so nothing else hides a round's L1 / L2 latency.
+template <bool F16>
 __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_ws34[8 * 6 * 256];  // 48 KiB
-    for (int i = threadIdx.x; i < 8 * 6 * 64; i += 256) st4(s_ws34 + 4 * i, ld4(a.ws34 + 4 * i));
+    __shared__ __attribute__((aligned(16))) float s_ws34[8 * 6 * 256];  // 48 KiB: fp32 [8][6] fragments or f16 hi|lo [8][3]
+    // fc_p (128 x 3) transposed + its bias: [x | y | z | b][128].  Read from global per use it was 128 stride-3 scalar loads
+    // per lane and made the point token the longest task of a group (34 000 cycles against 14 000 for a slice token): wave 0,
+    // which owns it, set the kernel's time
+    __shared__ __attribute__((aligned(16))) float s_fcp[4 * 128];
+    {
+        const float* wsrc = F16 ? a.ws34_16 : a.ws34;
+        for (int i = threadIdx.x; i < 8 * 6 * 64; i += 256) st4(s_ws34 + 4 * i, ld4(wsrc + 4 * i));
+        for (int i = threadIdx.x; i < 512; i += 256) {
+            const int c = i & 127, kx = i >> 7;
+            s_fcp[i] = kx < 3 ? a.fcp_w[c * 3 + kx] : a.fcp_b[c];
+        }
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -136,79 +155,105 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
             f32x4 acc[8];
             if (t == 0) {  // fc_p (models.py:79)
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 16 * j + 4 * g;
+                    const f32x4 wx = ld4(s_fcp + c), wy = ld4(s_fcp + 128 + c), wz = ld4(s_fcp + 256 + c), wb = ld4(s_fcp + 384 + c);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int c = 16 * j + 4 * g + i;
-                        acc[j][i] = a.fcp_w[c * 3 + 0] * x + a.fcp_w[c * 3 + 1] * y + a.fcp_w[c * 3 + 2] * z +
-                                    a.fcp_b[c];
-                    }
+                    for (int i = 0; i < 4; ++i) acc[j][i] = wx[i] * x + wy[i] * y + wz[i] * z + wb[i];   // same expression order as before
+                }
             } else {
                 const long img = (long)b * a.n_slices + (t - 1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = ld4(a.fcs_b + 16 * j + 4 * g);
-                // levels 0..2: projected maps (img, H, W, 128).  Loads are issued 16 at a time (two taps) into
-                // a staging array and only then consumed: left to itself the scheduler keeps ONE 16-byte
-                // load in flight per wave (load, s_waitcnt vmcnt(0), fma, ...), which made this gather 4x slower.
+                // levels 0..2: projected maps (img, H, W, 128): six rounds (level, tap pair) of 16 loads each, round r + 1 requested
+                // before round r is consumed.  (Loads are issued in whole rounds into staging arrays: left to itself the
+                // scheduler keeps ONE 16-byte load in flight per wave — load, s_waitcnt vmcnt(0), fma, ... — 4x slower.)
+                Tap4 tp3[3];
+                const float* base3[3];
 #pragma unroll
                 for (int l = 0; l < 3; ++l) {
                     const int W = S >> (4 - l);
-                    const Tap4 tp = make_taps(gx, gy, W, W);
-                    const float* base = a.proj[l] + img * (long)W * W * 128 + 4 * g;
+                    tp3[l] = make_taps(gx, gy, W, W);
+                    base3[l] = a.proj[l] + img * (long)W * W * 128 + 4 * g;
+                }
+                f32x4 v[2][2][8];
+                auto issue = [&](int r) {
+                    const int l = r >> 1, kp = r & 1;
 #pragma unroll
-                    for (int kp = 0; kp < 2; ++kp) {
-                        f32x4 v[2][8];
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const float* p = base3[l] + (long)tp3[l].off[2 * kp + k2] * 128;
 #pragma unroll
-                        for (int k2 = 0; k2 < 2; ++k2) {
-                            const float* p = base + (long)tp.off[2 * kp + k2] * 128;
+                        for (int j = 0; j < 8; ++j) v[r & 1][k2][j] = ld4(p + 16 * j);
+                    }
+                };
+                // levels 3,4 (raw 64 + 32 channels): requested before the last folded round is consumed
+                const Tap4 tpf = make_taps(gx, gy, S >> 1, S >> 1), tpq = make_taps(gx, gy, S, S);
+                f32x4 vf[4][4], v4[4][2];
+                issue(0);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) v[k2][j] = ld4(p + 16 * j);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);   // all 16 loads issued before the first use
+                for (int r = 0; r < 6; ++r) {
+                    if (r < 5) {
+                        issue(r + 1);
+                    } else {
+                        // F16: lane (m, g) owns channels 8g .. 8g+7 of every 32-channel block (two 16-byte loads); fp32 form:
+                        // channels 4g .. 4g+3 of every 16-channel block
+                        const float* bf = a.fine[0] + img * (long)(S >> 1) * (S >> 1) * 64 + (F16 ? 8 : 4) * g;
+                        const float* bq = a.fine[1] + img * (long)S * S * 32 + (F16 ? 8 : 4) * g;
 #pragma unroll
-                        for (int k2 = 0; k2 < 2; ++k2) {
-                            const float w = tp.w[2 * kp + k2];
+                        for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[j] += v[k2][j] * w;
+                            for (int u = 0; u < 4; ++u)
+                                vf[kk][u] = ld4(bf + (long)tpf.off[kk] * 64 + (F16 ? 32 * (u >> 1) + 4 * (u & 1) : 16 * u));
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) v4[kk][u] = ld4(bq + (long)tpq.off[kk] * 32 + (F16 ? 4 * u : 16 * u));
                         }
                     }
-                }
-                // levels 3,4: raw 64 + 32 channels -> B fragments of a K=96 GEMM with Ws34
-                f32x4 braw[6];
-                {
-                    const int W = S >> 1;
-                    const Tap4 tp = make_taps(gx, gy, W, W);
-                    const float* base = a.fine[0] + img * (long)W * W * 64 + 4 * g;
-                    f32x4 v[4][4];
+                    __builtin_amdgcn_sched_barrier(0);   // the next round's loads are out before this round's first use
+                    const int l = r >> 1, kp = r & 1;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const float w = tp3[l].w[2 * kp + k2];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) v[k][u] = ld4(base + (long)tp.off[k] * 64 + 16 * u);
-                    const int W4 = S;
-                    const Tap4 tq = make_taps(gx, gy, W4, W4);
-                    const float* base4 = a.fine[1] + img * (long)W4 * W4 * 32 + 4 * g;
-                    f32x4 v4[4][2];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) v4[k][u] = ld4(base4 + (long)tq.off[k] * 32 + 16 * u);
+                        for (int j = 0; j < 8; ++j) acc[j] += v[r & 1][k2][j] * w;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        braw[u] = v[0][u] * tp.w[0] + v[1][u] * tp.w[1] + v[2][u] * tp.w[2] + v[3][u] * tp.w[3];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        braw[4 + u] = v4[0][u] * tq.w[0] + v4[1][u] * tq.w[1] + v4[2][u] * tq.w[2] + v4[3][u] * tq.w[3];
                 }
+                // raw samples of levels 3, 4 -> B operand of the K = 96 product with Ws34
+                f32x4 braw[6];
 #pragma unroll
-                for (int u = 0; u < 6; ++u)
+                for (int u = 0; u < 4; ++u)
+                    braw[u] = vf[0][u] * tpf.w[0] + vf[1][u] * tpf.w[1] + vf[2][u] * tpf.w[2] + vf[3][u] * tpf.w[3];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        acc[j] = mfma4(ld4(s_ws34 + ((j * 6 + u) * 64 + lane) * 4), braw[u], acc[j]);
-                if (a.raw_out) {
-                    float* ro = a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 96 + 4 * g;
+                for (int u = 0; u < 2; ++u)
+                    braw[4 + u] = v4[0][u] * tpq.w[0] + v4[1][u] * tpq.w[1] + v4[2][u] * tpq.w[2] + v4[3][u] * tpq.w[3];
+                if (F16) {
+                    const _Float16* sw = reinterpret_cast<const _Float16*>(s_ws34);
 #pragma unroll
-                    for (int u = 0; u < 6; ++u) st4(ro + 16 * u, braw[u]);
+                    for (int kk = 0; kk < 3; ++kk) {   // k-slot 8g + t of step kk <-> raw channel 32 kk + 8g + t
+                        const float x8[8] = {braw[2 * kk][0], braw[2 * kk][1], braw[2 * kk][2], braw[2 * kk][3],
+                                             braw[2 * kk + 1][0], braw[2 * kk + 1][1], braw[2 * kk + 1][2], braw[2 * kk + 1][3]};
+                        s3d_half8 bh, bl;
+                        s3d_split8(x8, bh, bl);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const s3d_half8 fh = *reinterpret_cast<const s3d_half8*>(sw + (j * 3 + kk) * 1024 + lane * 8);
+                            const s3d_half8 fl = *reinterpret_cast<const s3d_half8*>(sw + (j * 3 + kk) * 1024 + 512 + lane * 8);
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bl, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, bh, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bh, acc[j], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            acc[j] = mfma4(ld4(s_ws34 + ((j * 6 + u) * 64 + lane) * 4), braw[u], acc[j]);
+                }
+                if (a.raw_out) {   // rows of 96 raw channels in channel order (braw[u]: see the load above for the lane's channels)
+                    float* ro = a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 96 + (F16 ? 8 : 4) * g;
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) st4(ro + (F16 ? 32 * (u >> 1) + 4 * (u & 1) : 16 * u), braw[u]);
                 }
             }
             // full 128-byte lines per query row (s3d_full_line_pair, common.h): tiles 2J, 2J + 1 of query m are exchanged
@@ -230,13 +275,29 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
     }
 }
 
+static int sampler_cu_count() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        n_cu = v;
+    }
+    return n_cu;
+}
 int launch_sample_tokens(const SampleArgs& a, hipStream_t stream) {
     S3D_CHECK_ARG(a.size % 16 == 0 && a.size >= 16, "sample: size %d", a.size);
     S3D_CHECK_ARG(a.n_slices >= 1 && a.n_slices + 1 <= S3D_N_TOKENS_MAX, "sample: n_slices %d", a.n_slices);
-    long blocks = a.g_count < 2048 ? a.g_count : 2048;
+    // one workgroup per CU (the kernel's registers allow no second one): with 2048 workgroups of 3 - 7 groups each the 48 KiB
+    // weight fill, the cold tap rows and the last, partly filled round cost 22 % (0.80 -> 0.62 ms per 100 k queries)
+    const long cap = sampler_cu_count();
+    long blocks = a.g_count < cap ? a.g_count : cap;
     if (blocks <= 0) return 0;
     if (blocks >= 8) blocks -= blocks % 8;
-    hipLaunchKernelGGL(sample_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    if (a.ws34_16)
+        hipLaunchKernelGGL(sample_tokens_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(sample_tokens_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1143,7 +1204,8 @@ __global__ __launch_bounds__(256) void sample_tokens_gt_kernel(const SampleGtArg
 int launch_sample_tokens_gt(const SampleGtArgs& a, hipStream_t stream) {
     S3D_CHECK_ARG(a.size % 16 == 0 && a.size >= 16, "sample_gt: size %d", a.size);
     S3D_CHECK_ARG(a.n_slices >= 1 && a.n_slices + 1 <= S3D_N_TOKENS_MAX, "sample_gt: n_slices %d", a.n_slices);
-    long blocks = a.g_count < 2048 ? a.g_count : 2048;
+    const long cap = sampler_cu_count();   // one workgroup per CU, as launch_sample_tokens
+    long blocks = a.g_count < cap ? a.g_count : cap;
     if (blocks <= 0) return 0;
     if (blocks >= 8) blocks -= blocks % 8;
     hipLaunchKernelGGL(sample_tokens_gt_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);

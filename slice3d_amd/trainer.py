@@ -285,7 +285,7 @@ class HipTrainer:
     # -- cross-rank BatchNorm statistics ----------------------------------------------------------------
     def _sync_bn_struct(self):
         """S3dSyncBn descriptor (include/slice3d_hip.h) whose callback all-reduces a slice of a device scratch buffer
-        with torch.distributed on the current stream — 63 small collectives per step (two per BatchNorm layer in the
+        with torch.distributed on the current stream — 60 small collectives per step (two per BatchNorm layer in the
         forward: means, then merged variances; one in the backward), issued from inside the library
         call between the kernel that produces the per-rank statistics and the one that consumes the global ones."""
         if not self.sync_bn or not self._exchange_on():
