@@ -80,6 +80,7 @@ struct SampleGtArgs {
     const float* proj[4];   // [0] = conv5_3 level (S/16) ... [3] = conv2_2 level (S/2); (n_img, W, W, 128)
     const float* fine;      // conv1_2 level (n_img, S, S, 64)
     const float* wraw;      // fragment image of fc_local[0].weight[:, 0:64]  [8 j][4 u][64 lanes][4]
+    const float* wraw16;    // the same block as f16 hi|lo fragment pairs ([8][2] tiles): split-precision form of the product (NULL: fp32)
     const float* bias;      // fc_local[0].bias
     int size, n_slices;
     const float *qry, *rot, *trans;

@@ -1107,9 +1107,15 @@ __device__ __forceinline__ void gt_query_xyz(const float* qry, const float* rot,
     }
 }
 
+// F16: the K = 64 product with the raw conv1_2 level on the f16x3 MFMA (see sample_tokens_kernel: the fp32 form is 128 dependent
+// 8-pass MFMAs per task); a lane then owns 8 consecutive channels of each 32-channel block
+template <bool F16>
 __global__ __launch_bounds__(256) void sample_tokens_gt_kernel(const SampleGtArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_w[8 * 4 * 256];  // 32 KiB: fc_local[0][:, :64] fragments
-    for (int i = threadIdx.x; i < 8 * 4 * 64; i += 256) st4(s_w + 4 * i, ld4(a.wraw + 4 * i));
+    __shared__ __attribute__((aligned(16))) float s_w[8 * 4 * 256];  // 32 KiB: fc_local[0][:, :64] fragments (fp32 [8][4] or f16 hi|lo [8][2])
+    {
+        const float* wsrc = F16 ? a.wraw16 : a.wraw;
+        for (int i = threadIdx.x; i < 8 * 4 * 64; i += 256) st4(s_w + 4 * i, ld4(wsrc + 4 * i));
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -1161,22 +1167,42 @@ __global__ __launch_bounds__(256) void sample_tokens_gt_kernel(const SampleGtArg
                 }
                 {
                     const Tap4 tp = make_taps(gx, gy, S, S);
-                    const float* base = a.fine + img * (long)S * S * 64 + 4 * g;
+                    const float* base = a.fine + img * (long)S * S * 64 + (F16 ? 8 : 4) * g;
                     f32x4 v[4][4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) v[k][u] = ld4(base + (long)tp.off[k] * 64 + 16 * u);
+                        for (int u = 0; u < 4; ++u)
+                            v[k][u] = ld4(base + (long)tp.off[k] * 64 + (F16 ? 32 * (u >> 1) + 4 * (u & 1) : 16 * u));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         braw[u] = v[0][u] * tp.w[0] + v[1][u] * tp.w[1] + v[2][u] * tp.w[2] + v[3][u] * tp.w[3];
                 }
+                if (F16) {
+                    const _Float16* sw = reinterpret_cast<const _Float16*>(s_w);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                    for (int kk = 0; kk < 2; ++kk) {   // k-slot 8g + t of step kk <-> raw channel 32 kk + 8g + t
+                        const float x8[8] = {braw[2 * kk][0], braw[2 * kk][1], braw[2 * kk][2], braw[2 * kk][3],
+                                             braw[2 * kk + 1][0], braw[2 * kk + 1][1], braw[2 * kk + 1][2], braw[2 * kk + 1][3]};
+                        s3d_half8 bh, bl;
+                        s3d_split8(x8, bh, bl);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        acc[j] = mfma4(ld4(s_w + ((j * 4 + u) * 64 + lane) * 4), braw[u], acc[j]);
+                        for (int j = 0; j < 8; ++j) {
+                            const s3d_half8 fh = *reinterpret_cast<const s3d_half8*>(sw + (j * 2 + kk) * 1024 + lane * 8);
+                            const s3d_half8 fl = *reinterpret_cast<const s3d_half8*>(sw + (j * 2 + kk) * 1024 + 512 + lane * 8);
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bl, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, bh, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bh, acc[j], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            acc[j] = mfma4(ld4(s_w + ((j * 4 + u) * 64 + lane) * 4), braw[u], acc[j]);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -1193,9 +1219,9 @@ __global__ __launch_bounds__(256) void sample_tokens_gt_kernel(const SampleGtArg
                 st4(o + 8 * 128 + 32 * J, vb);
             }
             if (a.raw_out) {
-                float* ro = a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 64 + 4 * g;
+                float* ro = a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 64 + (F16 ? 8 : 4) * g;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) st4(ro + 16 * u, braw[u]);
+                for (int u = 0; u < 4; ++u) st4(ro + (F16 ? 32 * (u >> 1) + 4 * (u & 1) : 16 * u), braw[u]);
             }
         }
     }
@@ -1208,7 +1234,10 @@ int launch_sample_tokens_gt(const SampleGtArgs& a, hipStream_t stream) {
     long blocks = a.g_count < cap ? a.g_count : cap;
     if (blocks <= 0) return 0;
     if (blocks >= 8) blocks -= blocks % 8;
-    hipLaunchKernelGGL(sample_tokens_gt_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    if (a.wraw16)
+        hipLaunchKernelGGL(sample_tokens_gt_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(sample_tokens_gt_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     S3D_LAUNCH_CHECK();
     return 0;
 }
