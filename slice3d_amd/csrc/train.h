@@ -149,6 +149,8 @@ struct SampleBwdArgs {
     float* dproj[3];         // zero-initialised by the caller; (n_img, H_l, W_l, 128)
     float* dfine[2];         // d pyramid levels 3, 4 (accumulated into)
     const float* ws34_t;     // fragment image of Ws34^T: [6][8] tiles (LINEAR_T pack of fc_s[:, 896:992])
+    const float* ws34_t16;   // the same matrix as f16 hi|lo fragment pairs ([6][4]): split-precision form of the product in the tiled
+                             // kernel (NULL: fp32)
     const float *qry, *rot, *trans;
     int flip_yz, size, n_slices;
     long n_qry, groups_per_batch, groups;

@@ -344,7 +344,10 @@ struct SbFold {
 // accumulators (5 / 12 tiles of 16 pixels) stay in registers for the whole tile and are flushed with one global atomic per
 // element.  That form cost 1 536 ds_add_f32 per (query, slice) row before — 3/4 of the kernel's 15.5 ms.  The RAW levels
 // (64 / 32 channels at S/2 and S: every query has its own pixels) keep the run-reduced LDS adds below.
-template <int GT>
+// F16 (split-precision training): the product with W_raw^T runs on the f16x3 MFMA (round 4: cycle stamps showed its fp32 form — 192
+// v_mfma_f32_16x16x4_f32 in chains of 32 dependent instructions per 16-query task, shared by the two waves of a SIMD — at 7 000 to
+// 23 000 of a task's ~50 000 cycles); a lane then reads 8 consecutive channels of each 32-channel block of its dX row.
+template <int GT, bool F16>
 __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const SampleBwdArgs a, const SbtGeom G) {
     using LV = SbLevels<GT>;
     using FD = SbFold<GT>;
@@ -360,7 +363,10 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
     const int* ends = a.bin_ends + (long)b * 65536;
     const long qs_lo = tile ? ends[256 * tile - 1] : 0, qs_hi = ends[256 * tile + 255];
     if (qs_lo >= qs_hi) return;
-    for (int i = threadIdx.x; i < NU * 8 * 64; i += SBT_THREADS) st4(s_wt + 4 * i, ld4(a.ws34_t + 4 * i));
+    {
+        const float* wsrc = F16 ? a.ws34_t16 : a.ws34_t;   // fp32 [NU][8] fragments or f16 hi|lo [NU][4] pairs: the same size
+        for (int i = threadIdx.x; i < NU * 8 * 64; i += SBT_THREADS) st4(s_wt + 4 * i, ld4(wsrc + 4 * i));
+    }
     for (int i = threadIdx.x; i < G.total / 4; i += SBT_THREADS) st4(s_acc + 4 * i, zero4());
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -406,17 +412,38 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
         const long qsc = qs < qs_lo ? qs_lo : (qs >= qs_hi ? qs_hi - 1 : qs);
         float gx, gy;
         project_slot(qsc, gx, gy);
-        const float* dp = a.dX + ((((long)b * a.groups_per_batch + gi) * T + t) * S3D_GROUP + m) * 128 + 4 * g;
+        const float* dp = a.dX + ((((long)b * a.groups_per_batch + gi) * T + t) * S3D_GROUP + m) * 128 + (F16 ? 8 : 4) * g;
         f32x4 dt[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dt[j] = qv ? ld4(dp + 16 * j) : zero4();
+        for (int j = 0; j < 8; ++j) dt[j] = qv ? ld4(dp + (F16 ? 32 * (j >> 1) + 4 * (j & 1) : 16 * j)) : zero4();
         f32x4 draw[NU];
+        if (F16) {
+            const _Float16* sw = reinterpret_cast<const _Float16*>(s_wt);
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            f32x4 c = zero4();
+            for (int u = 0; u < NU; ++u) draw[u] = zero4();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) c = mfma4(ld4(s_wt + ((u * 8 + j) * 64 + lane) * 4), dt[j], c);
-            draw[u] = c;
+            for (int kk = 0; kk < 4; ++kk) {   // k-slot 8g + t of step kk <-> token channel 32 kk + 8g + t
+                const float x8[8] = {dt[2 * kk][0], dt[2 * kk][1], dt[2 * kk][2], dt[2 * kk][3],
+                                     dt[2 * kk + 1][0], dt[2 * kk + 1][1], dt[2 * kk + 1][2], dt[2 * kk + 1][3]};
+                s3d_half8 bh, bl;
+                s3d_split8(x8, bh, bl);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const s3d_half8 fh = *reinterpret_cast<const s3d_half8*>(sw + (u * 4 + kk) * 1024 + lane * 8);
+                    const s3d_half8 fl = *reinterpret_cast<const s3d_half8*>(sw + (u * 4 + kk) * 1024 + 512 + lane * 8);
+                    draw[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bl, draw[u], 0, 0, 0);
+                    draw[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, bh, draw[u], 0, 0, 0);
+                    draw[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bh, draw[u], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                f32x4 c = zero4();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) c = mfma4(ld4(s_wt + ((u * 8 + j) * 64 + lane) * 4), dt[j], c);
+                draw[u] = c;
+            }
         }
 #pragma unroll
         for (int l = NF; l < 5; ++l) {
@@ -595,13 +622,19 @@ static int launch_sample_bwd_t(const SampleBwdArgs& a, hipStream_t stream) {
         if (fits && lds <= 160 * 1024) {
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)sample_bwd_tiled_kernel<GT>,
+                (void)hipFuncSetAttribute((const void*)sample_bwd_tiled_kernel<GT, false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)sample_bwd_tiled_kernel<GT, true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_set = true;
             }
             const long batch = a.groups / a.groups_per_batch;
-            hipLaunchKernelGGL(sample_bwd_tiled_kernel<GT>, dim3((unsigned)(batch * a.n_slices * 256)), dim3(SBT_THREADS), lds,
-                               stream, a, G);
+            if (a.ws34_t16)
+                hipLaunchKernelGGL((sample_bwd_tiled_kernel<GT, true>), dim3((unsigned)(batch * a.n_slices * 256)), dim3(SBT_THREADS),
+                                   lds, stream, a, G);
+            else
+                hipLaunchKernelGGL((sample_bwd_tiled_kernel<GT, false>), dim3((unsigned)(batch * a.n_slices * 256)), dim3(SBT_THREADS),
+                                   lds, stream, a, G);
             S3D_LAUNCH_CHECK();
             return 0;
         }
