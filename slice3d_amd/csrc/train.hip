@@ -203,34 +203,32 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
                 px[ps][t] = xp[row * xstride];
             }
     };
-    const float nf = n_ok ? 1.f : 0.f, cf = c_ok ? 1.f : 0.f;
     const long p_begin = (long)split * steps_per_split * 32;
     float csum = 0.f;   // this thread's rows of dY channel ch (bias gradient)
     gload(p_begin);
     for (int it = 0; it < steps_per_split; ++it) {
         const long pb = p_begin + (long)it * 32;
+        // hi / lo halves with the 1.5-VALU split (v_cvt_pk_f16_f32 + v_fma_mix: the same bits as convert - subtract - convert,
+        // which cost 3 per value here); the validity factor only matters in a step that reaches past the last row or for a
+        // padding channel — a uniform test
+        const bool tail_step = pb + 32 > P;
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            wl_half8 hi, lo;
+            float vd[8], vx[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const float v = pd[ps][t] * (pb + 16 * ps + 8 * rg + t < P ? nf : 0.f);
-                csum += v;
-                const _Float16 h = (_Float16)v;
-                hi[t] = h;
-                lo[t] = (_Float16)(v - (float)h);
+                const bool in = !tail_step || pb + 16 * ps + 8 * rg + t < P;
+                vd[t] = (in && n_ok) ? pd[ps][t] : 0.f;
+                vx[t] = (in && c_ok) ? px[ps][t] : 0.f;
+                csum += vd[t];
             }
-            *reinterpret_cast<wl_half8*>(&s_t[0][0][ch * WL_LD + 16 * ps + 8 * rg]) = hi;
-            *reinterpret_cast<wl_half8*>(&s_t[0][1][ch * WL_LD + 16 * ps + 8 * rg]) = lo;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float v = px[ps][t] * (pb + 16 * ps + 8 * rg + t < P ? cf : 0.f);
-                const _Float16 h = (_Float16)v;
-                hi[t] = h;
-                lo[t] = (_Float16)(v - (float)h);
-            }
-            *reinterpret_cast<wl_half8*>(&s_t[1][0][ch * WL_LD + 16 * ps + 8 * rg]) = hi;
-            *reinterpret_cast<wl_half8*>(&s_t[1][1][ch * WL_LD + 16 * ps + 8 * rg]) = lo;
+            s3d_half8 hi, lo;
+            s3d_split8(vd, hi, lo);
+            *reinterpret_cast<s3d_half8*>(&s_t[0][0][ch * WL_LD + 16 * ps + 8 * rg]) = hi;
+            *reinterpret_cast<s3d_half8*>(&s_t[0][1][ch * WL_LD + 16 * ps + 8 * rg]) = lo;
+            s3d_split8(vx, hi, lo);
+            *reinterpret_cast<s3d_half8*>(&s_t[1][0][ch * WL_LD + 16 * ps + 8 * rg]) = hi;
+            *reinterpret_cast<s3d_half8*>(&s_t[1][1][ch * WL_LD + 16 * ps + 8 * rg]) = lo;
         }
         __syncthreads();
         if (it + 1 < steps_per_split) gload(p_begin + (long)(it + 1) * 32);
