@@ -106,6 +106,18 @@ __device__ __forceinline__ void s3d_split4(const f32x4 a, s3d_half4& hi, s3d_hal
     hi = __builtin_bit_cast(s3d_half4, s3d_uint2{h0, h1});
     lo = __builtin_bit_cast(s3d_half4, s3d_uint2{l0, l1});
 }
+// v if bit `pos` of `bits` is set, else +0: the 1-bit signed field is the AND mask itself, 2 VALU (asm: hipcc rewrites the
+// builtin form into and + compare + select)
+__device__ __forceinline__ float s3d_gate_bit(float v, unsigned bits, int pos) {
+    unsigned mk;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mk) : "v"(bits), "v"(pos));
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & mk);
+}
+__device__ __forceinline__ float s3d_gate_bit_imm(float v, unsigned bits, int pos) {   // pos: a compile-time constant
+    unsigned mk;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mk) : "v"(bits), "n"(pos));
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & mk);
+}
 #define S3D_SPLIT_SETTLE()                          \
     __builtin_amdgcn_sched_barrier(0);              \
     asm volatile("s_nop 15" ::: "memory");          \

@@ -133,6 +133,18 @@ int launch_sample_planes(const float* plane, const float* grid, float* out, int 
 #define FWR_BLK_HALFS 8192   // one image of one 32-row block: hi 4096 halfs | lo 4096 halfs = 16 KiB
 __host__ __device__ inline int fwr_dperm(int q) { return (0x1320 >> (4 * ((q >> 2) & 3))) & 3; }   // {0,2,3,1}
 static inline size_t ffn_rec_image_floats(long P) { return (size_t)((P + 31) / 32) * 4096; }
+// Activity bits of the FFN hidden units (post-dropout h > 0), written by the training forward, read by the backward data
+// pass and both weight-gradient contractions.  One dword holds 32 units of one row: the four 32-unit chunks k = 0..3 of
+// group G (hidden units 128 G .. 128 G + 127), D tiles a = 0, 1, the lane quad g' — unit 128 G + 32 k + 16 a + 4 g' + i is
+// bit 4 k + a + FFN_MASK_POS(i): the forward takes the bits of a tile's four units from its two packed f16 pairs at once
+// (bits 0 / 16 of a pair, the second pair shifted by 2).  Dwords are laid out so that a wave's store of one (16-row tile,
+// group) is 256 contiguous bytes: [tile = row >> 4][G][g'][row & 15]  (per-row layouts left every 64-byte line open for the
+// whole kernel: 16 dword-sized writes, evicted half filled).
+#define FFN_MASK_POS(i) ((i) == 0 ? 0 : (i) == 1 ? 16 : (i) == 2 ? 2 : 18)
+__host__ __device__ inline size_t ffn_mask_dword(long row, int G, int gq) {
+    return ((size_t)(row >> 4) * 16 + G) * 64 + gq * 16 + (row & 15);
+}
+static inline size_t ffn_mask_dwords(long P) { return (size_t)((P + 31) / 32) * 32 * 64; }
 // imgd / imgr (optional, ffn_rec_image_floats(rows) floats each): D^T / R image of DY
 int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
                             const float* timg, float gate_scale, hipStream_t stream, float* imgd = nullptr,

@@ -49,7 +49,7 @@ __device__ __forceinline__ float quad_sum16(float v) {
 // ---------------------------------------------------------------------------------------------
 // Software-pipelined FFN.  MODE 0: layer (inference), 1: last layer + fc_out, 2 / 3: TRAINING forward with / without
 // dropout (activity bits of the hidden units for the backward, pre-LayerNorm output saved), 4: BACKWARD data path
-//     dA = (dY W2) * (bit ? gate_scale : 0),   dX = dA W1 + Dres
+//     dA = (dY W2) * bit,   dX = gate_scale * dA W1 + Dres
 // on the transposed weight image (W2^T chunks GEMM-1-shaped, W1^T chunks GEMM-2-shaped: launch_pack_ffn_f16x3_bwd), the
 // same loop with the gate in place of bias + ReLU and no LayerNorm.  128 rows per 4-wave workgroup, two workgroups per
 // CU, activations in registers as f16 hi/lo B fragments, W1/W2 stream through LDS in 32-hidden-unit chunks, the hidden
@@ -109,21 +109,23 @@ __device__ __forceinline__ void split4_pk(float a0, float a1, float a2, float a3
     h0 = __builtin_bit_cast(half2v, uh0); l0 = __builtin_bit_cast(half2v, ul0);
     h1 = __builtin_bit_cast(half2v, uh1); l1 = __builtin_bit_cast(half2v, ul1);
 }
+// relu as ONE v_max_f32: fmaxf on an MFMA result costs a canonicalising v_max first, and hipcc folds
+// __builtin_amdgcn_fmed3f(v, 0, inf) back into that pair (seen in the ISA: 8 v_max per D tile)
+__device__ __forceinline__ float relu1(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 // relu + split of the 4 pre-activations of one D tile: hi = f16(max(v,0)), lo = f16(max(v,0) - hi)
 __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h1, half2v& l0, half2v& l1) {
-    // relu as one v_med3_f32 (fmaxf on an MFMA result costs a canonicalising v_max first)
-    const float inf = __builtin_inff();
-    const float a0 = __builtin_amdgcn_fmed3f(v[0], 0.f, inf), a1 = __builtin_amdgcn_fmed3f(v[1], 0.f, inf),
-                a2 = __builtin_amdgcn_fmed3f(v[2], 0.f, inf), a3 = __builtin_amdgcn_fmed3f(v[3], 0.f, inf);
-    split4_pk(a0, a1, a2, a3, h0, h1, l0, l1);
+    split4_pk(relu1(v[0]), relu1(v[1]), relu1(v[2]), relu1(v[3]), h0, h1, l0, l1);
 }
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
 struct FfnTrainArgs {   // MODE 2
     float* Uout;     // pre-LayerNorm output u = x + dropout(FFN(x)), saved for the backward
     DropCfg dh, dq;  // hidden-unit / output dropout
-    unsigned* Mout;  // activity bits of the hidden units (post-dropout h > 0): dword [row][g][chunk>>2],
-                     // byte chunk&3, bit 4a+i  <->  hidden unit 32*chunk + 16a + 4g + i
+    unsigned* Mout;  // activity bits of the hidden units (post-dropout h > 0), layout: ffn_mask_dword / FFN_MASK_POS (decode.h)
     _Float16* ImgD;  // optional: D^T / R operand images of the INPUT rows for the weight-gradient kernel (decode.h)
     _Float16* ImgR;
 };
@@ -140,49 +142,56 @@ struct FfnActState {
     unsigned mw_next[PIPE_R];          // MODE 4: next group's dword (requested one group ahead)
     unsigned rm[PIPE_R];               // MODE 2: folded dropout counter of (row, hidden units 4g..4g+3) >> 2, see ffn_act4
     unsigned key;                      // MODE 2: stream key of the hidden-dropout site
+    unsigned h, h2;                    // MODE 2: the hash words of the NEXT D tile's four units (drawn one MFMA group ahead)
 };
+// MODE 2: hash words of D tile (a2, r2) of chunk c — the counter (row*2048 + unit) >> 2 = row*512 | (8c + 4a + g) never
+// carries into the row part: its fold is rm ^ (8c + 4a), one xor + add with the key instead of 64-bit adds and the high
+// word's multiply — the same hash value s3d_drop4 computes.  Data independent: drawn in the MFMA group BEFORE the one
+// that applies it (the odd groups of phase A carry no activation work), so the ~16 dependent VALU instructions (four of
+// them quarter-rate multiplies) do not queue up behind the tile's own 24.
+__device__ __forceinline__ void ffn_draw(FfnActState& as, int c, int a2, int r2) {
+    as.h = s3d_hash32_rounds((as.rm[r2] ^ (unsigned)(8 * c + 4 * a2)) + as.key);
+    as.h2 = s3d_drop_remix(as.h);
+    asm volatile("" : "+v"(as.h), "+v"(as.h2));   // stay in this scheduling region
+}
 // D tile (a2, r2) of chunk c: pre-activation -> f16 hi/lo halves of GEMM2's B operand
 template <int MODE>
 __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, half2v& l0, half2v& l1, FfnActState& as,
                                          const FfnTrainArgs& ta, const FfnBwdArgs& ba, int c, int a2, int r2) {
     if (MODE == 2 || MODE == 3) {
-        const float inf = __builtin_inff();
-        float a[4] = {__builtin_amdgcn_fmed3f(v[0], 0.f, inf), __builtin_amdgcn_fmed3f(v[1], 0.f, inf),
-                      __builtin_amdgcn_fmed3f(v[2], 0.f, inf), __builtin_amdgcn_fmed3f(v[3], 0.f, inf)};
+        float a[4] = {relu1(v[0]), relu1(v[1]), relu1(v[2]), relu1(v[3])};
         if (MODE == 2) {   // hidden-unit dropout (a template mode, not a run-time branch: the activation must stay in the
                            // MFMA group's basic block to be interleaved with it).  This mode is VALU-issue bound (the
                            // 192 MFMAs of two chunks leave 576 issue slots, 32-bit multiplies take four), so:
-                           //  * the counter (row*2048 + unit) >> 2 = row*512 | (8c + 4a + g) never carries into the row
-                           //    part: its fold is rm ^ (8c + 4a), one v_xad_u32 with the key instead of 64-bit adds and
-                           //    the high word's multiply — the same hash value s3d_drop4 computes;
+                           //  * the hash words were drawn one group ahead (ffn_draw);
                            //  * a kept unit keeps its value here, the factor 1/(1-p) multiplies the finished sums in
                            //    the epilogue (GEMM2 is linear in h);
-            const unsigned h = s3d_hash32_rounds((as.rm[r2] ^ (unsigned)(8 * c + 4 * a2)) + as.key), h2 = s3d_drop_remix(h);
+            const unsigned h = as.h, h2 = as.h2;
             a[0] = (h & 0xFFFFu) >= ta.dh.thresh ? a[0] : 0.f;
             a[1] = (h >> 16) >= ta.dh.thresh ? a[1] : 0.f;
             a[2] = (h2 & 0xFFFFu) >= ta.dh.thresh ? a[2] : 0.f;
             a[3] = (h2 >> 16) >= ta.dh.thresh ? a[3] : 0.f;
         }
-        // activity bits of the four a >= 0: min(bits(a), 1) each, gathered into a nibble and deposited with one shift-or
-        // (asm: hipcc turns the min into a float class test + select + shift)
-        {
-            unsigned b0, b1, b2, b3;
-            asm("v_min_u32 %0, 1, %1" : "=v"(b0) : "v"(a[0]));
-            asm("v_min_u32 %0, 1, %1" : "=v"(b1) : "v"(a[1]));
-            asm("v_min_u32 %0, 1, %1" : "=v"(b2) : "v"(a[2]));
-            asm("v_min_u32 %0, 1, %1" : "=v"(b3) : "v"(a[3]));
-            asm("v_lshl_or_b32 %0, %1, 1, %0" : "+v"(b0) : "v"(b1));
-            asm("v_lshl_or_b32 %0, %1, 1, %0" : "+v"(b2) : "v"(b3));
-            asm("v_lshl_or_b32 %0, %1, 2, %0" : "+v"(b0) : "v"(b2));
-            const unsigned sh = (unsigned)(8 * (c & 3) + 4 * a2);
-            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(as.mw[r2]) : "v"(b0), "s"(sh));
-        }
         split4_pk(a[0], a[1], a[2], a[3], h0, h1, l0, l1);
+        // activity bits from the packed hi halves (a >= 0: the f16 pattern is 0 or >= 1 as an integer; a value so small
+        // that its hi half is 0 has lo = 0 too and contributes nothing to the forward): min(u16, 1) of both halves at
+        // once, the two pairs merged and deposited with one shift-or each — 4 VALU per tile (FFN_MASK_POS, decode.h)
+        {
+            unsigned p0, p1;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(p0) : "v"(__builtin_bit_cast(unsigned, h0)), "s"(0x00010001u));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(p1) : "v"(__builtin_bit_cast(unsigned, h1)), "s"(0x00010001u));
+            asm("v_lshl_or_b32 %0, %1, 2, %0" : "+v"(p0) : "v"(p1));
+            const unsigned sh = (unsigned)(4 * (c & 3) + a2);
+            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(as.mw[r2]) : "v"(p0), "s"(sh));
+        }
     } else if (MODE == 4) {
-        const unsigned bits = as.mw[r2] >> (8 * (c & 3) + 4 * a2);
+        // gate = the unit's activity bit: a 1-bit signed field is the AND mask itself (2 VALU per value); a kept unit's
+        // dropout factor multiplies the finished sums in the epilogue (GEMM2 is linear in dA)
+        const unsigned bits = as.mw[r2] >> (4 * (c & 3) + a2);
         float a[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = ((bits >> i) & 1u) ? v[i] * ba.gate_scale : 0.f;
+        for (int i = 0; i < 4; ++i)
+            a[i] = s3d_gate_bit_imm(v[i], bits, FFN_MASK_POS(i));
         split4_pk(a[0], a[1], a[2], a[3], h0, h1, l0, l1);
     } else {
         relu_split4(v, h0, h1, l0, l1);
@@ -243,6 +252,10 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
             /* first USED (phase B), outside the MFMA cover */                                                       \
             asm volatile("" : "+v"(hl2[r2][2 * a2]), "+v"(hl2[r2][2 * a2 + 1]), "+v"(hh2[r2][2 * a2]),               \
                          "+v"(hh2[r2][2 * a2 + 1]));                                                                 \
+        } else if (MODE == 2) {          /* the next tile's dropout words (tile 0 of chunk c + 1 after the last) */   \
+            static_assert(PIPE_R == 2, "one activation tile every second group");                                    \
+            constexpr int nt = (((K) + 1) / 2) & 3;                                                                   \
+            ffn_draw(as, (K) == 7 ? c + 1 : c, nt / PIPE_R, nt % PIPE_R);                                             \
         }                                                                                                            \
         if (!LAST) {                                                                                                 \
             _Pragma("unroll") for (int i = 0; i < (SINGLE ? 1 : 3) * PIPE_R; ++i) {                                  \
@@ -360,11 +373,13 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
             as.rm[r] = s3d_hash32_fold((unsigned long long)(row0 + r * 16 + m) * (S3D_FFN / 4)) ^ (unsigned)g;
             as.key = s3d_stream_key(ta.dh.seed, ta.dh.site);
         }
+        as.h = as.h2 = 0u;
         if (MODE == 4) {   // activity bits: one dword per 4 chunks, the next group's requested one group ahead
-            as.mw[r] = ba.M[row * 64 + g * 16];
-            as.mw_next[r] = ba.M[row * 64 + g * 16 + 1];
+            as.mw[r] = ba.M[ffn_mask_dword(row, 0, g)];
+            as.mw_next[r] = ba.M[ffn_mask_dword(row, 1, g)];
         }
     }
+    if (MODE == 2) ffn_draw(as, 0, 0, 0);
     dma_publish_barrier();
     const float* sb = s_b1 + 4 * g;     // this lane's bias quad of D tile 0 of chunk 0; tile 1 at +16, chunk c at +32c
     const unsigned lw0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_w0 + lane * 8);
@@ -402,7 +417,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
 #pragma unroll
             for (int r = 0; r < PIPE_R; ++r) {
                 const long row = row0 + r * 16 + m;
-                if (row < rows) ta.Mout[row * 64 + g * 16 + (c >> 2)] = as.mw[r];
+                if (row < rows) ta.Mout[ffn_mask_dword(row, c >> 2, g)] = as.mw[r];   // 256 contiguous bytes per (tile, group)
                 as.mw[r] = 0u;
             }
         }
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
                 if (row >= rows) row = rows - 1;
                 const int nxt = (c >> 2) + 2;
                 as.mw[r] = as.mw_next[r];
-                as.mw_next[r] = ba.M[row * 64 + g * 16 + (nxt < NC / 4 ? nxt : NC / 4 - 1)];
+                as.mw_next[r] = ba.M[ffn_mask_dword(row, nxt < NC / 4 ? nxt : NC / 4 - 1, g)];
             }
         }
     };
@@ -520,8 +535,8 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
 #pragma unroll
             for (int J = 0; J < 4; ++J) {
                 const int col = 32 * J + 8 * ge;
-                store_pair(Yout, r, J, acc[r][2 * J] + ld4(ba.Dres + row * 128 + col),
-                           acc[r][2 * J + 1] + ld4(ba.Dres + row * 128 + col + 4));
+                store_pair(Yout, r, J, acc[r][2 * J] * ba.gate_scale + ld4(ba.Dres + row * 128 + col),
+                           acc[r][2 * J + 1] * ba.gate_scale + ld4(ba.Dres + row * 128 + col + 4));
             }
         }
         return;
@@ -642,8 +657,8 @@ int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, uns
 // ---------------------------------------------------------------------------------------------
 // FFN backward, data path (MODE 4 of the pipelined kernel):  given dY (gradient w.r.t. the lin2 output) and the
 // activity bits M of the hidden units (forward kernel, FfnTrainArgs::Mout),
-//   dA = (dY W2) * (bit ? gate_scale : 0)        [rows][2048], registers only
-//   dX = dA W1 + Dres                             [rows][128]
+//   dA = (dY W2) * bit                           [rows][2048], registers only
+//   dX = gate_scale * dA W1 + Dres                            [rows][128]
 // dY rows live in registers as f16 hi/lo B fragments, the transposed weights (W2^T chunk as GEMM-1-shaped fragments,
 // W1^T chunk as GEMM-2-shaped fragments; packed by pack_ffn_f16x3_kernel with swapped strides) stream through LDS.
 // ---------------------------------------------------------------------------------------------

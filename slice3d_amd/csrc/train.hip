@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
 #pragma unroll
         for (int e = 0; e < 2; ++e) acc[i][e] = zero4();
     float csum[2] = {0.f, 0.f};
-    const unsigned bitsel0 = 1u << (8 * wave + (m & 3));
+    const int bitpos0 = 4 * wave + FFN_MASK_POS(m & 3);   // + e: the D tile (decode.h)
 
     // lane byte addresses inside buffer 0: A fragment of q tile 0 (tile i at +1024 i, lo half at +8192), R fragment of K
     // step u, row tile 0 (row tile 1 at +4096, lo half at +8192; the R image follows the D^T image)
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
 
     // the step's mask dwords: thread (g' = tid >> 5, row = tid & 31) of the first 128 threads; rows past the end carry 0
     const unsigned* mbase = a.mask + blk0 * 32 * 64;                                           // uniform
-    const unsigned moff = (unsigned)((tid & 31) * 64 + ((tid >> 5) & 3) * 16 + hb);             // lane offset
+    const unsigned moff = (unsigned)ffn_mask_dword(tid & 31, hb, (tid >> 5) & 3);               // lane offset (layout: decode.h)
     const int rows_left = (int)(P - blk0 * 32 < (long)steps_per_split * 32 ? P - blk0 * 32 : (long)steps_per_split * 32);
     auto mask_of = [&](int step) -> unsigned {
         return step * 32 + (tid & 31) < rows_left ? (mbase + (size_t)step * 32 * 64)[moff] : 0u;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // activity bit, split: hidden unit (block-local) 32*wave + 16e + m -> mask byte `wave`, bit 4e + (m & 3) of dword
+        // activity bit, split: hidden unit (block-local) 32*wave + 16e + m -> bit 4*wave + e + FFN_MASK_POS(m & 3) of dword
         // g' = m >> 2 of the row; this lane's rows are 4g..4g+3 (tile 0) and 16+4g.. (tile 1)
         wl_half8 zh[2], zl[2];
         {
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
                 float v[8];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    v[t] = (mw[t] & (bitsel0 << (4 * e))) ? z[t >> 2][e][t & 3] : 0.f;
+                    v[t] = s3d_gate_bit(z[t >> 2][e][t & 3], mw[t], bitpos0 + e);
                     if (COLSUM) csum[e] += v[t];
                 }
                 s3d_split8(v, zh[e], zl[e]);
