@@ -95,7 +95,8 @@ int launch_tanh_bwd(const float* y_nchw, const float* dy_nchw, float* dz_nhwc, i
 // L1 loss: loss_acc[0] += scale*sum|a-b|; grad[i] (+)= scale*sign(a-b)
 // grad_mul: extra factor on the gradient only (the backward scale of the split-precision training path)
 int launch_l1_fwd_bwd(const float* a, const float* b, long n, float scale, float* grad, int accumulate_grad,
-                      float* partial, float* loss_acc, hipStream_t stream, float grad_mul = 1.f);
+                      float* partial, float* loss_acc, hipStream_t stream, float grad_mul = 1.f, int relu_mask = 0);
+#define S3D_L1_PARTIAL_FLOATS 2048   /* `partial` holds one float per block */
 // in-place multiply of up to S3D_SCALE_TABLE_MAX tensors by one factor (one launch)
 #define S3D_SCALE_TABLE_MAX 224
 struct ScaleTable {
@@ -112,7 +113,8 @@ struct ScaleTable {
 };
 int launch_scale_table(const ScaleTable& t, float s, hipStream_t stream);
 int launch_relu_mask_bwd(const float* y, float* dy, long n, hipStream_t stream);              // dy *= (y > 0)
-int launch_pool_bwd(const float* y, const float* dyp, float* dy, int n, int h, int w, int c, hipStream_t stream);
+int launch_pool_bwd(const float* y, const float* dyp, float* dy, int n, int h, int w, int c, hipStream_t stream,
+                    int relu_mask = 0);   // relu_mask: dy *= (y > 0) on the way out
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                 float bc1, float bc2, hipStream_t stream);
 // one launch for up to S3D_ADAM_TABLE_MAX tensors: parameter i is updated from g / m / v [off[i], off[i] + n[i])

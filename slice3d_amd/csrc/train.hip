@@ -92,50 +92,65 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, int n_cbl
             }
 }
 
+// Reduction of the split partials into the parameter gradient.  A workgroup owns 64 consecutive elements; its four waves
+// sum the splits sg, sg + 4, ... (eight loads in flight each) and meet in LDS in a fixed order — deterministic.  One thread
+// per element walking all splits left the in_proj gradient (49 152 elements x 342 splits = 67 MB) to 192 workgroups:
+// 360 us, latency-bound; ffn_wgrad_rec's reduction moves the same bytes in 12 us.
 template <bool BIAS>   // BIAS: the split-precision linear kernel left nsplit x N bias partials behind the weight partials
-__global__ void wgrad_reduce_kernel(const WgradArgs a, int nsplit, int Ktot) {
-    const long total = (long)a.N * Ktot;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total + (BIAS ? a.N : 0);
-         idx += (long)gridDim.x * blockDim.x) {
-        if (BIAS && idx >= total) {
-            const float* bp = a.partial + (size_t)nsplit * total + (idx - total);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int sp = 0;
-            for (; sp + 4 <= nsplit; sp += 4) {
-                s0 += bp[(size_t)sp * a.N];
-                s1 += bp[(size_t)(sp + 1) * a.N];
-                s2 += bp[(size_t)(sp + 2) * a.N];
-                s3 += bp[(size_t)(sp + 3) * a.N];
-            }
-            for (; sp < nsplit; ++sp) s0 += bp[(size_t)sp * a.N];
-            const float s = (s0 + s1) + (s2 + s3);
-            float* o = a.bias_out + (idx - total);
-            *o = a.accumulate ? *o + s : s;
-            continue;
-        }
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nsplit, int Ktot) {
+    __shared__ float s_p[3][64];
+    const long total = (long)a.N * Ktot, all = total + (BIAS ? a.N : 0);
+    const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    for (long base = (long)blockIdx.x * 64; base < all; base += (long)gridDim.x * 64) {
+        const long idx = base + e;
+        const bool live = idx < all;
+        const bool is_bias = BIAS && idx >= total;
+        // element `idx` of split sp: weight partials [sp][total], bias partials [sp][N] behind them
+        const float* src = is_bias ? a.partial + (size_t)nsplit * total + (idx - total) : a.partial + (live ? idx : 0);
+        const size_t stride = is_bias ? (size_t)a.N : (size_t)total;
         float s = 0.f;
-        int sp = 0;
-        for (; sp + 8 <= nsplit; sp += 8) {
-            float v[8];
+        if (live) {
+            int sp = sg;
+            for (; sp + 28 < nsplit; sp += 32) {
+                float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = a.partial[(size_t)(sp + k) * total + idx];
-            __builtin_amdgcn_sched_barrier(0);   // 8 loads in flight
-            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(sp + 4 * k) * stride];
+                __builtin_amdgcn_sched_barrier(0);   // 8 loads in flight
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; sp + 12 < nsplit; sp += 16) {
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = src[(size_t)(sp + 4 * k) * stride];
+                __builtin_amdgcn_sched_barrier(0);
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            for (; sp < nsplit; sp += 4) s += src[(size_t)sp * stride];
         }
-        for (; sp < nsplit; ++sp) s += a.partial[(size_t)sp * total + idx];
-        const int n = (int)(idx / Ktot), k = (int)(idx - (long)n * Ktot);
-        long o;
-        if (a.out_kind == S3D_PACK_LINEAR) {
-            o = (long)n * a.ld + k;
-        } else if (a.out_kind == S3D_PACK_CONV) {
-            const int tap = k / a.Cx, c = k - tap * a.Cx;
-            if (a.cin_begin + c >= a.cin_tot) continue;  // padded input channels (3 -> 16)
-            o = ((long)n * a.cin_tot + a.cin_begin + c) * (a.ks * a.ks) + tap;
-        } else {  // CONVT: n = ci, k = q*ct + co
-            const int q = k / a.ct, co = k - q * a.ct;
-            o = ((long)n * a.ct + co) * 4 + q;
+        if (sg) s_p[sg - 1][e] = s;
+        __syncthreads();
+        if (sg == 0 && live) {
+            s = (s + s_p[0][e]) + (s_p[1][e] + s_p[2][e]);
+            if (is_bias) {
+                float* o = a.bias_out + (idx - total);
+                *o = a.accumulate ? *o + s : s;
+            } else {
+                const int n = (int)(idx / Ktot), k = (int)(idx - (long)n * Ktot);
+                long o = -1;
+                if (a.out_kind == S3D_PACK_LINEAR) {
+                    o = (long)n * a.ld + k;
+                } else if (a.out_kind == S3D_PACK_CONV) {
+                    const int tap = k / a.Cx, c = k - tap * a.Cx;
+                    if (a.cin_begin + c < a.cin_tot)   // (else: padded input channels, 3 -> 16)
+                        o = ((long)n * a.cin_tot + a.cin_begin + c) * (a.ks * a.ks) + tap;
+                } else {  // CONVT: n = ci, k = q*ct + co
+                    const int q = k / a.ct, co = k - q * a.ct;
+                    o = ((long)n * a.ct + co) * 4 + q;
+                }
+                if (o >= 0) a.out[o] = a.accumulate ? a.out[o] + s : s;
+            }
         }
-        a.out[o] = a.accumulate ? a.out[o] + s : s;
+        __syncthreads();
     }
 }
 
@@ -823,7 +838,7 @@ static int launch_wgrad_conv3_f16x3(const WgradArgs& a, hipStream_t stream) {
                            Ktot);
     S3D_LAUNCH_CHECK();
     const long total = (long)a.N * Ktot;
-    const int rb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const int rb = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
     hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(rb), dim3(256), 0, stream, a, (int)splits, Ktot);
     S3D_LAUNCH_CHECK();
     return 0;
@@ -852,8 +867,8 @@ static int launch_wgrad_lin_f16x3(const WgradArgs& a, long P, hipStream_t stream
     hipLaunchKernelGGL(wgrad_lin_f16x3_kernel, dim3((unsigned)(n_nblk * n_cblk), (unsigned)splits), dim3(256), 0, stream,
                        a, n_cblk, P, spw);
     S3D_LAUNCH_CHECK();
-    const long total = (long)a.N * a.Cx;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const long total = (long)a.N * a.Cx + (a.bias_out ? a.N : 0);
+    const int blocks = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
     if (a.bias_out)
         hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream, a, (int)splits, a.Cx);
     else
@@ -916,7 +931,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
 #undef WG_CASE
     S3D_LAUNCH_CHECK();
     const long total = (long)a.N * Ktot;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const int blocks = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
     hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream, a, sy * 4, Ktot);
     S3D_LAUNCH_CHECK();
     return 0;
@@ -1643,18 +1658,41 @@ int launch_tanh_bwd(const float* y, const float* dy, float* dz, int n, int c, in
     return 0;
 }
 
-#define L1B 1024
+#define L1B S3D_L1_PARTIAL_FLOATS
+// sum |a - b| (per-block partials) and, optionally, its gradient scale * sign(a - b) written to / added into grad.
+// relu_mask: grad is the gradient w.r.t. a ReLU output `a` and what leaves is the gradient w.r.t. the ReLU's input —
+// the finished element (the accumulated value included) is zeroed where a <= 0 (the VGG loss taps: saves the separate
+// mask pass over the tensor).  Four elements per thread and step when n and the pointers allow 16-byte accesses.
+template <bool VEC>
 __global__ __launch_bounds__(256) void l1_fb_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
-                                                    float scale, float* __restrict__ grad, int acc_grad,
+                                                    float scale, float* __restrict__ grad, int acc_grad, int relu_mask,
                                                     float* __restrict__ partial) {   // scale: of the gradient
     __shared__ float red[4];
     float s = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const float d = a[i] - b[i];
-        s += fabsf(d);
-        if (grad) {
+    constexpr int V = VEC ? 4 : 1;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (long)gridDim.x * 256 * V) {
+        float av[4], bv[4], gv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (VEC) {
+            const f32x4 a4 = ld4(a + i), b4 = ld4(b + i);
+            f32x4 g4 = zero4();
+            if (grad && acc_grad) g4 = ld4(grad + i);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { av[t] = a4[t]; bv[t] = b4[t]; gv[t] = g4[t]; }
+        } else {
+            av[0] = a[i]; bv[0] = b[i];
+            if (grad && acc_grad) gv[0] = grad[i];
+        }
+#pragma unroll
+        for (int t = 0; t < V; ++t) {
+            const float d = av[t] - bv[t];
+            s += fabsf(d);
             const float gsign = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
-            grad[i] = acc_grad ? grad[i] + gsign : gsign;
+            gv[t] += gsign;
+            if (relu_mask && !(av[t] > 0.f)) gv[t] = 0.f;
+        }
+        if (grad) {
+            if (VEC) st4(grad + i, f32x4{gv[0], gv[1], gv[2], gv[3]});
+            else grad[i] = gv[0];
         }
     }
 #pragma unroll
@@ -1675,11 +1713,17 @@ __global__ __launch_bounds__(256) void scalar_final_kernel(const float* __restri
     if (threadIdx.x == 0) acc[0] += scale * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 int launch_l1_fwd_bwd(const float* a, const float* b, long n, float scale, float* grad, int accumulate_grad,
-                      float* partial, float* loss_acc, hipStream_t stream, float grad_mul) {
+                      float* partial, float* loss_acc, hipStream_t stream, float grad_mul, int relu_mask) {
     if (n <= 0) return 0;
-    const int blocks = (int)((n + 255) / 256 < L1B ? (n + 255) / 256 : L1B);
-    hipLaunchKernelGGL(l1_fb_kernel, dim3(blocks), dim3(256), 0, stream, a, b, n, scale * grad_mul, grad,
-                       accumulate_grad, partial);
+    const bool vec = n % 4 == 0 && (((size_t)a | (size_t)b | (size_t)grad) & 15) == 0;
+    const long work = vec ? n / 4 : n;
+    const int blocks = (int)((work + 255) / 256 < L1B ? (work + 255) / 256 : L1B);
+    if (vec)
+        hipLaunchKernelGGL(l1_fb_kernel<true>, dim3(blocks), dim3(256), 0, stream, a, b, n, scale * grad_mul, grad,
+                           accumulate_grad, relu_mask, partial);
+    else
+        hipLaunchKernelGGL(l1_fb_kernel<false>, dim3(blocks), dim3(256), 0, stream, a, b, n, scale * grad_mul, grad,
+                           accumulate_grad, relu_mask, partial);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, scale, loss_acc);
     S3D_LAUNCH_CHECK();
@@ -1709,9 +1753,10 @@ int launch_relu_mask_bwd(const float* y, float* dy, long n, hipStream_t stream) 
     return 0;
 }
 
-// max-pool 2x2 backward: y (N,H,W,C) pre-pool, dyp (N,H/2,W/2,C) -> dy (N,H,W,C), first maximum wins
+// max-pool 2x2 backward: y (N,H,W,C) pre-pool, dyp (N,H/2,W/2,C) -> dy (N,H,W,C), first maximum wins; relu_mask: y is a ReLU
+// output and dy leaves as the gradient w.r.t. the ReLU's input (zero where y <= 0)
 __global__ void pool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dyp, float* __restrict__ dy,
-                                int n, int h, int w, int c) {
+                                int n, int h, int w, int c, int relu_mask) {
     const int c4 = c >> 2, ho = h >> 1, wo = w >> 1;
     const long total = (long)n * ho * wo * c4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1739,14 +1784,15 @@ __global__ void pool_bwd_kernel(const float* __restrict__ y, const float* __rest
         for (int t = 0; t < 4; ++t) {
             f32x4 o;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = arg[i] == t ? d[i] : 0.f;
+            for (int i = 0; i < 4; ++i) o[i] = (arg[i] == t && !(relu_mask && !(v[t][i] > 0.f))) ? d[i] : 0.f;
             st4(dy + ((long)(ni * h + 2 * yy + (t >> 1)) * w + 2 * x + (t & 1)) * c + cc, o);
         }
     }
 }
-int launch_pool_bwd(const float* y, const float* dyp, float* dy, int n, int h, int w, int c, hipStream_t stream) {
+int launch_pool_bwd(const float* y, const float* dyp, float* dy, int n, int h, int w, int c, hipStream_t stream,
+                    int relu_mask) {
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_blocks((long)n * (h / 2) * (w / 2) * (c / 4))), dim3(256), 0, stream, y,
-                       dyp, dy, n, h, w, c);
+                       dyp, dy, n, h, w, c, relu_mask);
     S3D_LAUNCH_CHECK();
     return 0;
 }
