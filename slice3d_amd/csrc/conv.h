@@ -108,5 +108,8 @@ int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w,
 // VGG-loss helpers (conv.hip)
 int launch_vgg_prep(const float* pred, const float* target, const float* mean, const float* stdv, float* out,
                     int n_img, int size, hipStream_t stream);   // -> (2*n_img, S, S, 16) NHWC, normalised
+// conv1_1 + ReLU straight from the NCHW image pairs, split precision (replaces vgg_prep + the first conv): out (2*n_img, S, S, 64)
+int launch_vgg_first_f16x3(const float* pred, const float* target, const float* mean, const float* stdv, const float* w_oihw,
+                           const float* bias, float* out, int n_img, int size, hipStream_t stream);
 int launch_l1_diff(const float* a, const float* b, long n, float scale, float* partial, float* loss_acc,
                    hipStream_t stream);                         // loss_acc[0] += scale * sum|a-b| (deterministic)

@@ -1300,6 +1300,105 @@ __global__ void vgg_prep_kernel(const float* __restrict__ pred, const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// VGG conv1_1 (3 -> 64, 3x3) straight from the NCHW image pairs, split precision.  K = 3 channels x 9 taps = 27 fits ONE
+// k-step of v_mfma_f32_16x16x32_f16: lane (pixel m, g) gathers its eight (channel, tap) values of the pixel's
+// neighbourhood (k = 9 ci + 3 dy + dx = 8g + t; the image is L1 / L2 resident, each value is read by nine neighbours),
+// normalises them exactly as vgg_prep_kernel does (zero outside the image: the padding applies to the NORMALISED image)
+// and splits them; the 64 x 27 weights sit in registers as four hi / lo fragments.  12 MFMAs per 16 pixels; the kernel is
+// bound by its 64-channel output (conv_epilogue's full-line stores).  Replaces vgg_prep + the generic tile on the
+// 16-channel-padded image, which ran on the fp32 MFMA (C_in 16 is no multiple of the split path's 32): 1.85 ms of the
+// training step for 96 images.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vgg_first_f16x3_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                              const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                              const float* __restrict__ w, const ConvLaunch a, int n_img) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int S = a.H;
+    const long hw = (long)S * S;
+    chalf8 wh[4], wl[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = 8 * g + t < 27 ? w[(16 * nt + m) * 27 + 8 * g + t] : 0.f;   // OIHW: k = 9 ci + tap
+        s3d_split8(v, wh[nt], wl[nt]);
+    }
+    int koff[8], kdy[8], kdx[8];
+    float kmu[8], ksd[8];
+    bool kok[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int k = 8 * g + t, kc = k < 27 ? k : 0;
+        const int ci = kc / 9, r = kc - 9 * ci, dy = r / 3, dx = r - 3 * dy;
+        kok[t] = k < 27;
+        kdy[t] = dy - 1;
+        kdx[t] = dx - 1 + m;
+        koff[t] = ci * (int)hw;
+        kmu[t] = mean[ci];
+        ksd[t] = stdv[ci];
+    }
+    const int tiles_x = S >> 4;
+    const long n_tiles = (long)a.N * S * tiles_x;
+    // the NEXT tile's eight raw values are requested before this tile is worked on (a tile is a serial chain of a gather, a
+    // normalisation, 12 MFMAs and the stores: unpipelined the kernel ran at the latency of that chain, 1.0 ms for 96 images)
+    float raw[8];
+    unsigned okm = 0u;
+    auto gather = [&](long tile) {
+        const int tx = (int)(tile % tiles_x);
+        const long r = tile / tiles_x;
+        const int y = (int)(r % S), ni = (int)(r / S);
+        const float* src = ni < n_img ? pred + (long)ni * 3 * hw : target + (long)(ni - n_img) * 3 * hw;
+        okm = 0u;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int yy = y + kdy[t], xx = 16 * tx + kdx[t];
+            const bool ok = kok[t] && (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S;
+            okm |= ok ? 1u << t : 0u;
+            raw[t] = src[koff[t] + (ok ? yy * S + xx : 0)];
+        }
+    };
+    const long stride = (long)gridDim.x * 4;
+    long tile = (long)blockIdx.x * 4 + wave;
+    if (tile < n_tiles) gather(tile);
+    for (; tile < n_tiles; tile += stride) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = ((okm >> t) & 1u) ? ((raw[t] + 1.f) / 2.f - kmu[t]) / ksd[t] : 0.f;
+        if (tile + stride < n_tiles) gather(tile + stride);
+        chalf8 bh, bl;
+        s3d_split8(v, bh, bl);
+        S3D_SPLIT_SETTLE();   // partial-register split results feed the MFMAs below straight from registers
+        f32x4 acc[1][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bl, zero4(), 0, 0, 0);
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], bh, acc[0][nt], 0, 0, 0);
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bh, acc[0][nt], 0, 0, 0);
+        }
+        const int tx = (int)(tile % tiles_x);
+        const long r = tile / tiles_x;
+        const int pn[1] = {(int)(r / S)}, py[1] = {(int)(r % S)}, px[1] = {16 * tx + m};
+        const bool pv[1] = {true};
+        conv_epilogue<1, 4>(a, acc, pn, py, px, pv, 0, g);
+    }
+}
+// out: (2*n_img, S, S, 64) NHWC = relu(conv1_1(normalised [pred ; target]) + bias); w: the layer's OIHW fp32 weight
+int launch_vgg_first_f16x3(const float* pred, const float* target, const float* mean, const float* stdv, const float* w,
+                           const float* bias, float* out, int n_img, int size, hipStream_t stream) {
+    S3D_CHECK_ARG(size % 16 == 0 && (long)3 * size * size < (1L << 31), "vgg_first: size %d", size);
+    ConvLaunch a = {};
+    a.N = 2 * n_img; a.H = size; a.W = size; a.CoutPad = 64;
+    a.shift = bias; a.act = S3D_ACT_RELU;
+    a.out = out; a.out_mode = S3D_OUT_NHWC; a.cout_store = 64; a.out_cstride = 64;
+    const long n_tiles = (long)a.N * size * (size / 16);
+    const int blocks = (int)((n_tiles + 3) / 4 < 8192 ? (n_tiles + 3) / 4 : 8192);
+    hipLaunchKernelGGL(vgg_first_f16x3_kernel, dim3(blocks), dim3(256), 0, stream, pred, target, mean, stdv, w, a, n_img);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_vgg_prep(const float* pred, const float* target, const float* mean, const float* stdv, float* out,
                     int n_img, int size, hipStream_t stream) {
     const long total = 2L * n_img * size * size;
