@@ -918,7 +918,16 @@ __global__ void conv_splitk_finish_kernel(const ConvLaunch a, int nsplit) {
         const long p = idx / cq;
         const int co = (int)(idx - p * cq) * 4;
         f32x4 s = zero4();
-        for (int k = 0; k < nsplit; ++k) s += ld4(a.splitk_ws + ((size_t)k * P + p) * a.CoutPad + co);
+        const float* src = a.splitk_ws + (size_t)p * a.CoutPad + co;
+        const size_t stride = (size_t)P * a.CoutPad;
+        int k = 0;
+        for (; k + 4 <= nsplit; k += 4) {   // four partials in flight (the kernel is a few microseconds of load latency)
+            const f32x4 v0 = ld4(src + (size_t)k * stride), v1 = ld4(src + (size_t)(k + 1) * stride),
+                        v2 = ld4(src + (size_t)(k + 2) * stride), v3 = ld4(src + (size_t)(k + 3) * stride);
+            __builtin_amdgcn_sched_barrier(0);
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; k < nsplit; ++k) s += ld4(src + (size_t)k * stride);
         f32x4 acc[1][1] = {{s}};
         const int n = (int)(p / ((long)a.H * a.W));
         const int r = (int)(p - (long)n * a.H * a.W);
@@ -948,9 +957,22 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     // split-K when the pixel x channel tiling cannot fill the chip (deep encoder layers at batch 1)
     int splits = 1;
     const size_t out_floats = (size_t)a.N * a.H * a.W * a.CoutPad;
-    if (a.splitk_ws && a.out_mode == S3D_OUT_NHWC) {
-        while (nblk * splits < 512 && splits * 2 <= nchunk && (size_t)(splits * 2) * out_floats <= a.splitk_floats)
-            splits *= 2;
+    if (a.splitk_ws && a.out_mode == S3D_OUT_NHWC && nblk < 512) {
+        // The chip holds 512 of these workgroups at a time (two per CU).  A launch runs in ceil(workgroups / 512) rounds of
+        // (chunks per split + a fixed fetch / epilogue share) each: 640 workgroups of 3 chunks are two rounds, the second
+        // a quarter full, where 480 of 4 chunks are one.  Pick the split count with the least rounds x length (doubling
+        // until 512 workgroups was the rule before: it landed on 640 for every 64 x 64 x 320 layer of the LDM U-Net).
+        long best = -1;
+        for (int sp = 1; sp <= nchunk && (size_t)sp * out_floats <= a.splitk_floats; ++sp) {
+            const int c = (nchunk + sp - 1) / sp, se = (nchunk + c - 1) / c;
+            if (se != sp) continue;   // (the same chunking as a smaller count)
+            const long rounds = (nblk * se + 511) / 512;
+            const long cost = rounds * (2 * c + 3) + (se > 1 ? 1 + se / 8 : 0);   // half-chunk units; the finish pass reads `se` partials
+            if (best < 0 || cost < best) {
+                best = cost;
+                splits = se;
+            }
+        }
     }
     const int cps = (nchunk + splits - 1) / splits;
     splits = (nchunk + cps - 1) / cps;
