@@ -112,6 +112,15 @@ struct ScaleTable {
     }
 };
 int launch_scale_table(const ScaleTable& t, float s, hipStream_t stream);
+// ---- last layer in training, absorbed token-0 form (train2.hip) ----
+#define S3D_ABS_NA 544   /* xbar row: 4 x 128 mixed rows | 4 probability sums | zeros */
+int launch_attn_mix0_fwd(const float* X, const float* qt, float* xbar, long groups, int T, const DropCfg& drop, hipStream_t stream);
+int launch_attn_mix0_bwd(const float* X, const float* qt, const float* dxbar, float* dX, float* dqt, long groups, int T,
+                         const DropCfg& drop, hipStream_t stream);
+int launch_absorb_train(const float* in_w, const float* in_b, const float* out_w, float* M, float* mvec, float* Naug,
+                        hipStream_t stream);
+int launch_absorb_grad(const float* in_w, const float* in_b, const float* out_w, const float* dM, const float* dm,
+                       const float* dNaug, float* g_in_w, float* g_in_b, float* g_out_w, hipStream_t stream);
 int launch_relu_mask_bwd(const float* y, float* dy, long n, hipStream_t stream);              // dy *= (y > 0)
 int launch_pool_bwd(const float* y, const float* dyp, float* dy, int n, int h, int w, int c, hipStream_t stream,
                     int relu_mask = 0);   // relu_mask: dy *= (y > 0) on the way out

@@ -699,6 +699,233 @@ int launch_emb_grad(const float* dF0, const float* w, float* demds, int B, int n
 }
 
 // =============================================================================================
+// LAST layer in training, absorbed form (round 4).  Only token 0 of the layer is consumed (models.py:83): for that one query
+// row the K and V projections move off the 13 tokens, exactly as in inference (decode.h, launch_attn_last_mix) —
+//   qt_h = M_h x0 + m_h,  s_t = (qt_h . x_t) / sqrt(32),  p = softmax_t(s),  pd = dropout(p),
+//   xbar_h = sum_t pd_t x_t,  sigma_h = sum_t pd_t,   out = sum_h N_h xbar_h + sum_h sigma_h c_h + b_o
+// with M_h = Wk_h^T Wq_h, m_h = Wk_h^T bq_h, N_h = Wo[:, h] Wv_h, c_h = Wo[:, h] bv_h (bk cancels in the softmax: its gradient is
+// zero; sigma_h is 1 without dropout and carries bv through the probability dropout otherwise).  The stored-K|V form of rounds
+// 2-3 ran 17 passes over the 5.2 M-row token tensor for this layer (K|V projection, core forward / backward, dK|V, its weight
+// gradient, its data gradient: 9.9 ms of the step); here the tokens are read once forward, and read + written once backward.
+// The matrices are formed in double at every step (absorb_train_kernel), the gradients of M, m, N, c come out of the ordinary
+// weight-gradient kernels on the token-0 rows and are carried to in_proj / out_proj by absorb_grad_kernel (chain rule through
+// the 128 x 128 products).
+// xbar rows are S3D_ABS_NA = 544 wide: 4 x 128 mixed rows | 4 probability sums | zeros (a multiple of 32 for the GEMMs).
+// 32 lanes per query (4 channels each): the query's token rows (and, backward, their gradients) stay in registers.
+// =============================================================================================
+__device__ __forceinline__ float half32_allsum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+    v += __shfl_xor(v, 16, 64);                                                                                           // the other row of the half
+    return v;
+}
+template <int BWD>
+__global__ __launch_bounds__(256) void attn_mix0_kernel(const float* __restrict__ X, const float* __restrict__ qt,
+                                                        float* __restrict__ xbar, const float* __restrict__ dxbar,
+                                                        float* __restrict__ dX, float* __restrict__ dqt, long groups, int T,
+                                                        const DropCfg drop) {
+    const int qi = threadIdx.x >> 5, c4 = (threadIdx.x & 31) * 4;
+    const float scale = 0.17677669529663687f;   // 1/sqrt(32)
+    for (long item = blockIdx.x; item < 2 * groups; item += gridDim.x) {
+        const long grp = item >> 1;
+        const int mq = (int)(item & 1) * 8 + qi;
+        const long row0 = grp * S3D_GROUP + mq;
+        const float* xg = X + (grp * T * S3D_GROUP + mq) * 128 + c4;
+        f32x4 x[S3D_N_TOKENS_MAX], dx[S3D_N_TOKENS_MAX];
+#pragma unroll
+        for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+            const int tc = t < T ? t : T - 1;
+            x[t] = ld4(xg + (long)tc * S3D_GROUP * 128);
+            dx[t] = zero4();
+        }
+#pragma unroll 1
+        for (int h = 0; h < 4; ++h) {
+            const f32x4 q4 = ld4(qt + row0 * 512 + h * 128 + c4);
+            float p[S3D_N_TOKENS_MAX], mk[16];
+            float mx = -1e30f;
+#pragma unroll
+            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+                float d = q4[0] * x[t][0] + q4[1] * x[t][1] + q4[2] * x[t][2] + q4[3] * x[t][3];
+                d = half32_allsum(d) * scale;
+                p[t] = t < T ? d : -1e30f;
+                mx = fmaxf(mx, p[t]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+                p[t] = t < T ? expf(p[t] - mx) : 0.f;
+                den += p[t];
+            }
+            const float inv = 1.f / den;
+#pragma unroll
+            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) p[t] *= inv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {   // the masks of keys 4j .. 4j + 3 (index: ((row0 * 4 + head) * 16 + key), as attn_core0_kernel)
+                float m4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop.p > 0.f) s3d_drop4(drop, ((unsigned long long)row0 * 4 + h) * 16 + 4 * j, m4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mk[4 * j + i] = m4[i];
+            }
+            if (!BWD) {
+                f32x4 o = zero4();
+                float sg = 0.f;
+#pragma unroll
+                for (int t = 0; t < S3D_N_TOKENS_MAX; ++t)
+                    if (t < T) {
+                        const float pd = p[t] * mk[t];
+                        o += x[t] * pd;
+                        sg += pd;
+                    }
+                st4(xbar + row0 * S3D_ABS_NA + h * 128 + c4, o);
+                if (c4 == 0) xbar[row0 * S3D_ABS_NA + 512 + h] = sg;
+            } else {
+                const f32x4 g4 = ld4(dxbar + row0 * S3D_ABS_NA + h * 128 + c4);
+                const float gs = dxbar[row0 * S3D_ABS_NA + 512 + h];
+                float dp[S3D_N_TOKENS_MAX];
+                float dot = 0.f;
+#pragma unroll
+                for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+                    float d = g4[0] * x[t][0] + g4[1] * x[t][1] + g4[2] * x[t][2] + g4[3] * x[t][3];
+                    d = (half32_allsum(d) + gs) * mk[t];   // d loss / d probability
+                    dp[t] = t < T ? d : 0.f;
+                    dot += p[t] * dp[t];
+                }
+                f32x4 dq4 = zero4();
+#pragma unroll
+                for (int t = 0; t < S3D_N_TOKENS_MAX; ++t)
+                    if (t < T) {
+                        const float ds = p[t] * (dp[t] - dot) * scale;
+                        dq4 += x[t] * ds;
+                        dx[t] += g4 * (p[t] * mk[t]) + q4 * ds;
+                    }
+                st4(dqt + row0 * 512 + h * 128 + c4, dq4);
+            }
+        }
+        if (!BWD) {   // the zero padding of the row
+            if (c4 >= 4 && c4 <= S3D_ABS_NA - 516) st4(xbar + row0 * S3D_ABS_NA + 512 + c4, zero4());
+        } else {
+            float* dg = dX + (grp * T * S3D_GROUP + mq) * 128 + c4;
+#pragma unroll
+            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t)
+                if (t < T) st4(dg + (long)t * S3D_GROUP * 128, dx[t]);
+        }
+    }
+}
+int launch_attn_mix0_fwd(const float* X, const float* qt, float* xbar, long groups, int T, const DropCfg& drop,
+                         hipStream_t stream) {
+    if (groups <= 0) return 0;
+    S3D_CHECK_ARG(T >= 1 && T <= S3D_N_TOKENS_MAX, "attn mix0: T %d", T);
+    const long nb = 2 * groups < 16384 ? 2 * groups : 16384;
+    hipLaunchKernelGGL((attn_mix0_kernel<0>), dim3((unsigned)nb), dim3(256), 0, stream, X, qt, xbar, nullptr, nullptr, nullptr,
+                       groups, T, drop);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+// dX: every element of the [groups][T][16][128] token tensor is written (token 0's rows still lack the query path: dqt M)
+int launch_attn_mix0_bwd(const float* X, const float* qt, const float* dxbar, float* dX, float* dqt, long groups, int T,
+                         const DropCfg& drop, hipStream_t stream) {
+    if (groups <= 0) return 0;
+    S3D_CHECK_ARG(T >= 1 && T <= S3D_N_TOKENS_MAX, "attn mix0: T %d", T);
+    const long nb = 2 * groups < 16384 ? 2 * groups : 16384;
+    hipLaunchKernelGGL((attn_mix0_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, X, qt, nullptr, dxbar, dX, dqt, groups,
+                       T, drop);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// absorbed matrices of one step (double accumulation, rounded once):  M [512][128], m [512], Naug [128][S3D_ABS_NA]
+__global__ void absorb_train_kernel(const float* __restrict__ in_w, const float* __restrict__ in_b,
+                                    const float* __restrict__ out_w, float* __restrict__ M, float* __restrict__ mvec,
+                                    float* __restrict__ Naug) {
+    const float* Wq = in_w;
+    const float* Wk = in_w + 128 * 128;
+    const float* Wv = in_w + 256 * 128;
+    const int total = 512 * 128 + 512 + 128 * S3D_ABS_NA;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        if (idx < 512 * 128) {            // M[h*128 + c][k] = sum_d Wk[32h+d][c] Wq[32h+d][k]
+            const int r = idx >> 7, k = idx & 127, h = r >> 7, c = r & 127;
+            double s = 0.0;
+            for (int d = 0; d < 32; ++d) s += (double)Wk[(32 * h + d) * 128 + c] * (double)Wq[(32 * h + d) * 128 + k];
+            M[idx] = (float)s;
+        } else if (idx < 512 * 128 + 512) {   // m[h*128 + c] = sum_d Wk[32h+d][c] bq[32h+d]
+            const int r = idx - 512 * 128, h = r >> 7, c = r & 127;
+            double s = 0.0;
+            for (int d = 0; d < 32; ++d) s += (double)Wk[(32 * h + d) * 128 + c] * (double)in_b[32 * h + d];
+            mvec[r] = (float)s;
+        } else {
+            const int j = idx - 512 * 128 - 512, n = j / S3D_ABS_NA, kk = j - n * S3D_ABS_NA;
+            double s = 0.0;
+            if (kk < 512) {               // N[n][h*128 + c] = sum_d Wo[n][32h+d] Wv[32h+d][c]
+                const int h = kk >> 7, c = kk & 127;
+                for (int d = 0; d < 32; ++d) s += (double)out_w[n * 128 + 32 * h + d] * (double)Wv[(32 * h + d) * 128 + c];
+            } else if (kk < 516) {        // c_h[n] = sum_d Wo[n][32h+d] bv[32h+d]
+                const int h = kk - 512;
+                for (int d = 0; d < 32; ++d) s += (double)out_w[n * 128 + 32 * h + d] * (double)in_b[256 + 32 * h + d];
+            }
+            Naug[j] = (float)s;
+        }
+    }
+}
+int launch_absorb_train(const float* in_w, const float* in_b, const float* out_w, float* M, float* mvec, float* Naug,
+                        hipStream_t stream) {
+    hipLaunchKernelGGL(absorb_train_kernel, dim3(512), dim3(256), 0, stream, in_w, in_b, out_w, M, mvec, Naug);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+// chain rule from (dM, dm, dNaug) to in_proj (weight [384][128], bias [384]) and out_proj.weight [128][128]; every element
+// of the three gradients is written (the key bias's gradient is zero)
+__global__ void absorb_grad_kernel(const float* __restrict__ in_w, const float* __restrict__ in_b,
+                                   const float* __restrict__ out_w, const float* __restrict__ dM,
+                                   const float* __restrict__ dm, const float* __restrict__ dNaug,
+                                   float* __restrict__ g_in_w, float* __restrict__ g_in_b, float* __restrict__ g_out_w) {
+    const float* Wq = in_w;
+    const float* Wk = in_w + 128 * 128;
+    const float* Wv = in_w + 256 * 128;
+    const int total = 384 * 128 + 384 + 128 * 128;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        if (idx < 128 * 128) {                    // dWq[32h+d][k] = sum_c Wk[32h+d][c] dM[h*128+c][k]
+            const int r = idx >> 7, k = idx & 127, h = r >> 5;
+            for (int c = 0; c < 128; ++c) s += (double)Wk[r * 128 + c] * (double)dM[(h * 128 + c) * 128 + k];
+            g_in_w[idx] = (float)s;
+        } else if (idx < 256 * 128) {             // dWk[32h+d][c] = sum_k dM[h*128+c][k] Wq[32h+d][k] + dm[h*128+c] bq[32h+d]
+            const int j = idx - 128 * 128, r = j >> 7, c = j & 127, h = r >> 5;
+            for (int k = 0; k < 128; ++k) s += (double)dM[(h * 128 + c) * 128 + k] * (double)Wq[r * 128 + k];
+            s += (double)dm[h * 128 + c] * (double)in_b[r];
+            g_in_w[idx] = (float)s;
+        } else if (idx < 384 * 128) {             // dWv[32h+d][c] = sum_n Wo[n][32h+d] dN[n][h*128+c]
+            const int j = idx - 256 * 128, r = j >> 7, c = j & 127, h = r >> 5;
+            for (int n = 0; n < 128; ++n) s += (double)out_w[n * 128 + r] * (double)dNaug[n * S3D_ABS_NA + h * 128 + c];
+            g_in_w[idx] = (float)s;
+        } else if (idx < 384 * 128 + 384) {
+            const int r = idx - 384 * 128;
+            if (r < 128) {                        // dbq[32h+d] = sum_c Wk[32h+d][c] dm[h*128+c]
+                const int h = r >> 5;
+                for (int c = 0; c < 128; ++c) s += (double)Wk[r * 128 + c] * (double)dm[h * 128 + c];
+            } else if (r >= 256) {                // dbv[32h+d] = sum_n Wo[n][32h+d] dc_h[n]
+                const int rv = r - 256, h = rv >> 5;
+                for (int n = 0; n < 128; ++n) s += (double)out_w[n * 128 + rv] * (double)dNaug[n * S3D_ABS_NA + 512 + h];
+            }
+            g_in_b[r] = (float)s;
+        } else {                                  // dWo[n][32h+d] = sum_c dN[n][h*128+c] Wv[32h+d][c] + dc_h[n] bv[32h+d]
+            const int j = idx - 384 * 128 - 384, n = j >> 7, r = j & 127, h = r >> 5;
+            for (int c = 0; c < 128; ++c) s += (double)dNaug[n * S3D_ABS_NA + h * 128 + c] * (double)Wv[r * 128 + c];
+            s += (double)dNaug[n * S3D_ABS_NA + 512 + h] * (double)in_b[256 + r];
+            g_out_w[j] = (float)s;
+        }
+    }
+}
+int launch_absorb_grad(const float* in_w, const float* in_b, const float* out_w, const float* dM, const float* dm,
+                       const float* dNaug, float* g_in_w, float* g_in_b, float* g_out_w, hipStream_t stream) {
+    hipLaunchKernelGGL(absorb_grad_kernel, dim3(512), dim3(256), 0, stream, in_w, in_b, out_w, dM, dm, dNaug, g_in_w, g_in_b,
+                       g_out_w);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
 // Attention core of the LAST layer in training: only token 0 of that layer is consumed (models.py:83), so only
 // the token-0 query of every sample attends (to all T keys).  q0 [rows0][128]; kv [rows][256] (k | v, token rows
 // [group][T][16]); o0 / d_o0 / dq0 [rows0][128]; dkv [rows][256] (every element written).  16 lanes per query
