@@ -184,11 +184,6 @@ int launch_qry_rot_rows(const float* qry, const float* rot, int flip_yz, long n_
                         const int* perm,
                         float* out, hipStream_t stream);
 int launch_copy_cols(const float* src, float* dst, int rows, int csrc, int cdst, hipStream_t stream);
-// token-0 attention core of the last layer (training): see train2.hip
-int launch_attn_core0_fwd(const float* q0, const float* kv, float* o0, long groups, int T, const DropCfg& drop,
-                          hipStream_t stream);
-int launch_attn_core0_bwd(const float* q0, const float* kv, const float* d_o0, float* dq0, float* dkv, long groups, int T,
-                          const DropCfg& drop, hipStream_t stream);
 // fused attention-core backward with Q / K / V recomputed on chip (train_attnq.hip): x, dO (rows x 128) -> dQKV (rows x 384)
 struct LayerPtrs;
 int launch_attn_bwd_q(const float* x, const float* d_o, float* dqkv, long groups, int T, const LayerPtrs& w,

@@ -925,117 +925,3 @@ int launch_absorb_grad(const float* in_w, const float* in_b, const float* out_w,
     return 0;
 }
 
-// =============================================================================================
-// Attention core of the LAST layer in training: only token 0 of that layer is consumed (models.py:83), so only
-// the token-0 query of every sample attends (to all T keys).  q0 [rows0][128]; kv [rows][256] (k | v, token rows
-// [group][T][16]); o0 / d_o0 / dq0 [rows0][128]; dkv [rows][256] (every element written).  16 lanes per query
-// (4 per head, 8 head dims each), one 256-thread workgroup per group; dropout indexes the COMPACT token-0 rows:
-// [(row0 * 4 + head) * 16 + key].
-// =============================================================================================
-__device__ __forceinline__ float quad_allsum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-    return v;
-}
-#define AC0_SCALE 0.17677669529663687f
-template <int BWD>
-__global__ __launch_bounds__(256) void attn_core0_kernel(const float* __restrict__ q0, const float* __restrict__ kv,
-                                                         float* __restrict__ o0, const float* __restrict__ d_o0,
-                                                         float* __restrict__ dq0, float* __restrict__ dkv, long groups,
-                                                         int T, const DropCfg drop) {
-    const int mq = threadIdx.x >> 4, l16 = threadIdx.x & 15;
-    const int head = l16 >> 2, d0 = l16 * 8;   // channels d0 .. d0+7 = head dims 8*(l16&3) .. +7 of `head`
-    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        const long row0 = grp * S3D_GROUP + mq;
-        const f32x4 qa = ld4(q0 + row0 * 128 + d0), qb = ld4(q0 + row0 * 128 + d0 + 4);
-        const float* kvq = kv + (grp * T * S3D_GROUP + mq) * 256 + d0;
-        float sc[S3D_N_TOKENS_MAX];
-        float mx = -1e30f;
-#pragma unroll
-        for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
-            const int tc = t < T ? t : T - 1;
-            const f32x4 ka = ld4(kvq + (long)tc * S3D_GROUP * 256), kb = ld4(kvq + (long)tc * S3D_GROUP * 256 + 4);
-            float d = qa[0] * ka[0] + qa[1] * ka[1] + qa[2] * ka[2] + qa[3] * ka[3] + qb[0] * kb[0] + qb[1] * kb[1] +
-                      qb[2] * kb[2] + qb[3] * kb[3];
-            d = quad_allsum(d) * AC0_SCALE;
-            sc[t] = t < T ? d : -1e30f;
-            mx = fmaxf(mx, sc[t]);
-        }
-        float den = 0.f;
-#pragma unroll
-        for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
-            sc[t] = t < T ? expf(sc[t] - mx) : 0.f;
-            den += sc[t];
-        }
-        const float inv = 1.f / den;
-        float mk[S3D_N_TOKENS_MAX];
-#pragma unroll
-        for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
-            sc[t] *= inv;   // probability
-            mk[t] = drop.p > 0.f ? s3d_drop(drop, ((unsigned long long)row0 * 4 + head) * 16 + t) : 1.f;
-        }
-        if (!BWD) {
-            f32x4 oa = zero4(), ob = zero4();
-#pragma unroll
-            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t)
-                if (t < T) {
-                    const float p = sc[t] * mk[t];
-                    oa += ld4(kvq + (long)t * S3D_GROUP * 256 + 128) * p;
-                    ob += ld4(kvq + (long)t * S3D_GROUP * 256 + 132) * p;
-                }
-            st4(o0 + row0 * 128 + d0, oa);
-            st4(o0 + row0 * 128 + d0 + 4, ob);
-        } else {
-            const f32x4 ga = ld4(d_o0 + row0 * 128 + d0), gb = ld4(d_o0 + row0 * 128 + d0 + 4);
-            float* dkvq = dkv + (grp * T * S3D_GROUP + mq) * 256 + d0;
-            float dp[S3D_N_TOKENS_MAX];
-            float dot = 0.f;
-#pragma unroll
-            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t)
-                if (t < T) {
-                    const f32x4 va = ld4(kvq + (long)t * S3D_GROUP * 256 + 128), vb = ld4(kvq + (long)t * S3D_GROUP * 256 + 132);
-                    float d = ga[0] * va[0] + ga[1] * va[1] + ga[2] * va[2] + ga[3] * va[3] + gb[0] * vb[0] + gb[1] * vb[1] +
-                              gb[2] * vb[2] + gb[3] * vb[3];
-                    d = quad_allsum(d) * mk[t];      // d loss / d probability
-                    dp[t] = d;
-                    dot += sc[t] * d;
-                    const float pm = sc[t] * mk[t];  // d v = dropped probability * d o
-                    st4(dkvq + (long)t * S3D_GROUP * 256 + 128, ga * pm);
-                    st4(dkvq + (long)t * S3D_GROUP * 256 + 132, gb * pm);
-                }
-            f32x4 dqa = zero4(), dqb = zero4();
-#pragma unroll
-            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t)
-                if (t < T) {
-                    const float ds = sc[t] * (dp[t] - dot) * AC0_SCALE;
-                    const f32x4 ka = ld4(kvq + (long)t * S3D_GROUP * 256), kb = ld4(kvq + (long)t * S3D_GROUP * 256 + 4);
-                    dqa += ka * ds;
-                    dqb += kb * ds;
-                    st4(dkvq + (long)t * S3D_GROUP * 256, qa * ds);
-                    st4(dkvq + (long)t * S3D_GROUP * 256 + 4, qb * ds);
-                }
-            st4(dq0 + row0 * 128 + d0, dqa);
-            st4(dq0 + row0 * 128 + d0 + 4, dqb);
-        }
-    }
-}
-int launch_attn_core0_fwd(const float* q0, const float* kv, float* o0, long groups, int T, const DropCfg& drop,
-                          hipStream_t stream) {
-    if (groups <= 0) return 0;
-    S3D_CHECK_ARG(T >= 1 && T <= S3D_N_TOKENS_MAX, "attn core0: T %d", T);
-    const long nb = groups < 8192 ? groups : 8192;
-    hipLaunchKernelGGL((attn_core0_kernel<0>), dim3((unsigned)nb), dim3(256), 0, stream, q0, kv, o0, nullptr, nullptr, nullptr,
-                       groups, T, drop);
-    S3D_LAUNCH_CHECK();
-    return 0;
-}
-int launch_attn_core0_bwd(const float* q0, const float* kv, const float* d_o0, float* dq0, float* dkv, long groups, int T,
-                          const DropCfg& drop, hipStream_t stream) {
-    if (groups <= 0) return 0;
-    S3D_CHECK_ARG(T >= 1 && T <= S3D_N_TOKENS_MAX, "attn core0: T %d", T);
-    const long nb = groups < 8192 ? groups : 8192;
-    hipLaunchKernelGGL((attn_core0_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, q0, kv, nullptr, d_o0, dq0, dkv,
-                       groups, T, drop);
-    S3D_LAUNCH_CHECK();
-    return 0;
-}
