@@ -117,7 +117,15 @@ __device__ __forceinline__ float relu1(float v) {
     return r;
 }
 // relu + split of the 4 pre-activations of one D tile: hi = f16(max(v,0)), lo = f16(max(v,0) - hi)
+template <bool SINGLE>
 __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h1, half2v& l0, half2v& l1) {
+    if (SINGLE) {   // the single-pass mode pins 9 VALU slots per MFMA with sched_group_barrier, which does not count inline asm:
+                    // with the asm ReLU its groups ran dry and the mode lost 20 % (13.5 vs 16.8 M query-points/s) — builtin here
+        const float inf = __builtin_inff();
+        split4_pk(__builtin_amdgcn_fmed3f(v[0], 0.f, inf), __builtin_amdgcn_fmed3f(v[1], 0.f, inf),
+                  __builtin_amdgcn_fmed3f(v[2], 0.f, inf), __builtin_amdgcn_fmed3f(v[3], 0.f, inf), h0, h1, l0, l1);
+        return;
+    }
     split4_pk(relu1(v[0]), relu1(v[1]), relu1(v[2]), relu1(v[3]), h0, h1, l0, l1);
 }
 
@@ -155,7 +163,7 @@ __device__ __forceinline__ void ffn_draw(FfnActState& as, int c, int a2, int r2)
     asm volatile("" : "+v"(as.h), "+v"(as.h2));   // stay in this scheduling region
 }
 // D tile (a2, r2) of chunk c: pre-activation -> f16 hi/lo halves of GEMM2's B operand
-template <int MODE>
+template <int MODE, bool SINGLE>
 __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, half2v& l0, half2v& l1, FfnActState& as,
                                          const FfnTrainArgs& ta, const FfnBwdArgs& ba, int c, int a2, int r2) {
     if (MODE == 2 || MODE == 3) {
@@ -194,7 +202,7 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
             a[i] = s3d_gate_bit_imm(v[i], bits, FFN_MASK_POS(i));
         split4_pk(a[0], a[1], a[2], a[3], h0, h1, l0, l1);
     } else {
-        relu_split4(v, h0, h1, l0, l1);
+        relu_split4<SINGLE>(v, h0, h1, l0, l1);
     }
 }
 
@@ -247,7 +255,7 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
         }                                                                                                            \
         if ((K) % (4 / PIPE_R) == 0) {   /* 2 * PIPE_R D tiles over the 8 groups */                                   \
             constexpr int tile = (K) / (4 / PIPE_R), a2 = tile / PIPE_R, r2 = tile % PIPE_R;                         \
-            ffn_act4<MODE>(hd[a2][r2], hh2[r2][2 * a2], hh2[r2][2 * a2 + 1], hl2[r2][2 * a2], hl2[r2][2 * a2 + 1], as, ta, ba, c, a2, r2); \
+            ffn_act4<MODE, SINGLE>(hd[a2][r2], hh2[r2][2 * a2], hh2[r2][2 * a2 + 1], hl2[r2][2 * a2], hl2[r2][2 * a2 + 1], as, ta, ba, c, a2, r2); \
             /* tie the results into the side-effect chain: otherwise the low halves are emitted where they are */   \
             /* first USED (phase B), outside the MFMA cover */                                                       \
             asm volatile("" : "+v"(hl2[r2][2 * a2]), "+v"(hl2[r2][2 * a2 + 1]), "+v"(hh2[r2][2 * a2]),               \
