@@ -294,12 +294,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                 bp[mt] = S.p + (ok[mt] ? off : 0) + 8 * g;
             }
             const _Float16* wp = wimg + ((size_t)jt0 * KU32 + ubase + tap * cu) * 1024 + lane * 8;
-#pragma unroll 1
-            for (int c = 0; c < cu; ++c) {
-                // issue every load of this K chunk (2 per activation tile, 2 per weight tile) before the first
-                // use: left alone the scheduler interleaves load / wait / 4 MFMAs and exposes the L2 latency
-                f32x4 v0[MT], v1[MT];
-                chalf8 wh[NT], wl[NT];
+            // Every load of a K chunk (2 per activation tile, 2 per weight tile) is issued before its first use, and the NEXT
+            // chunk's loads before this chunk's MFMAs (two register sets, the loop unrolled by two): one chunk per L2 round
+            // trip made the small GEMMs of the LDM U-Net at batch 1 (32 x 32-pixel tiles, 20 chunks, 2.5 waves per SIMD) pure
+            // latency — 15 us for 1.3 GMAC.
+            auto issue = [&](int c, f32x4 (&v0)[MT], f32x4 (&v1)[MT], chalf8 (&wh)[NT], chalf8 (&wl)[NT]) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     v0[mt] = ok[mt] ? ld4(bp[mt] + 32 * c) : zero4();
@@ -311,7 +310,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                     wh[nt] = *reinterpret_cast<const chalf8*>(f);
                     wl[nt] = *reinterpret_cast<const chalf8*>(f + 512);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto consume = [&](const f32x4 (&v0)[MT], const f32x4 (&v1)[MT], const chalf8 (&wh)[NT], const chalf8 (&wl)[NT]) {
                 chalf8 bh[MT], bl[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -336,6 +336,34 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+                }
+            };
+            f32x4 p0[MT], p1[MT];
+            chalf8 pwh[NT], pwl[NT];
+            if constexpr (MT * NT <= 8) {   // (the 4 x 4 tile would need 300 registers for two sets: it has the MFMA work to cover a round trip)
+                f32x4 q0[MT], q1[MT];
+                chalf8 qwh[NT], qwl[NT];
+                issue(0, p0, p1, pwh, pwl);
+                int c = 0;
+#pragma unroll 1
+                for (; c + 1 < cu; c += 2) {
+                    issue(c + 1, q0, q1, qwh, qwl);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(p0, p1, pwh, pwl);
+                    if (c + 2 < cu) issue(c + 2, p0, p1, pwh, pwl);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(q0, q1, qwh, qwl);
+                }
+                if (c < cu) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(p0, p1, pwh, pwl);
+                }
+            } else {
+#pragma unroll 1
+                for (int c = 0; c < cu; ++c) {
+                    issue(c, p0, p1, pwh, pwl);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(p0, p1, pwh, pwl);
                 }
             }
         }
