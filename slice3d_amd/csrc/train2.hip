@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void attn_mix0_kernel(const float* __restrict_
 #pragma unroll
             for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) p[t] *= inv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {   // the masks of keys 4j .. 4j + 3 (index: ((row0 * 4 + head) * 16 + key), as attn_core0_kernel)
+            for (int j = 0; j < 4; ++j) {   // the masks of keys 4j .. 4j + 3 (index: ((row0 * 4 + head) * 16 + key): the compact token-0 rows)
                 float m4[4] = {1.f, 1.f, 1.f, 1.f};
                 if (drop.p > 0.f) s3d_drop4(drop, ((unsigned long long)row0 * 4 + h) * 16 + 4 * j, m4);
 #pragma unroll
