@@ -180,6 +180,8 @@ int launch_fc_out_bwd(const float* x, const float* w, const float* dsdf, float* 
 int launch_scalar_reduce(const float* a, const float* b, long n, int mode, float scale, float* out, int accumulate,
                          float* partial, hipStream_t stream);
 int launch_vgg_prep_bwd(const float* din16, const float* stdv, float* drec, int n_img, int size, hipStream_t stream);
+// Z (n_img, S, S, 32): channel ci*9 + tap of the 1x1 product dY w (27 valid) -> drec (n_img, 3, S, S) NCHW, accumulated
+int launch_vgg_first_bwd(const float* Z, const float* stdv, float* drec, int n_img, int size, hipStream_t stream);
 int launch_qry_rot_rows(const float* qry, const float* rot, int flip_yz, long n_qry, long gpb, long groups,
                         const int* perm,
                         float* out, hipStream_t stream);

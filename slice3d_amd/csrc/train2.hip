@@ -130,6 +130,51 @@ int launch_vgg_prep_bwd(const float* din16, const float* stdv, float* drec, int 
     return 0;
 }
 
+// ---- data gradient of VGG conv1_1 (64 -> 3, 3x3) + the input normalisation, in two steps: Z[p][ci*9 + tap] = sum_co dY[p][co]
+//      w[co][ci][tap] is a 1 x 1 convolution 64 -> 27 (the row-linear kernel: the generic 3x3 tile pads the 3 outputs to 16 and
+//      runs K = 576 for them, 0.87 ms), and d rec[n][ci][y][x] += 0.5 / std[ci] * sum_tap Z[(y, x) - d(tap)][ci*9 + tap] gathers the
+//      nine neighbours' entries from an 18 x 18-pixel halo of Z staged in LDS (zero outside the image).
+__global__ __launch_bounds__(256) void vgg_first_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ stdv,
+                                                            float* __restrict__ drec, int n_img, int size) {
+    __shared__ float s_z[18 * 18][33];   // (padded: the 27 entries of a pixel are read at a 33-float stride)
+    const int tiles = size >> 4;
+    const long hw = (long)size * size;
+    for (long t = blockIdx.x; t < (long)n_img * tiles * tiles; t += gridDim.x) {
+        const int tx = (int)(t % tiles), ty = (int)((t / tiles) % tiles);
+        const long ni = t / ((long)tiles * tiles);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 18 * 18 * 8; i += 256) {   // float4 slots: pixel * 8 + quad
+            const int pix = i >> 3, q = i & 7, hy = pix / 18, hx = pix - hy * 18;
+            const int y = 16 * ty + hy - 1, x = 16 * tx + hx - 1;
+            f32x4 v = zero4();
+            if ((unsigned)y < (unsigned)size && (unsigned)x < (unsigned)size) v = ld4(Z + ((ni * hw + (long)y * size + x) * 32) + 4 * q);
+            s_z[pix][4 * q] = v[0]; s_z[pix][4 * q + 1] = v[1]; s_z[pix][4 * q + 2] = v[2]; s_z[pix][4 * q + 3] = v[3];
+        }
+        __syncthreads();
+        const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {   // Y[q] read X[q + (dy-1, dx-1)] with tap (dy, dx): X[p] collects from q = p - (dy-1, dx-1)
+                const float* z = s_z[(ly + 1 - (dy - 1)) * 18 + (lx + 1 - (dx - 1))];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] += z[c * 9 + dy * 3 + dx];
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            drec[(ni * 3 + c) * hw + (long)(16 * ty + ly) * size + 16 * tx + lx] += acc[c] * (0.5f / stdv[c]);
+    }
+}
+int launch_vgg_first_bwd(const float* Z, const float* stdv, float* drec, int n_img, int size, hipStream_t stream) {
+    S3D_CHECK_ARG(size % 16 == 0, "vgg_first_bwd: size %d", size);
+    const long tiles = (long)n_img * (size / 16) * (size / 16);
+    hipLaunchKernelGGL(vgg_first_bwd_kernel, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, stream, Z, stdv, drec,
+                       n_img, size);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- rotated query coordinates of the token-0 rows, padded to 4 columns: [groups*16][4] = (x,y,z,0)
 __global__ void qry_rot_rows_kernel(const float* __restrict__ qry, const float* __restrict__ rot, int flip_yz,
                                     long n_qry, long gpb, long groups, const int* __restrict__ perm,
