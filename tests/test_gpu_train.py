@@ -102,6 +102,44 @@ def test_train_grads_match_oracle_autograd(b, s, q, ns, prec):
         assert rel < 2e-2, (k, rel)
 
 
+def test_dropout_masks_are_bernoulli_with_the_stated_rate_and_uncorrelated():
+    """The counter-based masks of dropout.h (exported by s3d_dropout_mask; the kernels draw exactly these): values are 0 or
+    1/(1-p), the keep rate of every 16-bit field position is 1 - p to sampling accuracy, neighbours (the four fields of one hash,
+    consecutive hashes, a row stride apart) and different sites / seeds are uncorrelated, and a stream does not depend on the
+    offset it is drawn from."""
+    from slice3d_amd import _lib
+    lib = _lib.load()
+    p, n = 0.1, 1 << 22
+
+    def draw(seed, site, idx0=0, count=n):
+        out = torch.empty(count, dtype=torch.float32, device="cuda")
+        _lib.check(lib.s3d_dropout_mask(seed, site, idx0, count, p, out.data_ptr(), None), "s3d_dropout_mask")
+        torch.cuda.synchronize()
+        return out
+
+    m = draw(12345678901, 6)
+    vals = torch.unique(m).cpu().tolist()
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / (1.0 - p)) < 1e-6, vals
+    k = (m > 0).double()
+    sigma = (p * (1 - p) / n) ** 0.5
+    assert abs(float(k.mean()) - (1 - p)) < 5 * sigma, float(k.mean())
+    for f in range(4):                                    # the four fields of a hash word pair
+        assert abs(float(k[f::4].mean()) - (1 - p)) < 5 * 2 * sigma, (f, float(k[f::4].mean()))
+    kc = k - k.mean()
+    var = float((kc * kc).mean())
+    for lag in (1, 2, 3, 4, 128, 2048):                   # inside a hash, the next hash, a channel row, a hidden row
+        c = float((kc[:-lag] * kc[lag:]).mean()) / var
+        assert abs(c) < 5 / n ** 0.5, (lag, c)
+    for other in (draw(12345678901, 7), draw(12345678902, 6)):   # another site, another seed
+        oc = (other > 0).double()
+        c = float(((oc - oc.mean()) * kc).mean()) / var
+        assert abs(c) < 5 / n ** 0.5, c
+    off = 1000003                                          # the same stream drawn from an offset (and past 2^32 elements)
+    assert torch.equal(draw(12345678901, 6, off, 4096), m[off:off + 4096])
+    hi = draw(12345678901, 6, (1 << 33) + 5, 1 << 16)
+    assert abs(float((hi > 0).double().mean()) - (1 - p)) < 5 * (p * (1 - p) / (1 << 16)) ** 0.5
+
+
 def _hip_dropout_masks(b, q, ns, p, seed):
     """Rebuild, in the oracle's (query, token, ...) layout, the masks the HIP kernels draw (s3d_dropout_mask)."""
     import ctypes as C
