@@ -102,6 +102,45 @@ def test_train_grads_match_oracle_autograd(b, s, q, ns, prec):
         assert rel < 2e-2, (k, rel)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_last_layer_absorbed_attention_gradients_by_projection(prec):
+    """The last decoder layer trains in the absorbed token-0 form (train2.hip: M = Wk^T Wq, N = Wo Wv; models.py:83 consumes
+    token 0 only) and its in_proj / out_proj gradients come out of a chain rule through those products.  Checked per
+    projection block against CPU autograd of the oracle's ordinary attention: the q, k and v row blocks of in_proj_weight, the
+    q and v blocks of in_proj_bias, out_proj.  The key bias cancels in the softmax: its gradient is written as exactly zero
+    here and is rounding noise in the oracle."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    b, s, q, ns = 2, 32, 600, 5
+    m, tr = make_trainer(ns, prec)
+    fd = make_feed_dict(b, s, q, ns, seed=4242)
+    sd = seeded_sd_from_shapes(_shapes(ns))
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and not k.startswith("vggptlossfunc"):
+            v.requires_grad_(True)
+    loss, parts, out, ts = ref_cpu.forward_train(sd, fd, ns, 0.0)
+    loss.backward()
+    tr.forward_backward({k: v.cuda() for k, v in fd.items()})
+    grads = {k: p.grad.cpu() for k, p in m.named_parameters() if k in tr.offsets}
+    pre = "att_decoder.layers.2.self_attn."
+    gw, rw = grads[pre + "in_proj_weight"], sd[pre + "in_proj_weight"].grad
+    gb, rb = grads[pre + "in_proj_bias"], sd[pre + "in_proj_bias"].grad
+    for name, sl in (("q", slice(0, 128)), ("k", slice(128, 256)), ("v", slice(256, 384))):
+        rel = float((gw[sl] - rw[sl]).norm() / rw[sl].norm())
+        assert rel < 2e-2, ("in_proj_weight", name, rel)
+    for name, sl in (("q", slice(0, 128)), ("v", slice(256, 384))):
+        rel = float((gb[sl] - rb[sl]).norm() / rb[sl].norm())
+        assert rel < 2e-2, ("in_proj_bias", name, rel)
+    assert float(gb[128:256].abs().max()) == 0.0
+    assert float(rb[128:256].norm()) < 1e-4 * float(rb.norm())
+    go, ro = grads[pre + "out_proj.weight"], sd[pre + "out_proj.weight"].grad
+    for h in range(4):                                     # per head column block
+        rel = float((go[:, 32 * h:32 * h + 32] - ro[:, 32 * h:32 * h + 32]).norm() / ro[:, 32 * h:32 * h + 32].norm())
+        assert rel < 2e-2, ("out_proj.weight", h, rel)
+    gob, rob = grads[pre + "out_proj.bias"], sd[pre + "out_proj.bias"].grad
+    assert float((gob - rob).norm() / rob.norm()) < 2e-2
+
+
 def test_dropout_masks_are_bernoulli_with_the_stated_rate_and_uncorrelated():
     """The counter-based masks of dropout.h (exported by s3d_dropout_mask; the kernels draw exactly these): values are 0 or
     1/(1-p), the keep rate of every 16-bit field position is 1 - p to sampling accuracy, neighbours (the four fields of one hash,
