@@ -502,7 +502,7 @@ def main():
         n_tok = args.n_slices + 1
         ffn_launches = max(counts["ffn_layer"], 1)
         ffn_ms = stage_ms["ffn_layer"] * args.steps / ffn_launches
-        # algorithmic FLOPs of the average launch (a step's 2 full FFN layers are split into <= 262 144-query passes)
+        # algorithmic FLOPs of the average launch (a step's 2 full FFN layers are launched on <= 262 144 queries at a time)
         ffn_flops = 2.0 * n_tok * args.n_qry * args.batch * FFN_FLOP_PER_ROW * args.steps / ffn_launches
         achieved = ffn_flops / (ffn_ms * 1e-3) / 1e12
         peak = F32_MFMA_PEAK_TFLOPS if args.prec == "f32" else F16_MFMA_PEAK_TFLOPS

@@ -724,8 +724,12 @@ extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, 
 // decode
 // =============================================================================================
 #ifndef S3D_CHUNK_GROUPS
-#define S3D_CHUNK_GROUPS 16384  // 262144 queries per pass: X = 16384*13*16*128*4 B = 1.74 GB
+#define S3D_CHUNK_GROUPS 32768  // 524288 queries per pass: X = 32768*13*16*128*4 B = 3.49 GB
 #endif
+// The FFN kernel is launched on at most this many groups at a time.  One pass over the bench's 400 k queries instead of two
+// saves the attention kernel, the token builder and the final layer a launch tail each (-0.23 ms per step); the FFN kernel
+// itself ran 0.5 % slower per row on a 3.5 GB launch than on a 1.7 GB one (tools/chunk_groups.sh), so it keeps the old size.
+#define S3D_FFN_LAUNCH_GROUPS 16384
 
 struct DecodeWs {
     size_t X, X0, perm, sortws, last, total;
@@ -856,12 +860,16 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
                 else
                     TRY(launch_attn_layer(X, nullptr, gc, T, lp, st));
             }
-            ProfScope prof_(last ? S3D_PROF_FFN_FINAL : S3D_PROF_FFN, st);
             if (!last) {
-                TRY(launch_ffn_layer(X, gc * T * S3D_GROUP, lp, nullptr, nullptr, nullptr, 1.f, gpb, n_qry, g0,
-                                     prec, nullptr, st));
+                for (long f0 = 0; f0 < gc; f0 += S3D_FFN_LAUNCH_GROUPS) {   // (rows are independent: any split is the same result)
+                    const long fc = gc - f0 < S3D_FFN_LAUNCH_GROUPS ? gc - f0 : S3D_FFN_LAUNCH_GROUPS;
+                    ProfScope prof_(S3D_PROF_FFN, st);
+                    TRY(launch_ffn_layer(X + (size_t)f0 * T * S3D_GROUP * 128, fc * T * S3D_GROUP, lp, nullptr, nullptr, nullptr,
+                                         1.f, gpb, n_qry, g0 + f0, prec, nullptr, st));
+                }
                 if (stages) TRY(launch_tok0_copy(X, stages + rows_all + (size_t)l * rows0_all, gc, T, 0, 128, st));
             } else {
+                ProfScope prof_(S3D_PROF_FFN_FINAL, st);
                 if (stages) {   // the final kernel keeps the layer's output rows in registers (LayerNorm -> fc_out): the capture
                                 // runs the full-row form of the same kernel on a copy of the token-0 rows
                     float* d = stages + rows_all + (size_t)l * rows0_all;
