@@ -1,4 +1,5 @@
 # decode pass size: the previous product (16384 groups per pass), one pass with one FFN launch (32768), the product (32768 with FFN launches of 16384)
+# variant libraries: copies of the tree built with `make EXTRA=-DS3D_CHUNK_GROUPS=...` (lib_cg32768: one FFN launch per pass) and the previous commit's build (lib_base)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 B="--cpu-sample 0 --ldm-steps 0 --train-steps 0 --gt-train-steps 0 --c4-steps 0 --f16-steps 0 --mesh-steps 0 --pmc 0 --steps 20 --warmup 3"
 for r in 1 2 3; do
