@@ -32,6 +32,68 @@ F_MIN_PER_QUERY = 35.96e6           # exact decoder FLOPs/query 
 ATTN_FLOP_PER_TOKEN = 2 * (3 * 128 * 128 + 128 * 128) + 2 * 2 * 13 * 128   # in_proj + out_proj + (QK^T, PV) over 13 keys
 
 
+def _r(x, nd=4):
+    """Round every float of a JSON-able value to `nd` significant decimals (the driver keeps ~2 KB of the line's tail)."""
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x))
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+class _ClockSampler:
+    """Samples every GPU's shader clock (MHz) and socket power (W) from sysfs every 50 ms on a host thread while a leg runs and
+    reports the card that drew the most power — the one under load: the sysfs card order is not HIP's device order
+    (this part's clock depends on the data the matrix pipes see: profiles/r02_ffn_data_power.md)."""
+
+    def __init__(self):
+        import glob
+        self.cards = []
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            hw = sorted(glob.glob(os.path.dirname(f) + "/hwmon/hwmon*/power1_*"))
+            fp = next((h for h in hw if h.endswith("power1_input")), None) or next((h for h in hw if h.endswith("power1_average")), None)
+            self.cards.append({"sclk_file": f, "power_file": fp, "sclk": [], "power": []})
+        self._stop = False
+        self._th = None
+
+    def _read(self):
+        for c in self.cards:
+            try:
+                for line in open(c["sclk_file"]):
+                    if "*" in line:
+                        c["sclk"].append(float(line.split(":")[1].lower().split("mhz")[0]))
+                if c["power_file"]:
+                    c["power"].append(float(open(c["power_file"]).read()) * 1e-6)
+            except (OSError, ValueError, IndexError):
+                pass
+
+    def __enter__(self):
+        import threading
+        if self.cards:
+            def loop():
+                while not self._stop:
+                    self._read()
+                    time.sleep(0.05)
+            self._th = threading.Thread(target=loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th:
+            self._th.join()
+
+    def result(self):
+        drop = lambda v: v[len(v) // 4:] if len(v) >= 8 else v      # the first quarter is the ramp
+        m = lambda v: sum(v) / len(v) if v else None
+        best = max(self.cards, key=lambda c: m(drop(c["power"])) or 0.0, default=None)
+        if best is None:
+            return None, None
+        return m(drop(best["sclk"])), m(drop(best["power"]))
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -97,21 +159,15 @@ def cpu_baseline(sd, fd, n_slices, n_sample, gpu_sdf, runs=5):
         sdf = box["s"]
     per_q = (t_sample + t_tokens) / n_sample
     err = float((gpu_sdf[:, :n_sample].cpu() - sdf).abs().max())
+    # (how the figure is formed: DESIGN.md section 5 "bench line glossary")
     return {
         "value": n_qry / (t_unet + per_q * n_qry), "unit": "query-points/s", "cores": best_n, "kind": "port",
-        "host_cores": host, "cpu_model": _cpu_model(), "runs": "1 warm-up + median of %d per stage" % runs,
-        "sample": "oracle/ref_cpu.py (torch-CPU fp32 restatement of the reference path): U-Net once at %d^2 + %d of "
-                  "the %d queries per object through sample / fc_s / transformer in chunks of %d; value = "
-                  "Q/(t_unet + Q*t_query) at the best thread count of a probe over {8,16,32,64,all cores}"
-                  % (fd_cpu["img_input"].shape[-1], n_sample, n_qry, chunk),
+        "host_cores": host, "cpu_model": _cpu_model(),
+        "sample": "oracle/ref_cpu.py: U-Net once at %d^2 + %d of %d queries/object in chunks of %d; 1 warm-up + median of %d; "
+                  "best thread count of a probe" % (fd_cpu["img_input"].shape[-1], n_sample, n_qry, chunk, runs),
         "stages": {"unet_s": t_unet, "sample_us_per_query": t_sample / n_sample * 1e6,
                    "decoder_tokens_us_per_query": t_tokens / n_sample * 1e6},
         "thread_probe_s_per_256_queries": probe,
-        "decoder_only_qps": 1.0 / per_q,
-        "reference_as_written": "the reference's own eval_points loop re-runs the U-Net and VGG19 for every 3000-query "
-                                "chunk (reconstruct.py:74-102): 772 query-points/s at 256^2 on the authoring container's "
-                                "8 vCPUs, measured with the real reference code (BASELINE.md section 2); it cannot travel "
-                                "to the GPU box, so the figure above is the encode-once port",
     }, err
 
 
@@ -151,8 +207,7 @@ def _pmc_traffic(args, kname):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (
-        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of the timed loop, "
-        "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch (FETCH %.0f KiB, WRITE %.0f KiB)" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+        "in-run rocprofv3 --pmc passes: (2*FETCH %.0f + WRITE %.0f) KiB/launch" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
 
 
 def _self_launch(n):
@@ -180,9 +235,14 @@ def main():
     ap.add_argument("--n-slices", type=int, default=12)
     ap.add_argument("--batch", type=int, default=4, help="objects per GPU per step (BASELINE C2: B = 1..4)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="timed runs per stage of the CPU baseline (median; BASELINE.md section 4)")
     ap.add_argument("--prec", default="f16x3", choices=["f32", "f16x3"], help="arithmetic mode of the decoder GEMMs")
     ap.add_argument("--f16-steps", type=int, default=5, help="timed steps of the single-pass f16 throughput mode, reported "
                                                               "separately with its error (0 = skip)")
+    ap.add_argument("--f32-steps", type=int, default=3, help="timed steps of the exact fp32-MFMA mode, reported beside the headline "
+                                                              "(0 = skip)")
+    ap.add_argument("--noise-steps", type=int, default=30, help="timed steps on white-noise images with the clock sampled "
+                                                                "(SURVEY 8(d)'s inputs; 0 = skip)")
     ap.add_argument("--c4-steps", type=int, default=2, help="timed dense 256^3 grid evaluations (BASELINE configs[3]; 0 = skip)")
     ap.add_argument("--c4-res", type=int, default=256)
     ap.add_argument("--mesh-steps", type=int, default=2, help="timed reconstruct.py-default mesh extractions (MISE 64 -> 256 + "
@@ -193,7 +253,12 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child pass: inference loop only
     ap.add_argument("--train-steps", type=int, default=10, help="timed training steps for train_samples_per_s (0 = skip)")
     ap.add_argument("--gt-train-steps", type=int, default=5, help="timed Slices3DGTModel training steps (0 = skip)")
+    ap.add_argument("--infer-only", action="store_true", help="the headline loop alone (A/B scripts): every secondary leg off")
     args = ap.parse_args()
+    if args.infer_only:
+        for k in ("cpu_sample", "f16_steps", "f32_steps", "noise_steps", "c4_steps", "mesh_steps", "ldm_steps", "train_steps",
+                  "gt_train_steps", "pmc"):
+            setattr(args, k, 0)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU under torch.distributed.run on
@@ -252,8 +317,12 @@ def main():
     dt = time.perf_counter() - t0
     if args.pmc_child:      # counter pass under rocprofv3: only the timed loop's launches are wanted
         return
+    rank_ms = [dt / args.steps * 1e3]
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                       # per-rank times: a straggler shows in the first curve
+        rank_ms = [float(v.item()) / args.steps * 1e3 for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stage_ms, counts = {}, {}
@@ -287,39 +356,64 @@ def main():
         k_ms = kms.value / max(kn.value, 1)
         ch = sum(p.shape[-1] for p in code.pyramid)
         alg = args.n_slices * args.n_qry * (ch * 4 + 8) + sum(p.numel() * 4 for p in code.pyramid)
-        sample_roof = {"kernel": "sample_pyramid_kernel (sample_from_planes x5 + cat semantics, materialises (12,Q,992) fp32)",
+        sample_roof = {"kernel": "sample_pyramid_kernel (sample_from_planes x5 + cat, stand-alone op)",
                        "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                        "frac": alg / (k_ms * 1e-3) / 1e9 / 8000.0, "kernel_ms": k_ms, "alg_bytes": alg,
                        "op_ms_incl_locality_sort": ms, "op_gbps_incl_locality_sort": alg / (ms * 1e-3) / 1e9,
-                       "note": "algorithmic bytes: output write + grid read + pyramid once; `achieved` = the gather / "
-                               "row-store kernel (HIP events around it, s3d_prof), op_* = the whole "
-                               "s3d_sample_pyramid_fwd call including the query sort it visits the points in"}
+                       }
         del code, feats
 
     # ---- throughput mode (NOT the headline): single-pass f16 MFMA, what BASELINE configs[1]'s "bf16" names; fails the
     #      1e-4 gate by construction, so it is reported beside the headline with its measured error ----
-    f16_mode = None
-    if args.f16_steps > 0 and rank == 0:
-        m16 = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="test", prec="f16")
-        load_seeded(m16, 0)
-        m16.cuda().eval()
-
-        def step16():
-            return m16.decode_sdf(fd["qry_norot"], m16.encode(fd))
+    def time_mode(prec, steps, feed):
+        """ms per step of the headline workload in another arithmetic mode / on another feed (2 warm-up steps)."""
+        m = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="test", prec=prec)
+        load_seeded(m, 0)
+        m.cuda().eval()
         for _ in range(2):
-            o16 = step16()
+            o = m.decode_sdf(feed["qry_norot"], m.encode(feed))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(args.f16_steps):
-            o16 = step16()
+        for _ in range(steps):
+            o = m.decode_sdf(feed["qry_norot"], m.encode(feed))
         torch.cuda.synchronize()
-        ms16 = (time.perf_counter() - t1) / args.f16_steps * 1e3
-        f16_mode = {"workload": "the headline workload with --prec f16 (operands rounded to f16, one MFMA per product, fp32 "
-                                "accumulate): NOT fp32-class, not comparable with `value`",
-                    "ms_per_step": ms16, "query_points_per_s": args.n_qry * args.batch / (ms16 * 1e-3),
+        return (time.perf_counter() - t1) / steps * 1e3, o
+
+    qps = lambda ms: args.n_qry * args.batch / (ms * 1e-3)
+    f16_mode = f32_mode = noise_leg = None
+    if args.f16_steps > 0 and rank == 0:
+        ms16, o16 = time_mode("f16", args.f16_steps, fd)
+        f16_mode = {"ms_per_step": ms16, "query_points_per_s": qps(ms16),
                     "max_abs_diff_vs_headline_mode": float((o16 - out).abs().max()),
                     "mean_abs_diff_vs_headline_mode": float((o16 - out).abs().mean())}
-        del m16, o16
+        del o16
+    # ---- the cost of the f16x3 choice: the same workload with exact fp32 MFMAs (v_mfma_f32_16x16x4_f32) ----
+    if args.f32_steps > 0 and rank == 0 and args.prec != "f32":
+        ms32, o32 = time_mode("f32", args.f32_steps, fd)
+        f32_mode = {"ms_per_step": ms32, "query_points_per_s": qps(ms32),
+                    "max_abs_diff_vs_headline_mode": float((o32 - out).abs().max())}
+        del o32
+    # ---- SURVEY 8(d)'s white-noise images (uniform(-1,1)): this part's clock depends on the operands' bit activity, so
+    #      the same step is timed on both feeds with the shader clock / socket power sampled from sysfs ----
+    if args.noise_steps > 0 and rank == 0:
+        fdn = make_feed_dict(args.batch, args.img_size, args.n_qry, args.n_slices, seed=1234, smooth=False,
+                             with_slices=False, device="cuda")
+        noise_leg = {}
+        for tag, feed in (("smooth", fd), ("noise", fdn)):
+            for _ in range(2):
+                step_on = model.decode_sdf(feed["qry_norot"], model.encode(feed))
+            torch.cuda.synchronize()
+            with _ClockSampler() as cs:
+                t1 = time.perf_counter()
+                for _ in range(args.noise_steps):
+                    step_on = model.decode_sdf(feed["qry_norot"], model.encode(feed))
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t1) / args.noise_steps * 1e3
+            mhz, watts = cs.result()
+            noise_leg[tag] = {"ms_per_step": ms, "sclk_mhz": mhz, "power_w": watts}
+        noise_leg["query_points_per_s"] = qps(noise_leg["noise"]["ms_per_step"])
+        noise_leg["steps"] = args.noise_steps
+        del fdn, step_on
 
     # ---- BASELINE configs[3]: reconstruct.py --mc_res0 256 --mc_up_steps 0 — the dense 256^3 logit grid of ONE object
     #      (16.7 M queries, coordinates generated in-kernel), copied to the host as Generator3D does.  With N ranks the
@@ -356,12 +450,9 @@ def main():
             t = torch.tensor([t_dev, t_host], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             t_dev, t_host = (float(v) for v in t.tolist())
-        c4 = {"workload": "dense %d^3 grid of one object (U-Net encode + %d queries, in-kernel coordinates), "
-                          "BASELINE configs[3]" % (args.c4_res, n_grid),
-              "seconds_device": t_dev, "seconds_incl_d2h": t_host, "query_points_per_s": n_grid / t_dev,
-              "query_points_per_s_incl_d2h": n_grid / t_host, "n_gpus": world,
-              "split": "one slab of the grid's linear index per rank + all_gather of the logits" if world > 1 else "single GPU",
-              "scaling": "strong", "dtype": args.prec}
+        # BASELINE configs[3]; N ranks: one slab of the grid's linear index per rank + all_gather of the logits (strong scaling)
+        c4 = {"res": args.c4_res, "seconds_device": t_dev, "seconds_incl_d2h": t_host, "query_points_per_s": n_grid / t_dev,
+              "query_points_per_s_incl_d2h": n_grid / t_host, "n_gpus": world, "scaling": "strong"}
         del grid, host
 
     # ---- reconstruct.py at its default options (mc_res0 64, two upsampling steps): MISE refinement on the
@@ -381,9 +472,7 @@ def main():
                 mesh, mst = gm.generate_mesh(fdm)
                 torch.cuda.synchronize()
                 tms.append(time.perf_counter() - t1)
-            mesh_leg = {"workload": "Generator3D.generate_mesh, reconstruct.py defaults (MISE 64 -> 256, threshold 0.5), device MISE + "
-                                    "HIP marching cubes, random-weight field",
-                        "seconds_per_mesh": sorted(tms)[len(tms) // 2], "seconds_eval_points": mst.get("time (eval points)"),
+            mesh_leg = {"seconds_per_mesh": sorted(tms)[len(tms) // 2], "seconds_eval_points": mst.get("time (eval points)"),
                         "seconds_marching_cubes": mst.get("time (marching cubes)"), "vertices": int(len(mesh.vertices)),
                         "faces": int(len(mesh.faces))}
             del gm, mesh
@@ -424,8 +513,9 @@ def main():
                                                                         else "DDIM sampler loop, eager launches")
 
         lms, lmode = time_ldm(lx, lt, lc)
-        ldm = {"workload": "gen_slices LDM UNetModel denoise step, objaverse-ldm-kl-8.yaml, batch 1 (222 GFLOP)",
-               "ms_per_step": lms, "tflops_algorithmic": 0.222 / lms * 1e3, "dtype": args.prec, "launch": lmode}
+        # gen_slices LDM UNetModel denoise step, objaverse-ldm-kl-8.yaml, batch 1 = 222 GFLOP
+        ldm = {"ms_per_step": lms, "tflops_algorithmic": 0.222 / lms * 1e3, "dtype": args.prec,
+               "graph_replay": "graph" in lmode}
         # the same step on a batch of 4 latents (the sampler's classifier-free pair x 2 objects): what the small kernels of
         # the batch-1 step cost in utilisation
         lx4, lt4 = lx.repeat(4, 1, 1, 1).contiguous(), lt.repeat(4)
@@ -469,9 +559,8 @@ def main():
             gtr.train_step(gfd)
         torch.cuda.synchronize()
         gms = (time.perf_counter() - t1) / args.gt_train_steps * 1e3
-        gt_train = {"workload": "Slices3DGTModel train_step (fwd + L1 + bwd + Adam), 16 objects x %d slices at 128^2, "
-                                "256 queries each, dropout 0.1 (reg_slices/options.py defaults)" % args.n_slices,
-                    "ms_per_step": gms, "samples_per_s": 16 / gms * 1e3, "dtype": args.prec}
+        # Slices3DGTModel train_step (fwd + L1 + bwd + Adam), 16 objects x 12 slices at 128^2, 256 queries each, dropout 0.1
+        gt_train = {"ms_per_step": gms, "samples_per_s": 16 / gms * 1e3}
         del gtr, gm, gfd
 
     # ---- secondary metric: training samples/s (train.py:41-53 train_step, B = 1 object per GPU) ----
@@ -528,66 +617,60 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         decode_ms = sum(stage_ms[k] for k in ("sample_tokens", "attn_layer", "ffn_layer", "ffn_final"))
+        unet_tf = args.batch * UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"]
+        attn_tf = args.n_qry * args.batch * 2 * n_tok * ATTN_FLOP_PER_TOKEN / (stage_ms["attn_layer"] * 1e-3) / 1e12
+        # Key order: the driver keeps ~2 KB of the line's tail, so the contract keys and the long objects come first and
+        # every secondary result sits at the end, numbers only (what each key means: DESIGN.md section 5, "bench line glossary").
         res = {
             "metric": "occupancy query-points/sec (U-Net encode + per-query decode, 256^2 x 12 slices)",
             "value": q_total / dt, "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
-            "config": {"workload": "reg_slices regression inference, %d^2 x %d slices, %d query points/object, "
-                                   "%d objects per GPU per step (BASELINE configs[1], C2: B = 1..4); arithmetic: %s"
-                                   % (args.img_size, args.n_slices, args.n_qry, args.batch,
-                                      "exact fp32 MFMA" if args.prec == "f32" else
-                                      "fp32 operands split into f16 hi+lo, 3 f16 MFMAs per product, fp32 accumulate "
-                                      "(fp32-class accuracy, passes the 1e-4 parity gate)"),
+            "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic-smooth",
+            "config": {"workload": "reg_slices inference %d^2 x %d slices, %d queries/object, %d objects/GPU/step (BASELINE configs[1])"
+                                   % (args.img_size, args.n_slices, args.n_qry, args.batch),
                        "img_size": args.img_size, "n_slices": args.n_slices, "n_qry": args.n_qry,
                        "objects_per_step": world * args.batch, "parallelism": "objects x%d (no collective)" % world},
+            "ms_per_step_rank_min_max": [min(rank_ms), max(rank_ms)],
             "roofline": {"kernel": ("ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_pipe_kernel<0>")
                                    + " (decoder FFN 128->2048->128 + residual + LN2)",
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "note": ("algorithmic FLOPs (one product = one MAC); in f16x3 mode each product costs 3 f16 "
-                                  "MFMA MACs, so the matrix pipe executes 3x `achieved`; under this load the chip "
-                                  "sustains ~1.96-2.0 GHz under its 1400 W power cap (1.24 kW averaged over the step, "
-                                  "profiles/r02_clock_power_under_load.md; the "
-                                  "same kernel on all-zero operands runs 2.35 GHz and 0.24 of peak, "
-                                  "profiles/r02_ffn_data_power.md), peak is quoted at 2.4 GHz; a register-resident loop of nothing but this MFMA on random f16 operands sustains 1.65 PFLOP/s at the cap (profiles/r03_mfma_power_ceiling.md), so the kernel's 3x matrix work is ~0.87 of what the socket can power" if args.prec != "f32" else "exact fp32 MFMA"),
+                         "note": ("algorithmic FLOPs; f16x3 = 3 f16 MFMAs per fp32 product, the pipe executes 3x `achieved`; "
+                                  "power-capped (DESIGN.md section 5)" if args.prec != "f32" else "exact fp32 MFMA"),
                          "mfma_pipe_tflops": achieved * (3 if args.prec != "f32" else 1),
                          "traffic_source": traffic_src,
                          "avg_launch_ms": ffn_ms, "launches": counts["ffn_layer"],
                          "alg_flop_per_launch": ffn_flops},
             "secondary_rooflines": [
                 sample_roof,
-                {"kernel": "U-Net conv stack (conv_igemm_f16x3_kernel family, 33 launches)", "bound": "mfma",
-                 "achieved": args.batch * UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"],
-                 "peak": peak, "unit": "TFLOP/s",
-                 "frac": args.batch * UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"] / peak,
-                 "note": "algorithmic FLOPs 241.97 GFLOP/object at 256^2 (SURVEY 8d) / whole unet_encode stage time"},
-                {"kernel": "attention stage (attn_layer_q_kernel, layers 0-1, + the absorbed-form last layer)", "bound": "mfma",
-                 "achieved": args.n_qry * args.batch * 2 * (args.n_slices + 1) * ATTN_FLOP_PER_TOKEN / (stage_ms["attn_layer"] * 1e-3) / 1e12,
-                 "peak": peak, "unit": "TFLOP/s",
-                 "frac": args.n_qry * args.batch * 2 * (args.n_slices + 1) * ATTN_FLOP_PER_TOKEN / (stage_ms["attn_layer"] * 1e-3) / 1e12 / peak,
-                 "note": "algorithmic FLOPs of layers 0-1 only (in_proj 98 304 + out_proj 32 768 + 13-key core 6 656 per token; the "
-                         "last layer's token-0 form is not counted) / the whole attn_layer stage time"},
+                {"kernel": "U-Net conv stack", "bound": "mfma", "achieved": unet_tf, "peak": peak, "unit": "TFLOP/s",
+                 "frac": unet_tf / peak},
+                {"kernel": "attention stage (attn_layer_q_kernel x2 + absorbed last layer)", "bound": "mfma",
+                 "achieved": attn_tf, "peak": peak, "unit": "TFLOP/s", "frac": attn_tf / peak},
             ],
-            "throughput_mode_f16": f16_mode,
-            "c4_dense_grid": c4,
-            "ldm_denoise_step": ldm,
-            "mesh_extraction": mesh_leg,
-            "gt_train_step": gt_train,
-            "stage_ms_per_step": stage_ms,
             "decode_tflops_fmin": args.n_qry * args.batch * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,
-            "train_samples_per_s": (world * args.batch / (train_ms * 1e-3)) if train_ms else None,
-            "train_ms_per_step": train_ms,
-            "train_config": "train_step (fwd + 3 losses + bwd + grad all-reduce + Adam), B=%d objects/GPU, %d^2 x %d slices, "
-                            "Q=%d, dropout 0.1, batch-statistic BatchNorm; forward / data-gradient / weight-gradient GEMMs in --prec "
-                            "(power-of-two backward scale), narrow and strided conv weight gradients fp32 MFMA"
-                            % (args.batch, args.img_size, args.n_slices, args.n_qry),
         }
+        err = None
         if world == 1 and args.cpu_sample > 0:
             base, err = cpu_baseline(sd_cpu, {k: v[:1] for k, v in fd.items()}, args.n_slices,
-                                     min(args.cpu_sample, args.n_qry), out[:1])
+                                     min(args.cpu_sample, args.n_qry), out[:1], runs=args.cpu_runs)
             res["cpu_baseline"] = base
+        # ---- the tail: every secondary number of the run ----
+        res["stage_ms_per_step"] = {k: v for k, v in stage_ms.items() if v}
+        if err is not None:
             res["parity_vs_oracle"] = {"max_abs_err": err, "n": min(args.cpu_sample, args.n_qry), "tol": 1e-4}
+        res["exact_f32_mode"] = f32_mode
+        res["white_noise"] = noise_leg
+        res["throughput_mode_f16"] = f16_mode
+        res["c4_dense_grid"] = c4
+        res["ldm_denoise_step"] = ldm
+        res["mesh_extraction"] = mesh_leg
+        res["gt_train_step"] = gt_train
+        res["train_ms_per_step"] = train_ms
+        res["train_samples_per_s"] = (world * args.batch / (train_ms * 1e-3)) if train_ms else None
+        exact = ("value", "ms_per_step", "roofline")      # contract numbers stay unrounded (value == queries / time exactly)
+        res = {k: (v if k in exact else _r(v)) for k, v in res.items()}
+        res["roofline"] = {k: (v if k in ("achieved", "peak", "frac") else _r(v)) for k, v in res["roofline"].items()}
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

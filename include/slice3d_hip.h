@@ -138,7 +138,18 @@ typedef struct {
 
 int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, const S3dLatent* out, int prec, void* stream);
 
+/* Decode workspace.  The decoder walks the queries in passes; `s3d_decode_workspace_bytes` sizes the preferred pass
+ * (<= 524 288 queries: 6.4 GB for any larger job — X 3.5 GB, the absorbed last layer's scratch 2.7 GB), and
+ * `s3d_decode_workspace_bytes_min` the smallest one the library accepts (65 536 queries per pass: 0.8 GB).  A workspace between
+ * the two makes the decode calls halve the pass until it fits (more launch tails, same results); below the minimum they
+ * return S3D_E_WORKSPACE. */
 size_t s3d_decode_workspace_bytes(int batch, long n_qry, int n_slices);
+size_t s3d_decode_workspace_bytes_min(int batch, long n_qry, int n_slices);
+/* 1 (default): everything on the caller's stream.  2 (or env S3D_DECODE_LANES=2): passes of >= 131 072 queries run their two
+ * halves' layer chains on the caller's stream and on a library-owned side stream (created once per device, ordered behind
+ * the caller's stream by events on both ends of every call), so one half's attention kernels share the CUs with the other
+ * half's FFN kernels.  Same results bit for bit; measured time-neutral on MI355X (profiles/r05_lanes_ab.md), kept opt-in. */
+int s3d_decode_set_lanes(int n);
 /* qry (B,Q,3); rot (B,3,3) or NULL; trans (B,4,3) = trans_mat_wo_rot_tp; flip_yz != 0 selects the
  * mode='test' prologue (y,z negated, no rotation; models.py:53-56).  sdf_out (B,Q). */
 int s3d_decode_points_fwd(const void* head_packed, const S3dLatent* latent, const float* qry,

@@ -726,6 +726,7 @@ extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, 
 #ifndef S3D_CHUNK_GROUPS
 #define S3D_CHUNK_GROUPS 32768  // 524288 queries per pass: X = 32768*13*16*128*4 B = 3.49 GB
 #endif
+#define S3D_CHUNK_GROUPS_MIN 4096   // smallest pass a caller's workspace may force (s3d_decode_workspace_bytes_min)
 // The FFN kernel is launched on at most this many groups at a time.  One pass over the bench's 400 k queries instead of two
 // saves the attention kernel, the token builder and the final layer a launch tail each (-0.23 ms per step); the FFN kernel
 // itself ran 0.5 % slower per row on a 3.5 GB launch than on a 1.7 GB one (tools/chunk_groups.sh), so it keeps the old size.
@@ -733,15 +734,17 @@ extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, 
 
 struct DecodeWs {
     size_t X, X0, perm, sortws, last, total;
+    long chunk;   // groups per pass
 };
 // scratch of the absorbed last-layer attention per query row: x0 | u (128 each), qt | xbar (512 each)
 #define S3D_LAST_ROW_FLOATS (2 * 128 + 2 * 512)
 #define S3D_SORT_MIN_QUERIES 4096   // below this the sort costs more than the locality buys
-static DecodeWs decode_ws(int batch, long n_qry, int ns) {
+static DecodeWs decode_ws(int batch, long n_qry, int ns, long chunk_groups = S3D_CHUNK_GROUPS) {
     const long gpb = (n_qry + S3D_GROUP - 1) / S3D_GROUP;
     long g = gpb * batch;
-    if (g > S3D_CHUNK_GROUPS) g = S3D_CHUNK_GROUPS;
+    if (g > chunk_groups) g = chunk_groups;
     DecodeWs W;
+    W.chunk = chunk_groups;
     W.X = 0;
     W.X0 = (size_t)g * (ns + 1) * S3D_GROUP * 128;
     W.perm = W.X0 + (size_t)g * S3D_GROUP * 128;
@@ -750,10 +753,67 @@ static DecodeWs decode_ws(int batch, long n_qry, int ns) {
     W.total = W.last + (size_t)g * S3D_GROUP * S3D_LAST_ROW_FLOATS;
     return W;
 }
+// the pass size a workspace of `bytes` allows: the preferred one, else halved down to S3D_CHUNK_GROUPS_MIN (a decode of
+// >= 524 288 queries needs 6.4 GB at the preferred size, 0.8 GB at the smallest; smaller passes cost launch tails only)
+static bool decode_ws_fit(int batch, long n_qry, int ns, size_t bytes, DecodeWs& W) {
+    for (long c = S3D_CHUNK_GROUPS; c >= S3D_CHUNK_GROUPS_MIN; c >>= 1) {
+        W = decode_ws(batch, n_qry, ns, c);
+        if (bytes >= W.total * sizeof(float)) return true;
+    }
+    return false;
+}
 
 extern "C" size_t s3d_decode_workspace_bytes(int batch, long n_qry, int n_slices) {
     return decode_ws(batch, n_qry, n_slices).total * sizeof(float);
 }
+extern "C" size_t s3d_decode_workspace_bytes_min(int batch, long n_qry, int n_slices) {
+    return decode_ws(batch, n_qry, n_slices, S3D_CHUNK_GROUPS_MIN).total * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two decode lanes (round 5, OPT-IN: measured time-neutral, profiles/r05_lanes_ab.md — 35.51 against 35.54 ms per step;
+// every matrix kernel of the decoder already runs at the socket's power cap, so filling one kernel's idle matrix cycles with
+// another's only lowers the clock).  The attention kernel (matrix pipe 52 % busy, latency-bound phases) and the FFN kernel (79 %
+// busy, power-bound) each hold one wave per SIMD per workgroup, two workgroups per CU: run back to back the chip sees
+// attention || attention, then FFN || FFN.  With the pass split into two halves whose layer chains run on two streams, offset
+// by one attention launch, a CU holds one workgroup of each kind during every attention phase but the first — the attention
+// waves' VALU / LDS phases fill the FFN waves' idle matrix cycles.  The second stream and its events are created lazily per
+// device and live for the process; everything is ordered behind the caller's stream (fork after the token builder, join
+// before the call returns its last launch), so the caller still sees one in-order stream.  Results are bit-identical: rows
+// are independent and every kernel sees the rows it saw before.
+// ---------------------------------------------------------------------------------------------
+struct DecodeLanes {
+    hipStream_t aux = nullptr;
+    hipEvent_t stagger = nullptr, join = nullptr;
+    bool ok = false;
+};
+static int g_decode_lanes = -1;   // -1: not configured (env S3D_DECODE_LANES, default 1)
+extern "C" int s3d_decode_set_lanes(int n) {
+    S3D_CHECK_ARG(n == 1 || n == 2, "decode_set_lanes: %d (1 or 2)", n);
+    g_decode_lanes = n;
+    return 0;
+}
+static int decode_lanes() {
+    if (g_decode_lanes < 0) {
+        const char* e = getenv("S3D_DECODE_LANES");
+        g_decode_lanes = (e && atoi(e) == 2) ? 2 : 1;
+    }
+    return g_decode_lanes;
+}
+static DecodeLanes* decode_lanes_for_device() {
+    static DecodeLanes lanes[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    DecodeLanes& L = lanes[dev & 63];
+    if (!L.ok) {
+        if (hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&L.stagger, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&L.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        L.ok = true;
+    }
+    return &L;
+}
+#define S3D_LANES_MIN_GROUPS 8192   // below 131 072 queries per pass the halves do not fill the chip
 
 static LayerPtrs layer_ptrs(const float* b, const HeadLayout& H, int l) {
     LayerPtrs p;
@@ -806,11 +866,12 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
     S3D_CHECK_ARG(ns >= 1 && ns <= 12, "decode: n_slices %d", ns);
     S3D_CHECK_ARG(lat->n_img == batch * ns, "decode: latent has %d images, expected %d", lat->n_img, batch * ns);
     S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3 || prec == S3D_PREC_F16, "decode: precision mode %d not built", prec);
-    const DecodeWs W = decode_ws(batch, n_qry, ns);
-    if (workspace_bytes < W.total * sizeof(float)) {
-        s3d_set_error("decode: workspace %zu < %zu bytes", workspace_bytes, W.total * sizeof(float));
+    DecodeWs W;
+    if (!decode_ws_fit(batch, n_qry, ns, workspace_bytes, W)) {
+        s3d_set_error("decode: workspace %zu < %zu bytes (s3d_decode_workspace_bytes_min)", workspace_bytes, W.total * sizeof(float));
         return S3D_E_WORKSPACE;
     }
+    const long CHUNK = W.chunk;
     const HeadLayout H = head_layout();
     const float* b = (const float*)head_packed;
     float* X = (float*)workspace + W.X;
@@ -826,11 +887,11 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
         perm = pm;
     }
     // stage capture (s3d_decode_points_stages_fwd): one pass, queries in caller order
-    S3D_CHECK_ARG(!stages || (G <= S3D_CHUNK_GROUPS && !perm), "decode stages: at most %d unsorted queries per object",
+    S3D_CHECK_ARG(!stages || (G <= CHUNK && !perm), "decode stages: at most %d unsorted queries per object",
                   (int)S3D_SORT_MIN_QUERIES - 1);
     const size_t rows_all = (size_t)G * T * S3D_GROUP * 128, rows0_all = (size_t)G * S3D_GROUP * 128;
-    for (long g0 = 0; g0 < G; g0 += S3D_CHUNK_GROUPS) {
-        const long gc = G - g0 < S3D_CHUNK_GROUPS ? G - g0 : S3D_CHUNK_GROUPS;
+    for (long g0 = 0; g0 < G; g0 += CHUNK) {
+        const long gc = G - g0 < CHUNK ? G - g0 : CHUNK;
         SampleArgs sa = {};
         for (int l = 0; l < 3; ++l) sa.proj[l] = lat->proj[l];
         sa.fine[0] = lat->fine[0]; sa.fine[1] = lat->fine[1];
@@ -848,41 +909,74 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
             s3d_set_error("decode stages: memcpy failed");
             return (int)hipErrorUnknown;
         }
-        for (int l = 0; l < S3D_N_LAYERS; ++l) {
-            const LayerPtrs lp = layer_ptrs(b, H, l);
-            const bool last = l == S3D_N_LAYERS - 1;
-            {
-                ProfScope prof_(S3D_PROF_ATTN, st);
-                if (last)          // only token 0 of the last layer is consumed (models.py:83): absorbed form, every mode
-                    TRY(attn_last_layer(b, H, lp, X, X0, gc, T, (float*)workspace + W.last, prec, st));
-                else if (prec != S3D_PREC_F32)
-                    TRY(launch_attn_layer_q(X, gc, T, lp, st, prec == S3D_PREC_F16));
-                else
-                    TRY(launch_attn_layer(X, nullptr, gc, T, lp, st));
-            }
-            if (!last) {
-                for (long f0 = 0; f0 < gc; f0 += S3D_FFN_LAUNCH_GROUPS) {   // (rows are independent: any split is the same result)
-                    const long fc = gc - f0 < S3D_FFN_LAUNCH_GROUPS ? gc - f0 : S3D_FFN_LAUNCH_GROUPS;
-                    ProfScope prof_(S3D_PROF_FFN, st);
-                    TRY(launch_ffn_layer(X + (size_t)f0 * T * S3D_GROUP * 128, fc * T * S3D_GROUP, lp, nullptr, nullptr, nullptr,
-                                         1.f, gpb, n_qry, g0 + f0, prec, nullptr, st));
+        // the three encoder layers + fc_out on groups [gs, gs + gn) of this pass, enqueued on stream s
+        auto run_layers = [&](hipStream_t s, long gs, long gn, hipEvent_t after_first_attn) -> int {
+            float* Xs = X + (size_t)gs * T * S3D_GROUP * 128;
+            float* X0s = X0 + (size_t)gs * S3D_GROUP * 128;
+            float* lasts = (float*)workspace + W.last + (size_t)gs * S3D_GROUP * S3D_LAST_ROW_FLOATS;
+            for (int l = 0; l < S3D_N_LAYERS; ++l) {
+                const LayerPtrs lp = layer_ptrs(b, H, l);
+                const bool last = l == S3D_N_LAYERS - 1;
+                {
+                    ProfScope prof_(S3D_PROF_ATTN, s);
+                    if (last)          // only token 0 of the last layer is consumed (models.py:83): absorbed form, every mode
+                        TRY(attn_last_layer(b, H, lp, Xs, X0s, gn, T, lasts, prec, s));
+                    else if (prec != S3D_PREC_F32)
+                        TRY(launch_attn_layer_q(Xs, gn, T, lp, s, prec == S3D_PREC_F16));
+                    else
+                        TRY(launch_attn_layer(Xs, nullptr, gn, T, lp, s));
                 }
-                if (stages) TRY(launch_tok0_copy(X, stages + rows_all + (size_t)l * rows0_all, gc, T, 0, 128, st));
-            } else {
-                ProfScope prof_(S3D_PROF_FFN_FINAL, st);
-                if (stages) {   // the final kernel keeps the layer's output rows in registers (LayerNorm -> fc_out): the capture
-                                // runs the full-row form of the same kernel on a copy of the token-0 rows
-                    float* d = stages + rows_all + (size_t)l * rows0_all;
-                    if (hipMemcpyAsync(d, X0, rows0_all * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-                        s3d_set_error("decode stages: memcpy failed");
-                        return (int)hipErrorUnknown;
+                if (l == 0 && after_first_attn && hipEventRecord(after_first_attn, s) != hipSuccess) {
+                    s3d_set_error("decode: hipEventRecord failed");
+                    return (int)hipErrorUnknown;
+                }
+                if (!last) {
+                    for (long f0 = 0; f0 < gn; f0 += S3D_FFN_LAUNCH_GROUPS) {   // (rows are independent: any split is the same result)
+                        const long fc = gn - f0 < S3D_FFN_LAUNCH_GROUPS ? gn - f0 : S3D_FFN_LAUNCH_GROUPS;
+                        ProfScope prof_(S3D_PROF_FFN, s);
+                        TRY(launch_ffn_layer(Xs + (size_t)f0 * T * S3D_GROUP * 128, fc * T * S3D_GROUP, lp, nullptr, nullptr, nullptr,
+                                             1.f, gpb, n_qry, g0 + gs + f0, prec, nullptr, s));
                     }
-                    TRY(launch_ffn_layer(d, gc * S3D_GROUP, lp, nullptr, nullptr, nullptr, 1.f, gpb, n_qry, g0, prec,
-                                         nullptr, st));
+                    if (stages) TRY(launch_tok0_copy(Xs, stages + rows_all + (size_t)l * rows0_all, gn, T, 0, 128, s));
+                } else {
+                    ProfScope prof_(S3D_PROF_FFN_FINAL, s);
+                    if (stages) {   // the final kernel keeps the layer's output rows in registers (LayerNorm -> fc_out): the capture
+                                    // runs the full-row form of the same kernel on a copy of the token-0 rows
+                        float* d = stages + rows_all + (size_t)l * rows0_all;
+                        if (hipMemcpyAsync(d, X0s, rows0_all * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                            s3d_set_error("decode stages: memcpy failed");
+                            return (int)hipErrorUnknown;
+                        }
+                        TRY(launch_ffn_layer(d, gn * S3D_GROUP, lp, nullptr, nullptr, nullptr, 1.f, gpb, n_qry, g0 + gs, prec,
+                                             nullptr, s));
+                    }
+                    TRY(launch_ffn_layer(X0s, gn * S3D_GROUP, lp, b + H.fco_w, b + H.fco_b, out, sign, gpb, n_qry, g0 + gs,
+                                         prec, perm, s));
                 }
-                TRY(launch_ffn_layer(X0, gc * S3D_GROUP, lp, b + H.fco_w, b + H.fco_b, out, sign, gpb, n_qry, g0,
-                                     prec, perm, st));
             }
+            return 0;
+        };
+        DecodeLanes* lanes = (!stages && prec != S3D_PREC_F32 && gc >= S3D_LANES_MIN_GROUPS && decode_lanes() == 2)
+                                 ? decode_lanes_for_device() : nullptr;
+        if (!lanes) {
+            TRY(run_layers(st, 0, gc, nullptr));
+        } else {
+            // lane 0 = the first half on the caller's stream; lane 1 = the second half on the side stream, released when lane
+            // 0's first attention launch is done (and with it the token builder): from then on one lane's attention phases
+            // meet the other lane's FFN phases
+            const long h0 = (gc / 2 + 7) / 8 * 8;
+            TRY(run_layers(st, 0, h0, lanes->stagger));
+            if (hipStreamWaitEvent(lanes->aux, lanes->stagger, 0) != hipSuccess) {
+                s3d_set_error("decode: hipStreamWaitEvent failed");
+                return (int)hipErrorUnknown;
+            }
+            const int rc = run_layers(lanes->aux, h0, gc - h0, nullptr);
+            // join even on failure: the caller's stream must not run ahead of work already enqueued on the side stream
+            if (hipEventRecord(lanes->join, lanes->aux) != hipSuccess || hipStreamWaitEvent(st, lanes->join, 0) != hipSuccess) {
+                s3d_set_error("decode: lane join failed");
+                return (int)hipErrorUnknown;
+            }
+            if (rc) return rc;
         }
     }
     return 0;

@@ -114,7 +114,15 @@ __device__ __forceinline__ float colmax16(float v) {
 // operations), the per-head stores of the training kernels.  n must not exceed the real count (a larger n lets the barrier
 // pass before the set has landed), so the callers use these counts only where every counted operation is issued
 // unconditionally (T >= 9: both halves of every full-line store pair have active lanes) and fall back to 8 otherwise.
+// The counts are hand-derived from the source and hold only while hipcc emits exactly the counted operations (a dropped or
+// merged one would let a slot be read before its DMA lands: silently wrong rows).  -DS3D_AQ_SAFE_BARRIERS builds every
+// counted barrier as the always-safe vmcnt(8) form; `make` also builds that variant (libslice3d_hip_safe.so) and
+// tests/test_gpu_barriers.py holds the two libraries' outputs bit-identical.
+#ifdef S3D_AQ_SAFE_BARRIERS
+#define AQ_BARRIER_N(n) AQ_BARRIER()
+#else
 #define AQ_BARRIER_N(n)                                          \
     asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");        \
     asm volatile("s_barrier" ::: "memory")
+#endif
 #define AQ3_SLOT_HALFS (8 * 1024)    // 8 fragment pairs = 16 KiB

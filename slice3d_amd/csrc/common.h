@@ -162,6 +162,40 @@ __device__ __forceinline__ void s3d_full_line_pair(const f32x4 v0, const f32x4 v
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Per-device one-time kernel attributes.  hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: a
+// process that drives a second GPU must raise that device's limit too, so the "done" state is a bit per device ordinal
+// (setting the attribute twice from two racing threads is harmless; the bit is published only after the calls returned).
+// Returns 0 or the hipError_t of the failing call.
+#include <atomic>
+#include <initializer_list>
+static inline int s3d_set_max_lds(std::atomic<unsigned long long>& done, std::initializer_list<const void*> kernels, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    for (const void* k : kernels) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            s3d_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) on device %d: %s", bytes, dev, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+// CU count of the current device (cached per device ordinal)
+static inline int s3d_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int v = cache[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cache[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // Workgroup barrier that publishes LDS-DMA (global_load_lds) data: a wave must see ITS OWN requests land before it
 // arrives, because the other waves read those bytes right after the barrier.  __syncthreads() alone does not wait
 // on vmcnt (the compiler only guards a wave's own later LDS reads), which left a window in which a wave could read

@@ -275,16 +275,7 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
     }
 }
 
-static int sampler_cu_count() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        n_cu = v;
-    }
-    return n_cu;
-}
+static int sampler_cu_count() { return s3d_cu_count(); }   // one workgroup per CU of the CURRENT device
 int launch_sample_tokens(const SampleArgs& a, hipStream_t stream) {
     S3D_CHECK_ARG(a.size % 16 == 0 && a.size >= 16, "sample: size %d", a.size);
     S3D_CHECK_ARG(a.n_slices >= 1 && a.n_slices + 1 <= S3D_N_TOKENS_MAX, "sample: n_slices %d", a.n_slices);
@@ -451,12 +442,8 @@ int launch_attn_layer(float* X, float* x0_out, long groups, int T, const LayerPt
     S3D_CHECK_ARG(x0_out == nullptr, "attn: the token-0-only form of this kernel was retired (use the absorbed last layer)");
     if (groups <= 0) return 0;
     const size_t lds = (size_t)S3D_N_TOKENS_MAX * 16 * (QKV_LD + OH_LD) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    TRY_RET(s3d_set_max_lds(attr_done, {(const void*)attn_layer_kernel<false>}, lds));
     const long blocks = groups < 4096 ? groups : 4096;
     hipLaunchKernelGGL(attn_layer_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, X, x0_out, groups, T, w);
     S3D_LAUNCH_CHECK();

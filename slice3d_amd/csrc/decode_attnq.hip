@@ -430,13 +430,9 @@ static int launch_attn_q_any(float* X, long groups, int T, const LayerPtrs& w, h
     if (groups <= 0) return 0;
     S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr, "attn_q: T %d", T);
     const size_t lds = (size_t)(4 * AQ3_SLOT_HALFS) * 2 + 768 * 4;   // 64 KiB ring + the small vectors
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)attn_layer_q_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    TRY_RET(s3d_set_max_lds(attr_done, {(const void*)attn_layer_q_kernel<false, false>, (const void*)attn_layer_q_kernel<true, false>,
+                                        (const void*)attn_layer_q_kernel<false, true>}, lds));
     const long blocks = 2 * groups < 4096 ? 2 * groups : 4096;
     const _Float16* img = reinterpret_cast<const _Float16*>(w.aq16);
     const AttnTrainArgs none = {};

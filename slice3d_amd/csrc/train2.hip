@@ -665,14 +665,9 @@ static int launch_sample_bwd_t(const SampleBwdArgs& a, hipStream_t stream) {
         G.total = off;
         const size_t lds = (size_t)(LV::NU * 8 * 256 + off + 2 * FD::NF * SBT_CHUNK * 4) * sizeof(float);
         if (fits && lds <= 160 * 1024) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)sample_bwd_tiled_kernel<GT, false>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)sample_bwd_tiled_kernel<GT, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_set = true;
-            }
+            static std::atomic<unsigned long long> attr_done{0};
+            TRY_RET(s3d_set_max_lds(attr_done, {(const void*)sample_bwd_tiled_kernel<GT, false>,
+                                                (const void*)sample_bwd_tiled_kernel<GT, true>}, 160 * 1024));
             const long batch = a.groups / a.groups_per_batch;
             if (a.ws34_t16)
                 hipLaunchKernelGGL((sample_bwd_tiled_kernel<GT, true>), dim3((unsigned)(batch * a.n_slices * 256)), dim3(SBT_THREADS),

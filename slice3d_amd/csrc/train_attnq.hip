@@ -306,11 +306,8 @@ int launch_attn_bwd_q(const float* x, const float* d_o, float* dqkv, long groups
     if (groups <= 0) return 0;
     S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr && x && d_o && dqkv, "attn_bwd_q: T %d", T);
     const size_t lds = (size_t)(4 * AQ3_SLOT_HALFS) * 2 + 384 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    TRY_RET(s3d_set_max_lds(attr_done, {(const void*)attn_bwd_q_kernel}, lds));
     const long blocks = 2 * groups < 4096 ? 2 * groups : 4096;
     AttnBwdArgs a = {x, d_o, dqkv, d0};
     hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a, groups, T,

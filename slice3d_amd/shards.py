@@ -174,10 +174,15 @@ class ShardLoader:
             views = rng.integers(0, self.nv, len(ids)) if self.split == "train" else np.full(len(ids), min(4, self.nv - 1))
             yield self.make_batch(ids, views, batch_no=b)
 
-    def make_batch(self, ids, views, batch_no=0):
+    def make_batch(self, ids, views, *, batch_no=None):
         """The batch of shapes `ids` seen from `views` (both 1-D integer arrays).  batch_no = its index inside the epoch
         (the iterator passes it): with (seed, epoch, rank, item) it keys the train split's query subsets, so iterating an
-        epoch twice — or resuming in its middle — replays the same subsets."""
+        epoch twice — or resuming in its middle — replays the same subsets.  A direct caller (a custom sampler) that has no
+        batch index may leave it out: the key is then a hash of `ids` and `views`, so different batches still draw
+        different subsets and the same batch replays its own."""
+        if batch_no is None:
+            import zlib
+            batch_no = zlib.crc32(np.asarray(ids, dtype=np.int64).tobytes() + np.asarray(views, dtype=np.int64).tobytes())
         from . import _lib
         if self._lib is None:
             self._lib = _lib.load()

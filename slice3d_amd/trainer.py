@@ -317,7 +317,8 @@ class HipTrainer:
     # -- data-parallel exchange step ------------------------------------------------------------------
     def _exchange_on(self):
         """True when the collectives of the step must be issued: more than one rank — or S3D_FORCE_COLLECTIVES=1 inside an
-        initialised process group of ONE rank (test switch: pushes the bucketed gradient all-reduces through the
+        initialised process group of ONE rank (TEST-ONLY switch, read here so that tests/test_gpu_rccl.py can drive the
+        production step unchanged; it has no effect at world size > 1 and must not be set in a real job: pushes the bucketed gradient all-reduces through the
         event-ordered side stream and the sync-BN callback's collectives through RCCL on a single GPU; every sum over one
         rank is the identity, so the step's results do not change)."""
         if self._world() > 1:

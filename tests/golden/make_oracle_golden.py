@@ -1,0 +1,48 @@
+"""Writes tests/golden/oracle_*.npz: the CPU ORACLE's (oracle/ref_cpu.py) outputs for the slow fixed-seed cases of the GPU
+suite, so that the GPU box stops recomputing them in every `-m gpu` run (370 of 615 s in round 4).
+
+The numbers come from the very functions the tests call when a file is missing (or S3D_LIVE_ORACLE=1): this script imports
+the test modules and runs their `_oc_*` / `_*_oracle*` functions with S3D_LIVE_ORACLE=1, in the authoring container (CPU only;
+the full-size training case takes ~20-30 minutes of its 8 cores because of the fp64 pass).  Nothing here touches the
+reference: these are goldens of the ORACLE (itself pinned against the reference by tests/test_oracle.py and make_golden.py),
+and every family keeps a live oracle case in the suite.
+
+    python tests/golden/make_oracle_golden.py [case ...]        # default: all cases
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TESTS = os.path.dirname(HERE)
+ROOT = os.path.dirname(TESTS)
+sys.path[:0] = [ROOT, TESTS]
+os.environ["S3D_LIVE_ORACLE"] = "1"
+
+import torch  # noqa: E402
+
+import test_gpu_gt  # noqa: E402
+import test_gpu_parity  # noqa: E402
+import test_gpu_train  # noqa: E402
+from helpers import oracle_golden_path  # noqa: E402
+
+CASES = {
+    "full256": test_gpu_parity._oc_full256,
+    "white_s256_q6000": test_gpu_parity._oc_white,
+    "sweep24": test_gpu_parity._oc_sweep,
+    "gt_white_s128_q5000": test_gpu_gt._oc_gt_white,
+    "train_128_16k": test_gpu_train._big_case_oracle,
+    "smooth_b1_s128_q16384_n12": lambda: test_gpu_train._smooth_case_oracle(1, 128, 16384, 12),
+    "train_full_b4_s256": test_gpu_train._full_size_oracle_compact,
+}
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    for name in (sys.argv[1:] or list(CASES)):
+        t0 = time.time()
+        z = CASES[name]()
+        path = oracle_golden_path(name)
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in z.items()})
+        print("%-28s %6.1f s  %7.2f MB  %d arrays" % (name, time.time() - t0, os.path.getsize(path) / 1e6, len(z)), flush=True)

@@ -29,11 +29,11 @@ def _free_port():
     return p
 
 
-def _spawn(fn, *args):
+def _spawn(fn, *args, world=2):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=fn, args=(r, 2, port, ret) + args) for r in range(2)]
+    procs = [ctx.Process(target=fn, args=(r, world, port, ret) + args) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -42,16 +42,26 @@ def _spawn(fn, *args):
     return ret.get(timeout=10)
 
 
-def _train_worker(rank, world, port, ret, golden, sync_bn, overlap, prec):
+def _init(rank, world, port, backend):
+    """gloo: every rank on GPU 0 (one-GPU test box); nccl: one rank per GPU over RCCL (tests/test_gpu_multi.py)."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+
+
+def _train_worker(rank, world, port, ret, golden, sync_bn, overlap, prec, backend="gloo"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from helpers import check_grads_against_golden
     from slice3d_amd.models import Slices3DRegModel
     from slice3d_amd.trainer import HipTrainer
     from slice3d_amd.weights import load_seeded
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    _init(rank, world, port, backend)
     z = np.load(os.path.join(GOLDEN, golden + ".npz"))
     batch = {k: torch.from_numpy(z[k][rank:rank + 1]).cuda() for k in KEYS}
     m = load_seeded(Slices3DRegModel(n_slices=12, mode="train"), 0).cuda()
@@ -81,7 +91,7 @@ def _train_worker(rank, world, port, ret, golden, sync_bn, overlap, prec):
         msg = "ok worst %.2e" % worst
     except AssertionError as e:
         msg = "rank %d: %r" % (rank, e)
-    gathered = [None, None]
+    gathered = [None] * world
     dist.all_gather_object(gathered, msg)
     if rank == 0:
         ret.put(gathered)
@@ -103,23 +113,21 @@ def test_ddp_world2_sync_bn_reproduces_the_reference_full_batch(prec):
     assert all(m.startswith("ok") for m in msgs), msgs
 
 
-def _recon_worker(rank, world, port, ret):
+def _recon_worker(rank, world, port, ret, backend="gloo", cases=((64, 12, 2), (64, 40, 0))):
     from slice3d_amd.generator import Generator3D
     from slice3d_amd.models import Slices3DRegModel
     from slice3d_amd.synth import make_feed_dict
     from slice3d_amd.weights import load_seeded
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    model = load_seeded(Slices3DRegModel(n_slices=12, mode="test", prec="f16x3"), 0).cuda().eval()
-    fd = {k: v.cuda() for k, v in make_feed_dict(1, 64, 16, 12, seed=77, with_slices=False).items()}
+    _init(rank, world, port, backend)
     ok = True
-    for res0, ups in ((12, 2), (40, 0)):
+    for size, res0, ups in cases:
+        model = load_seeded(Slices3DRegModel(img_size=size, n_slices=12, mode="test", prec="f16x3"), 0).cuda().eval()
+        fd = {k: v.cuda() for k, v in make_feed_dict(1, size, 16, 12, seed=77, with_slices=False).items()}
         kw = dict(resolution0=res0, upsampling_steps=ups, pred_type="sdf")
         sharded = Generator3D(model, **kw).generate_value_grid(fd)                       # slabs + all_gather
         alone = Generator3D(model, shard_queries=False, **kw).generate_value_grid(fd)    # this rank does it all
         ok = ok and np.array_equal(sharded, alone)
-    t = torch.tensor([1.0 if ok else 0.0])
+    t = torch.tensor([1.0 if ok else 0.0], device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
         ret.put(float(t))

@@ -90,16 +90,25 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     cpu_baseline fields the driver and the judge read, whole-job value consistent with ms_per_step, parity inside."""
     import json
     out = run([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "1", "--n-qry", "4096",
-               "--img-size", "64", "--cpu-sample", "256", "--train-steps", "1", "--c4-steps", "1", "--c4-res", "32",
-               "--ldm-steps", "0", "--gt-train-steps", "0", "--f16-steps", "1", "--mesh-steps", "0"], ROOT)
+               "--img-size", "64", "--cpu-sample", "256", "--cpu-runs", "1", "--train-steps", "1", "--c4-steps", "1", "--c4-res", "32",
+               "--ldm-steps", "0", "--gt-train-steps", "0", "--f16-steps", "1", "--mesh-steps", "0", "--f32-steps", "1",
+               "--noise-steps", "2"], ROOT)
     lines = [ln for ln in out.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
+    assert len(lines[0]) < 4096, len(lines[0])         # the driver keeps ~2 KB of the tail: the line stays short
     r = json.loads(lines[0])
+    tail = lines[0][-2000:]                            # ... and the secondary results sit in that tail
+    for k in ("exact_f32_mode", "white_noise", "throughput_mode_f16", "c4_dense_grid", "ldm_denoise_step", "mesh_extraction",
+              "gt_train_step", "train_ms_per_step", "train_samples_per_s"):
+        assert '"%s":' % k in tail, k
+    for v in r.values():                               # prose lives in DESIGN.md, not in the line
+        assert not isinstance(v, str) or len(v) <= 160
+    assert all(len(v) <= 160 for d in (r["roofline"], r["cpu_baseline"], r["config"]) for v in d.values() if isinstance(v, str))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in r, k
     assert r["unit"] == "query-points/s" and r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1
-    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and r["data"] == "synthetic"
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and r["data"] == "synthetic-smooth"
     assert "workload" in r["config"] and "model" not in r["config"]
     assert abs(r["value"] - 4096 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
     rf = r["roofline"]
@@ -110,6 +119,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r["parity_vs_oracle"]["max_abs_err"] < r["parity_vs_oracle"]["tol"]
     assert r["train_samples_per_s"] > 0 and r["c4_dense_grid"]["query_points_per_s"] > 0
     assert r["throughput_mode_f16"]["max_abs_diff_vs_headline_mode"] > 0
+    assert r["exact_f32_mode"]["ms_per_step"] > 0 and r["exact_f32_mode"]["max_abs_diff_vs_headline_mode"] < 1e-4
+    wn = r["white_noise"]
+    assert wn["noise"]["ms_per_step"] > 0 and wn["smooth"]["ms_per_step"] > 0 and wn["query_points_per_s"] > 0
+    assert r["ms_per_step_rank_min_max"][0] <= r["ms_per_step_rank_min_max"][1]
 
 
 def test_bench_self_launches_two_ranks_on_one_gpu():
@@ -123,7 +136,8 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
                         "--n-qry", "4096", "--img-size", "64", "--cpu-sample", "0", "--train-steps", "1", "--c4-steps", "1",
-                        "--c4-res", "32", "--ldm-steps", "1", "--gt-train-steps", "0", "--f16-steps", "0", "--mesh-steps", "0"],
+                        "--c4-res", "32", "--ldm-steps", "1", "--gt-train-steps", "0", "--f16-steps", "0", "--mesh-steps", "0",
+                        "--f32-steps", "0", "--noise-steps", "0"],
                        cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -132,6 +146,8 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["steps"] == 2
     assert abs(res["value"] - 2 * 4096 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
     c4 = res["c4_dense_grid"]
-    assert c4["n_gpus"] == 2 and c4["scaling"] == "strong" and "slab" in c4["split"] and c4["query_points_per_s"] > 0
+    assert c4["n_gpus"] == 2 and c4["scaling"] == "strong" and c4["query_points_per_s"] > 0
     assert res["ldm_denoise_step"]["n_gpus"] == 2 and res["ldm_denoise_step"]["steps_per_s_all_gpus"] > 0
     assert res["train_samples_per_s"] > 0 and "roofline" in res
+    lo, hi = res["ms_per_step_rank_min_max"]            # per-rank times: a straggler is visible in the line
+    assert 0 < lo <= hi and abs(hi - res["ms_per_step"]) < 1e-3 * hi

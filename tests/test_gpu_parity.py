@@ -45,6 +45,86 @@ def to_gpu(fd):
     return {k: v.cuda() for k, v in fd.items()}
 
 
+def _oracle_case(name, compute):
+    """Oracle outputs of a fixed-seed case as a dict of numpy arrays: the committed tests/golden/oracle_<name>.npz (written
+    by tests/golden/make_oracle_golden.py from `compute` itself) or, without the file / with S3D_LIVE_ORACLE=1, computed
+    here.  Shared by the precision-parametrised tests."""
+    from helpers import load_oracle_golden
+    if name not in _oracle_cache:
+        z = load_oracle_golden(name)
+        _oracle_cache[name] = compute() if z is None else z
+    return _oracle_cache[name]
+
+
+def _probe(x, phase=0, step=4):
+    """The strided pixel probe the oracle goldens keep of an image tensor (..., H, W)."""
+    return x[..., (1 + phase) % step::step, (2 + phase) % step::step]
+
+
+def _c4_indices(nx=256):
+    """Grid indices of the dense-grid test: 4096 random ones, the 8 corners, both sides of every 262 144-query pass boundary,
+    512 of the last pass, the last index."""
+    n = nx ** 3
+    rng = np.random.default_rng(5)
+    corners = [(ix * nx + iy) * nx + iz for ix in (0, nx - 1) for iy in (0, nx - 1) for iz in (0, nx - 1)]
+    edges = [k * 262144 + d for k in range(1, 64) for d in (-1, 0)]
+    return np.unique(np.concatenate([rng.choice(n, 4096, replace=False), corners, edges,
+                                     rng.integers(n - 262144, n, 512), [n - 1]])).astype(np.int64)
+
+
+def _c4_points(idx, nx=256):
+    idx_t = torch.from_numpy(idx)
+    lin = torch.linspace(-0.5, 0.5, nx)
+    return torch.stack([lin[idx_t // (nx * nx)], lin[(idx_t // nx) % nx], lin[idx_t % nx]], -1).unsqueeze(0)
+
+
+def _oc_full256():
+    """Oracle at BASELINE configs[1]'s inference shape (256^2 x 12 slices, seed 2024): sdf on the 4096-query subset of the
+    full-size test, slices_rec on the pixel probe, and sdf on the dense-grid test's indices (same image, same pyramid)."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    sd = seeded_sd_from_shapes(_shapes(12))
+    fd = make_feed_dict(1, 256, 100000, 12, seed=2024, with_slices=False)
+    idx = torch.from_numpy(np.random.default_rng(0).choice(100000, 4096, replace=False))
+    with torch.no_grad():
+        feats, rec = ref_cpu.unet_forward(sd, fd["img_input"], 12)
+        qr = ref_cpu.rotate_queries({"qry_norot": fd["qry_norot"][:, idx]}, "test")
+        sub = ref_cpu.decode_points(sd, feats, qr, fd["trans_mat_wo_rot_tp"], 12)
+        qc = ref_cpu.rotate_queries({"qry_norot": _c4_points(_c4_indices())}, "test")
+        c4 = ref_cpu.decode_points(sd, feats, qc, fd["trans_mat_wo_rot_tp"], 12)
+    return {"sdf_sub": sub.numpy(), "rec_probe": _probe(rec).contiguous().numpy(), "c4_sdf": c4.reshape(-1).numpy()}
+
+
+def _oc_white():
+    """fp32 and fp64 oracle on SURVEY 8(d)'s white-noise inputs (seed 1234, 256^2, 6000 queries)."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    fd = make_feed_dict(1, 256, 6000, 12, seed=1234, smooth=False, with_slices=False)
+    sd = seeded_sd_from_shapes(_shapes(12))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    r32 = ref_cpu.forward(sd, fd, mode="test", n_slices=12, with_vgg=False)
+    r64 = ref_cpu.forward(sd64, {k: v.double() for k, v in fd.items()}, mode="test", n_slices=12, with_vgg=False)
+    return {"sdf32": r32["sdf_pred"].numpy(), "sdf64": r64["sdf_pred"].numpy(),
+            "rec64_probe": _probe(r64["slices_rec"]).contiguous().numpy(),      # float64
+            "e_img_ref": np.array([float((r32["slices_rec"].double() - r64["slices_rec"]).abs().max())])}
+
+
+SWEEP_SEED, SWEEP_N = 20260928, 24
+
+
+def _oc_sweep():
+    """Oracle outputs of the 24 sweep shapes: sdf whole, slices_rec on the pixel probe (phase = case index)."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    z = {}
+    for i, (b, s, q, ns, mode) in enumerate(_sweep_cases(SWEEP_SEED, SWEEP_N)):
+        fd = make_feed_dict(b, s, q, ns, seed=7000 + i, with_slices=False)
+        ref = ref_cpu.forward(seeded_sd_from_shapes(_shapes(ns)), fd, mode=mode, n_slices=ns, with_vgg=False)
+        z["sdf:%d" % i] = ref["sdf_pred"].numpy()
+        z["rec:%d" % i] = _probe(ref["slices_rec"], i).contiguous().numpy()
+    return z
+
+
 def test_native_library_is_loaded():
     from slice3d_amd import _lib
     lib = _lib.load()
@@ -148,27 +228,20 @@ def test_forward_matches_oracle(b, s, q, ns, mode, prec):
 
 @pytest.mark.parametrize("prec", PRECS)
 def test_full_size_256_matches_oracle(prec):
-    """BASELINE configs[1] shape: 256^2 x 12 slices; 100k queries decoded on the GPU, a 4096-query
-    subset checked against the oracle (the oracle needs ~2 s for the U-Net + ~1 s for 4096 queries)."""
-    from oracle import ref_cpu
+    """BASELINE configs[1] shape: 256^2 x 12 slices; 100k queries decoded on the GPU, a 4096-query subset and every fourth
+    pixel of slices_rec checked against the oracle (committed outputs: _oc_full256)."""
     from slice3d_amd.synth import make_feed_dict
     model = get_model(12, "test", prec)
-    sd = seeded_sd_from_shapes(_shapes(12))
     fd = make_feed_dict(1, 256, 100000, 12, seed=2024, with_slices=False)
     out = model(to_gpu(fd))
     sdf = out["sdf_pred"].cpu()
     assert sdf.shape == (1, 100000) and torch.isfinite(sdf).all()
     idx = torch.from_numpy(np.random.default_rng(0).choice(100000, 4096, replace=False))
-    if "full256" not in _oracle_cache:
-        fd_sub = dict(fd)
-        fd_sub["qry_norot"] = fd["qry_norot"][:, idx]
-        with torch.no_grad():
-            feats, rec = ref_cpu.unet_forward(sd, fd["img_input"], 12)
-            qr = ref_cpu.rotate_queries(fd_sub, "test")
-            _oracle_cache["full256"] = (feats, rec, ref_cpu.decode_points(sd, feats, qr, fd["trans_mat_wo_rot_tp"], 12))
-    feats, rec, ref = _oracle_cache["full256"]
-    assert (sdf[:, idx] - ref).abs().max() < TOL
-    assert (out["slices_rec"].cpu().view(12, 3, 256, 256) - rec).abs().max() < TOL
+    z = _oracle_case("full256", _oc_full256)
+    assert (sdf[:, idx] - torch.from_numpy(z["sdf_sub"])).abs().max() < TOL
+    rec = out["slices_rec"].cpu().view(12, 3, 256, 256)
+    assert torch.isfinite(rec).all()
+    assert (_probe(rec) - torch.from_numpy(z["rec_probe"])).abs().max() < TOL
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -240,6 +313,45 @@ def test_decode_is_bit_reproducible_run_to_run(prec):
         first = model.decode_sdf(fd["qry_norot"], code).clone()
         for _ in range(8):
             assert torch.equal(model.decode_sdf(fd["qry_norot"], code), first)
+
+
+def test_two_decode_lanes_and_smaller_passes_give_the_same_bits():
+    """The pass of >= 131 072 queries is decoded as two halves whose layer chains run on the caller's stream and on the
+    library's side stream (s3d_decode_set_lanes, api.hip): same bits as everything on one stream, and as a decode whose
+    workspace only allows smaller passes (s3d_decode_workspace_bytes_min: the pass is halved until it fits); a workspace
+    below the minimum is refused loudly."""
+    import ctypes as C
+    from slice3d_amd import _lib
+    from slice3d_amd.synth import make_feed_dict
+    lib = _lib.load()
+    model = get_model(12, "test", "f16x3")
+    fd = to_gpu(make_feed_dict(2, 64, 150000, 12, seed=31, with_slices=False))
+    code = model.encode(fd)
+    try:
+        assert lib.s3d_decode_set_lanes(1) == 0
+        one = model.decode_sdf(fd["qry_norot"], code).clone()
+        assert lib.s3d_decode_set_lanes(2) == 0
+        for _ in range(3):
+            assert torch.equal(model.decode_sdf(fd["qry_norot"], code), one)
+        assert lib.s3d_decode_set_lanes(3) != 0
+    finally:
+        lib.s3d_decode_set_lanes(1)
+    b, q = 2, 150000
+    full, small = lib.s3d_decode_workspace_bytes(b, q, 12), lib.s3d_decode_workspace_bytes_min(b, q, 12)
+    assert small < full
+    out = torch.empty((b, q), dtype=torch.float32, device="cuda")
+    tm = fd["trans_mat_wo_rot_tp"]
+    for nbytes, ok in ((small, True), ((small + full) // 2, True), (small - 4096, False)):
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda")
+        out.zero_()
+        rc = lib.s3d_decode_points_fwd(model._head_packed.data_ptr(), C.byref(code._latent_struct), fd["qry_norot"].data_ptr(),
+                                       None, tm.data_ptr(), 1, out.data_ptr(), b, q, 12, model.prec, ws.data_ptr(), nbytes,
+                                       None)
+        torch.cuda.synchronize()
+        if ok:
+            assert rc == 0 and torch.equal(out, one), nbytes
+        else:
+            assert rc != 0 and b"workspace" in lib.s3d_last_error()
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -444,37 +556,19 @@ def test_dense_256_cubed_grid_matches_oracle(prec):
     through s3d_decode_grid_fwd (64 passes of 262 144 in-kernel coordinates), copied to the host like
     Generator3D does, and checked against the oracle on 4096 random grid indices plus the 8 corners, both
     sides of every pass boundary and 512 indices of the last pass."""
-    from oracle import ref_cpu
     from slice3d_amd.synth import make_feed_dict
     model = get_model(12, "test", prec)
-    sd = seeded_sd_from_shapes(_shapes(12))
     fd = make_feed_dict(1, 256, 16, 12, seed=2024, with_slices=False)   # same image as the full-size test
     nx = 256
-    n = nx ** 3
     code = model.encode(to_gpu(fd))
     grid = model.decode_grid(code, nx)
     torch.cuda.synchronize()
     g = grid.cpu()
     assert g.shape == (nx, nx, nx) and torch.isfinite(g).all()
-    rng = np.random.default_rng(5)
-    corners = [(ix * nx + iy) * nx + iz for ix in (0, nx - 1) for iy in (0, nx - 1) for iz in (0, nx - 1)]
-    edges = [k * 262144 + d for k in range(1, 64) for d in (-1, 0)]
-    idx = np.unique(np.concatenate([rng.choice(n, 4096, replace=False), corners, edges,
-                                    rng.integers(n - 262144, n, 512), [n - 1]])).astype(np.int64)
+    idx = _c4_indices(nx)
     idx_t = torch.from_numpy(idx)
-    lin = torch.linspace(-0.5, 0.5, nx)
-    pts = torch.stack([lin[idx_t // (nx * nx)], lin[(idx_t // nx) % nx], lin[idx_t % nx]], -1).unsqueeze(0)
-    if "full256" in _oracle_cache:
-        feats = _oracle_cache["full256"][0]
-    else:
-        with torch.no_grad():
-            feats, _ = ref_cpu.unet_forward(sd, fd["img_input"], 12)
-    key = "c4_ref"
-    if key not in _oracle_cache:
-        qr = ref_cpu.rotate_queries({"qry_norot": pts}, "test")
-        with torch.no_grad():
-            _oracle_cache[key] = ref_cpu.decode_points(sd, feats, qr, fd["trans_mat_wo_rot_tp"], 12)
-    ref = _oracle_cache[key]
+    pts = _c4_points(idx, nx)
+    ref = torch.from_numpy(_oracle_case("full256", _oc_full256)["c4_sdf"])
     err = float((g.reshape(-1)[idx_t] + ref.reshape(-1)).abs().max())      # grid holds logits = -sdf
     print("dense 256^3 (%s): max |grid + oracle sdf| over %d indices = %.3e" % (prec, len(idx), err))
     assert err < TOL, err
@@ -490,29 +584,22 @@ def test_white_noise_images_within_the_reference_rounding_floor(prec):
     by ~1e-4 in ANY fp32 evaluation, the reference included.  The gate is therefore stated against an fp64
     evaluation of the oracle:  max|hip - ref_fp64| <= max|ref_fp32 - ref_fp64| + eps  (eps = 5e-5, half the
     smooth-image tolerance), and the median error must be fp32-class (< 1e-5)."""
-    from oracle import ref_cpu
     from slice3d_amd.synth import make_feed_dict
     model = get_model(12, "test", prec)
-    if "white" not in _oracle_cache:
-        fd = make_feed_dict(1, 256, 6000, 12, seed=1234, smooth=False, with_slices=False)   # SURVEY 8(d) seed and size
-        sd = seeded_sd_from_shapes(_shapes(12))
-        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-        fd64 = {k: v.double() for k, v in fd.items()}
-        r32 = ref_cpu.forward(sd, fd, mode="test", n_slices=12, with_vgg=False)
-        r64 = ref_cpu.forward(sd64, fd64, mode="test", n_slices=12, with_vgg=False)
-        _oracle_cache["white"] = (fd, r32, r64)
-    fd, r32, r64 = _oracle_cache["white"]
+    fd = make_feed_dict(1, 256, 6000, 12, seed=1234, smooth=False, with_slices=False)   # SURVEY 8(d) seed and size
+    z = _oracle_case("white_s256_q6000", _oc_white)
+    r32, r64 = torch.from_numpy(z["sdf32"]).double(), torch.from_numpy(z["sdf64"])
     out = model(to_gpu(fd))
     hip = out["sdf_pred"].cpu().double()
-    e_hip = (hip - r64["sdf_pred"]).abs()
-    e_ref = (r32["sdf_pred"].double() - r64["sdf_pred"]).abs()
+    e_hip = (hip - r64).abs()
+    e_ref = (r32 - r64).abs()
     print("white noise (%s): max|hip-f64| %.3e  max|ref32-f64| %.3e  median %.3e / %.3e" %
           (prec, float(e_hip.max()), float(e_ref.max()), float(e_hip.median()), float(e_ref.median())))
     assert float(e_hip.max()) <= float(e_ref.max()) + 5e-5
     assert float(e_hip.median()) < 1e-5
-    e_img = (out["slices_rec"].cpu().double() - r64["slices_rec"]).abs().max()
-    e_img_ref = (r32["slices_rec"].double() - r64["slices_rec"]).abs().max()
-    assert float(e_img) <= float(e_img_ref) + 5e-5
+    assert torch.isfinite(out["slices_rec"]).all()
+    e_img = (_probe(out["slices_rec"].cpu().double()) - torch.from_numpy(z["rec64_probe"])).abs().max()
+    assert float(e_img) <= float(z["e_img_ref"][0]) + 5e-5       # e_img_ref: the fp32 oracle's distance over ALL pixels
 
 
 def test_single_pass_f16_throughput_mode_runs_and_reports_its_error():
@@ -556,21 +643,25 @@ def _sweep_cases(seed, n):
 def test_shape_sweep_matches_oracle(prec):
     """24 shapes drawn from a fixed seed (new ones each round would make the suite a moving target): the C-ABI path against
     the oracle on every one of them, in both arithmetic modes."""
-    from oracle import ref_cpu
     from slice3d_amd.synth import make_feed_dict
     worst = 0.0
-    n_cases = int(os.environ.get("S3D_SWEEP_N", "24"))   # a longer one-off sweep: S3D_SWEEP_N=200 (profiles/r02_shape_sweep.md)
-    for i, (b, s, q, ns, mode) in enumerate(_sweep_cases(20260928, n_cases)):
+    n_cases = int(os.environ.get("S3D_SWEEP_N", str(SWEEP_N)))   # a longer one-off sweep: S3D_SWEEP_N=200 (profiles/r02_shape_sweep.md)
+    z = _oracle_case("sweep24", _oc_sweep) if n_cases == SWEEP_N else None     # committed oracle outputs of the 24 shapes
+    for i, (b, s, q, ns, mode) in enumerate(_sweep_cases(SWEEP_SEED, n_cases)):
         model = get_model(ns, mode, prec)
-        key = ("sweep", i)
-        if key not in _oracle_cache:
-            sd = seeded_sd_from_shapes(_shapes(ns))
-            fd = make_feed_dict(b, s, q, ns, seed=7000 + i, with_slices=False)
-            _oracle_cache[key] = (fd, ref_cpu.forward(sd, fd, mode=mode, n_slices=ns, with_vgg=False))
-        fd, ref = _oracle_cache[key]
+        fd = make_feed_dict(b, s, q, ns, seed=7000 + i, with_slices=False)
+        if z is not None:
+            ref_sdf, ref_rec = torch.from_numpy(z["sdf:%d" % i]), torch.from_numpy(z["rec:%d" % i])
+        else:
+            from oracle import ref_cpu
+            key = ("sweep", i)
+            if key not in _oracle_cache:
+                _oracle_cache[key] = ref_cpu.forward(seeded_sd_from_shapes(_shapes(ns)), fd, mode=mode, n_slices=ns, with_vgg=False)
+            ref_sdf, ref_rec = _oracle_cache[key]["sdf_pred"], _probe(_oracle_cache[key]["slices_rec"], i)
         out = model(to_gpu(fd))
-        e_sdf = float((out["sdf_pred"].cpu() - ref["sdf_pred"]).abs().max())
-        e_img = float((out["slices_rec"].cpu() - ref["slices_rec"]).abs().max())
+        assert torch.isfinite(out["slices_rec"]).all()
+        e_sdf = float((out["sdf_pred"].cpu() - ref_sdf).abs().max())
+        e_img = float((_probe(out["slices_rec"].cpu(), i) - ref_rec).abs().max())
         assert e_sdf < TOL and e_img < TOL, ((b, s, q, ns, mode), e_sdf, e_img)
         worst = max(worst, e_sdf, e_img)
     print("shape sweep (%s): worst deviation %.2e over %d shapes" % (prec, worst, n_cases))

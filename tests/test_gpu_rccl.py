@@ -116,7 +116,7 @@ def test_bench_prints_its_contract_as_one_rccl_rank_under_the_launcher():
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
            "--warmup", "1", "--img-size", "64", "--n-qry", "4096", "--batch", "1", "--cpu-sample", "0", "--f16-steps", "0",
            "--c4-steps", "0", "--mesh-steps", "0", "--ldm-steps", "0", "--train-steps", "1", "--gt-train-steps", "0",
-           "--pmc", "0"]
+           "--pmc", "0", "--f32-steps", "0", "--noise-steps", "0"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", S3D_FORCE_COLLECTIVES="1", OMP_NUM_THREADS="8")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
