@@ -523,6 +523,19 @@ def main():
         lms4, _ = time_ldm(lx4, lt4, lc4)
         ldm["batch4_ms_per_step"] = lms4
         ldm["batch4_tflops_algorithmic"] = 4 * 0.222 / lms4 * 1e3
+        # the precision configs[4] names: single-pass f16 convolutions (prec='f16'), with its deviation from the headline mode
+        if args.prec == "f16x3":
+            with torch.no_grad():
+                ref_out = um(lx, lt, c_fmaps=lc)
+            del um
+            um = load_seeded(UNetModel(prec="f16", **cfg), 0).cuda().eval()
+            lms16, _ = time_ldm(lx, lt, lc)
+            with torch.no_grad():
+                o16 = um(lx, lt, c_fmaps=lc)
+            ldm["f16_ms_per_step"] = lms16
+            ldm["f16_tflops_algorithmic"] = 0.222 / lms16 * 1e3
+            ldm["f16_max_abs_diff_vs_headline_mode"] = float((o16 - ref_out).abs().max())
+            del o16, ref_out
         del um, lx, lc, lx4, lc4
         # the 128 x 128 latent of 256^2 slice generation (configs[4]): convolutions x4, the 16 384-token attention x16
         um = load_seeded(UNetModel(prec=args.prec, **dict(cfg, image_size=128)), 0).cuda().eval()

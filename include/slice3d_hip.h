@@ -261,8 +261,22 @@ int s3d_conv_pack(const float* w, const float* bias, int cout, int cin0, int cin
 int s3d_conv_fwd(const void* packed, const float* x0, const float* x1, const float* residual, float* out, int N,
                  int H, int W, int cout, int cin0, int cin1, int ks, int prec, void* workspace,
                  size_t workspace_bytes, void* stream);
+/* GroupNorm32 -> [FiLM] -> [SiLU] -> Conv2d(3x3) as ONE operator (openaimodel.py:188-194 ResBlock.in_layers, :229-236
+ * out_layers with use_scale_shift_norm): s3d_group_norm_stats_fwd writes the partial moments of cat([x0, x1]) into `stats`
+ * (s3d_group_norm_stats_floats(N, groups) floats, layout private to the library), s3d_conv_gn_fwd normalises while it stages
+ * its input tile — the normalised tensor is never written.  Served for ks == 3, split precision (f16x3 / f16), cin0, cin1,
+ * cout multiples of 32, cin0 + cin1 <= 1536, groups <= 32; other shapes are refused with S3D_E_ARG (use
+ * s3d_group_norm_fwd + s3d_conv_fwd).  film: (N, film_stride >= 2 (cin0 + cin1)) rows of scale | shift, or NULL. */
+size_t s3d_group_norm_stats_floats(int N, int groups);
+int s3d_group_norm_stats_fwd(const float* x0, int c0, const float* x1, int c1, float* stats, int N, int HW, int groups,
+                             void* stream);
+int s3d_conv_gn_fwd(const void* packed, const float* x0, const float* x1, const float* residual, float* out, int N, int H,
+                    int W, int cout, int cin0, int cin1, int ks, int prec, const float* stats, const float* gamma,
+                    const float* beta, const float* film, long film_stride, int groups, float eps, int silu, void* workspace,
+                    size_t workspace_bytes, void* stream);
 /* GroupNorm32 (util.py normalization) [+ FiLM: y*(1+scale)+shift, film = (N, 2C), openaimodel.py:268-270] [+ SiLU].
- * stats: N*groups*200 floats of scratch (mean / rstd per group, then the per-slice partial moments). */
+ * stats: s3d_group_norm_stats_floats(N, groups) floats of scratch (N*groups*192 since round 4; a smaller buffer is
+ * overrun silently — size it with the function). */
 int s3d_group_norm_fwd(const float* x, const float* gamma, const float* beta, const float* film, float* y,
                        float* stats, int N, int HW, int C, int groups, float eps, int silu, void* stream);
 /* the same with film rows read in place from a wider tensor: image n's (scale | shift) at film + n * film_stride floats

@@ -843,8 +843,10 @@ static int rows_linear(const float* b, size_t w32, size_t w16, int n, int k, con
 
 // X [gc][T][16][128] (input of the last layer) -> X0 [gc*16][128] = LN1(x0 + out_proj(attention of token 0)),
 // see launch_attn_last_mix.  scratch: gc*16*S3D_LAST_ROW_FLOATS floats.
+// fold_ln: X0 receives the pre-LayerNorm sums u and the caller's final FFN kernel normalises them in its prologue
+// (launch_ffn_layer(..., pre_ln1 = true): the ln_fwd launch and one round trip of the token-0 rows are gone)
 static int attn_last_layer(const float* b, const HeadLayout& H, const LayerPtrs& lp, const float* X, float* X0, long gc,
-                           int T, float* scratch, int prec, hipStream_t st) {
+                           int T, float* scratch, int prec, hipStream_t st, bool fold_ln = false) {
     const long rows0 = gc * S3D_GROUP;
     float* x0 = scratch;
     float* u = x0 + rows0 * 128;
@@ -853,8 +855,8 @@ static int attn_last_layer(const float* b, const HeadLayout& H, const LayerPtrs&
     TRY(launch_tok0_copy(const_cast<float*>(X), x0, gc, T, 0, 128, st));
     TRY(rows_linear(b, H.last.wm, H.last.wm16, 512, 128, b + H.last.bm, x0, rows0, qt, nullptr, prec, st));
     TRY(launch_attn_last_mix(X, qt, xbar, gc, T, st));
-    TRY(rows_linear(b, H.last.wn, H.last.wn16, 128, 512, b + H.last.bn, xbar, rows0, u, x0, prec, st));
-    return launch_ln_fwd(u, lp.ln1g, lp.ln1b, X0, rows0, st);
+    TRY(rows_linear(b, H.last.wn, H.last.wn16, 128, 512, b + H.last.bn, xbar, rows0, fold_ln ? X0 : u, x0, prec, st));
+    return fold_ln ? 0 : launch_ln_fwd(u, lp.ln1g, lp.ln1b, X0, rows0, st);
 }
 
 static int decode_impl(const void* head_packed, const S3dLatent* lat, const float* qry, const float* rot,
@@ -910,6 +912,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
             return (int)hipErrorUnknown;
         }
         // the three encoder layers + fc_out on groups [gs, gs + gn) of this pass, enqueued on stream s
+        const bool fold_ln = prec != S3D_PREC_F32;   // LayerNorm1 of the last layer in the final FFN kernel's prologue
         auto run_layers = [&](hipStream_t s, long gs, long gn, hipEvent_t after_first_attn) -> int {
             float* Xs = X + (size_t)gs * T * S3D_GROUP * 128;
             float* X0s = X0 + (size_t)gs * S3D_GROUP * 128;
@@ -920,7 +923,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
                 {
                     ProfScope prof_(S3D_PROF_ATTN, s);
                     if (last)          // only token 0 of the last layer is consumed (models.py:83): absorbed form, every mode
-                        TRY(attn_last_layer(b, H, lp, Xs, X0s, gn, T, lasts, prec, s));
+                        TRY(attn_last_layer(b, H, lp, Xs, X0s, gn, T, lasts, prec, s, fold_ln));
                     else if (prec != S3D_PREC_F32)
                         TRY(launch_attn_layer_q(Xs, gn, T, lp, s, prec == S3D_PREC_F16));
                     else
@@ -943,7 +946,9 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
                     if (stages) {   // the final kernel keeps the layer's output rows in registers (LayerNorm -> fc_out): the capture
                                     // runs the full-row form of the same kernel on a copy of the token-0 rows
                         float* d = stages + rows_all + (size_t)l * rows0_all;
-                        if (hipMemcpyAsync(d, X0s, rows0_all * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                        if (fold_ln) {   // X0 holds the pre-LayerNorm sums (the final kernel normalises them itself): the capture's copy is normalised here
+                            TRY(launch_ln_fwd(X0s, lp.ln1g, lp.ln1b, d, gn * S3D_GROUP, s));
+                        } else if (hipMemcpyAsync(d, X0s, rows0_all * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
                             s3d_set_error("decode stages: memcpy failed");
                             return (int)hipErrorUnknown;
                         }
@@ -951,7 +956,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
                                              nullptr, s));
                     }
                     TRY(launch_ffn_layer(X0s, gn * S3D_GROUP, lp, b + H.fco_w, b + H.fco_b, out, sign, gpb, n_qry, g0 + gs,
-                                         prec, perm, s));
+                                         prec, perm, s, fold_ln));
                 }
             }
             return 0;

@@ -13,6 +13,23 @@ struct ConvSrc {
     int bdiv, bmod, sbcast;
 };
 
+// GroupNorm (+ FiLM) (+ SiLU) of a convolution's INPUT, applied while the LDS-staged 3x3 kernel parks its input tile (round 5:
+// the latent-diffusion U-Net's GN -> SiLU -> conv3x3 chains, openaimodel.py:188-194,229-236).  The statistics come as the
+// partial moments the GroupNorm statistics kernels write; every workgroup merges the moments of its image (Chan's formula,
+// as gn_apply_kernel does) into a per-channel affine table in LDS, so no normalised tensor is written or read.
+#define S3D_GN_SLICES 64
+#define S3D_GN_CMAX 1536     // channels of the widest GroupNorm input of the LDM U-Net (768 + 768 skip concat)
+struct ConvGn {
+    const float* part;    // [N * groups][S3D_GN_SLICES][3] = (count, mean, M2) per pixel slab; NULL = no GroupNorm
+    const float* gamma;   // [C]
+    const float* beta;    // [C]
+    const float* film;    // optional (N, film_ld): scale[C] | shift[C] ->  y * (1 + scale) + shift
+    long film_ld;
+    int groups;
+    float eps;
+    int silu;
+};
+
 enum { S3D_ACT_NONE = 0, S3D_ACT_RELU = 1, S3D_ACT_TANH = 2 };
 enum { S3D_OUT_NHWC = 0, S3D_OUT_CONVT = 1, S3D_OUT_NCHW = 2 };
 
@@ -45,6 +62,7 @@ struct ConvLaunch {
     float* splitk_ws;    // optional scratch for split-K partial sums (few-pixel deep layers); NULL = never split
     size_t splitk_floats;
     DropCfg drop;        // NHWC mode only: v *= dropout mask (index = output element index), before the residual
+    ConvGn gn;           // LDS-staged 3x3 kernel only (launch_conv refuses it elsewhere): GroupNorm of the input, see ConvGn
 };
 
 int launch_conv(const ConvLaunch& a, hipStream_t stream);

@@ -774,12 +774,15 @@ static int launch_lin_stream(const ConvLaunch& a, hipStream_t stream) {
 // one buffer (22.5 KiB, seven workgroups per CU) for layers whose K is one or two chunks — there a workgroup's life is a
 // fetch, a split and 108-216 MFMAs per wave, nothing overlaps inside it, and what hides the fetch latency is the number
 // of OTHER workgroups on the CU (the 32- and 64-channel layers at full resolution: 0.51 / 0.34 ms -> see DESIGN.md).
-template <int MT, int WP, int WC, int NBUF>
+template <int MT, int WP, int WC, int NBUF, bool GN = false>
 __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch a, int tiles_x, int tiles_y,
                                                                 int chunks_per_split) {
     static_assert(MT * WP == 8 && WP * WC == 4, "tile is 8 rows, 4 waves");
     constexpr int NT = 2, CO_WG = WC * NT * 16;
     __shared__ __attribute__((aligned(16))) _Float16 s_in[NBUF][2][C3_HALO * C3_PXS];   // [buf][hi|lo]
+    // GN: per-channel affine table of this image's GroupNorm (+ FiLM), A | B, and the merged (mean, rstd) per group
+    __shared__ __attribute__((aligned(16))) float s_gn[GN ? 2 * S3D_GN_CMAX : 4];
+    __shared__ float s_gst[GN ? 64 : 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int wp = wave % WP, wc = wave / WP;
@@ -806,8 +809,12 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
     constexpr int NSLOT = C3_HALO * 8;              // 1440 float4 per chunk
     constexpr int NPRE = (NSLOT + 255) / 256;       // 6
     f32x4 pre[NPRE];
-    auto fetch = [&](const ConvSrc& S, int c) {
+    unsigned pre_ok = 0u;     // GN: which of the prefetched slots lie inside the image (zero padding pads the NORMALISED input)
+    int pre_cb = 0;           // GN: first channel of the prefetched chunk in the concatenated input
+    auto fetch = [&](const ConvSrc& S, int c, int cbase) {
         const int ni = (S.bmod ? n % S.bmod : n) / S.bdiv;
+        pre_ok = 0u;
+        pre_cb = cbase + 32 * c;
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
             const int slot = threadIdx.x + 256 * i;
@@ -818,6 +825,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
             const long off = ((long)(ni * a.H + (ok ? y : 0)) * a.W + (ok ? x : 0)) * S.C + 32 * c + 4 * q4;
             const f32x4 v = ld4(S.p + off);           // always a valid address; masked below
             pre[i] = ok ? v : zero4();
+            if (GN && ok) pre_ok |= 1u << i;
         }
     };
     auto park = [&](int buf) {
@@ -827,6 +835,16 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
             const int slot = threadIdx.x + 256 * i;
             if (slot < NSLOT) {
                 const int pix = slot >> 3, q4 = slot & 7;
+                if (GN) {   // y = x * A[c] + B[c] (GroupNorm, gamma / beta, FiLM folded), SiLU; outside the image: 0
+                    const f32x4 A = ld4(s_gn + pre_cb + 4 * q4), B = ld4(s_gn + S3D_GN_CMAX + pre_cb + 4 * q4);
+                    f32x4 t = pre[i] * A + B;
+                    if (a.gn.silu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            t[e] = t[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t[e]));
+                    }
+                    pre[i] = (pre_ok >> i) & 1u ? t : zero4();
+                }
                 half4_t hi, lo;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -846,7 +864,62 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
     // split-K: blockIdx.y owns chunks [ch_lo, ch_hi) and writes raw partial sums (deep layers have few pixels)
     const int ch_lo = blockIdx.y * chunks_per_split;
     const int nchunk = min(cu0 + cu1, ch_lo + chunks_per_split);
-    fetch(a.src[ch_lo < cu0 ? 0 : 1], ch_lo < cu0 ? ch_lo : ch_lo - cu0);
+    fetch(a.src[ch_lo < cu0 ? 0 : 1], ch_lo < cu0 ? ch_lo : ch_lo - cu0, ch_lo < cu0 ? 0 : a.src[0].C);
+    if (GN) {
+        // merge this image's slab moments per group (eight lanes per group, then three pairwise Chan merges: gn_apply_kernel's
+        // scheme), then the affine table of all input channels; the first chunk's loads are in flight meanwhile
+        const int Ct = a.src[0].C + (a.nsrc > 1 ? a.src[1].C : 0), groups = a.gn.groups, cpg = Ct / groups;
+        for (int i0 = 0; i0 < groups; i0 += 32) {
+            const int i = i0 + (threadIdx.x >> 3), j = threadIdx.x & 7;
+            float cnt = 0.f, mean = 0.f, m2 = 0.f;
+            if (i < groups) {
+                float nb[S3D_GN_SLICES / 8], mb[S3D_GN_SLICES / 8], qb[S3D_GN_SLICES / 8];
+#pragma unroll
+                for (int k = 0; k < S3D_GN_SLICES / 8; ++k) {
+                    const float* q = a.gn.part + 3 * ((size_t)(n * groups + i) * S3D_GN_SLICES + j + 8 * k);
+                    nb[k] = q[0]; mb[k] = q[1]; qb[k] = q[2];
+                }
+#pragma unroll
+                for (int k = 0; k < S3D_GN_SLICES / 8; ++k) {
+                    if (nb[k] == 0.f) continue;
+                    const float tot = cnt + nb[k], d = mb[k] - mean;
+                    mean += d * nb[k] / tot;
+                    m2 += qb[k] + d * d * cnt * nb[k] / tot;
+                    cnt = tot;
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                const float cb = __shfl_xor(cnt, o, 64), mbb = __shfl_xor(mean, o, 64), qbb = __shfl_xor(m2, o, 64);
+                const float tot = cnt + cb;
+                if (tot > 0.f) {
+                    const float d = mbb - mean;
+                    const float nm = (cnt * mean + cb * mbb) / tot;
+                    m2 = m2 + qbb + d * d * cnt * cb / tot;
+                    mean = nm;
+                }
+                cnt = tot;
+            }
+            if (i < groups && j == 0) {
+                s_gst[2 * i] = mean;
+                s_gst[2 * i + 1] = 1.f / sqrtf(m2 / cnt + a.gn.eps);
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < Ct; c += 256) {
+            const int gi = c / cpg;
+            float A = s_gst[2 * gi + 1] * a.gn.gamma[c];
+            float B = a.gn.beta[c] - s_gst[2 * gi] * A;
+            if (a.gn.film) {
+                const float sc = 1.f + a.gn.film[(long)n * a.gn.film_ld + c];
+                A *= sc;
+                B = B * sc + a.gn.film[(long)n * a.gn.film_ld + Ct + c];
+            }
+            s_gn[c] = A;
+            s_gn[S3D_GN_CMAX + c] = B;
+        }
+        __syncthreads();
+    }
     park(ch_lo & (NBUF - 1));
     __syncthreads();
 #pragma unroll 1
@@ -864,7 +937,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
         }
         if (ch + 1 < nchunk) {
             const int s1 = ch + 1 < cu0 ? 0 : 1;
-            fetch(a.src[s1], s1 ? ch + 1 - cu0 : ch + 1);
+            fetch(a.src[s1], s1 ? ch + 1 - cu0 : ch + 1, s1 ? a.src[0].C : 0);
         }
         const _Float16* sh = s_in[ch & (NBUF - 1)][0];
         const _Float16* sl = s_in[ch & (NBUF - 1)][1];
@@ -1007,7 +1080,16 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     dim3 grid((unsigned)nblk, (unsigned)splits);
     constexpr int one_buf_max = 2;   // chunks per workgroup up to which the single-buffer variant runs
     const bool one = cps <= one_buf_max;   // 32-channel-output layers only: measured -13 % there, +5 % on the 64-wide tile
-    if (co_wg == 64) {
+    if (a.gn.part) {   // GroupNorm of the input in the staging path (LDM U-Net): its own instantiations (12.5 KiB of table)
+        int ct = 0;
+        for (int s = 0; s < a.nsrc; ++s) ct += a.src[s].C;
+        S3D_CHECK_ARG(ct <= S3D_GN_CMAX && a.gn.groups >= 1 && a.gn.groups <= 32 && ct % a.gn.groups == 0 && a.gn.gamma && a.gn.beta,
+                      "conv: fused GroupNorm over %d channels in %d groups", ct, a.gn.groups);
+        if (co_wg == 64)
+            hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<4, 2, 2, 2, true>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
+        else
+            hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<2, 4, 1, 2, true>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
+    } else if (co_wg == 64) {
         hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<4, 2, 2, 2>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
     } else {
         if (one) hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<2, 4, 1, 1>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
@@ -1065,6 +1147,7 @@ int launch_conv(const ConvLaunch& a_in, hipStream_t stream) {
     S3D_CHECK_ARG(a.out_mode != S3D_OUT_CONVT || (a.drop.p <= 0.f && !a.gate && !a.residual && !a.out_accumulate),
                   "conv: ConvTranspose output takes no dropout / gate / residual / accumulate");
     if (conv3x3_lds_eligible(a)) return launch_conv3x3_lds(a, stream);
+    S3D_CHECK_ARG(!a.gn.part, "conv: a fused GroupNorm needs the LDS-staged 3x3 kernel (ks 3, stride 1, channel counts multiples of 32)");
     if (lin_stream_eligible(a)) return launch_lin_stream(a, stream);
     if (lin_rows_eligible(a)) return launch_lin_rows(a, stream);
     const long P = (long)a.N * a.H * a.W;

@@ -67,7 +67,7 @@ int launch_attn_layer(float* X, float* x0_out, long groups, int T, const LayerPt
 // rows x 128 in place; if sdf_out != NULL: final layer, writes sign*(fc_out(LN2(..))) per row instead.
 int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w, const float* fco_b,
                      float* sdf_out, float sign, long groups_per_batch, long n_qry, long g_begin, int prec,
-                     const int* perm, hipStream_t stream);
+                     const int* perm, hipStream_t stream, bool pre_ln1 = false);
 // image-space locality sort of the queries of each batch item (counting sort on the Morton code of the
 // projected pixel at 256^2): perm[b*Q + slot] = query index, ascending query index inside a bin (deterministic).
 // ws: query_sort_ws_ints(B, Q) ints; on return ws[b*65536 + k] = end of bin k in perm[b] (bin/tile ranges).
@@ -148,7 +148,7 @@ static inline size_t ffn_mask_dwords(long P) { return (size_t)((P + 31) / 32) * 
 // imgd / imgr (optional, ffn_rec_image_floats(rows) floats each): D^T / R image of DY
 int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
                             const float* timg, float gate_scale, hipStream_t stream, float* imgd = nullptr,
-                            float* imgr = nullptr);
+                            float* imgr = nullptr, const DropCfg* dy_mask = nullptr);
 int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipStream_t stream);
 // imgd / imgr (optional): D^T / R image of Xin
 int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
@@ -176,5 +176,6 @@ int launch_absorb_last(const float* in_w, const float* in_b, const float* out_w,
 int launch_pack_attn_q_f16x3(const float* win, const float* wout, float* out, hipStream_t stream);
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
-                           long g_begin, const int* perm, hipStream_t stream, bool single_pass = false);
+                           long g_begin, const int* perm, hipStream_t stream, bool single_pass = false,
+                           bool pre_ln1 = false);   // pre_ln1 (final layer only): the rows are pre-LayerNorm1 sums, normalised in the prologue
 int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream);

@@ -143,6 +143,9 @@ struct FfnBwdArgs {     // MODE 4
     float gate_scale;      // value of a kept unit's dropout factor
     _Float16* ImgD;        // optional: D^T / R operand images of the dY rows (decode.h)
     _Float16* ImgR;
+    DropCfg dq;            // p > 0: the rows handed in are du (the LayerNorm backward's output) and dY = du * mask of the FFN's
+                           // output dropout is rebuilt here from the counter-based masks (index row * 128 + channel, as the
+                           // forward's epilogue draws them) instead of being stored and re-read
 };
 // per-wave state of the activation stage between GEMM1 and GEMM2
 struct FfnActState {
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
                                                                    const float* fco_w, const float* fco_b,
                                                                    float* sdf_out, float sign, long groups_per_batch,
                                                                    long n_qry, long g_begin, const int* perm,
-                                                                   const FfnTrainArgs ta, const FfnBwdArgs ba) {
+                                                                   const FfnTrainArgs ta, const FfnBwdArgs ba, const int pre_ln1) {
     constexpr bool FINAL = MODE == 1;
     constexpr int NC = S3D_FFN_NCHUNK;
     // THREE distinct LDS objects: hipcc tags their accesses with alias scopes, so a ds_read of one weight buffer is not
@@ -366,10 +369,50 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
         long row = row0 + r * 16 + m;
         if (row >= rows) row = rows - 1;
         const float* p = X + row * 128 + 8 * g;
+        // FINAL with pre_ln1: the rows handed in are the pre-LayerNorm sums u of the last layer's attention block and
+        // LayerNorm1 (w.ln1g / w.ln1b) is applied here, on the row's 32 values per lane and a quad reduction — the ln_fwd
+        // launch and one round trip of the token-0 rows are gone (same arithmetic as ln_fwd_kernel: two-pass mean / variance)
+        float lmean = 0.f, lrstd = 1.f;
+        if (FINAL && pre_ln1) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
+                sacc += ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+            }
+            lmean = quad_sum16(sacc) * (1.f / 128.f);
+            float vacc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) vacc += (a[t] - lmean) * (a[t] - lmean) + (b[t] - lmean) * (b[t] - lmean);
+            }
+            lrstd = 1.f / sqrtf(quad_sum16(vacc) * (1.f / 128.f) + 1e-5f);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const f32x4 a = ld4(p + 32 * u), b = ld4(p + 32 * u + 4);
-            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            if (FINAL && pre_ln1) {
+                const f32x4 ga = ld4(w.ln1g + 32 * u + 8 * g), gb = ld4(w.ln1g + 32 * u + 8 * g + 4);
+                const f32x4 ba4 = ld4(w.ln1b + 32 * u + 8 * g), bb4 = ld4(w.ln1b + 32 * u + 8 * g + 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    v[t] = (v[t] - lmean) * lrstd * ga[t] + ba4[t];
+                    v[4 + t] = (v[4 + t] - lmean) * lrstd * gb[t] + bb4[t];
+                }
+            }
+            if (MODE == 4 && ba.dq.p > 0.f) {
+                float mk0[4], mk1[4];
+                s3d_drop4(ba.dq, (unsigned long long)row * 128 + 32 * u + 8 * g, mk0);
+                s3d_drop4(ba.dq, (unsigned long long)row * 128 + 32 * u + 8 * g + 4, mk1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    v[t] *= mk0[t];
+                    v[4 + t] *= mk1[t];
+                }
+            }
             split8(v, xh[r][u], xl[r][u]);
         }
 #pragma unroll
@@ -615,8 +658,10 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
 #define PIPE_ROWS_PER_WG (PIPE_WAVES * PIPE_R * 16)
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
-                           long g_begin, const int* perm, hipStream_t stream, bool single_pass) {
+                           long g_begin, const int* perm, hipStream_t stream, bool single_pass, bool pre_ln1) {
     if (rows <= 0) return 0;
+    S3D_CHECK_ARG(!pre_ln1 || sdf_out, "ffn: the LayerNorm1 prologue belongs to the final layer's kernel");
+    const int PRE_LN_ARG = pre_ln1 ? 1 : 0;
     const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
     const FfnTrainArgs ta = {};
     const FfnBwdArgs ba = {};
@@ -624,16 +669,16 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
     if (single_pass) {
         if (sdf_out)
             hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, true>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
-                               sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba);
+                               sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba, PRE_LN_ARG);
         else
             hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, true>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
-                               sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba);
+                               sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba, PRE_LN_ARG);
     } else if (sdf_out) {
         hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, false>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
-                           sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba);
+                           sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba, PRE_LN_ARG);
     } else {
         hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, false>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
-                           sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba);
+                           sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba, PRE_LN_ARG);
     }
     S3D_LAUNCH_CHECK();
     return 0;
@@ -653,11 +698,11 @@ int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, uns
     if (drop_hidden.p > 0.f)
         hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<2, false>), grid, block, 0, stream, Xin, Yout, rows,
                            reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr,
-                           ta, ba);
+                           ta, ba, 0);
     else
         hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<3, false>), grid, block, 0, stream, Xin, Yout, rows,
                            reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr,
-                           ta, ba);
+                           ta, ba, 0);
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -671,16 +716,18 @@ int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, uns
 // W1^T chunk as GEMM-2-shaped fragments; packed by pack_ffn_f16x3_kernel with swapped strides) stream through LDS.
 // ---------------------------------------------------------------------------------------------
 int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
-                            const float* timg, float gate_scale, hipStream_t stream, float* imgd, float* imgr) {
+                            const float* timg, float gate_scale, hipStream_t stream, float* imgd, float* imgr,
+                            const DropCfg* dy_mask) {
     if (rows <= 0) return 0;
     S3D_CHECK_ARG((imgd == nullptr) == (imgr == nullptr), "ffn bwd dx: both operand images or none");
     const FfnTrainArgs ta = {};
-    const FfnBwdArgs ba = {Dres, M, gate_scale, reinterpret_cast<_Float16*>(imgd), reinterpret_cast<_Float16*>(imgr)};
+    FfnBwdArgs ba = {Dres, M, gate_scale, reinterpret_cast<_Float16*>(imgd), reinterpret_cast<_Float16*>(imgr), make_drop(0, 0.f, 0)};
+    if (dy_mask) ba.dq = *dy_mask;
     const LayerPtrs w = {};
     const dim3 grid((unsigned)((rows + PIPE_ROWS_PER_WG - 1) / PIPE_ROWS_PER_WG)), block(PIPE_THREADS);
     hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<4, false>), grid, block, 0, stream, DY, DX, rows,
                        reinterpret_cast<const _Float16*>(timg), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr, ta,
-                       ba);
+                       ba, 0);
     S3D_LAUNCH_CHECK();
     return 0;
 }

@@ -4,13 +4,14 @@
 // "conv1d"s run on the conv engine (conv.hip); this file adds GroupNorm(32)+SiLU(+FiLM), the spatial
 // self-attention, nearest-2x upsampling, 2x2 average pooling, the small timestep-embedding linears.
 #include "ldm_ops.h"
+#include "conv.h"
 
 // ---------------------------------------------------------------------------------------------
 // GroupNorm(32, C): statistics per (image, group) over HW x (C/32) values in fp32 (as torch's native_group_norm).
 // ---------------------------------------------------------------------------------------------
 // Stage 1: block (image, group, slice) -> (count, mean, M2) of its slice of the HW pixels (two passes over the slice,
 // which stays in L2).  Stage 2 (inside the apply kernel): the slices are merged with Chan's parallel-variance formula.
-#define GN_SLICES 64
+#define GN_SLICES S3D_GN_SLICES   // (conv.h: the fused-GroupNorm convolution merges the same partial moments)
 // Input = channel concatenation of x (C0 channels) and x1 (C - C0 channels; NULL when C0 == C): the th.cat([h, hs.pop()],
 // dim=1) in front of the output blocks' first ResBlock (openaimodel.py:750) is never materialised — the GroupNorm groups
 // straddle the two tensors, so the concatenation happens in this kernel's loads (its OUTPUT is one tensor).
@@ -204,7 +205,7 @@ template <int EPT>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ film,
                                                         long film_ld, float* __restrict__ y, int HW, int C, int groups,
-                                                        float eps, int silu) {
+                                                        float eps, int silu, float* __restrict__ part) {
     __shared__ float red[16];
     const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
     const int cpg = C / groups;
@@ -237,7 +238,19 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const f
         const float d = i < total ? v[k] - mean : 0.f;
         q += d * d;
     }
-    const float rstd = 1.f / sqrtf(block_sum(q) / (float)total + eps);
+    const float m2 = block_sum(q);
+    if (part) {   // statistics only (the consuming convolution normalises while it stages its input, conv.hip): one real
+                  // slab — slot 0 — and empty ones, the layout of the sliced statistics kernels
+        if (threadIdx.x < GN_SLICES) {
+            float* o = part + 3 * ((size_t)blockIdx.x * GN_SLICES + threadIdx.x);
+            const bool first = threadIdx.x == 0;
+            o[0] = first ? (float)total : 0.f;
+            o[1] = first ? mean : 0.f;
+            o[2] = first ? m2 : 0.f;
+        }
+        return;
+    }
+    const float rstd = 1.f / sqrtf(m2 / (float)total + eps);
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         const long i = threadIdx.x + 1024L * k;
@@ -251,10 +264,13 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const f
     }
 }
 
+// y == NULL: statistics only — `stats` receives the partial moments [N * groups][GN_SLICES][3] a fused-GroupNorm convolution
+// (ConvGn, conv.h) merges; gamma / beta / film are then unused
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
                       int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream, const float* x1,
                       int C0, long film_ld) {
     if (film_ld <= 0) film_ld = 2L * C;   // rows of a dense (N, 2C) film tensor
+    const bool stats_only = y == nullptr;
     S3D_CHECK_ARG(C % groups == 0 && C % 4 == 0 && N >= 1 && HW >= 1, "group_norm: C=%d groups=%d", C, groups);
     if (!x1) C0 = C;
     S3D_CHECK_ARG(C0 >= 4 && C0 <= C && C0 % 4 == 0 && (C - C0) % 4 == 0, "group_norm: source split %d | %d", C0, C - C0);
@@ -267,7 +283,7 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
 #define GN_CASE(e)                                                                                                     \
     if (per_thread <= e) {                                                                                             \
         hipLaunchKernelGGL((gn_fused_kernel<e>), grid, dim3(1024), 0, stream, src, gamma, beta, film, film_ld, y, HW, C, groups, eps, \
-                           silu);                                                                                      \
+                           silu, stats_only ? stats : nullptr);                                                        \
         S3D_LAUNCH_CHECK();                                                                                            \
         return 0;                                                                                                      \
     }
@@ -282,6 +298,7 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
     else
         hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, src, HW, C, groups, stats);
     S3D_LAUNCH_CHECK();
+    if (stats_only) return 0;
     const long total = (long)N * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), (size_t)N * groups * 2 * sizeof(float), stream, src, stats,

@@ -60,7 +60,7 @@ class AttentionBlock(nn.Module):
 class UNetModel(nn.Module):
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0, channel_mult=(1, 2, 4, 8), num_heads=-1, use_scale_shift_norm=False, resblock_updown=False,
-                 backend="hip", prec="f16x3"):
+                 backend="hip", prec="f16x3", fuse_gn=True, branch_streams=True):
         super().__init__()
         if not resblock_updown:
             raise NotImplementedError("conv_resample down/up-sampling is not built (the Slice3D configuration uses "
@@ -69,6 +69,12 @@ class UNetModel(nn.Module):
             raise ValueError("num_heads must be set")
         self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
         self.out_channels, self.num_heads, self.prec, self.backend = out_channels, num_heads, prec, backend
+        # a ResBlock's 1x1 skip_connection does not depend on its GroupNorm -> conv chain: it runs on a side stream (a parallel
+        # branch of the captured HIP graph) beside the chain's small kernels (openaimodel.py:240-246, :272-275)
+        self.branch_streams = branch_streams
+        self._side = None
+        self._ws_side = None
+        self.fuse_gn = fuse_gn    # GroupNorm -> SiLU -> conv3x3 as one operator where the kernel serves the shape (s3d_conv_gn_fwd)
         ted = model_channels * 4
         self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
         self.input_blocks = nn.ModuleList([nn.Sequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
@@ -122,7 +128,11 @@ class UNetModel(nn.Module):
         return C.c_void_p(torch.cuda.current_stream(self._dev()).cuda_stream)
 
     def _precv(self):
-        return _lib.PREC_F16X3 if self.prec == "f16x3" else _lib.PREC_F32
+        return {"f16x3": _lib.PREC_F16X3, "f16": _lib.PREC_F16, "f32": _lib.PREC_F32}[self.prec]
+
+    def _attn_precv(self):
+        # prec='f16' (single-pass convolutions, the throughput mode): the attention operators keep their split-precision form
+        return _lib.PREC_F32 if self.prec == "f32" else _lib.PREC_F16X3
 
     def _params_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -151,7 +161,16 @@ class UNetModel(nn.Module):
         self._packed = {}
         for mod in self.modules():
             if isinstance(mod, ResBlock):
-                self._packed[id(mod.in_layers[2])] = self._pack_conv(mod.in_layers[2])
+                # an output block's first convolution reads cat([h, skip]): packed as a two-source K loop when the fused
+                # GroupNorm + convolution operator serves the block (the sources are then normalised as they are staged),
+                # as one source behind the stand-alone GroupNorm otherwise (its output is one tensor)
+                cw = mod.in_layers[2].weight
+                split = mod.cat_split
+                if split is not None and not (self.fuse_gn and self.prec != "f32" and not (mod.up or mod.down)
+                                              and cw.shape[0] % 32 == 0 and split[0] % 32 == 0 and split[1] % 32 == 0
+                                              and sum(split) <= 1536):
+                    split = None
+                self._packed[id(mod.in_layers[2])] = self._pack_conv(mod.in_layers[2], split=split)
                 self._packed[id(mod.out_layers[3])] = self._pack_conv(mod.out_layers[3])
                 if isinstance(mod.skip_connection, nn.Conv2d):   # two-source K loop over (h, skip) for the output blocks
                     self._packed[id(mod.skip_connection)] = self._pack_conv(mod.skip_connection, split=mod.cat_split)
@@ -174,24 +193,85 @@ class UNetModel(nn.Module):
     # ------------------------------------------------------------------------------------------
     # primitive wrappers (channels-last tensors)
     # ------------------------------------------------------------------------------------------
-    def _conv(self, conv, x0, x1=None, residual=None):
+    def _conv(self, conv, x0, x1=None, residual=None, side=False):
         lib = self._lib
         buf, cout, cin0, cin1, ks = self._packed[id(conv)]
         n, h, w, _ = x0.shape
         out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x0.device)
         if self._ws is None:
             self._ws = torch.empty(8 << 20, dtype=torch.float32, device=x0.device)     # split-K scratch
+        ws = self._ws
+        if side:     # a convolution on the side stream must not share the main chain's split-K scratch
+            if self._ws_side is None:
+                self._ws_side = torch.empty(2 << 20, dtype=torch.float32, device=x0.device)
+            ws = self._ws_side
         _lib.check(lib.s3d_conv_fwd(buf.data_ptr(), x0.data_ptr(), x1.data_ptr() if x1 is not None else None,
                                     residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w, cout,
-                                    cin0, cin1, ks, self._precv(), self._ws.data_ptr(), self._ws.numel() * 4,
+                                    cin0, cin1, ks, self._precv(), ws.data_ptr(), ws.numel() * 4,
                                     self._stream()), "s3d_conv_fwd")
+        return out
+
+    def _skip_branch(self, blk, xs, skip):
+        """The ResBlock's 1x1 skip_connection on the side stream (forked behind everything the current stream has queued,
+        i.e. behind the producers of xs / skip); returns (tensor, join) — call join() on the main stream before the tensor is
+        read there.  Inside a HIP-graph capture the fork / join become graph edges: the branch runs beside the chain."""
+        cur = torch.cuda.current_stream(xs.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(xs.device)
+        side = self._side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            res = self._conv(blk.skip_connection, xs, x1=skip, side=True)
+        for t in (xs, skip):                  # allocated on the main stream, read on the side stream
+            if t is not None:
+                t.record_stream(side)
+
+        def join():
+            cur.wait_stream(side)
+            res.record_stream(cur)            # allocated on the side stream, read on the main stream
+        return res, join
+
+    def _gn_conv_fusable(self, conv, x):
+        """GroupNorm -> [FiLM] -> SiLU -> conv3x3 as one operator (s3d_conv_gn_fwd): the LDS-staged split-precision kernel's
+        shapes — 3x3, every channel count a multiple of 32, at most 1536 input channels."""
+        _, cout, cin0, cin1, ks = self._packed[id(conv)]
+        return (self.fuse_gn and self.prec != "f32" and ks == 3 and cout % 32 == 0 and cin0 % 32 == 0 and cin1 % 32 == 0
+                and cin0 + cin1 <= 1536 and x.shape[-1] == cin0)   # (a concatenated input needs the two-source pack)
+
+    def _gn_conv(self, gn, conv, x, x1=None, film=None, residual=None, before_conv=None):
+        """conv(silu(film(group_norm(cat([x, x1]))))) (+ residual) without writing the normalised tensor: statistics kernel,
+        then the convolution normalises while it stages its input (openaimodel.py:188-194, :229-236, :262-270)."""
+        lib = self._lib
+        buf, cout, cin0, cin1, ks = self._packed[id(conv)]
+        n, h, w, c = x.shape
+        c1 = x1.shape[-1] if x1 is not None else 0
+        if (c, c1) != (cin0, cin1):
+            raise _lib.S3dError("fused GroupNorm convolution: sources (%d, %d) do not match the packed split (%d, %d)" % (c, c1, cin0, cin1))
+        stats = torch.empty(lib.s3d_group_norm_stats_floats(n, gn.num_groups), dtype=torch.float32, device=x.device)
+        _lib.check(lib.s3d_group_norm_stats_fwd(x.data_ptr(), c, x1.data_ptr() if x1 is not None else None, c1,
+                                                stats.data_ptr(), n, h * w, gn.num_groups, self._stream()),
+                   "s3d_group_norm_stats_fwd")
+        fp, fld = (None, 0)
+        if film is not None:
+            ft, off = film
+            fp, fld = ft.data_ptr() + 4 * off, ft.shape[1]
+        if before_conv is not None:      # join of the side stream that produced `residual` (after the statistics launch)
+            before_conv()
+        out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+        if self._ws is None:
+            self._ws = torch.empty(8 << 20, dtype=torch.float32, device=x.device)     # split-K scratch
+        _lib.check(lib.s3d_conv_gn_fwd(buf.data_ptr(), x.data_ptr(), x1.data_ptr() if x1 is not None else None,
+                                       residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w, cout,
+                                       cin0, cin1, ks, self._precv(), stats.data_ptr(), gn.weight.data_ptr(),
+                                       gn.bias.data_ptr(), fp, fld, gn.num_groups, C.c_float(gn.eps), 1,
+                                       self._ws.data_ptr(), self._ws.numel() * 4, self._stream()), "s3d_conv_gn_fwd")
         return out
 
     def _group_norm(self, gn, x, film=None, silu=True, x1=None):
         """GroupNorm(+FiLM)(+SiLU) of x, or of the channel concatenation [x, x1] (never materialised)."""
         lib = self._lib
         n, h, w, c = x.shape
-        stats = torch.empty((n, gn.num_groups, 200), dtype=torch.float32, device=x.device)
+        stats = torch.empty(lib.s3d_group_norm_stats_floats(n, gn.num_groups), dtype=torch.float32, device=x.device)
         if x1 is not None:
             c1 = x1.shape[-1]
             y = torch.empty((n, h, w, c + c1), dtype=torch.float32, device=x.device)
@@ -255,25 +335,36 @@ class UNetModel(nn.Module):
         """ResBlock._forward (openaimodel.py:253-275); x (and skip: the block input is cat([x, skip]))."""
         # th.cat([h, hs.pop()], dim=1) (openaimodel.py:750) is never built: the GroupNorm reads both tensors (its groups
         # straddle them) and the 1x1 skip_connection walks them as the two sources of its K loop
-        h = self._group_norm(blk.in_layers[0], x, silu=True, x1=skip)
-        xs = x
-        if blk.up or blk.down:
-            if skip is not None:
-                raise NotImplementedError("resampling ResBlock on a concatenated input (not in this architecture)")
-            h = self._resample(h, blk.up)
-            xs = self._resample(x, blk.up)
-        h = self._conv(blk.in_layers[2], h)
-        off, rows = self._film_off[id(blk)]
         if not blk.use_scale_shift_norm:
             raise NotImplementedError("ResBlock without use_scale_shift_norm is not built")
-        # (N, 2*Cout) = scale | shift: columns [off, off + rows) of the stacked emb_layers output, read in place
-        h = self._group_norm(blk.out_layers[0], h, film=(self._film_all, off), silu=True)
+        resampling = blk.up or blk.down
+        if resampling and skip is not None:
+            raise NotImplementedError("resampling ResBlock on a concatenated input (not in this architecture)")
+        xs = self._resample(x, blk.up) if resampling else x
+        # the skip path first: it only needs the block's input, so its 1x1 convolution forks off here and runs beside the chain
+        join = None
         if isinstance(blk.skip_connection, nn.Conv2d):
-            res = self._conv(blk.skip_connection, xs, x1=skip)
+            if self.branch_streams:
+                res, join = self._skip_branch(blk, xs, skip)
+            else:
+                res = self._conv(blk.skip_connection, xs, x1=skip)
         elif skip is not None:
             raise NotImplementedError("identity skip connection on a concatenated input (not in this architecture)")
         else:
             res = xs
+        if resampling:             # GroupNorm -> SiLU -> resample -> conv: the resampling sits between, nothing to fuse
+            h = self._conv(blk.in_layers[2], self._resample(self._group_norm(blk.in_layers[0], x, silu=True), blk.up))
+        elif self._gn_conv_fusable(blk.in_layers[2], x):
+            h = self._gn_conv(blk.in_layers[0], blk.in_layers[2], x, x1=skip)
+        else:
+            h = self._conv(blk.in_layers[2], self._group_norm(blk.in_layers[0], x, silu=True, x1=skip))
+        # (N, 2*Cout) = scale | shift: columns [off, off + rows) of the stacked emb_layers output, read in place
+        off, rows = self._film_off[id(blk)]
+        if self._gn_conv_fusable(blk.out_layers[3], h):
+            return self._gn_conv(blk.out_layers[0], blk.out_layers[3], h, film=(self._film_all, off), residual=res, before_conv=join)
+        h = self._group_norm(blk.out_layers[0], h, film=(self._film_all, off), silu=True)
+        if join is not None:
+            join()
         return self._conv(blk.out_layers[3], h, residual=res)
 
     def _attention_block(self, blk, x):
@@ -285,7 +376,7 @@ class UNetModel(nn.Module):
         att = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
         ch = c // blk.num_heads
         # long sequences of narrow heads: the f16-MFMA kernel with fp32-class logits and pre-split K / V (ldm_attn.hip)
-        use_mfma = self._precv() == _lib.PREC_F16X3
+        use_mfma = self._attn_precv() == _lib.PREC_F16X3
         ws_bytes = lib.s3d_qkv_attention_ws_bytes(n, h * w, blk.num_heads, ch) if use_mfma else 0
         if ws_bytes and h * w >= 1024:
             ws = self._attn_ws.get(x.device)
@@ -294,7 +385,7 @@ class UNetModel(nn.Module):
             _lib.check(lib.s3d_qkv_attention_ws_fwd(qkv.data_ptr(), att.data_ptr(), n, h * w, blk.num_heads, ch, ws.data_ptr(),
                                                     ws_bytes, self._stream()), "s3d_qkv_attention_ws_fwd")
         else:
-            _lib.check(lib.s3d_qkv_attention_fwd(qkv.data_ptr(), att.data_ptr(), n, h * w, blk.num_heads, ch, self._precv(),
+            _lib.check(lib.s3d_qkv_attention_fwd(qkv.data_ptr(), att.data_ptr(), n, h * w, blk.num_heads, ch, self._attn_precv(),
                                                  self._stream()), "s3d_qkv_attention_fwd")
         return self._conv(blk.proj_out, att, residual=x)
 

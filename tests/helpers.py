@@ -112,8 +112,8 @@ def live_oracle():
     return os.environ.get("S3D_LIVE_ORACLE") == "1"
 
 
-def oracle_golden_path(name):
-    return os.path.join(GOLDEN, "oracle_%s.npz" % name)
+def oracle_golden_path(name, out_dir=None):
+    return os.path.join(out_dir or GOLDEN, "oracle_%s.npz" % name)
 
 
 def load_oracle_golden(name):
