@@ -262,17 +262,18 @@ int s3d_conv_fwd(const void* packed, const float* x0, const float* x1, const flo
                  int H, int W, int cout, int cin0, int cin1, int ks, int prec, void* workspace,
                  size_t workspace_bytes, void* stream);
 /* GroupNorm32 -> [FiLM] -> [SiLU] -> Conv2d(3x3) as ONE operator (openaimodel.py:188-194 ResBlock.in_layers, :229-236
- * out_layers with use_scale_shift_norm): s3d_group_norm_stats_fwd writes the partial moments of cat([x0, x1]) into `stats`
- * (s3d_group_norm_stats_floats(N, groups) floats, layout private to the library), s3d_conv_gn_fwd normalises while it stages
- * its input tile — the normalised tensor is never written.  Served for ks == 3, split precision (f16x3 / f16), cin0, cin1,
- * cout multiples of 32, cin0 + cin1 <= 1536, groups <= 32; other shapes are refused with S3D_E_ARG (use
- * s3d_group_norm_fwd + s3d_conv_fwd).  film: (N, film_stride >= 2 (cin0 + cin1)) rows of scale | shift, or NULL. */
+ * out_layers with use_scale_shift_norm): s3d_group_norm_table_fwd folds the statistics of cat([x0, x1]), gamma / beta and the
+ * FiLM rows (film: (N, film_stride >= 2 (c0 + c1)) rows of scale | shift, or NULL) into a per-(image, channel) affine table
+ * (N * 2 * (c0 + c1) floats: A | B of y = x * A + B; stats = s3d_group_norm_stats_floats(N, groups) floats of scratch);
+ * s3d_conv_gn_fwd applies it (+ SiLU) while it stages its input tile — the normalised tensor is never written.  Served for
+ * ks == 3, split precision (f16x3 / f16), cin0, cin1, cout multiples of 32, cin0 + cin1 <= 1536; other shapes are refused
+ * with S3D_E_ARG (use s3d_group_norm_fwd + s3d_conv_fwd). */
 size_t s3d_group_norm_stats_floats(int N, int groups);
-int s3d_group_norm_stats_fwd(const float* x0, int c0, const float* x1, int c1, float* stats, int N, int HW, int groups,
-                             void* stream);
+int s3d_group_norm_table_fwd(const float* x0, int c0, const float* x1, int c1, const float* gamma, const float* beta,
+                             const float* film, long film_stride, float* table, float* stats, int N, int HW, int groups,
+                             float eps, void* stream);
 int s3d_conv_gn_fwd(const void* packed, const float* x0, const float* x1, const float* residual, float* out, int N, int H,
-                    int W, int cout, int cin0, int cin1, int ks, int prec, const float* stats, const float* gamma,
-                    const float* beta, const float* film, long film_stride, int groups, float eps, int silu, void* workspace,
+                    int W, int cout, int cin0, int cin1, int ks, int prec, const float* table, int silu, void* workspace,
                     size_t workspace_bytes, void* stream);
 /* GroupNorm32 (util.py normalization) [+ FiLM: y*(1+scale)+shift, film = (N, 2C), openaimodel.py:268-270] [+ SiLU].
  * stats: s3d_group_norm_stats_floats(N, groups) floats of scratch (N*groups*192 since round 4; a smaller buffer is

@@ -125,9 +125,8 @@ SYMBOLS = {
     "s3d_conv_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "s3d_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "s3d_group_norm_stats_floats": (_sz, [_i, _i]),
-    "s3d_group_norm_stats_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
-    "s3d_conv_gn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_long, _i, _f, _i,
-                             _vp, _sz, _vp]),
+    "s3d_group_norm_table_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, C.c_long, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "s3d_conv_gn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "s3d_group_norm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "s3d_group_norm_film_fwd": (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "s3d_group_norm2_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),

@@ -14,19 +14,15 @@ struct ConvSrc {
 };
 
 // GroupNorm (+ FiLM) (+ SiLU) of a convolution's INPUT, applied while the LDS-staged 3x3 kernel parks its input tile (round 5:
-// the latent-diffusion U-Net's GN -> SiLU -> conv3x3 chains, openaimodel.py:188-194,229-236).  The statistics come as the
-// partial moments the GroupNorm statistics kernels write; every workgroup merges the moments of its image (Chan's formula,
-// as gn_apply_kernel does) into a per-channel affine table in LDS, so no normalised tensor is written or read.
+// the latent-diffusion U-Net's GN -> SiLU -> conv3x3 chains, openaimodel.py:188-194,229-236).  The GroupNorm statistics
+// launch leaves a per-(image, channel) affine table  y = x * A + B  (statistics, gamma / beta and the FiLM scale / shift folded:
+// ldm_ops.hip); every workgroup copies its image's table into LDS once, so no normalised tensor is written or read.
+// (First form, measured neutral: every workgroup merged the 64 slab moments of its image itself — 2-3 us of dependent loads
+// in front of workgroups that live 8-15 us.)
 #define S3D_GN_SLICES 64
 #define S3D_GN_CMAX 1536     // channels of the widest GroupNorm input of the LDM U-Net (768 + 768 skip concat)
 struct ConvGn {
-    const float* part;    // [N * groups][S3D_GN_SLICES][3] = (count, mean, M2) per pixel slab; NULL = no GroupNorm
-    const float* gamma;   // [C]
-    const float* beta;    // [C]
-    const float* film;    // optional (N, film_ld): scale[C] | shift[C] ->  y * (1 + scale) + shift
-    long film_ld;
-    int groups;
-    float eps;
+    const float* table;   // [N][2][C]: A | B of every input channel; NULL = no GroupNorm
     int silu;
 };
 

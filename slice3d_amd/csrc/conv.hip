@@ -780,9 +780,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
     static_assert(MT * WP == 8 && WP * WC == 4, "tile is 8 rows, 4 waves");
     constexpr int NT = 2, CO_WG = WC * NT * 16;
     __shared__ __attribute__((aligned(16))) _Float16 s_in[NBUF][2][C3_HALO * C3_PXS];   // [buf][hi|lo]
-    // GN: per-channel affine table of this image's GroupNorm (+ FiLM), A | B, and the merged (mean, rstd) per group
+    // GN: per-channel affine table of this image's GroupNorm (+ FiLM), A | B
     __shared__ __attribute__((aligned(16))) float s_gn[GN ? 2 * S3D_GN_CMAX : 4];
-    __shared__ float s_gst[GN ? 64 : 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int wp = wave % WP, wc = wave / WP;
@@ -865,58 +864,12 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
     const int ch_lo = blockIdx.y * chunks_per_split;
     const int nchunk = min(cu0 + cu1, ch_lo + chunks_per_split);
     fetch(a.src[ch_lo < cu0 ? 0 : 1], ch_lo < cu0 ? ch_lo : ch_lo - cu0, ch_lo < cu0 ? 0 : a.src[0].C);
-    if (GN) {
-        // merge this image's slab moments per group (eight lanes per group, then three pairwise Chan merges: gn_apply_kernel's
-        // scheme), then the affine table of all input channels; the first chunk's loads are in flight meanwhile
-        const int Ct = a.src[0].C + (a.nsrc > 1 ? a.src[1].C : 0), groups = a.gn.groups, cpg = Ct / groups;
-        for (int i0 = 0; i0 < groups; i0 += 32) {
-            const int i = i0 + (threadIdx.x >> 3), j = threadIdx.x & 7;
-            float cnt = 0.f, mean = 0.f, m2 = 0.f;
-            if (i < groups) {
-                float nb[S3D_GN_SLICES / 8], mb[S3D_GN_SLICES / 8], qb[S3D_GN_SLICES / 8];
-#pragma unroll
-                for (int k = 0; k < S3D_GN_SLICES / 8; ++k) {
-                    const float* q = a.gn.part + 3 * ((size_t)(n * groups + i) * S3D_GN_SLICES + j + 8 * k);
-                    nb[k] = q[0]; mb[k] = q[1]; qb[k] = q[2];
-                }
-#pragma unroll
-                for (int k = 0; k < S3D_GN_SLICES / 8; ++k) {
-                    if (nb[k] == 0.f) continue;
-                    const float tot = cnt + nb[k], d = mb[k] - mean;
-                    mean += d * nb[k] / tot;
-                    m2 += qb[k] + d * d * cnt * nb[k] / tot;
-                    cnt = tot;
-                }
-            }
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-                const float cb = __shfl_xor(cnt, o, 64), mbb = __shfl_xor(mean, o, 64), qbb = __shfl_xor(m2, o, 64);
-                const float tot = cnt + cb;
-                if (tot > 0.f) {
-                    const float d = mbb - mean;
-                    const float nm = (cnt * mean + cb * mbb) / tot;
-                    m2 = m2 + qbb + d * d * cnt * cb / tot;
-                    mean = nm;
-                }
-                cnt = tot;
-            }
-            if (i < groups && j == 0) {
-                s_gst[2 * i] = mean;
-                s_gst[2 * i + 1] = 1.f / sqrtf(m2 / cnt + a.gn.eps);
-            }
-        }
-        __syncthreads();
-        for (int c = threadIdx.x; c < Ct; c += 256) {
-            const int gi = c / cpg;
-            float A = s_gst[2 * gi + 1] * a.gn.gamma[c];
-            float B = a.gn.beta[c] - s_gst[2 * gi] * A;
-            if (a.gn.film) {
-                const float sc = 1.f + a.gn.film[(long)n * a.gn.film_ld + c];
-                A *= sc;
-                B = B * sc + a.gn.film[(long)n * a.gn.film_ld + Ct + c];
-            }
-            s_gn[c] = A;
-            s_gn[S3D_GN_CMAX + c] = B;
+    if (GN) {   // this image's affine table -> LDS (the first chunk's halo loads are in flight meanwhile)
+        const int Ct = a.src[0].C + (a.nsrc > 1 ? a.src[1].C : 0);
+        const float* tb = a.gn.table + (size_t)n * 2 * Ct;
+        for (int i = threadIdx.x; i < Ct / 4; i += 256) {
+            st4(s_gn + 4 * i, ld4(tb + 4 * i));
+            st4(s_gn + S3D_GN_CMAX + 4 * i, ld4(tb + Ct + 4 * i));
         }
         __syncthreads();
     }
@@ -1080,11 +1033,10 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     dim3 grid((unsigned)nblk, (unsigned)splits);
     constexpr int one_buf_max = 2;   // chunks per workgroup up to which the single-buffer variant runs
     const bool one = cps <= one_buf_max;   // 32-channel-output layers only: measured -13 % there, +5 % on the 64-wide tile
-    if (a.gn.part) {   // GroupNorm of the input in the staging path (LDM U-Net): its own instantiations (12.5 KiB of table)
+    if (a.gn.table) {   // GroupNorm of the input in the staging path (LDM U-Net): its own instantiations (12 KiB of table)
         int ct = 0;
         for (int s = 0; s < a.nsrc; ++s) ct += a.src[s].C;
-        S3D_CHECK_ARG(ct <= S3D_GN_CMAX && a.gn.groups >= 1 && a.gn.groups <= 32 && ct % a.gn.groups == 0 && a.gn.gamma && a.gn.beta,
-                      "conv: fused GroupNorm over %d channels in %d groups", ct, a.gn.groups);
+        S3D_CHECK_ARG(ct <= S3D_GN_CMAX, "conv: fused GroupNorm over %d channels", ct);
         if (co_wg == 64)
             hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<4, 2, 2, 2, true>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
         else
@@ -1147,7 +1099,7 @@ int launch_conv(const ConvLaunch& a_in, hipStream_t stream) {
     S3D_CHECK_ARG(a.out_mode != S3D_OUT_CONVT || (a.drop.p <= 0.f && !a.gate && !a.residual && !a.out_accumulate),
                   "conv: ConvTranspose output takes no dropout / gate / residual / accumulate");
     if (conv3x3_lds_eligible(a)) return launch_conv3x3_lds(a, stream);
-    S3D_CHECK_ARG(!a.gn.part, "conv: a fused GroupNorm needs the LDS-staged 3x3 kernel (ks 3, stride 1, channel counts multiples of 32)");
+    S3D_CHECK_ARG(!a.gn.table, "conv: a fused GroupNorm needs the LDS-staged 3x3 kernel (ks 3, stride 1, channel counts multiples of 32)");
     if (lin_stream_eligible(a)) return launch_lin_stream(a, stream);
     if (lin_rows_eligible(a)) return launch_lin_rows(a, stream);
     const long P = (long)a.N * a.H * a.W;

@@ -5,7 +5,8 @@
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
                       int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream,
                       const float* x1 = nullptr, int C0 = 0,    // x1: second source, channels [C0, C) of the input
-                      long film_ld = 0);                        // floats between the film rows of consecutive images (0: 2C)
+                      long film_ld = 0,                         // floats between the film rows of consecutive images (0: 2C)
+                      float* table = nullptr);                  // non-NULL: write the affine table [N][2][C] instead of y (ldm_ops.hip)
 int launch_qkv_attention(const float* qkv, float* out, int N, int T, int heads, int ch, int prec, hipStream_t stream);
 // ldm_attn.hip: long-sequence attention on the f16 MFMA with fp32-class logits; workspace = pre-split K / V block images
 size_t qkv_attention_ws_bytes(int N, int T, int heads, int ch);   // 0: head width not served (use launch_qkv_attention)

@@ -197,6 +197,64 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnSrc src, const fl
     }
 }
 
+// Sliced statistics -> the affine table of the fused-GroupNorm convolution: one workgroup per image merges the slab moments of
+// every group (eight lanes per group + three pairwise Chan merges, as gn_apply_kernel) and writes A | B of all channels.
+__global__ __launch_bounds__(256) void gn_table_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ film,
+                                                       long film_ld, float* __restrict__ table, int C, int groups, float eps) {
+    __shared__ float s_st[2 * 64];
+    const int n = blockIdx.x;
+    for (int i0 = 0; i0 < groups; i0 += 32) {
+        const int i = i0 + (threadIdx.x >> 3), j = threadIdx.x & 7;
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+        if (i < groups) {
+            float nb[GN_SLICES / 8], mb[GN_SLICES / 8], qb[GN_SLICES / 8];
+#pragma unroll
+            for (int k = 0; k < GN_SLICES / 8; ++k) {
+                const float* q = part + 3 * ((size_t)(n * groups + i) * GN_SLICES + j + 8 * k);
+                nb[k] = q[0]; mb[k] = q[1]; qb[k] = q[2];
+            }
+#pragma unroll
+            for (int k = 0; k < GN_SLICES / 8; ++k) {
+                if (nb[k] == 0.f) continue;
+                const float tot = cnt + nb[k], d = mb[k] - mean;
+                mean += d * nb[k] / tot;
+                m2 += qb[k] + d * d * cnt * nb[k] / tot;
+                cnt = tot;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const float cb = __shfl_xor(cnt, o, 64), mbb = __shfl_xor(mean, o, 64), qbb = __shfl_xor(m2, o, 64);
+            const float tot = cnt + cb;
+            if (tot > 0.f) {
+                const float d = mbb - mean;
+                const float nm = (cnt * mean + cb * mbb) / tot;
+                m2 = m2 + qbb + d * d * cnt * cb / tot;
+                mean = nm;
+            }
+            cnt = tot;
+        }
+        if (i < groups && j == 0) {
+            s_st[2 * i] = mean;
+            s_st[2 * i + 1] = 1.f / sqrtf(m2 / cnt + eps);
+        }
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int gi = c / cpg;
+        float A = s_st[2 * gi + 1] * gamma[c], B = beta[c] - s_st[2 * gi] * A;
+        if (film) {
+            const float sc = 1.f + film[(long)n * film_ld + c];
+            A *= sc;
+            B = B * sc + film[(long)n * film_ld + C + c];
+        }
+        table[(size_t)n * 2 * C + c] = A;
+        table[(size_t)n * 2 * C + C + c] = B;
+    }
+}
+
 // One-launch variant for the maps of this U-Net (<= 64 x 64): a 1024-thread workgroup owns one (image, group), keeps
 // its HW x C/32 values in registers (EPT per thread), reduces mean and centred second moment through LDS and writes
 // the normalised values - statistics, apply, FiLM and SiLU in one pass over the data instead of two launches
@@ -205,7 +263,7 @@ template <int EPT>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ film,
                                                         long film_ld, float* __restrict__ y, int HW, int C, int groups,
-                                                        float eps, int silu, float* __restrict__ part) {
+                                                        float eps, int silu, float* __restrict__ table) {
     __shared__ float red[16];
     const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
     const int cpg = C / groups;
@@ -239,14 +297,19 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const f
         q += d * d;
     }
     const float m2 = block_sum(q);
-    if (part) {   // statistics only (the consuming convolution normalises while it stages its input, conv.hip): one real
-                  // slab — slot 0 — and empty ones, the layout of the sliced statistics kernels
-        if (threadIdx.x < GN_SLICES) {
-            float* o = part + 3 * ((size_t)blockIdx.x * GN_SLICES + threadIdx.x);
-            const bool first = threadIdx.x == 0;
-            o[0] = first ? (float)total : 0.f;
-            o[1] = first ? mean : 0.f;
-            o[2] = first ? m2 : 0.f;
+    if (table) {   // no normalised output: this group's rows of the affine table y = x * A + B (gamma / beta / FiLM folded) that the
+                   // consuming convolution applies while it stages its input (ConvGn, conv.h)
+        const float rs = 1.f / sqrtf(m2 / (float)total + eps);
+        if ((int)threadIdx.x < cpg) {
+            const int c = gidx * cpg + threadIdx.x;
+            float A = rs * gamma[c], B = beta[c] - mean * A;
+            if (film) {
+                const float sc = 1.f + film[(long)n * film_ld + c];
+                A *= sc;
+                B = B * sc + film[(long)n * film_ld + C + c];
+            }
+            table[(size_t)n * 2 * C + c] = A;
+            table[(size_t)n * 2 * C + C + c] = B;
         }
         return;
     }
@@ -264,13 +327,14 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const f
     }
 }
 
-// y == NULL: statistics only — `stats` receives the partial moments [N * groups][GN_SLICES][3] a fused-GroupNorm convolution
-// (ConvGn, conv.h) merges; gamma / beta / film are then unused
+// table != NULL (then y is unused): no normalised output — the per-(image, channel) affine table [N][2][C] = A | B of
+// y = x * A + B with the statistics, gamma / beta and FiLM folded, which a fused-GroupNorm convolution (ConvGn, conv.h) applies
+// while it stages its input
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
                       int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream, const float* x1,
-                      int C0, long film_ld) {
+                      int C0, long film_ld, float* table) {
     if (film_ld <= 0) film_ld = 2L * C;   // rows of a dense (N, 2C) film tensor
-    const bool stats_only = y == nullptr;
+    S3D_CHECK_ARG(!table || groups <= 64, "group_norm table: %d groups", groups);
     S3D_CHECK_ARG(C % groups == 0 && C % 4 == 0 && N >= 1 && HW >= 1, "group_norm: C=%d groups=%d", C, groups);
     if (!x1) C0 = C;
     S3D_CHECK_ARG(C0 >= 4 && C0 <= C && C0 % 4 == 0 && (C - C0) % 4 == 0, "group_norm: source split %d | %d", C0, C - C0);
@@ -283,7 +347,7 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
 #define GN_CASE(e)                                                                                                     \
     if (per_thread <= e) {                                                                                             \
         hipLaunchKernelGGL((gn_fused_kernel<e>), grid, dim3(1024), 0, stream, src, gamma, beta, film, film_ld, y, HW, C, groups, eps, \
-                           silu, stats_only ? stats : nullptr);                                                        \
+                           silu, table);                                                                               \
         S3D_LAUNCH_CHECK();                                                                                            \
         return 0;                                                                                                      \
     }
@@ -298,7 +362,11 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
     else
         hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, src, HW, C, groups, stats);
     S3D_LAUNCH_CHECK();
-    if (stats_only) return 0;
+    if (table) {
+        hipLaunchKernelGGL(gn_table_kernel, dim3(N), dim3(256), 0, stream, stats, gamma, beta, film, film_ld, table, C, groups, eps);
+        S3D_LAUNCH_CHECK();
+        return 0;
+    }
     const long total = (long)N * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), (size_t)N * groups * 2 * sizeof(float), stream, src, stats,

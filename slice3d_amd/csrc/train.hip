@@ -1925,6 +1925,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ u
     const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
     const f32x4 ga = ld4(gamma + 4 * l);
     f32x4 dg = zero4(), db = zero4(), dm = zero4();
+    // (Round 5: four rows in flight per 32-lane group measured SLOWER, 1.44 against 1.27 ms average per call — the kernel runs at
+    // 5.6 TB/s over its four row streams, it is bandwidth-bound, not latency-bound; profiles/r05_train_experiments.md.)
     for (long row = (long)blockIdx.x * 8 + sub; row < rows; row += (long)gridDim.x * 8) {
         const f32x4 v = ld4(u + row * 128 + 4 * l);
         const f32x4 g = ld4(dy + row * 128 + 4 * l);

@@ -60,7 +60,7 @@ class AttentionBlock(nn.Module):
 class UNetModel(nn.Module):
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0, channel_mult=(1, 2, 4, 8), num_heads=-1, use_scale_shift_norm=False, resblock_updown=False,
-                 backend="hip", prec="f16x3", fuse_gn=True, branch_streams=True):
+                 backend="hip", prec="f16x3", fuse_gn=True, branch_streams=False):
         super().__init__()
         if not resblock_updown:
             raise NotImplementedError("conv_resample down/up-sampling is not built (the Slice3D configuration uses "
@@ -69,8 +69,11 @@ class UNetModel(nn.Module):
             raise ValueError("num_heads must be set")
         self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
         self.out_channels, self.num_heads, self.prec, self.backend = out_channels, num_heads, prec, backend
-        # a ResBlock's 1x1 skip_connection does not depend on its GroupNorm -> conv chain: it runs on a side stream (a parallel
-        # branch of the captured HIP graph) beside the chain's small kernels (openaimodel.py:240-246, :272-275)
+        # a ResBlock's 1x1 skip_connection does not depend on its GroupNorm -> conv chain: with branch_streams it runs on a side
+        # stream (a parallel branch of the captured HIP graph) beside the chain's small kernels (openaimodel.py:240-246,
+        # :272-275).  OFF by default: measured SLOWER on MI355X — 4.45 against 4.18 ms per step at batch 1, with runs of 7-8 ms
+        # (tools/ldm_ab.py, profiles/r05_ldm_experiments.md): the graph's cross-branch dependencies cost more than the 17
+        # overlapped 14 us kernels return
         self.branch_streams = branch_streams
         self._side = None
         self._ws_side = None
@@ -248,13 +251,15 @@ class UNetModel(nn.Module):
         if (c, c1) != (cin0, cin1):
             raise _lib.S3dError("fused GroupNorm convolution: sources (%d, %d) do not match the packed split (%d, %d)" % (c, c1, cin0, cin1))
         stats = torch.empty(lib.s3d_group_norm_stats_floats(n, gn.num_groups), dtype=torch.float32, device=x.device)
-        _lib.check(lib.s3d_group_norm_stats_fwd(x.data_ptr(), c, x1.data_ptr() if x1 is not None else None, c1,
-                                                stats.data_ptr(), n, h * w, gn.num_groups, self._stream()),
-                   "s3d_group_norm_stats_fwd")
+        table = torch.empty((n, 2, c + c1), dtype=torch.float32, device=x.device)
         fp, fld = (None, 0)
         if film is not None:
             ft, off = film
             fp, fld = ft.data_ptr() + 4 * off, ft.shape[1]
+        _lib.check(lib.s3d_group_norm_table_fwd(x.data_ptr(), c, x1.data_ptr() if x1 is not None else None, c1,
+                                                gn.weight.data_ptr(), gn.bias.data_ptr(), fp, fld, table.data_ptr(),
+                                                stats.data_ptr(), n, h * w, gn.num_groups, C.c_float(gn.eps), self._stream()),
+                   "s3d_group_norm_table_fwd")
         if before_conv is not None:      # join of the side stream that produced `residual` (after the statistics launch)
             before_conv()
         out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
@@ -262,8 +267,7 @@ class UNetModel(nn.Module):
             self._ws = torch.empty(8 << 20, dtype=torch.float32, device=x.device)     # split-K scratch
         _lib.check(lib.s3d_conv_gn_fwd(buf.data_ptr(), x.data_ptr(), x1.data_ptr() if x1 is not None else None,
                                        residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w, cout,
-                                       cin0, cin1, ks, self._precv(), stats.data_ptr(), gn.weight.data_ptr(),
-                                       gn.bias.data_ptr(), fp, fld, gn.num_groups, C.c_float(gn.eps), 1,
+                                       cin0, cin1, ks, self._precv(), table.data_ptr(), 1,
                                        self._ws.data_ptr(), self._ws.numel() * 4, self._stream()), "s3d_conv_gn_fwd")
         return out
 
