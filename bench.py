@@ -163,8 +163,8 @@ def cpu_baseline(sd, fd, n_slices, n_sample, gpu_sdf, runs=5):
     return {
         "value": n_qry / (t_unet + per_q * n_qry), "unit": "query-points/s", "cores": best_n, "kind": "port",
         "host_cores": host, "cpu_model": _cpu_model(),
-        "sample": "oracle/ref_cpu.py: U-Net once at %d^2 + %d of %d queries/object in chunks of %d; 1 warm-up + median of %d; "
-                  "best thread count of a probe" % (fd_cpu["img_input"].shape[-1], n_sample, n_qry, chunk, runs),
+        "sample": "oracle/ref_cpu.py: U-Net at %d^2 + %d of %d queries/object; median of %d; best thread count of a probe"
+                  % (fd_cpu["img_input"].shape[-1], n_sample, n_qry, runs),
         "stages": {"unet_s": t_unet, "sample_us_per_query": t_sample / n_sample * 1e6,
                    "decoder_tokens_us_per_query": t_tokens / n_sample * 1e6},
         "thread_probe_s_per_256_queries": probe,
@@ -207,7 +207,7 @@ def _pmc_traffic(args, kname):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (
-        "in-run rocprofv3 --pmc passes: (2*FETCH %.0f + WRITE %.0f) KiB/launch" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+        "in-run rocprofv3 --pmc: (2*FETCH %.0f + WRITE %.0f) KiB" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
 
 
 def _self_launch(n):
@@ -356,7 +356,7 @@ def main():
         k_ms = kms.value / max(kn.value, 1)
         ch = sum(p.shape[-1] for p in code.pyramid)
         alg = args.n_slices * args.n_qry * (ch * 4 + 8) + sum(p.numel() * 4 for p in code.pyramid)
-        sample_roof = {"kernel": "sample_pyramid_kernel (sample_from_planes x5 + cat, stand-alone op)",
+        sample_roof = {"kernel": "sample_pyramid_kernel (sample_from_planes x5 + cat)",
                        "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                        "frac": alg / (k_ms * 1e-3) / 1e9 / 8000.0, "kernel_ms": k_ms, "alg_bytes": alg,
                        "op_ms_incl_locality_sort": ms, "op_gbps_incl_locality_sort": alg / (ms * 1e-3) / 1e9,
@@ -639,7 +639,7 @@ def main():
             "value": q_total / dt, "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic-smooth",
-            "config": {"workload": "reg_slices inference %d^2 x %d slices, %d queries/object, %d objects/GPU/step (BASELINE configs[1])"
+            "config": {"workload": "reg_slices inference %d^2 x %d slices, %d queries/object, %d objects/GPU/step (configs[1])"
                                    % (args.img_size, args.n_slices, args.n_qry, args.batch),
                        "img_size": args.img_size, "n_slices": args.n_slices, "n_qry": args.n_qry,
                        "objects_per_step": world * args.batch, "parallelism": "objects x%d (no collective)" % world},
@@ -648,8 +648,8 @@ def main():
                                    + " (decoder FFN 128->2048->128 + residual + LN2)",
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "note": ("algorithmic FLOPs; f16x3 = 3 f16 MFMAs per fp32 product, the pipe executes 3x `achieved`; "
-                                  "power-capped (DESIGN.md section 5)" if args.prec != "f32" else "exact fp32 MFMA"),
+                         "note": ("algorithmic FLOPs; the pipe executes 3x (f16x3); power-capped, DESIGN.md s5"
+                                  if args.prec != "f32" else "exact fp32 MFMA"),
                          "mfma_pipe_tflops": achieved * (3 if args.prec != "f32" else 1),
                          "traffic_source": traffic_src,
                          "avg_launch_ms": ffn_ms, "launches": counts["ffn_layer"],
@@ -658,7 +658,7 @@ def main():
                 sample_roof,
                 {"kernel": "U-Net conv stack", "bound": "mfma", "achieved": unet_tf, "peak": peak, "unit": "TFLOP/s",
                  "frac": unet_tf / peak},
-                {"kernel": "attention stage (attn_layer_q_kernel x2 + absorbed last layer)", "bound": "mfma",
+                {"kernel": "attention stage (2 layers + absorbed last layer)", "bound": "mfma",
                  "achieved": attn_tf, "peak": peak, "unit": "TFLOP/s", "frac": attn_tf / peak},
             ],
             "decode_tflops_fmin": args.n_qry * args.batch * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,

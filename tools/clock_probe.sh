@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power|fclk" | head -6
 echo "--- under load (bench.py inference only, sampled every 0.25 s) ---"
-python bench.py --steps 150 --warmup 5 --cpu-sample 0 --train-steps 0 --gt-train-steps 0 --ldm-steps 0 --mesh-steps 0 > /tmp/b.json 2>/dev/null &
+python bench.py --steps 150 --warmup 5 --infer-only > /tmp/b.json 2>/dev/null &
 BP=$!
 sleep 6
 for i in $(seq 1 12); do
