@@ -269,12 +269,29 @@ int s3d_conv_fwd(const void* packed, const float* x0, const float* x1, const flo
  * ks == 3, split precision (f16x3 / f16), cin0, cin1, cout multiples of 32, cin0 + cin1 <= 1536; other shapes are refused
  * with S3D_E_ARG (use s3d_group_norm_fwd + s3d_conv_fwd). */
 size_t s3d_group_norm_stats_floats(int N, int groups);
+/* A convolution output whose split-K finish pass is deferred to its consumer (s3d_conv_gn_fwd with nsplit_out != NULL reported
+ * nsplit > 1): the raw partial sums [nsplit][N*H*W][cout] sit in the convolution's workspace; `out` (N,H,W,cout) is written by
+ * whoever consumes the descriptor — the next GroupNorm's statistics kernel (s3d_group_norm_table_fwd / s3d_group_norm_partial_fwd:
+ * it sums the splits, adds the bias of `conv_packed` and `residual`, stores `out` and goes on with the values) or
+ * s3d_conv_finish_fwd.  The descriptor is dead once the workspace is reused (the next split-K convolution). */
+typedef struct {
+    const float* part;
+    int nsplit;
+    const void* conv_packed;   /* the producing convolution's packed weights (holds its bias) */
+    int cout, cin0, cin1, ks;
+    const float* residual;     /* or NULL */
+    float* out;
+} S3dConvPartial;
 int s3d_group_norm_table_fwd(const float* x0, int c0, const float* x1, int c1, const float* gamma, const float* beta,
                              const float* film, long film_stride, float* table, float* stats, int N, int HW, int groups,
-                             float eps, void* stream);
+                             float eps, const S3dConvPartial* x0_partial, void* stream);
+int s3d_group_norm_partial_fwd(const S3dConvPartial* x0_partial, const float* gamma, const float* beta, const float* film,
+                               long film_stride, float* y, float* stats, int N, int HW, int groups, float eps, int silu,
+                               void* stream);
 int s3d_conv_gn_fwd(const void* packed, const float* x0, const float* x1, const float* residual, float* out, int N, int H,
                     int W, int cout, int cin0, int cin1, int ks, int prec, const float* table, int silu, void* workspace,
-                    size_t workspace_bytes, void* stream);
+                    size_t workspace_bytes, int* nsplit_out, void* stream);
+int s3d_conv_finish_fwd(const S3dConvPartial* partial, int N, int H, int W, void* stream);
 /* GroupNorm32 (util.py normalization) [+ FiLM: y*(1+scale)+shift, film = (N, 2C), openaimodel.py:268-270] [+ SiLU].
  * stats: s3d_group_norm_stats_floats(N, groups) floats of scratch (N*groups*192 since round 4; a smaller buffer is
  * overrun silently — size it with the function). */

@@ -48,6 +48,11 @@ class S3dHeadParams(C.Structure):
                 ("fc_out_w", C.c_void_p), ("fc_out_b", C.c_void_p)]
 
 
+class S3dConvPartial(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("nsplit", C.c_int), ("conv_packed", C.c_void_p), ("cout", C.c_int), ("cin0", C.c_int),
+                ("cin1", C.c_int), ("ks", C.c_int), ("residual", C.c_void_p), ("out", C.c_void_p)]
+
+
 class S3dVggParams(C.Structure):
     _fields_ = [("conv", S3dConvParams * 14), ("mean", C.c_void_p), ("std", C.c_void_p)]
 
@@ -125,8 +130,10 @@ SYMBOLS = {
     "s3d_conv_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "s3d_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "s3d_group_norm_stats_floats": (_sz, [_i, _i]),
-    "s3d_group_norm_table_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, C.c_long, _vp, _vp, _i, _i, _i, _f, _vp]),
-    "s3d_conv_gn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "s3d_group_norm_table_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, C.c_long, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "s3d_group_norm_partial_fwd": (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "s3d_conv_gn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp]),
+    "s3d_conv_finish_fwd": (_i, [_vp, _i, _i, _i, _vp]),
     "s3d_group_norm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "s3d_group_norm_film_fwd": (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "s3d_group_norm2_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),

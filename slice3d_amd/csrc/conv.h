@@ -59,9 +59,14 @@ struct ConvLaunch {
     size_t splitk_floats;
     DropCfg drop;        // NHWC mode only: v *= dropout mask (index = output element index), before the residual
     ConvGn gn;           // LDS-staged 3x3 kernel only (launch_conv refuses it elsewhere): GroupNorm of the input, see ConvGn
+    int* splits_out;     // HOST pointer, optional.  Non-NULL: a split-K launch leaves its raw partial sums in splitk_ws
+                         // ([split][pixel][CoutPad]) and skips the finish pass — *splits_out = number of splits (1: `out` is
+                         // final) — for a consumer that sums them itself (the GroupNorm statistics kernels, ldm_ops.hip)
 };
 
 int launch_conv(const ConvLaunch& a, hipStream_t stream);
+// the finish pass of a split-K launch on its own (a.splitk_ws holds `nsplit` partials): sums them, applies the epilogue of `a`
+int launch_conv_splitk_finish(const ConvLaunch& a, int nsplit, hipStream_t stream);
 
 // weight / epilogue packers (device kernels behind them)
 enum { S3D_PACK_LINEAR = 0, S3D_PACK_CONV = 1, S3D_PACK_CONVT = 2, S3D_PACK_CONV_DGRAD = 3,

@@ -991,6 +991,14 @@ __global__ void conv_splitk_finish_kernel(const ConvLaunch a, int nsplit) {
     }
 }
 
+int launch_conv_splitk_finish(const ConvLaunch& a, int nsplit, hipStream_t stream) {
+    const long total = (long)(((size_t)a.N * a.H * a.W * a.CoutPad) >> 2);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(blocks), dim3(256), 0, stream, a, nsplit);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}
+
 static bool conv3x3_lds_eligible(const ConvLaunch& a) {
     if (a.ks != 3 || a.stride > 1 || (a.Hin && a.Hin != a.H) || (a.Win && a.Win != a.W)) return false;
     if (!a.wpk16 || a.KU % 2 || a.CoutPad % 32) return false;
@@ -1048,12 +1056,11 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
         else hipLaunchKernelGGL((conv3x3_lds_f16x3_kernel<2, 4, 1, 2>), grid, dim3(256), 0, stream, a, tiles_x, tiles_y, cps);
     }
     S3D_LAUNCH_CHECK();
-    if (splits > 1) {
-        const long total = (long)(out_floats >> 2);
-        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(blocks), dim3(256), 0, stream, a, splits);
-        S3D_LAUNCH_CHECK();
+    if (a.splits_out) {
+        *a.splits_out = splits;
+        if (splits > 1) return 0;   // the consumer sums the partials (and applies bias / residual) itself
     }
+    if (splits > 1) return launch_conv_splitk_finish(a, splits, stream);
     return 0;
 }
 

@@ -19,8 +19,46 @@ struct GnSrc {
     const float* x;
     const float* x1;
     int C0;
+    // Round 5: source 0 as the raw split-K partial sums of the convolution that produces it (conv.hip: [split][pixel][C0]).
+    // The statistics kernels read every element exactly once: they add the splits up in split order (the order of
+    // conv_splitk_finish_kernel: the same bits), add the bias and the residual, write the finished tensor to `fin` and go
+    // on with the value — the convolution's finish pass (70 launches of ~5 us per denoising step) is gone.
+    const float* part;      // NULL: x is a finished tensor
+    int nsplit;
+    long pstride;           // floats between consecutive splits (= N * HW * C0)
+    const float* pshift;    // [C0] bias, or NULL
+    const float* pres;      // residual (N, HW, C0), or NULL
+    float* fin;             // finished tensor (N, HW, C0)
+    __device__ __forceinline__ f32x4 part4(long p, int c) const {   // elements (pixel p, channels c..c+3) of source 0, finished
+        const float* q = part + p * C0 + c;
+        f32x4 sacc = zero4();
+        int k = 0;
+        for (; k + 4 <= nsplit; k += 4) {   // four partials in flight, summed as the finish kernel sums them
+            const f32x4 v0 = ld4(q + (long)k * pstride), v1 = ld4(q + (long)(k + 1) * pstride), v2 = ld4(q + (long)(k + 2) * pstride),
+                        v3 = ld4(q + (long)(k + 3) * pstride);
+            sacc += (v0 + v1) + (v2 + v3);
+        }
+        for (; k < nsplit; ++k) sacc += ld4(q + (long)k * pstride);
+        if (pshift) sacc += ld4(pshift + c);
+        if (pres) sacc += ld4(pres + p * C0 + c);
+        st4(fin + p * C0 + c, sacc);
+        return sacc;
+    }
+    __device__ __forceinline__ float part1(long p, int c) const {
+        const float* q = part + p * C0 + c;
+        float sacc = 0.f;
+        int k = 0;
+        for (; k + 4 <= nsplit; k += 4)
+            sacc += (q[(long)k * pstride] + q[(long)(k + 1) * pstride]) + (q[(long)(k + 2) * pstride] + q[(long)(k + 3) * pstride]);
+        for (; k < nsplit; ++k) sacc += q[(long)k * pstride];
+        if (pshift) sacc += pshift[c];
+        if (pres) sacc += pres[p * C0 + c];
+        fin[p * C0 + c] = sacc;
+        return sacc;
+    }
     __device__ __forceinline__ float at(long n_hw_p, int c, int C) const {   // element (pixel index over N*HW, channel)
-        return c < C0 ? x[n_hw_p * C0 + c] : x1[n_hw_p * (C - C0) + (c - C0)];
+        if (c < C0) return part ? part1(n_hw_p, c) : x[n_hw_p * C0 + c];
+        return x1[n_hw_p * (C - C0) + (c - C0)];
     }
 };
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnSrc src, int HW, int C, int groups,
@@ -76,7 +114,8 @@ __global__ __launch_bounds__(1024) void gn_stats_rows_kernel(const GnSrc src, in
     const int c = 4 * cqi;
     auto row = [&](int p) {
         const long q = (long)n * HW + p;
-        return c < src.C0 ? ld4(src.x + q * src.C0 + c) : ld4(src.x1 + q * (C - src.C0) + (c - src.C0));
+        if (c < src.C0) return src.part ? src.part4(q, c) : ld4(src.x + q * src.C0 + c);
+        return ld4(src.x1 + q * (C - src.C0) + (c - src.C0));
     };
     if (pr < lanes) {
         f32x4 a1 = zero4(), a2 = zero4();
@@ -332,13 +371,20 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const GnSrc src, const f
 // while it stages its input
 int launch_group_norm(const float* x, const float* gamma, const float* beta, const float* film, float* y, float* stats,
                       int N, int HW, int C, int groups, float eps, int silu, hipStream_t stream, const float* x1,
-                      int C0, long film_ld, float* table) {
+                      int C0, long film_ld, float* table, const GnPartial* part) {
     if (film_ld <= 0) film_ld = 2L * C;   // rows of a dense (N, 2C) film tensor
     S3D_CHECK_ARG(!table || groups <= 64, "group_norm table: %d groups", groups);
+    S3D_CHECK_ARG(!part || (part->part && part->fin && part->nsplit >= 1), "group_norm: bad partial-sum source");
     S3D_CHECK_ARG(C % groups == 0 && C % 4 == 0 && N >= 1 && HW >= 1, "group_norm: C=%d groups=%d", C, groups);
     if (!x1) C0 = C;
     S3D_CHECK_ARG(C0 >= 4 && C0 <= C && C0 % 4 == 0 && (C - C0) % 4 == 0, "group_norm: source split %d | %d", C0, C - C0);
-    const GnSrc src = {x, x1, C0};
+    GnSrc src = {x, x1, C0, nullptr, 0, 0, nullptr, nullptr, nullptr};
+    if (part) {
+        S3D_CHECK_ARG(C0 % 4 == 0, "group_norm: partial-sum source needs C0 %% 4 == 0");
+        src.x = part->fin;      // (what a second pass over the input reads: the finished tensor)
+        src.part = part->part; src.nsplit = part->nsplit; src.pstride = (long)N * HW * C0;
+        src.pshift = part->shift; src.pres = part->res; src.fin = part->fin;
+    }
     {
         const long per_thread = ((long)HW * (C / groups) + 1023) / 1024;
         if (per_thread <= 8 || (per_thread <= 24 && N * groups >= 128)) {   // (with >= 128 workgroups the one-launch form wins again)   // small maps: one launch (a (image, group) slab in the registers of one workgroup); larger ones
@@ -359,8 +405,10 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
     if (C <= 2048 && groups <= 1024)   // (LDS: 7 C floats) coalesced one-pass partial moments (all channels of a pixel slab per workgroup)
         hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(N * GN_SLICES), dim3(1024),
                            (size_t)(3 * C + 2 * (1024 / (C / 4)) * C) * sizeof(float), stream, src, HW, C, groups, stats);
-    else
+    else {
+        S3D_CHECK_ARG(!part, "group_norm: partial-sum source with C = %d > 2048", C);
         hipLaunchKernelGGL(gn_stats_kernel, dim3(N * groups * GN_SLICES), dim3(256), 0, stream, src, HW, C, groups, stats);
+    }
     S3D_LAUNCH_CHECK();
     if (table) {
         hipLaunchKernelGGL(gn_table_kernel, dim3(N), dim3(256), 0, stream, stats, gamma, beta, film, film_ld, table, C, groups, eps);
@@ -369,6 +417,7 @@ int launch_group_norm(const float* x, const float* gamma, const float* beta, con
     }
     const long total = (long)N * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    src.part = nullptr;   // the statistics kernel has written the finished tensor (src.x == part->fin)
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), (size_t)N * groups * 2 * sizeof(float), stream, src, stats,
                        gamma, beta, film, film_ld, y, N, HW, C, groups, eps, silu);
     S3D_LAUNCH_CHECK();

@@ -60,7 +60,7 @@ class AttentionBlock(nn.Module):
 class UNetModel(nn.Module):
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0, channel_mult=(1, 2, 4, 8), num_heads=-1, use_scale_shift_norm=False, resblock_updown=False,
-                 backend="hip", prec="f16x3", fuse_gn=True, branch_streams=False):
+                 backend="hip", prec="f16x3", fuse_gn=True, branch_streams=False, defer_finish=False):
         super().__init__()
         if not resblock_updown:
             raise NotImplementedError("conv_resample down/up-sampling is not built (the Slice3D configuration uses "
@@ -77,6 +77,14 @@ class UNetModel(nn.Module):
         self.branch_streams = branch_streams
         self._side = None
         self._ws_side = None
+        # defer_finish: a fused-GroupNorm 3x3 convolution that ran split-K leaves its raw partial sums to the NEXT GroupNorm's
+        # statistics kernel, which adds them up (+ bias + residual), stores the finished tensor and goes on with the values:
+        # the convolution's own finish pass (one ~5 us launch behind ~60 of the step's 70 3x3 convolutions) is gone.  OFF by
+        # default: bit-identical and measured 0.6 % SLOWER (4.203 against 4.179 ms per step, tools/ldm_ab.py,
+        # profiles/r05_ldm_experiments.md) — the statistics kernels, latency-bound themselves, pay for the 5-14 partials per
+        # element what the finish launches cost
+        self.defer_finish = defer_finish
+        self._pending = None      # (tensor, S3dConvPartial, (n, h, w), keep-alive refs) of the one deferred output, or None
         self.fuse_gn = fuse_gn    # GroupNorm -> SiLU -> conv3x3 as one operator where the kernel serves the shape (s3d_conv_gn_fwd)
         ted = model_channels * 4
         self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
@@ -196,7 +204,25 @@ class UNetModel(nn.Module):
     # ------------------------------------------------------------------------------------------
     # primitive wrappers (channels-last tensors)
     # ------------------------------------------------------------------------------------------
+    # -- deferred split-K finish ------------------------------------------------------------------------
+    def _take_pending(self, x):
+        """The S3dConvPartial of x if x is the tensor whose finish pass is still owed (and hand the duty to the caller)."""
+        p = self._pending
+        if p is not None and p[0] is x:
+            self._pending = None
+            return p
+        return None
+
+    def _finish_pending(self):
+        """Run the owed finish pass on its own (a consumer that is not a GroupNorm comes first, or the workspace is needed)."""
+        p = self._pending
+        if p is not None:
+            self._pending = None
+            _, desc, (n, h, w), _ = p
+            _lib.check(self._lib.s3d_conv_finish_fwd(C.byref(desc), n, h, w, self._stream()), "s3d_conv_finish_fwd")
+
     def _conv(self, conv, x0, x1=None, residual=None, side=False):
+        self._finish_pending()
         lib = self._lib
         buf, cout, cin0, cin1, ks = self._packed[id(conv)]
         n, h, w, _ = x0.shape
@@ -241,34 +267,53 @@ class UNetModel(nn.Module):
         return (self.fuse_gn and self.prec != "f32" and ks == 3 and cout % 32 == 0 and cin0 % 32 == 0 and cin1 % 32 == 0
                 and cin0 + cin1 <= 1536 and x.shape[-1] == cin0)   # (a concatenated input needs the two-source pack)
 
-    def _gn_conv(self, gn, conv, x, x1=None, film=None, residual=None, before_conv=None):
-        """conv(silu(film(group_norm(cat([x, x1]))))) (+ residual) without writing the normalised tensor: statistics kernel,
-        then the convolution normalises while it stages its input (openaimodel.py:188-194, :229-236, :262-270)."""
+    def _gn_table(self, gn, x, x1=None, film=None):
+        """Statistics of group_norm(cat([x, x1])) folded with gamma / beta / FiLM into the per-channel affine table a fused
+        convolution applies (s3d_group_norm_table_fwd).  If x is the deferred output of a split-K convolution this launch is
+        also its finish pass (it sums the partials, adds bias and residual and stores x)."""
         lib = self._lib
-        buf, cout, cin0, cin1, ks = self._packed[id(conv)]
         n, h, w, c = x.shape
         c1 = x1.shape[-1] if x1 is not None else 0
-        if (c, c1) != (cin0, cin1):
-            raise _lib.S3dError("fused GroupNorm convolution: sources (%d, %d) do not match the packed split (%d, %d)" % (c, c1, cin0, cin1))
         stats = torch.empty(lib.s3d_group_norm_stats_floats(n, gn.num_groups), dtype=torch.float32, device=x.device)
         table = torch.empty((n, 2, c + c1), dtype=torch.float32, device=x.device)
         fp, fld = (None, 0)
         if film is not None:
             ft, off = film
             fp, fld = ft.data_ptr() + 4 * off, ft.shape[1]
+        pend = self._take_pending(x)
+        if pend is None:
+            self._finish_pending()
         _lib.check(lib.s3d_group_norm_table_fwd(x.data_ptr(), c, x1.data_ptr() if x1 is not None else None, c1,
                                                 gn.weight.data_ptr(), gn.bias.data_ptr(), fp, fld, table.data_ptr(),
-                                                stats.data_ptr(), n, h * w, gn.num_groups, C.c_float(gn.eps), self._stream()),
+                                                stats.data_ptr(), n, h * w, gn.num_groups, C.c_float(gn.eps),
+                                                C.byref(pend[1]) if pend is not None else None, self._stream()),
                    "s3d_group_norm_table_fwd")
-        if before_conv is not None:      # join of the side stream that produced `residual` (after the statistics launch)
-            before_conv()
+        return table
+
+    def _gn_conv_apply(self, conv, x, x1, table, residual=None):
+        """conv(silu(x * A + B)) (+ residual) with the table of _gn_table: the normalised tensor is never written
+        (s3d_conv_gn_fwd; openaimodel.py:188-194, :229-236, :262-270).  With defer_finish a split-K launch leaves its finish
+        pass to the next consumer (self._pending)."""
+        lib = self._lib
+        buf, cout, cin0, cin1, ks = self._packed[id(conv)]
+        n, h, w, c = x.shape
+        c1 = x1.shape[-1] if x1 is not None else 0
+        if (c, c1) != (cin0, cin1):
+            raise _lib.S3dError("fused GroupNorm convolution: sources (%d, %d) do not match the packed split (%d, %d)" % (c, c1, cin0, cin1))
+        self._finish_pending()           # (the split-K scratch is about to be overwritten)
         out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
         if self._ws is None:
             self._ws = torch.empty(8 << 20, dtype=torch.float32, device=x.device)     # split-K scratch
+        nsplit = C.c_int(1)
         _lib.check(lib.s3d_conv_gn_fwd(buf.data_ptr(), x.data_ptr(), x1.data_ptr() if x1 is not None else None,
                                        residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w, cout,
                                        cin0, cin1, ks, self._precv(), table.data_ptr(), 1,
-                                       self._ws.data_ptr(), self._ws.numel() * 4, self._stream()), "s3d_conv_gn_fwd")
+                                       self._ws.data_ptr(), self._ws.numel() * 4,
+                                       C.byref(nsplit) if self.defer_finish else None, self._stream()), "s3d_conv_gn_fwd")
+        if nsplit.value > 1:             # `out` is still to be written: by the next GroupNorm, or by _finish_pending()
+            desc = _lib.S3dConvPartial(self._ws.data_ptr(), nsplit.value, buf.data_ptr(), cout, cin0, cin1, ks,
+                                       residual.data_ptr() if residual is not None else None, out.data_ptr())
+            self._pending = (out, desc, (n, h, w), (residual, buf))
         return out
 
     def _group_norm(self, gn, x, film=None, silu=True, x1=None):
@@ -276,6 +321,20 @@ class UNetModel(nn.Module):
         lib = self._lib
         n, h, w, c = x.shape
         stats = torch.empty(lib.s3d_group_norm_stats_floats(n, gn.num_groups), dtype=torch.float32, device=x.device)
+        pend = self._take_pending(x) if x1 is None else None
+        if pend is not None:             # x's split-K partials: the statistics kernel of this GroupNorm is its finish pass
+            y = torch.empty_like(x)
+            fp, fld = (None, 0)
+            if isinstance(film, tuple):
+                fp, fld = film[0].data_ptr() + 4 * film[1], film[0].shape[1]
+            elif film is not None:
+                fp, fld = film.data_ptr(), film.shape[1]
+            _lib.check(lib.s3d_group_norm_partial_fwd(C.byref(pend[1]), gn.weight.data_ptr(), gn.bias.data_ptr(), fp, fld,
+                                                      y.data_ptr(), stats.data_ptr(), n, h * w, gn.num_groups,
+                                                      C.c_float(gn.eps), 1 if silu else 0, self._stream()),
+                       "s3d_group_norm_partial_fwd")
+            return y
+        self._finish_pending()
         if x1 is not None:
             c1 = x1.shape[-1]
             y = torch.empty((n, h, w, c + c1), dtype=torch.float32, device=x.device)
@@ -300,6 +359,7 @@ class UNetModel(nn.Module):
         return y
 
     def _resample(self, x, up):
+        self._finish_pending()
         lib = self._lib
         n, h, w, c = x.shape
         y = torch.empty((n, h * 2, w * 2, c) if up else (n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
@@ -317,6 +377,7 @@ class UNetModel(nn.Module):
         return out
 
     def _add(self, a, b):
+        self._finish_pending()
         lib = self._lib
         out = torch.empty_like(a)
         _lib.check(lib.s3d_add_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), self._stream()), "s3d_add_fwd")
@@ -344,8 +405,14 @@ class UNetModel(nn.Module):
         resampling = blk.up or blk.down
         if resampling and skip is not None:
             raise NotImplementedError("resampling ResBlock on a concatenated input (not in this architecture)")
+        # 1. the GroupNorm of the input FIRST: if x is a deferred split-K output its statistics launch finishes it
+        fuse_in = not resampling and self._gn_conv_fusable(blk.in_layers[2], x)
+        if fuse_in:
+            table_in = self._gn_table(blk.in_layers[0], x, x1=skip)
+        else:
+            hn = self._group_norm(blk.in_layers[0], x, silu=True, x1=skip)
+        # 2. the skip path: it only needs the block's (finished) input
         xs = self._resample(x, blk.up) if resampling else x
-        # the skip path first: it only needs the block's input, so its 1x1 convolution forks off here and runs beside the chain
         join = None
         if isinstance(blk.skip_connection, nn.Conv2d):
             if self.branch_streams:
@@ -356,16 +423,18 @@ class UNetModel(nn.Module):
             raise NotImplementedError("identity skip connection on a concatenated input (not in this architecture)")
         else:
             res = xs
-        if resampling:             # GroupNorm -> SiLU -> resample -> conv: the resampling sits between, nothing to fuse
-            h = self._conv(blk.in_layers[2], self._resample(self._group_norm(blk.in_layers[0], x, silu=True), blk.up))
-        elif self._gn_conv_fusable(blk.in_layers[2], x):
-            h = self._gn_conv(blk.in_layers[0], blk.in_layers[2], x, x1=skip)
+        # 3. in_layers convolution (GroupNorm -> SiLU -> resample -> conv: the resampling sits between, nothing to fuse)
+        if fuse_in:
+            h = self._gn_conv_apply(blk.in_layers[2], x, skip, table_in)
         else:
-            h = self._conv(blk.in_layers[2], self._group_norm(blk.in_layers[0], x, silu=True, x1=skip))
-        # (N, 2*Cout) = scale | shift: columns [off, off + rows) of the stacked emb_layers output, read in place
+            h = self._conv(blk.in_layers[2], self._resample(hn, blk.up) if resampling else hn)
+        # 4. out_layers; (N, 2*Cout) = scale | shift: columns [off, off + rows) of the stacked emb_layers output, read in place
         off, rows = self._film_off[id(blk)]
         if self._gn_conv_fusable(blk.out_layers[3], h):
-            return self._gn_conv(blk.out_layers[0], blk.out_layers[3], h, film=(self._film_all, off), residual=res, before_conv=join)
+            table_out = self._gn_table(blk.out_layers[0], h, film=(self._film_all, off))
+            if join is not None:
+                join()
+            return self._gn_conv_apply(blk.out_layers[3], h, None, table_out, residual=res)
         h = self._group_norm(blk.out_layers[0], h, film=(self._film_all, off), silu=True)
         if join is not None:
             join()
@@ -416,6 +485,7 @@ class UNetModel(nn.Module):
             self.repack()
         dev = self._dev()
         n = x.shape[0]
+        self._pending = None
         t = timesteps.to(device=dev, dtype=torch.float32).contiguous()
         t_emb = torch.empty((n, self.model_channels), dtype=torch.float32, device=dev)
         _lib.check(lib.s3d_timestep_embedding_fwd(t.data_ptr(), t_emb.data_ptr(), n, self.model_channels,
@@ -440,6 +510,7 @@ class UNetModel(nn.Module):
             h = self._run(module, h, emb, skip=hs.pop())
         hn = self._group_norm(self.out[0], h, silu=True)
         o = self._conv(self.out[2], hn)                                       # (N, H, W, out_channels)
+        self._finish_pending()                                                # (nothing is owed here: the stem of `out` is not split-K)
         nn_, hh, ww, cc = o.shape
         out = torch.empty((nn_, cc, hh, ww), dtype=torch.float32, device=dev)
         _lib.check(lib.s3d_nhwc_to_nchw(o.data_ptr(), out.data_ptr(), nn_, cc, hh, ww, self._stream()), "s3d_nhwc_to_nchw")

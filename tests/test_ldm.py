@@ -81,6 +81,10 @@ def test_ldm_fused_group_norm_convolution_equals_the_two_operator_form(name, cfg
     d = np.abs(outs[True] - outs[False]).max() / scale
     print("LDM %s: fused vs two-operator GroupNorm: %.2e of max|y|" % (name, d))
     assert 0 < d < 2e-5      # (not bit-identical: the fused path really ran)
+    # the split-K finish passes deferred to the next GroupNorm's statistics kernel (opt-in, measured neutral) against each
+    # convolution finishing itself: the splits are added in the same order, bias and residual joined in the same order — the same bits
+    m = load_seeded(UNetModel(defer_finish=True, **cfg), 0).cuda().eval()
+    assert np.array_equal(m(x.cuda(), t.cuda(), c_fmaps=cf).cpu().numpy(), outs[True])
     # the ResBlocks' skip convolutions on a side stream (opt-in: a parallel branch of the sampler's HIP graph, measured slower):
     # the same kernels on the same data in another order of launch — the same bits
     m = load_seeded(UNetModel(branch_streams=True, **cfg), 0).cuda().eval()

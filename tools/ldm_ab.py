@@ -21,9 +21,9 @@ lc = {k: (torch.randn(1, c, r, r, generator=g) * 0.5).cuda()
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 for rep in range(2):
     for prec in ("f16x3", "f16"):
-        for fuse in (False, True):
-            for branch in (False, True):
-                um = load_seeded(UNetModel(prec=prec, fuse_gn=fuse, branch_streams=branch, **cfg), 0).cuda().eval()
+        for fuse, branch, defer in ((False, False, False), (True, False, False), (True, False, True), (True, True, True)):
+            if True:
+                um = load_seeded(UNetModel(prec=prec, fuse_gn=fuse, branch_streams=branch, defer_finish=defer, **cfg), 0).cuda().eval()
                 smp = DDIMSampler(um)
                 x_T, cc = lx[:, :4].contiguous(), lx[:, 4:].contiguous()
                 gen = torch.Generator(device="cuda").manual_seed(0)
@@ -33,5 +33,5 @@ for rep in range(2):
                 smp.sample(200, x_T, cc, lc, eta=1.0, generator=gen, n_steps=steps)
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t1) / steps * 1e3
-                print("prec %-5s fuse_gn %-5s branch %-5s graph %-5s  %.3f ms/step" % (prec, fuse, branch, bool(smp._graph), ms), flush=True)
+                print("prec %-5s fuse_gn %-5s defer_finish %-5s branch %-5s graph %-5s  %.3f ms/step" % (prec, fuse, defer, branch, bool(smp._graph), ms), flush=True)
                 del um, smp
