@@ -46,6 +46,14 @@ class Generator3D(object):
         self.vol_bound = vol_bound
         if pred_type == "occ":
             raise ValueError("the regression model only produces sdf_pred (SURVEY.md section 0); use pred_type='sdf'")
+        # reconstruct.py:205-240 runs these three post-processing branches through `self.model.decode(p, c).logits` under
+        # autograd w.r.t. the POINTS (estimate_normals :244-270, refine_mesh :272-331) and through simplify_mesh (:231-235);
+        # the reference's own model has no decode(), so they are dead code there (AttributeError) and reconstruct.py never
+        # enables them.  Here they are refused loudly instead of being accepted and ignored.
+        if with_normals or refinement_step or simplify_nfaces is not None:
+            raise NotImplementedError("Generator3D: with_normals / refinement_step / simplify_nfaces need gradients of the "
+                                      "logits w.r.t. the query points (reconstruct.py:244-331) or the mesh simplifier; "
+                                      "not built (dead branches of the reference: its model has no decode())")
         self._code = None
 
     # -- per-object state -----------------------------------------------------------------------

@@ -125,3 +125,15 @@ def test_bench_self_launch_builds_a_torchrun_job(monkeypatch):
     assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
     assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_generator3d_refuses_the_reference_dead_post_processing_branches():
+    """reconstruct.py:205-240: with_normals / refinement_step / simplify_nfaces run through model.decode(p, c).logits under
+    autograd w.r.t. the points — dead in the reference (its model has no decode()).  They must not be accepted and ignored."""
+    from slice3d_amd.generator import Generator3D
+    for kw in (dict(with_normals=True), dict(refinement_step=30), dict(simplify_nfaces=5000)):
+        with pytest.raises(NotImplementedError):
+            Generator3D(object(), pred_type="sdf", **kw)
+    with pytest.raises(ValueError):
+        Generator3D(object(), pred_type="occ")
+    Generator3D(object(), pred_type="sdf")
