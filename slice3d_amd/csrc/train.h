@@ -167,6 +167,10 @@ struct SampleBwdArgs {
     long n_qry, groups_per_batch, groups;
     const int* perm;         // optional: token rows are in sorted order, perm[b*Q + slot] = query (s3d_query_sort)
     const int* bin_ends;     // with perm: [B][65536] end offset of every Morton bin (launch_query_sort's ws)
+    float* gxy;              // optional scratch, B * n_qry * 2 floats (with perm): the projected image coordinates of every
+                             // SORTED slot, filled by a pre-pass of launch_sample_bwd — the tiled kernel then loads a slot's
+                             // (gx, gy) with one coalesced read instead of walking perm -> qry -> rotate -> project (three
+                             // dependent global loads) 2 x n_slices times per query
     int gt;                  // Slices3DGTModel levels: dproj[0..2] + dfine[0] are the four folded 128-ch maps
                              // (S/16 ... S/2), dfine[1] the raw 64-ch conv1_2 map, ws34_t the [4][8] image of Wraw^T
 };

@@ -335,6 +335,13 @@ struct SbtGeom {
     int W[5], C[5], fw[5], off[5];   // level width, channels, footprint width, LDS float offset
     int total;                       // floats of LDS accumulators
 };
+// LDS accumulators of the raw levels: a footprint pixel's C channels are followed by SBT_PAD unused floats (round 5).  With the
+// dense stride (64 / 32 floats = 64 / 32 banks) every pixel's channel c sat in the SAME bank: the ds_add_f32 of a tap — active
+// lanes = the tails of the row's runs, i.e. different pixels, same channel — was a 16-way bank conflict, and cycle stamps
+// (tools/patches/sample_bwd_stamps.patch) showed the level loop at 31-50 k cycles per 16-query group with the other waves'
+// fragment reads queued behind it (72 MFMAs taking 8-25 k cycles).  A stride of C + 16 floats moves consecutive pixels by 16
+// banks: four neighbouring pixels x four channel quads per instruction are conflict-free.
+#define SBT_PAD 16
 __device__ __forceinline__ unsigned compact8(unsigned v) {   // even bits of a 16-bit Morton code
     v &= 0x5555u;
     v = (v | (v >> 1)) & 0x3333u;
@@ -392,6 +399,33 @@ struct SbFold {
 // F16 (split-precision training): the product with W_raw^T runs on the f16x3 MFMA (round 4: cycle stamps showed its fp32 form — 192
 // v_mfma_f32_16x16x4_f32 in chains of 32 dependent instructions per 16-query task, shared by the two waves of a SIMD — at 7 000 to
 // 23 000 of a task's ~50 000 cycles); a lane then reads 8 consecutive channels of each 32-channel block of its dX row.
+// pre-pass of the tiled kernel: gxy[b][slot] = projected, clamped image coordinates of the query in sorted slot `slot`
+// (models.py:28-36 after the rotation of :58-60) — the same expressions, in the same order, as the tiled kernel used in place
+__global__ void sbt_project_kernel(const SampleBwdArgs a, int batch) {
+    const long total = (long)batch * a.n_qry;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / a.n_qry);
+        const long q = a.perm[i];
+        const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
+        const float* Tm = a.trans + b * 12;
+        float x = p[0], y = p[1], z = p[2];
+        if (a.flip_yz) {
+            y = -y; z = -z;
+        } else if (a.rot) {
+            const float* R = a.rot + b * 9;
+            const float rx = x * R[0] + y * R[3] + z * R[6];
+            const float ry = x * R[1] + y * R[4] + z * R[7];
+            const float rz = x * R[2] + y * R[5] + z * R[8];
+            x = rx; y = ry; z = rz;
+        }
+        const float X = x * Tm[0] + y * Tm[3] + z * Tm[6] + Tm[9];
+        const float Y = x * Tm[1] + y * Tm[4] + z * Tm[7] + Tm[10];
+        const float Z = x * Tm[2] + y * Tm[5] + z * Tm[8] + Tm[11];
+        a.gxy[2 * i] = fminf(fmaxf(2.f * (X / Z - 0.5f), -1.f), 1.f);
+        a.gxy[2 * i + 1] = fminf(fmaxf(2.f * (Y / Z - 0.5f), -1.f), 1.f);
+    }
+}
+
 template <int GT, bool F16>
 __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const SampleBwdArgs a, const SbtGeom G) {
     using LV = SbLevels<GT>;
@@ -428,6 +462,11 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
     const float* Tm = a.trans + b * 12;
     // image coordinates of sorted slot qs of this object (clamped into the tile's range by the caller)
     auto project_slot = [&](long qs, float& gx, float& gy) {
+        if (a.gxy) {   // pre-pass (sbt_project_kernel): one coalesced 8-byte load
+            const s3d_float2 g2 = *reinterpret_cast<const s3d_float2*>(a.gxy + 2 * ((long)b * a.n_qry + qs));
+            gx = g2[0]; gy = g2[1];
+            return;
+        }
         const long q = a.perm[(long)b * a.n_qry + qs];
         const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
         float x = p[0], y = p[1], z = p[2];
@@ -521,7 +560,7 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
             if (regular) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float* o = lbase + (tp.ok[k] ? tp.lofs[k] : 0) * C;
+                    float* o = lbase + (tp.ok[k] ? tp.lofs[k] : 0) * (C + SBT_PAD);
                     const bool wr = tail && tp.ok[k];
 #pragma unroll
                     for (int j = 0; j < nv; ++j) {
@@ -543,7 +582,7 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
                 for (int k = 0; k < 4; ++k) {
                     if (tp.w[k] == 0.f) continue;
                     if (tp.lofs[k] >= 0) {
-                        float* o = lbase + tp.lofs[k] * C;
+                        float* o = lbase + tp.lofs[k] * (C + SBT_PAD);
 #pragma unroll
                         for (int j = 0; j < nv; ++j) atomic_add4(o + 16 * j, draw[LV::draw0(l) + j] * tp.w[k]);
                     } else {   // rounding put the tap one pixel outside the footprint: global atomic
@@ -637,9 +676,9 @@ __global__ __launch_bounds__(SBT_THREADS) void sample_bwd_tiled_kernel(const Sam
         float* gmap = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + img * (long)W * W * C;
         const int c4 = C >> 2, n4 = fw * fw * c4;
         for (int i = threadIdx.x; i < n4; i += SBT_THREADS) {
-            const f32x4 v = ld4(s_acc + G.off[l] + 4 * i);
-            if (v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f) continue;
             const int pix = i / c4, c = (i - pix * c4) * 4;
+            const f32x4 v = ld4(s_acc + G.off[l] + pix * (C + SBT_PAD) + c);
+            if (v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f) continue;
             const int y = oy[l] + pix / fw, x = ox[l] + pix % fw;
             if (x < W && y < W) atomic_add4(gmap + ((long)y * W + x) * C + c, v);
         }
@@ -659,7 +698,7 @@ static int launch_sample_bwd_t(const SampleBwdArgs& a, hipStream_t stream) {
             G.C[l] = LV::C(l);
             G.fw[l] = (16 * (G.W[l] - 1) + 254) / 255 + 2;
             G.off[l] = off;
-            if (l >= FD::NF) off += G.fw[l] * G.fw[l] * G.C[l];                   // raw levels: LDS accumulators
+            if (l >= FD::NF) off += G.fw[l] * G.fw[l] * (G.C[l] + SBT_PAD);       // raw levels: LDS accumulators (padded pixel stride)
             else fits = fits && G.fw[l] * G.fw[l] <= 16 * FD::nmt(l);             // folded levels: register tiles
         }
         G.total = off;
@@ -669,6 +708,12 @@ static int launch_sample_bwd_t(const SampleBwdArgs& a, hipStream_t stream) {
             TRY_RET(s3d_set_max_lds(attr_done, {(const void*)sample_bwd_tiled_kernel<GT, false>,
                                                 (const void*)sample_bwd_tiled_kernel<GT, true>}, 160 * 1024));
             const long batch = a.groups / a.groups_per_batch;
+            if (a.gxy) {
+                const long total = batch * a.n_qry;
+                hipLaunchKernelGGL(sbt_project_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256),
+                                   0, stream, a, (int)batch);
+                S3D_LAUNCH_CHECK();
+            }
             if (a.ws34_t16)
                 hipLaunchKernelGGL((sample_bwd_tiled_kernel<GT, true>), dim3((unsigned)(batch * a.n_slices * 256)), dim3(SBT_THREADS),
                                    lds, stream, a, G);
