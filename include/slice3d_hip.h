@@ -48,6 +48,13 @@ extern "C" {
                                   * BASELINE configs[1]'s "bf16" names; fails the 1e-4 parity gate by construction and is
                                   * reported separately with its measured error (bench.py `throughput_mode_f16`).
                                   * Inference entry points of Slices3DRegModel / Slices3DGTModel only. */
+#define S3D_PREC_BF16 3          /* THROUGHPUT MODE on the bf16 MFMA (round 5), Slices3DRegModel inference only: the decoder's
+                                  * attention and FFN GEMMs (94 % of the decoder's FLOPs; layers 0-1 and the final FFN) run
+                                  * v_mfma_f32_16x16x32_bf16 on bf16-rounded operands (weights from a bf16 image, activations
+                                  * through v_cvt_pk_bf16_f32), one MFMA per product, fp32 accumulation; every other
+                                  * contraction of the path (U-Net, latent projections, token builder, absorbed last-layer
+                                  * GEMMs) runs as in S3D_PREC_F16.  Same MFMA rate as S3D_PREC_F16, 8 significand bits
+                                  * instead of 11: reported with its measured error (bench.py `throughput_mode_bf16`). */
 
 int s3d_version(void);
 const char* s3d_last_error(void);           /* thread-local, valid until the next failing call */

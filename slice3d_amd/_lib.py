@@ -14,6 +14,7 @@ N_LAYERS = 3
 PREC_F32 = 0
 PREC_F16X3 = 1
 PREC_F16 = 2          # single-pass f16 MFMA: throughput mode, not fp32-class (inference only)
+PREC_BF16 = 3         # the decoder's attention / FFN GEMMs on the bf16 MFMA, the rest as PREC_F16 (Slices3DRegModel inference only)
 PROF_UNET, PROF_LATENT, PROF_SAMPLE, PROF_ATTN, PROF_FFN, PROF_FFN_FINAL, PROF_VGG, PROF_SAMPLE_PYR = range(8)
 PROF_NAMES = ("unet_encode", "latent_build", "sample_tokens", "attn_layer", "ffn_layer", "ffn_final", "vgg_loss",
               "sample_pyramid")

@@ -345,7 +345,9 @@ extern "C" int s3d_unet_encode_fwd(const void* packed, const float* img, const S
                                    float* slices_rec, int B, int S, int ns, int prec, void* workspace,
                                    size_t workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3 || prec == S3D_PREC_F16, "unet_encode: precision mode %d", prec);
+    S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3 || prec == S3D_PREC_F16 || prec == S3D_PREC_BF16,
+                  "unet_encode: precision mode %d", prec);
+    if (prec == S3D_PREC_BF16) prec = S3D_PREC_F16;   // the bf16 mode covers the decoder's attention / FFN GEMMs; the conv engine runs single-pass f16
     struct PrecScope { PrecScope(int p) { g_desc_prec = p; } ~PrecScope() { g_desc_prec = S3D_PREC_F32; } } ps_(prec);
     S3D_CHECK_ARG(packed && img && out && workspace, "unet_encode: null argument");
     S3D_CHECK_ARG(B >= 1 && S >= 16 && S % 16 == 0, "unet_encode: B=%d S=%d (S must be a multiple of 16)", B, S);
@@ -616,6 +618,8 @@ HeadLayout head_layout() {
         H.L[l].ln2b = take(128);
         H.L[l].wf16 = take((size_t)S3D_FFN_NCHUNK * 8192);
         H.L[l].aq16 = take((size_t)(96 + 32) * 512);
+        H.L[l].wfb16 = take((size_t)S3D_FFN_NCHUNK * 8192);      // bf16 twins of the two images (S3D_PREC_BF16)
+        H.L[l].aqb16 = take((size_t)(96 + 32) * 512);
     }
     H.fco_w = take(128);
     H.fco_b = take(4);
@@ -654,6 +658,8 @@ static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLa
         TRY(copy_vec(b + H.L[l].ln2b, p.norm2_b, 128, st));
         TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wf16, st));
         TRY(launch_pack_attn_q_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].aq16, st));
+        TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wfb16, st, 1));
+        TRY(launch_pack_attn_q_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].aqb16, st, 1));
     }
     {   // absorbed token-0 attention of the last layer (launch_attn_last_mix)
         PackBatchSuspend now;   // `dense` is reused: these packs must run between the two absorb launches
@@ -701,6 +707,7 @@ extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, 
                   "latent_build: latent.fine must alias pyramid levels 3,4");
     const HeadLayout H = head_layout();
     const float* b = (const float*)head_packed;
+    if (prec == S3D_PREC_BF16) prec = S3D_PREC_F16;   // (see s3d_unet_encode_fwd)
     ProfScope prof_(S3D_PROF_LATENT, st);
     const int lc[3] = {512, 256, 128};
     for (int l = 0; l < 3; ++l) {
@@ -822,6 +829,8 @@ static LayerPtrs layer_ptrs(const float* b, const HeadLayout& H, int l) {
     p.w2 = b + H.L[l].w2; p.b2 = b + H.L[l].b2; p.ln2g = b + H.L[l].ln2g; p.ln2b = b + H.L[l].ln2b;
     p.wf16 = b + H.L[l].wf16;
     p.aq16 = b + H.L[l].aq16;
+    p.wfb16 = b + H.L[l].wfb16;
+    p.aqb16 = b + H.L[l].aqb16;
     return p;
 }
 
@@ -867,7 +876,11 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
     S3D_CHECK_ARG(batch >= 1 && n_qry >= 1, "decode: batch=%d n_qry=%ld", batch, n_qry);
     S3D_CHECK_ARG(ns >= 1 && ns <= 12, "decode: n_slices %d", ns);
     S3D_CHECK_ARG(lat->n_img == batch * ns, "decode: latent has %d images, expected %d", lat->n_img, batch * ns);
-    S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3 || prec == S3D_PREC_F16, "decode: precision mode %d not built", prec);
+    S3D_CHECK_ARG(prec == S3D_PREC_F32 || prec == S3D_PREC_F16X3 || prec == S3D_PREC_F16 || prec == S3D_PREC_BF16,
+                  "decode: precision mode %d not built", prec);
+    const bool bf16 = prec == S3D_PREC_BF16;   // attention + FFN GEMMs on the bf16 MFMA; everything else as S3D_PREC_F16
+    if (bf16) prec = S3D_PREC_F16;
+    const int ffn_prec = bf16 ? S3D_PREC_BF16 : prec;
     DecodeWs W;
     if (!decode_ws_fit(batch, n_qry, ns, workspace_bytes, W)) {
         s3d_set_error("decode: workspace %zu < %zu bytes (s3d_decode_workspace_bytes_min)", workspace_bytes, W.total * sizeof(float));
@@ -925,7 +938,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
                     if (last)          // only token 0 of the last layer is consumed (models.py:83): absorbed form, every mode
                         TRY(attn_last_layer(b, H, lp, Xs, X0s, gn, T, lasts, prec, s, fold_ln));
                     else if (prec != S3D_PREC_F32)
-                        TRY(launch_attn_layer_q(Xs, gn, T, lp, s, prec == S3D_PREC_F16));
+                        TRY(launch_attn_layer_q(Xs, gn, T, lp, s, prec == S3D_PREC_F16, bf16));
                     else
                         TRY(launch_attn_layer(Xs, nullptr, gn, T, lp, s));
                 }
@@ -938,7 +951,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
                         const long fc = gn - f0 < S3D_FFN_LAUNCH_GROUPS ? gn - f0 : S3D_FFN_LAUNCH_GROUPS;
                         ProfScope prof_(S3D_PROF_FFN, s);
                         TRY(launch_ffn_layer(Xs + (size_t)f0 * T * S3D_GROUP * 128, fc * T * S3D_GROUP, lp, nullptr, nullptr, nullptr,
-                                             1.f, gpb, n_qry, g0 + gs + f0, prec, nullptr, s));
+                                             1.f, gpb, n_qry, g0 + gs + f0, ffn_prec, nullptr, s));
                     }
                     if (stages) TRY(launch_tok0_copy(Xs, stages + rows_all + (size_t)l * rows0_all, gn, T, 0, 128, s));
                 } else {
@@ -952,11 +965,11 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
                             s3d_set_error("decode stages: memcpy failed");
                             return (int)hipErrorUnknown;
                         }
-                        TRY(launch_ffn_layer(d, gn * S3D_GROUP, lp, nullptr, nullptr, nullptr, 1.f, gpb, n_qry, g0 + gs, prec,
+                        TRY(launch_ffn_layer(d, gn * S3D_GROUP, lp, nullptr, nullptr, nullptr, 1.f, gpb, n_qry, g0 + gs, ffn_prec,
                                              nullptr, s));
                     }
                     TRY(launch_ffn_layer(X0s, gn * S3D_GROUP, lp, b + H.fco_w, b + H.fco_b, out, sign, gpb, n_qry, g0 + gs,
-                                         prec, perm, s, fold_ln));
+                                         ffn_prec, perm, s, fold_ln));
                 }
             }
             return 0;

@@ -11,8 +11,12 @@ typedef _Float16 half8q __attribute__((ext_vector_type(8)));
 #define AQ_WO_HALFS (8 * 1024)     // per head: 8 fragment pairs = 16 KiB
 
 __device__ __forceinline__ half8q ldq8(const _Float16* p) { return *reinterpret_cast<const half8q*>(p); }
-template <bool SINGLE>
+// BF (S3D_PREC_BF16): single pass on the bf16 MFMA; the 16-bit lanes of the "hi" operands then hold bf16 bit patterns
+typedef __bf16 bf8q __attribute__((ext_vector_type(8)));
+typedef short short4q __attribute__((ext_vector_type(4)));
+template <bool SINGLE, bool BF = false>
 __device__ __forceinline__ f32x4 mfma3q(const half8q ah, const half8q al, const half8q bh, const half8q bl, f32x4 c) {
+    if (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8q, ah), __builtin_bit_cast(bf8q, bh), c, 0, 0, 0);
     if (!SINGLE) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
@@ -39,6 +43,20 @@ __device__ __forceinline__ void split8pk(const f32x4 a, const f32x4 b, half8q& h
     hi = __builtin_bit_cast(half8q, uint4q{h0, h1, h2, h3});
     lo = __builtin_bit_cast(half8q, uint4q{l0, l1, l2, l3});
 }
+// bf16 forms of the two splits (BF mode: only the high halves are operands; the low halves mirror them and are never read)
+typedef __bf16 bf2q __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pair_q(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(float2q{a, b}, bf2q));
+}
+template <bool BF>
+__device__ __forceinline__ void split8x(const f32x4 a, const f32x4 b, half8q& hi, half8q& lo) {
+    if (BF) {
+        hi = __builtin_bit_cast(half8q, uint4q{bf16_pair_q(a[0], a[1]), bf16_pair_q(a[2], a[3]), bf16_pair_q(b[0], b[1]), bf16_pair_q(b[2], b[3])});
+        lo = hi;
+    } else {
+        split8pk(a, b, hi, lo);
+    }
+}
 // four values -> the A / B operand of the 16-deep MFMA (v_mfma_f32_16x16x16_f16: lane group g carries k = 4g..4g+3)
 typedef _Float16 half4q __attribute__((ext_vector_type(4)));
 typedef unsigned uint2q __attribute__((ext_vector_type(2)));
@@ -49,8 +67,18 @@ __device__ __forceinline__ void split4pk(const f32x4 a, half4q& hi, half4q& lo) 
     hi = __builtin_bit_cast(half4q, uint2q{h0, h1});
     lo = __builtin_bit_cast(half4q, uint2q{l0, l1});
 }
-template <bool SINGLE>
+template <bool BF>
+__device__ __forceinline__ void split4x(const f32x4 a, half4q& hi, half4q& lo) {
+    if (BF) {
+        hi = __builtin_bit_cast(half4q, uint2q{bf16_pair_q(a[0], a[1]), bf16_pair_q(a[2], a[3])});
+        lo = hi;
+    } else {
+        split4pk(a, hi, lo);
+    }
+}
+template <bool SINGLE, bool BF = false>
 __device__ __forceinline__ f32x4 mfma3h(const half4q ah, const half4q al, const half4q bh, const half4q bl, f32x4 c) {
+    if (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4q, ah), __builtin_bit_cast(short4q, bh), c, 0, 0, 0);
     if (!SINGLE) {
         c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);

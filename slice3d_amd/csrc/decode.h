@@ -19,6 +19,7 @@ struct HeadLayout {
         size_t w1, b1, w2, b2, ln2g, ln2b;   // w1: [128 tiles][8] image; w2: chunked [64][8][2] image
         size_t wf16;                         // f16 hi/lo chunk image of lin1/lin2 (64 x 32 KiB), decode_f16.hip
         size_t aq16;                         // in_proj / out_proj fragments of the query-major attention kernel
+        size_t wfb16, aqb16;                 // the same two images with bf16 bit patterns (S3D_PREC_BF16)
     } L[S3D_N_LAYERS];
     size_t fco_w, fco_b;
     // token-0-only attention of the LAST layer in absorbed form (launch_attn_last_mix): fragment images (fp32 | f16
@@ -31,7 +32,7 @@ struct HeadLayout {
 HeadLayout head_layout();
 
 struct LayerPtrs {
-    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b, *wf16, *aq16;
+    const float *inw, *inb, *outw, *outb, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b, *wf16, *aq16, *wfb16, *aqb16;
 };
 
 struct SampleArgs {
@@ -154,7 +155,8 @@ int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipS
 int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
                                  const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
                                  hipStream_t stream, float* imgd = nullptr, float* imgr = nullptr);
-int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass = false);
+int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass = false,
+                        bool bf16 = false);
 // training forward of the attention block, query-major (decode_attnq.hip): y = LN1(u), u = xin + dropout1(out_proj(MHA(xin)) + b),
 // o = MHA output before out_proj; nothing else is kept (the fused backward of train_attnq.hip recomputes Q / K / V)
 int launch_attn_layer_q_train(const float* xin, float* y, float* u, float* o, long groups, int T, const LayerPtrs& w,
@@ -173,9 +175,9 @@ int launch_attn_last_mix(const float* X, const float* qt, float* xbar, long grou
 //   kind 1: out [128][512] = N (column h*128 + c), bias_out [128] = n
 int launch_absorb_last(const float* in_w, const float* in_b, const float* out_w, const float* out_b, float* out,
                        float* bias_out, int kind, hipStream_t stream);
-int launch_pack_attn_q_f16x3(const float* win, const float* wout, float* out, hipStream_t stream);
+int launch_pack_attn_q_f16x3(const float* win, const float* wout, float* out, hipStream_t stream, int bf16 = 0);
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
                            long g_begin, const int* perm, hipStream_t stream, bool single_pass = false,
-                           bool pre_ln1 = false);   // pre_ln1 (final layer only): the rows are pre-LayerNorm1 sums, normalised in the prologue
-int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream);
+                           bool pre_ln1 = false, bool bf16 = false);   // pre_ln1 (final layer only): the rows are pre-LayerNorm1 sums, normalised in the prologue
+int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream, int bf16 = 0);

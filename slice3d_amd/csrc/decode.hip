@@ -598,9 +598,10 @@ __global__ __launch_bounds__(256) void ffn_layer_kernel(const float* X, float* Y
 int launch_ffn_layer(float* X, long rows, const LayerPtrs& w, const float* fco_w, const float* fco_b,
                      float* sdf_out, float sign, long groups_per_batch, long n_qry, long g_begin, int prec,
                      const int* perm, hipStream_t stream, bool pre_ln1) {
-    if (prec == S3D_PREC_F16X3 || prec == S3D_PREC_F16)
-        return launch_ffn_layer_f16x3(X, rows, w, w.wf16, fco_w, fco_b, sdf_out, sign, groups_per_batch, n_qry, g_begin,
-                                      perm, stream, prec == S3D_PREC_F16, pre_ln1);
+    if (prec == S3D_PREC_F16X3 || prec == S3D_PREC_F16 || prec == S3D_PREC_BF16)
+        return launch_ffn_layer_f16x3(X, rows, w, prec == S3D_PREC_BF16 ? w.wfb16 : w.wf16, fco_w, fco_b, sdf_out, sign,
+                                      groups_per_batch, n_qry, g_begin, perm, stream, prec != S3D_PREC_F16X3, pre_ln1,
+                                      prec == S3D_PREC_BF16);
     S3D_CHECK_ARG(prec == S3D_PREC_F32 && !pre_ln1, "ffn: precision mode %d not built (LayerNorm prologue: split precision only)", prec);
     if (rows <= 0) return 0;
     const long blocks = (rows + 4 * FFN_R * 16 - 1) / (4 * FFN_R * 16);

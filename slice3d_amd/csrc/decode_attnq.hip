@@ -29,9 +29,10 @@ struct AttnTrainArgs {
     float* O;           // attention output rows (128 = 4 heads x 32)
     DropCfg d0, d1;
 };
-template <bool SINGLE, bool TRAIN>   // SINGLE: S3D_PREC_F16, one f16 MFMA per projection product (the 13x13 core stays on the fp32 MFMA)
+template <bool SINGLE, bool TRAIN, bool BF = false>   // BF: S3D_PREC_BF16, single pass on the bf16 MFMA (inference); SINGLE: S3D_PREC_F16, one f16 MFMA per projection product (the 13x13 core stays on the fp32 MFMA)
 __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long groups, int T, const _Float16* wimg,
                                                                const LayerPtrs w, const AttnTrainArgs ta) {
+    static_assert(!BF || (SINGLE && !TRAIN), "the bf16 mode is a single-pass inference mode");
     extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // ring 4 x 16 KiB, then the small vectors
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: no waterfall around M0
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) split8pk(xf[r][u][0], xf[r][u][1], xh[r][u], xl[r][u]);
+            for (int u = 0; u < 4; ++u) split8x<BF>(xf[r][u][0], xf[r][u][1], xh[r][u], xl[r][u]);
         const bool more_items = item + gridDim.x < items;
 #pragma unroll 1
         for (int h = 0; h < 4; ++h) {
@@ -180,11 +181,11 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
         if (part < 2) { /* D^T = W X^T */                                                                    \
-            d[0][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xh[0][U], xl[0][U], (U) == 0 ? c0[j] : d[0][j]);    \
-            d[1][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xh[1][U], xl[1][U], (U) == 0 ? c0[j] : d[1][j]);    \
+            d[0][j] = mfma3q<SINGLE, BF>(fh[B][j], fl[B][j], xh[0][U], xl[0][U], (U) == 0 ? c0[j] : d[0][j]);    \
+            d[1][j] = mfma3q<SINGLE, BF>(fh[B][j], fl[B][j], xh[1][U], xl[1][U], (U) == 0 ? c0[j] : d[1][j]);    \
         } else { /* D = X W^T */                                                                             \
-            d[0][j] = mfma3q<SINGLE>(xh[0][U], xl[0][U], fh[B][j], fl[B][j], (U) == 0 ? c0[j] : d[0][j]);    \
-            d[1][j] = mfma3q<SINGLE>(xh[1][U], xl[1][U], fh[B][j], fl[B][j], (U) == 0 ? c0[j] : d[1][j]);    \
+            d[0][j] = mfma3q<SINGLE, BF>(xh[0][U], xl[0][U], fh[B][j], fl[B][j], (U) == 0 ? c0[j] : d[0][j]);    \
+            d[1][j] = mfma3q<SINGLE, BF>(xh[1][U], xl[1][U], fh[B][j], fl[B][j], (U) == 0 ? c0[j] : d[1][j]);    \
         }                                                                                                    \
     }                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);
@@ -234,13 +235,13 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                 half8q kh[2], kl[2], qh[2], ql[2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    split8pk(kd[r][0], kd[r][1], kh[r], kl[r]);
-                    split8pk(qd[r][0] * scale, qd[r][1] * scale, qh[r], ql[r]);
+                    split8x<BF>(kd[r][0], kd[r][1], kh[r], kl[r]);
+                    split8x<BF>(qd[r][0] * scale, qd[r][1] * scale, qh[r], ql[r]);
                 }
                 AQ_SETTLE()
                 f32x4 s[2];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) s[r] = mfma3q<SINGLE>(kh[r], kl[r], qh[r], ql[r], zero4());
+                for (int r = 0; r < 2; ++r) s[r] = mfma3q<SINGLE, BF>(kh[r], kl[r], qh[r], ql[r], zero4());
                 half4q ph[2], pl[2], vh[2][2], vl[2][2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
@@ -268,18 +269,18 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
                         s3d_drop4(ta.d0, (rowq * 4 + (unsigned)h) * 16 + 4 * go, mk);
                         pr = f32x4{pr[0] * mk[0], pr[1] * mk[1], pr[2] * mk[2], pr[3] * mk[3]};
                     }
-                    split4pk(pr, ph[r], pl[r]);
+                    split4x<BF>(pr, ph[r], pl[r]);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) split4pk(vd[r][j], vh[r][j], vl[r][j]);
+                    for (int j = 0; j < 2; ++j) split4x<BF>(vd[r][j], vh[r][j], vl[r][j]);
                 }
                 AQ_SETTLE()
                 f32x4 od[2][2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) od[r][j] = mfma3h<SINGLE>(vh[r][j], vl[r][j], ph[r], pl[r], zero4());
+                    for (int j = 0; j < 2; ++j) od[r][j] = mfma3h<SINGLE, BF>(vh[r][j], vl[r][j], ph[r], pl[r], zero4());
 #pragma unroll
-                for (int r = 0; r < 2; ++r) split8pk(od[r][0], od[r][1], oh[r], ol[r]);
+                for (int r = 0; r < 2; ++r) split8x<BF>(od[r][0], od[r][1], oh[r], ol[r]);
                 if (TRAIN) {   // O rows of this head: tiles j = 0, 1 are dims 4g + i and 16 + 4g + i of token m = one 128-byte
                                // line per token after the lane exchange (s3d_full_line_pair)
                     int mo = m, go = g;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
         _Pragma("unroll") for (int r = 0; r < 2; ++r)                                                        \
-            acc_o[r][2 * (G) + q] = mfma3q<SINGLE>(wh[B][q], wl[B][q], oh[r], ol[r], acc_o[r][2 * (G) + q]); \
+            acc_o[r][2 * (G) + q] = mfma3q<SINGLE, BF>(wh[B][q], wl[B][q], oh[r], ol[r], acc_o[r][2 * (G) + q]); \
     }                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);
                 AQ_O_READS(0, 0)
@@ -426,17 +427,20 @@ __global__ __launch_bounds__(256, 2) void attn_layer_q_kernel(float* X, long gro
 }
 
 static int launch_attn_q_any(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass,
-                             const AttnTrainArgs* ta) {
+                             const AttnTrainArgs* ta, bool bf16 = false) {
     if (groups <= 0) return 0;
     S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr, "attn_q: T %d", T);
     const size_t lds = (size_t)(4 * AQ3_SLOT_HALFS) * 2 + 768 * 4;   // 64 KiB ring + the small vectors
     static std::atomic<unsigned long long> attr_done{0};
     TRY_RET(s3d_set_max_lds(attr_done, {(const void*)attn_layer_q_kernel<false, false>, (const void*)attn_layer_q_kernel<true, false>,
-                                        (const void*)attn_layer_q_kernel<false, true>}, lds));
+                                        (const void*)attn_layer_q_kernel<false, true>, (const void*)attn_layer_q_kernel<true, false, true>}, lds));
     const long blocks = 2 * groups < 4096 ? 2 * groups : 4096;
-    const _Float16* img = reinterpret_cast<const _Float16*>(w.aq16);
+    const _Float16* img = reinterpret_cast<const _Float16*>(bf16 ? w.aqb16 : w.aq16);
+    S3D_CHECK_ARG(!bf16 || (single_pass && !ta && w.aqb16), "attn_q: the bf16 mode is a single-pass inference mode with its own image");
     const AttnTrainArgs none = {};
-    if (ta)
+    if (bf16)
+        hipLaunchKernelGGL((attn_layer_q_kernel<true, false, true>), dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T, img, w, none);
+    else if (ta)
         hipLaunchKernelGGL((attn_layer_q_kernel<false, true>), dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T, img, w, *ta);
     else if (single_pass)
         hipLaunchKernelGGL((attn_layer_q_kernel<true, false>), dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T, img, w, none);
@@ -445,8 +449,8 @@ static int launch_attn_q_any(float* X, long groups, int T, const LayerPtrs& w, h
     S3D_LAUNCH_CHECK();
     return 0;
 }
-int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass) {
-    return launch_attn_q_any(X, groups, T, w, stream, single_pass, nullptr);
+int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass, bool bf16) {
+    return launch_attn_q_any(X, groups, T, w, stream, single_pass, nullptr, bf16);
 }
 // training forward of the block (see the kernel): xin -> y = LN1(u), u = xin + dropout1(out_proj(MHA(xin))), o = MHA output
 int launch_attn_layer_q_train(const float* xin, float* y, float* u, float* o, long groups, int T, const LayerPtrs& w,
@@ -461,7 +465,7 @@ int launch_attn_layer_q_train(const float* xin, float* y, float* u, float* o, lo
 //   frag = 96 + h*8 + jc          : row m <-> output channel 32(jc>>1) + 8(m>>2) + 4(jc&1) + (m&3),
 //                                   k-slot 8g + t <-> head dim 16(t>>2) + 4g + (t&3)
 __global__ void pack_attn_q_f16x3_kernel(const float* __restrict__ win, const float* __restrict__ wout,
-                                         _Float16* __restrict__ out) {
+                                         _Float16* __restrict__ out, int bf16) {
     const int total = (96 + 32) * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int lane = idx & 63, frag = idx >> 6;
@@ -482,6 +486,11 @@ __global__ void pack_attn_q_f16x3_kernel(const float* __restrict__ win, const fl
         _Float16* dst = out + (size_t)frag * 1024 + lane * 8;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
+            if (bf16) {   // bf16 bit patterns (S3D_PREC_BF16), no low halves
+                dst[t] = __builtin_bit_cast(_Float16, (unsigned short)(bf16_pair_q(v[t], 0.f) & 0xFFFFu));
+                dst[512 + t] = (_Float16)0.f;
+                continue;
+            }
             const _Float16 hh = (_Float16)v[t];
             dst[t] = hh;
             dst[512 + t] = (_Float16)(v[t] - (float)hh);
@@ -489,9 +498,9 @@ __global__ void pack_attn_q_f16x3_kernel(const float* __restrict__ win, const fl
     }
 }
 
-int launch_pack_attn_q_f16x3(const float* win, const float* wout, float* out, hipStream_t stream) {
+int launch_pack_attn_q_f16x3(const float* win, const float* wout, float* out, hipStream_t stream, int bf16) {
     hipLaunchKernelGGL(pack_attn_q_f16x3_kernel, dim3(32), dim3(256), 0, stream, win, wout,
-                       reinterpret_cast<_Float16*>(out));
+                       reinterpret_cast<_Float16*>(out), bf16);
     S3D_LAUNCH_CHECK();
     return 0;
 }

@@ -32,6 +32,34 @@ __device__ __forceinline__ f32x4 mfma3(const half8 ah, const half8 al, const hal
     return c;
 }
 __device__ __forceinline__ half8 ldh8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
+// ---------------------------------------------------------------------------------------------
+// BF (S3D_PREC_BF16, round 5): the single-pass mode on the bf16 MFMA — what BASELINE configs[1] literally names.  The 16-bit
+// lanes of the operand containers (half8 / half2v) then hold bf16 bit patterns: weights from the bf16 image
+// (launch_pack_ffn_f16x3(..., bf16 = 1)), activations rounded by v_cvt_pk_bf16_f32.  Same rate as the f16 instruction, 8
+// significand bits instead of 11: a throughput mode further from fp32 than S3D_PREC_F16, never the headline.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <bool BF>
+__device__ __forceinline__ f32x4 mfma_hh(const half8 a, const half8 b, const f32x4 c) {
+    if (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned bf16_pair(float a, float b) {   // bf16(a) | bf16(b) << 16, round to nearest even
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf2_t));
+}
+__device__ __forceinline__ float bf16_lane(const half8 v, int t) {   // the fp32 value of bf16 lane t
+    return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, v[t]) << 16);
+}
+// rows in BF mode: hi = bf16(x) (the MFMA operand), lo = f16(x - hi) (only the epilogue's residual reads it)
+__device__ __forceinline__ void split8_bf(const float (&x)[8], half8& hi, half8& lo) {
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    const u4_t h = {bf16_pair(x[0], x[1]), bf16_pair(x[2], x[3]), bf16_pair(x[4], x[5]), bf16_pair(x[6], x[7])};
+    hi = __builtin_bit_cast(half8, h);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) lo[t] = (_Float16)(x[t] - bf16_lane(hi, t));
+}
 // global -> LDS copy of one 32 KiB weight chunk by LDS-DMA (1 KiB per wave-instruction, no VGPR staging)
 __device__ __forceinline__ void dma_chunk32k(const _Float16* gsrc, _Float16* ldst, int wave, int lane, int nwaves) {
     for (int piece = wave; piece < 32; piece += nwaves)
@@ -117,8 +145,15 @@ __device__ __forceinline__ float relu1(float v) {
     return r;
 }
 // relu + split of the 4 pre-activations of one D tile: hi = f16(max(v,0)), lo = f16(max(v,0) - hi)
-template <bool SINGLE>
+template <bool SINGLE, bool BF = false>
 __device__ __forceinline__ void relu_split4(const f32x4 v, half2v& h0, half2v& h1, half2v& l0, half2v& l1) {
+    if (BF) {   // bf16 halves of relu(v); the low halves are not used by the single-pass product
+        const float inf = __builtin_inff();
+        h0 = __builtin_bit_cast(half2v, bf16_pair(__builtin_amdgcn_fmed3f(v[0], 0.f, inf), __builtin_amdgcn_fmed3f(v[1], 0.f, inf)));
+        h1 = __builtin_bit_cast(half2v, bf16_pair(__builtin_amdgcn_fmed3f(v[2], 0.f, inf), __builtin_amdgcn_fmed3f(v[3], 0.f, inf)));
+        l0 = h0; l1 = h1;
+        return;
+    }
     if (SINGLE) {   // the single-pass mode pins 9 VALU slots per MFMA with sched_group_barrier, which does not count inline asm:
                     // with the asm ReLU its groups ran dry and the mode lost 20 % (13.5 vs 16.8 M query-points/s) — builtin here
         const float inf = __builtin_inff();
@@ -166,7 +201,7 @@ __device__ __forceinline__ void ffn_draw(FfnActState& as, int c, int a2, int r2)
     asm volatile("" : "+v"(as.h), "+v"(as.h2));   // stay in this scheduling region
 }
 // D tile (a2, r2) of chunk c: pre-activation -> f16 hi/lo halves of GEMM2's B operand
-template <int MODE, bool SINGLE>
+template <int MODE, bool SINGLE, bool BF = false>
 __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, half2v& l0, half2v& l1, FfnActState& as,
                                          const FfnTrainArgs& ta, const FfnBwdArgs& ba, int c, int a2, int r2) {
     if (MODE == 2 || MODE == 3) {
@@ -205,7 +240,7 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
             a[i] = s3d_gate_bit_imm(v[i], bits, FFN_MASK_POS(i));
         split4_pk(a[0], a[1], a[2], a[3], h0, h1, l0, l1);
     } else {
-        relu_split4<SINGLE>(v, h0, h1, l0, l1);
+        relu_split4<SINGLE, BF>(v, h0, h1, l0, l1);
     }
 }
 
@@ -251,14 +286,14 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
                     hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s], xh[r][u], hn[a][r], 0, 0, 0);           \
             }                                                                                                        \
             _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                        \
-                hn[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xh[r][u], hn[a][r], 0, 0, 0);               \
+                hn[a][r] = mfma_hh<BF>(fh[s], xh[r][u], hn[a][r]);                                                   \
         } else if ((K) == 7) {                                                                                       \
             DS_READ(vh[0], lw, 16384);                                                                               \
             DS_READ(vl[0], lw, 24576);                                                                               \
         }                                                                                                            \
         if ((K) % (4 / PIPE_R) == 0) {   /* 2 * PIPE_R D tiles over the 8 groups */                                   \
             constexpr int tile = (K) / (4 / PIPE_R), a2 = tile / PIPE_R, r2 = tile % PIPE_R;                         \
-            ffn_act4<MODE, SINGLE>(hd[a2][r2], hh2[r2][2 * a2], hh2[r2][2 * a2 + 1], hl2[r2][2 * a2], hl2[r2][2 * a2 + 1], as, ta, ba, c, a2, r2); \
+            ffn_act4<MODE, SINGLE, BF>(hd[a2][r2], hh2[r2][2 * a2], hh2[r2][2 * a2 + 1], hl2[r2][2 * a2], hl2[r2][2 * a2 + 1], as, ta, ba, c, a2, r2); \
             /* tie the results into the side-effect chain: otherwise the low halves are emitted where they are */   \
             /* first USED (phase B), outside the MFMA cover */                                                       \
             asm volatile("" : "+v"(hl2[r2][2 * a2]), "+v"(hl2[r2][2 * a2 + 1]), "+v"(hh2[r2][2 * a2]),               \
@@ -294,7 +329,7 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
                 acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[s], hh[r], acc[r][J], 0, 0, 0);                \
         }                                                                                                            \
         _Pragma("unroll") for (int r = 0; r < PIPE_R; ++r)                                                            \
-            acc[r][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[s], hh[r], acc[r][J], 0, 0, 0);                    \
+            acc[r][J] = mfma_hh<BF>(vh[s], hh[r], acc[r][J]);                                                        \
         SB();                                                                                                        \
     }
 
@@ -302,7 +337,7 @@ __device__ __forceinline__ void ffn_act4(const f32x4 v, half2v& h0, half2v& h1, 
 // pre-activations costs no moves).  Every group of 6 MFMAs is its own scheduling region (sched_barrier): the order
 // written here IS the issue order.  lw = LDS byte address of this lane's fragment slot in the current weight buffer,
 // lb = of its bias quad of the NEXT chunk.
-template <int MODE, bool LAST, bool SINGLE>
+template <int MODE, bool LAST, bool SINGLE, bool BF = false>
 __device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned lb, const half8 (&xh)[PIPE_R][4],
                                               const half8 (&xl)[PIPE_R][4], f32x4 (&acc)[PIPE_R][8],
                                               const f32x4 (&hd)[2][PIPE_R], f32x4 (&hn)[2][PIPE_R], FfnActState& as,
@@ -332,7 +367,7 @@ __device__ __forceinline__ void ffn_pipe_iter(const unsigned lw, const unsigned 
 }
 
 // SINGLE: S3D_PREC_F16 — only the hi*hi product of every split (one MFMA per product; not fp32-class)
-template <int MODE, bool SINGLE>
+template <int MODE, bool SINGLE, bool BF = false>
 __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 : 1) void ffn_layer_f16x3_pipe_kernel(const float* X, float* Yout, long rows,
                                                                    const _Float16* wimg, const LayerPtrs w,
                                                                    const float* fco_w, const float* fco_b,
@@ -340,6 +375,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
                                                                    long n_qry, long g_begin, const int* perm,
                                                                    const FfnTrainArgs ta, const FfnBwdArgs ba, const int pre_ln1) {
     constexpr bool FINAL = MODE == 1;
+    static_assert(!BF || (SINGLE && MODE <= 1), "the bf16 mode is a single-pass inference mode");
     constexpr int NC = S3D_FFN_NCHUNK;
     // THREE distinct LDS objects: hipcc tags their accesses with alias scopes, so a ds_read of one weight buffer is not
     // guarded (s_waitcnt vmcnt(0)) against the LDS-DMA refill of the OTHER buffer in flight — with one two-buffer array
@@ -413,7 +449,8 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
                     v[4 + t] *= mk1[t];
                 }
             }
-            split8(v, xh[r][u], xl[r][u]);
+            if (BF) split8_bf(v, xh[r][u], xl[r][u]);
+            else split8(v, xh[r][u], xl[r][u]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[r][j] = zero4();
@@ -456,7 +493,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
                     for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, xh[r][u], hdA[a][r], 0, 0, 0);
                 }
 #pragma unroll
-                for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, xh[r][u], hdA[a][r], 0, 0, 0);
+                for (int r = 0; r < PIPE_R; ++r) hdA[a][r] = mfma_hh<BF>(fh, xh[r][u], hdA[a][r]);
             }
     }
     __syncthreads();   // every wave is done with buffer 1 before the first refill overwrites it
@@ -492,12 +529,12 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
         dma_w1(c + 2, s_w1);
         dma_pieces(wimg + (size_t)(c + 1) * F16_CHUNK_HALFS, s_w1, 16, 32, wave, lane);
         SB();
-        ffn_pipe_iter<MODE, false, SINGLE>(lw0, lb0 + (c + 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB, as, ta, ba, c);
+        ffn_pipe_iter<MODE, false, SINGLE, BF>(lw0, lb0 + (c + 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB, as, ta, ba, c);
         dma_publish_barrier();
         dma_w1(c + 3, s_w0);
         dma_pieces(wimg + (size_t)(c + 2) * F16_CHUNK_HALFS, s_w0, 16, 32, wave, lane);
         SB();
-        ffn_pipe_iter<MODE, false, SINGLE>(lw1, lb0 + (c + 2) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdB, hdA, as, ta, ba, c + 1);
+        ffn_pipe_iter<MODE, false, SINGLE, BF>(lw1, lb0 + (c + 2) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdB, hdA, as, ta, ba, c + 1);
         if ((MODE == 2 || MODE == 3 || MODE == 4) && (c & 2)) group_done(c + 1);
         dma_publish_barrier();
     }
@@ -505,9 +542,9 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
     dma_w1(NC - 1, s_w1);
     dma_pieces(wimg + (size_t)(NC - 1) * F16_CHUNK_HALFS, s_w1, 16, 32, wave, lane);
     SB();
-    ffn_pipe_iter<MODE, false, SINGLE>(lw0, lb0 + (NC - 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB, as, ta, ba, NC - 2);
+    ffn_pipe_iter<MODE, false, SINGLE, BF>(lw0, lb0 + (NC - 1) * S3D_FFN_CHUNK * 4, xh, xl, acc, hdA, hdB, as, ta, ba, NC - 2);
     dma_publish_barrier();
-    ffn_pipe_iter<MODE, true, SINGLE>(lw1, lb0, xh, xl, acc, hdB, hdA, as, ta, ba, NC - 1);
+    ffn_pipe_iter<MODE, true, SINGLE, BF>(lw1, lb0, xh, xl, acc, hdB, hdA, as, ta, ba, NC - 1);
     if (MODE == 2 || MODE == 3) group_done(NC - 1);
     if (MODE >= 2) {   // operand images of this wave's 32 rows for the weight-gradient kernel (layout: decode.h).  Written HERE, after
                        // the loop: in the prologue their 32 stores sat in front of the publishing barrier's vmcnt(0)
@@ -614,7 +651,7 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
                 const int t = 4 * (j & 1) + i;
                 float f = MODE == 2 ? acc[r][j][i] * ta.dh.scale + b2[i] : acc[r][j][i] + b2[i];   // hidden-dropout factor, see ffn_act4
                 if (MODE == 2) f *= mq4[i];
-                y[j][i] = f + ((float)xh[r][j >> 1][t] + (float)xl[r][j >> 1][t]);
+                y[j][i] = f + ((BF ? bf16_lane(xh[r][j >> 1], t) : (float)xh[r][j >> 1][t]) + (float)xl[r][j >> 1][t]);
                 s += y[j][i];
             }
             if ((MODE == 2 || MODE == 3) && (j & 1)) store_pair(ta.Uout, r, j >> 1, y[j - 1], y[j]);
@@ -658,15 +695,23 @@ __global__ __launch_bounds__(PIPE_THREADS, (PIPE_R == 2 && PIPE_WAVES == 4) ? 2 
 #define PIPE_ROWS_PER_WG (PIPE_WAVES * PIPE_R * 16)
 int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float* wimg, const float* fco_w,
                            const float* fco_b, float* sdf_out, float sign, long groups_per_batch, long n_qry,
-                           long g_begin, const int* perm, hipStream_t stream, bool single_pass, bool pre_ln1) {
+                           long g_begin, const int* perm, hipStream_t stream, bool single_pass, bool pre_ln1, bool bf16) {
     if (rows <= 0) return 0;
+    S3D_CHECK_ARG(!bf16 || single_pass, "ffn: the bf16 mode is a single-pass mode");
     S3D_CHECK_ARG(!pre_ln1 || sdf_out, "ffn: the LayerNorm1 prologue belongs to the final layer's kernel");
     const int PRE_LN_ARG = pre_ln1 ? 1 : 0;
     const _Float16* img = reinterpret_cast<const _Float16*>(wimg);
     const FfnTrainArgs ta = {};
     const FfnBwdArgs ba = {};
     const dim3 grid((unsigned)((rows + PIPE_ROWS_PER_WG - 1) / PIPE_ROWS_PER_WG)), block(PIPE_THREADS);
-    if (single_pass) {
+    if (bf16) {   // wimg: the bf16 image of the layer
+        if (sdf_out)
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, true, true>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
+                               sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba, PRE_LN_ARG);
+        else
+            hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<0, true, true>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
+                               sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba, PRE_LN_ARG);
+    } else if (single_pass) {
         if (sdf_out)
             hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<1, true>), grid, block, 0, stream, X, X, rows, img, w, fco_w, fco_b,
                                sdf_out, sign, groups_per_batch, n_qry, g_begin, perm, ta, ba, PRE_LN_ARG);
@@ -737,8 +782,8 @@ int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* 
 // (output n, hidden h) of the GEMM-2-shaped operand is w2[n*s2n + h*s2h].  Forward image: (lin1, 128, 1),
 // (lin2, 2048, 1); backward ("transposed") image: (lin2, 1, 2048), (lin1, 1, 128).
 __global__ void pack_ffn_f16x3_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
-                                      _Float16* __restrict__ out, int s1h, int s1k, int s2n, int s2h) {
-    // one thread per (chunk, which, frag, lane): writes 8 hi halfs and 8 lo halfs
+                                      _Float16* __restrict__ out, int s1h, int s1k, int s2n, int s2h, int bf16) {
+    // one thread per (chunk, which, frag, lane): writes 8 hi halfs and 8 lo halfs (bf16: bf16 bit patterns, zero low halves)
     const int total = S3D_FFN_NCHUNK * 2 * 8 * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int lane = idx & 63, frag = (idx >> 6) & 7, which = (idx >> 9) & 1, c = idx >> 10;
@@ -759,6 +804,11 @@ __global__ void pack_ffn_f16x3_kernel(const float* __restrict__ w1, const float*
         _Float16* dst = out + (size_t)c * F16_CHUNK_HALFS + which * 8192 + (frag * 64 + lane) * 8;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
+            if (bf16) {
+                dst[t] = __builtin_bit_cast(_Float16, (unsigned short)(bf16_pair(v[t], 0.f) & 0xFFFFu));
+                dst[4096 + t] = (_Float16)0.f;
+                continue;
+            }
             const _Float16 h = (_Float16)v[t];
             dst[t] = h;
             dst[4096 + t] = (_Float16)(v[t] - (float)h);
@@ -766,15 +816,15 @@ __global__ void pack_ffn_f16x3_kernel(const float* __restrict__ w1, const float*
     }
 }
 
-int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream) {
+int launch_pack_ffn_f16x3(const float* w1, const float* w2, float* out, hipStream_t stream, int bf16) {
     hipLaunchKernelGGL(pack_ffn_f16x3_kernel, dim3(256), dim3(256), 0, stream, w1, w2,
-                       reinterpret_cast<_Float16*>(out), 128, 1, S3D_FFN, 1);
+                       reinterpret_cast<_Float16*>(out), 128, 1, S3D_FFN, 1, bf16);
     S3D_LAUNCH_CHECK();
     return 0;
 }
 int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(pack_ffn_f16x3_kernel, dim3(256), dim3(256), 0, stream, w2, w1,
-                       reinterpret_cast<_Float16*>(out), 1, S3D_FFN, 1, 128);
+                       reinterpret_cast<_Float16*>(out), 1, S3D_FFN, 1, 128, 0);
     S3D_LAUNCH_CHECK();
     return 0;
 }

@@ -201,7 +201,7 @@ class Slices3DRegModel(nn.Module):
         self.vggptlossfunc = VGGPerceptualLoss()
         self.n_slices = n_slices
         self.backend = backend
-        self.prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16": _lib.PREC_F16}[prec]
+        self.prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16": _lib.PREC_F16, "bf16": _lib.PREC_BF16}[prec]
         self.prec_name = prec
         self.train_dropout = 0.1     # nn.TransformerEncoderLayer's default, what the reference trains with (models.py:18)
         self.train_seed = 0

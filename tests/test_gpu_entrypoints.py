@@ -98,7 +98,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert len(lines[0]) < 4096, len(lines[0])         # the driver keeps ~2 KB of the tail: the line stays short
     r = json.loads(lines[0])
     tail = lines[0][-2000:]                            # ... and the secondary results sit in that tail
-    for k in ("exact_f32_mode", "white_noise", "throughput_mode_f16", "c4_dense_grid", "ldm_denoise_step", "mesh_extraction",
+    for k in ("exact_f32_mode", "white_noise", "throughput_mode_f16", "throughput_mode_bf16", "c4_dense_grid", "ldm_denoise_step", "mesh_extraction",
               "gt_train_step", "train_ms_per_step", "train_samples_per_s"):
         assert '"%s":' % k in tail, k
     for v in r.values():                               # prose lives in DESIGN.md, not in the line

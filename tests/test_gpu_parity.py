@@ -624,6 +624,34 @@ def test_single_pass_f16_throughput_mode_runs_and_reports_its_error():
     assert e3 < TOL < e_sdf < 5e-2 and e_img < 1e-2
 
 
+def test_bf16_decoder_mode_runs_and_reports_its_error():
+    """prec='bf16' (S3D_PREC_BF16): the decoder's attention and FFN GEMMs on v_mfma_f32_16x16x32_bf16 with bf16-rounded
+    operands (the precision BASELINE configs[1] literally names), everything else as the single-pass f16 mode.  A throughput
+    mode further from fp32 than 'f16' (8 significand bits instead of 11): it must run through the kernels, stay a sane
+    approximation (0.3 on sdf for these weights; the U-Net, which it does not touch, within the f16 mode's 1e-2) and sit
+    further from the oracle than the f16 mode does."""
+    from oracle import ref_cpu
+    from slice3d_amd.synth import make_feed_dict
+    mb = get_model(12, "test", "bf16")
+    m16 = get_model(12, "test", "f16")
+    sd = seeded_sd_from_shapes(_shapes(12))
+    fd = make_feed_dict(1, 64, 6000, 12, seed=55, with_slices=False)
+    a = mb(to_gpu(fd))
+    b = m16(to_gpu(fd))
+    ref = ref_cpu.forward(sd, fd, mode="test", n_slices=12, with_vgg=False)
+    e_bf = float((a["sdf_pred"].cpu() - ref["sdf_pred"]).abs().max())
+    e_16 = float((b["sdf_pred"].cpu() - ref["sdf_pred"]).abs().max())
+    e_img = float((a["slices_rec"].cpu() - ref["slices_rec"]).abs().max())
+    print("bf16 decoder mode: max|sdf - oracle| %.3e (single-pass f16: %.3e), max|slices_rec - oracle| %.3e" % (e_bf, e_16, e_img))
+    assert torch.isfinite(a["sdf_pred"]).all()
+    assert e_16 < e_bf < 0.3 and e_img < 1e-2
+    # decode is deterministic and chunk-invariant in this mode too
+    code = mb.encode(to_gpu(fd))
+    full = mb.decode_sdf(fd["qry_norot"].cuda(), code)
+    part = mb.decode_sdf(fd["qry_norot"][:, 1000:3000].contiguous().cuda(), code)
+    assert torch.equal(full[:, 1000:3000], part)
+
+
 def _sweep_cases(seed, n):
     """Deterministic pseudo-random shape sweep: image sizes that are multiples of 16, ragged query counts around the
     16-query group / 8-query attention item / chunk boundaries, every slice count the C ABI accepts, both prologues."""
