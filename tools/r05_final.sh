@@ -2,8 +2,10 @@
 # HBM counters and SQ counters of the inference kernels, marker trace.  Outputs -> gpurun_out/r05f/
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r05f; mkdir -p $O
+if [ -z "$S3D_PROFILES_ONLY" ]; then   # S3D_PROFILES_ONLY=1: only the traces and counters
 python -m pytest tests -m gpu -x -q --durations=15 > $O/pytest.log 2>&1; tail -22 $O/pytest.log
 python bench.py > $O/bench.json 2> $O/bench.err; wc -c $O/bench.json; tail -c 2200 $O/bench.json
+fi
 BENCH="$GRAFT_REPO_ROOT/bench.py --infer-only"
 (cd /tmp && rm -rf /tmp/p1 && rocprofv3 --kernel-trace -d /tmp/p1 -o b -- python $BENCH --steps 10 --warmup 2 > /tmp/p1.json 2>/dev/null)
 python tools/rocpd_summary.py $(find /tmp/p1 -name "*.db" | head -1) > $O/r05_bench_f16x3_kernel_stats.md
