@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S3D_VERSION 100          /* 0.1.0 */
+#define S3D_VERSION 110          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported, s3d_decode_last_fused */
 #define S3D_E_ARG (-1)           /* bad argument / unsupported shape */
 #define S3D_E_WORKSPACE (-2)     /* workspace or packed-weight buffer too small */
 
@@ -155,7 +155,12 @@ size_t s3d_decode_workspace_bytes_min(int batch, long n_qry, int n_slices);
 /* 1 (default): everything on the caller's stream.  2 (or env S3D_DECODE_LANES=2): passes of >= 131 072 queries run their two
  * halves' layer chains on the caller's stream and on a library-owned side stream (created once per device, ordered behind
  * the caller's stream by events on both ends of every call), so one half's attention kernels share the CUs with the other
- * half's FFN kernels.  Same results bit for bit; measured time-neutral on MI355X (profiles/r05_lanes_ab.md), kept opt-in. */
+ * half's FFN kernels.  Same results bit for bit; measured time-neutral on MI355X (profiles/r05_lanes_ab.md), kept opt-in.
+ * Thread safety: the setting is process-wide (an atomic).  The side stream and its two events are shared by every caller of a
+ * device; a call holds that device's mutex from its fork to its join (host-side enqueue time only), so host threads may
+ * decode concurrently on one device with different caller streams — their side-stream work is serialised, never interleaved.
+ * The objects are created under the same mutex, all or nothing; when they cannot be created the call runs in its one-stream
+ * form. */
 int s3d_decode_set_lanes(int n);
 /* qry (B,Q,3); rot (B,3,3) or NULL; trans (B,4,3) = trans_mat_wo_rot_tp; flip_yz != 0 selects the
  * mode='test' prologue (y,z negated, no rotation; models.py:53-56).  sdf_out (B,Q). */
@@ -265,6 +270,10 @@ int s3d_gt_decode_grid_fwd(const void* head_packed, const S3dGtLatent* latent, c
 size_t s3d_conv_packed_bytes(int cout, int cin0, int cin1, int ks);
 int s3d_conv_pack(const float* w, const float* bias, int cout, int cin0, int cin1, int ks, void* packed,
                   size_t packed_bytes, void* stream);
+/* prec (since version 110): S3D_PREC_F32 = exact fp32 MFMA; S3D_PREC_F16X3 = three f16 MFMAs per product (fp32-class);
+ * S3D_PREC_F16 = the single-pass throughput mode (ONE f16 MFMA per product, operands rounded to f16 — not fp32-class; before
+ * version 110 this value selected the exact fp32 path here).  Layers without an f16 weight image (channel counts that are not
+ * multiples of 32: the stem) run the exact fp32 MFMA in every mode.  Any other value (S3D_PREC_BF16 included): S3D_E_ARG. */
 int s3d_conv_fwd(const void* packed, const float* x0, const float* x1, const float* residual, float* out, int N,
                  int H, int W, int cout, int cin0, int cin1, int ks, int prec, void* workspace,
                  size_t workspace_bytes, void* stream);
@@ -276,6 +285,9 @@ int s3d_conv_fwd(const void* packed, const float* x0, const float* x1, const flo
  * ks == 3, split precision (f16x3 / f16), cin0, cin1, cout multiples of 32, cin0 + cin1 <= 1536; other shapes are refused
  * with S3D_E_ARG (use s3d_group_norm_fwd + s3d_conv_fwd). */
 size_t s3d_group_norm_stats_floats(int N, int groups);
+/* 1 if s3d_conv_gn_fwd serves the shape (H, W <= 0: map size not known yet), else 0 — the single statement of the fused
+ * operator's eligibility; on 0 run s3d_group_norm_fwd + s3d_conv_fwd. */
+int s3d_conv_gn_supported(int cout, int cin0, int cin1, int ks, int prec, int H, int W, int has_workspace);
 /* A convolution output whose split-K finish pass is deferred to its consumer (s3d_conv_gn_fwd with nsplit_out != NULL reported
  * nsplit > 1): the raw partial sums [nsplit][N*H*W][cout] sit in the convolution's workspace; `out` (N,H,W,cout) is written by
  * whoever consumes the descriptor — the next GroupNorm's statistics kernel (s3d_group_norm_table_fwd / s3d_group_norm_partial_fwd:

@@ -133,6 +133,7 @@ SYMBOLS = {
     "s3d_group_norm_stats_floats": (_sz, [_i, _i]),
     "s3d_group_norm_table_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, C.c_long, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "s3d_group_norm_partial_fwd": (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "s3d_conv_gn_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "s3d_conv_gn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp]),
     "s3d_conv_finish_fwd": (_i, [_vp, _i, _i, _i, _vp]),
     "s3d_group_norm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
@@ -216,7 +217,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.s3d_version() < 100:
+    if lib.s3d_version() < 110:
         raise S3dError("libslice3d_hip.so too old: %d" % lib.s3d_version())
     _lib = lib
     return lib

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <vector>
+#include <mutex>
 
 #include <math.h>
 
@@ -641,7 +642,10 @@ static int copy_vec(float* dst, const float* src, size_t n, hipStream_t st) {
     return 0;
 }
 
-static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLayout& H, hipStream_t st) {
+// bf16_twins: also pack the bf16 images of the FFN / attention fragments (S3D_PREC_BF16, an inference mode of
+// Slices3DRegModel).  The GT head (api_gt.inc rejects S3D_PREC_BF16) and the trainer's head (repacked with the weights every
+// step, never decoded in bf16) skip them: 6.9 MB and 6 pack launches per head.
+static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLayout& H, hipStream_t st, bool bf16_twins) {
     for (int l = 0; l < S3D_N_LAYERS; ++l) {
         const S3dLayerParams& p = layers[l];
         TRY(pack_linear(p.in_proj_w, b + H.L[l].inw, 384, 384, 128, 128, 0, st));
@@ -658,8 +662,10 @@ static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLa
         TRY(copy_vec(b + H.L[l].ln2b, p.norm2_b, 128, st));
         TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wf16, st));
         TRY(launch_pack_attn_q_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].aq16, st));
-        TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wfb16, st, 1));
-        TRY(launch_pack_attn_q_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].aqb16, st, 1));
+        if (bf16_twins) {
+            TRY(launch_pack_ffn_f16x3(p.lin1_w, p.lin2_w, b + H.L[l].wfb16, st, 1));
+            TRY(launch_pack_attn_q_f16x3(p.in_proj_w, p.out_proj_w, b + H.L[l].aqb16, st, 1));
+        }
     }
     {   // absorbed token-0 attention of the last layer (launch_attn_last_mix)
         PackBatchSuspend now;   // `dense` is reused: these packs must run between the two absorb launches
@@ -675,7 +681,7 @@ static int pack_head_layers(const S3dLayerParams* layers, float* b, const HeadLa
     return 0;
 }
 
-extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed_bytes, void* stream) {
+static int head_pack_impl(const S3dHeadParams* P, void* packed, size_t packed_bytes, void* stream, bool bf16_twins) {
     hipStream_t st = (hipStream_t)stream;
     S3D_CHECK_ARG(P && packed, "head_pack: null argument");
     const HeadLayout H = head_layout();
@@ -692,10 +698,13 @@ extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed
     for (int l = 0; l < 3; ++l) TRY(pack_linear(P->fc_s_w + lo[l], b + H.wproj16[l], 128, 128, lc[l], 992, 0, st, 1));
     TRY(pack_linear(P->fc_s_w + 896, b + H.ws34, 128, 128, 96, 992, 0, st));
     TRY(pack_linear(P->fc_s_w + 896, b + H.ws34_16, 128, 128, 96, 992, 0, st, 1));
-    TRY(pack_head_layers(P->layer, b, H, st));
+    TRY(pack_head_layers(P->layer, b, H, st, bf16_twins));
     TRY(copy_vec(b + H.fco_w, P->fc_out_w, 128, st));
     TRY(copy_vec(b + H.fco_b, P->fc_out_b, 1, st));
     return 0;
+}
+extern "C" int s3d_head_pack(const S3dHeadParams* P, void* packed, size_t packed_bytes, void* stream) {
+    return head_pack_impl(P, packed, packed_bytes, stream, true);
 }
 
 extern "C" int s3d_latent_build(const void* head_packed, const S3dPyramid* pyr, const S3dLatent* out, int prec,
@@ -789,36 +798,56 @@ extern "C" size_t s3d_decode_workspace_bytes_min(int batch, long n_qry, int n_sl
 // before the call returns its last launch), so the caller still sees one in-order stream.  Results are bit-identical: rows
 // are independent and every kernel sees the rows it saw before.
 // ---------------------------------------------------------------------------------------------
+// Thread safety: the side stream and its two events are per-device state shared by every caller of that device.
+// Two host threads decoding on one device with different caller streams must not interleave their fork / join records (A
+// records stagger, B records stagger, A waits: A's side-stream work would be ordered behind B's token builder, not its own),
+// so the whole fork-to-join section of a call holds the device's mutex (the enqueue only: microseconds; the GPU work of two
+// callers then simply queues on the one side stream).  Creation is under the same mutex and all-or-nothing.
 struct DecodeLanes {
+    std::mutex mu;
     hipStream_t aux = nullptr;
     hipEvent_t stagger = nullptr, join = nullptr;
     bool ok = false;
 };
-static int g_decode_lanes = -1;   // -1: not configured (env S3D_DECODE_LANES, default 1)
+static std::atomic<int> g_decode_lanes{-1};   // -1: not configured (env S3D_DECODE_LANES, default 1)
 extern "C" int s3d_decode_set_lanes(int n) {
     S3D_CHECK_ARG(n == 1 || n == 2, "decode_set_lanes: %d (1 or 2)", n);
-    g_decode_lanes = n;
+    g_decode_lanes.store(n, std::memory_order_relaxed);
     return 0;
 }
 static int decode_lanes() {
-    if (g_decode_lanes < 0) {
+    int v = g_decode_lanes.load(std::memory_order_relaxed);
+    if (v < 0) {   // (two racing first callers read the same environment: both store the same value)
         const char* e = getenv("S3D_DECODE_LANES");
-        g_decode_lanes = (e && atoi(e) == 2) ? 2 : 1;
+        v = (e && atoi(e) == 2) ? 2 : 1;
+        g_decode_lanes.store(v, std::memory_order_relaxed);
     }
-    return g_decode_lanes;
+    return v;
 }
+// the current device's lanes, or nullptr when they cannot be created; the caller locks L->mu around its fork-to-join section
+// and calls decode_lanes_ready(L) under that lock
 static DecodeLanes* decode_lanes_for_device() {
     static DecodeLanes lanes[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    DecodeLanes& L = lanes[dev & 63];
-    if (!L.ok) {
-        if (hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&L.stagger, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&L.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-        L.ok = true;
+    return &lanes[dev & 63];
+}
+static bool decode_lanes_ready(DecodeLanes& L) {   // under L.mu
+    if (L.ok) return true;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool made = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess;
+    if (!made) {   // nothing half-made survives: a later call starts from scratch instead of leaking a stream per call
+        if (e1) (void)hipEventDestroy(e1);
+        if (e0) (void)hipEventDestroy(e0);
+        if (s) (void)hipStreamDestroy(s);
+        (void)hipGetLastError();
+        return false;
     }
-    return &L;
+    L.aux = s; L.stagger = e0; L.join = e1; L.ok = true;
+    return true;
 }
 #define S3D_LANES_MIN_GROUPS 8192   // below 131 072 queries per pass the halves do not fill the chip
 
@@ -976,12 +1005,20 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
         };
         DecodeLanes* lanes = (!stages && prec != S3D_PREC_F32 && gc >= S3D_LANES_MIN_GROUPS && decode_lanes() == 2)
                                  ? decode_lanes_for_device() : nullptr;
+        std::unique_lock<std::mutex> lanes_lock;
+        if (lanes) {
+            lanes_lock = std::unique_lock<std::mutex>(lanes->mu);
+            if (!decode_lanes_ready(*lanes)) {   // no side stream on this device: the one-stream form, same results
+                lanes_lock.unlock();
+                lanes = nullptr;
+            }
+        }
         if (!lanes) {
             TRY(run_layers(st, 0, gc, nullptr));
         } else {
             // lane 0 = the first half on the caller's stream; lane 1 = the second half on the side stream, released when lane
             // 0's first attention launch is done (and with it the token builder): from then on one lane's attention phases
-            // meet the other lane's FFN phases
+            // meet the other lane's FFN phases.  The device's mutex is held from the fork to the join (see DecodeLanes).
             const long h0 = (gc / 2 + 7) / 8 * 8;
             TRY(run_layers(st, 0, h0, lanes->stagger));
             if (hipStreamWaitEvent(lanes->aux, lanes->stagger, 0) != hipSuccess) {

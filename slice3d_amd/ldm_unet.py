@@ -146,7 +146,9 @@ class UNetModel(nn.Module):
         return _lib.PREC_F32 if self.prec == "f32" else _lib.PREC_F16X3
 
     def _params_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # fuse_gn / prec decide the two-source packing of the output blocks' first convolutions: toggling either after a
+        # repack() must repack (a stale split made s3d_conv_gn_fwd refuse the call)
+        return (self.fuse_gn, self.prec) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     @staticmethod
     def _pad16(c):
@@ -177,9 +179,8 @@ class UNetModel(nn.Module):
                 # as one source behind the stand-alone GroupNorm otherwise (its output is one tensor)
                 cw = mod.in_layers[2].weight
                 split = mod.cat_split
-                if split is not None and not (self.fuse_gn and self.prec != "f32" and not (mod.up or mod.down)
-                                              and cw.shape[0] % 32 == 0 and split[0] % 32 == 0 and split[1] % 32 == 0
-                                              and sum(split) <= 1536):
+                if split is not None and not (not (mod.up or mod.down)
+                                              and self._gn_conv_served(cw.shape[0], split[0], split[1], cw.shape[2])):
                     split = None
                 self._packed[id(mod.in_layers[2])] = self._pack_conv(mod.in_layers[2], split=split)
                 self._packed[id(mod.out_layers[3])] = self._pack_conv(mod.out_layers[3])
@@ -260,12 +261,17 @@ class UNetModel(nn.Module):
             res.record_stream(cur)            # allocated on the side stream, read on the main stream
         return res, join
 
+    def _gn_conv_served(self, cout, cin0, cin1, ks, h=0, w=0):
+        """The C side's own statement of what s3d_conv_gn_fwd serves (s3d_conv_gn_supported) — the one source of both the
+        two-source packing decision of repack() and the fused / unfused choice of forward()."""
+        return bool(self.fuse_gn and self.prec != "f32" and
+                    self._lib.s3d_conv_gn_supported(cout, cin0, cin1, ks, self._precv(), h, w, 1))
+
     def _gn_conv_fusable(self, conv, x):
-        """GroupNorm -> [FiLM] -> SiLU -> conv3x3 as one operator (s3d_conv_gn_fwd): the LDS-staged split-precision kernel's
-        shapes — 3x3, every channel count a multiple of 32, at most 1536 input channels."""
+        """GroupNorm -> [FiLM] -> SiLU -> conv3x3 as one operator (s3d_conv_gn_fwd)."""
         _, cout, cin0, cin1, ks = self._packed[id(conv)]
-        return (self.fuse_gn and self.prec != "f32" and ks == 3 and cout % 32 == 0 and cin0 % 32 == 0 and cin1 % 32 == 0
-                and cin0 + cin1 <= 1536 and x.shape[-1] == cin0)   # (a concatenated input needs the two-source pack)
+        return (self._gn_conv_served(cout, cin0, cin1, ks, x.shape[1], x.shape[2])
+                and x.shape[-1] == cin0)   # (a concatenated input needs the two-source pack)
 
     def _gn_table(self, gn, x, x1=None, film=None):
         """Statistics of group_norm(cat([x, x1])) folded with gamma / beta / FiLM into the per-channel affine table a fused
