@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S3D_VERSION 110          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported, s3d_decode_last_fused */
+#define S3D_VERSION 111          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused */
 #define S3D_E_ARG (-1)           /* bad argument / unsupported shape */
 #define S3D_E_WORKSPACE (-2)     /* workspace or packed-weight buffer too small */
 
@@ -162,6 +162,13 @@ size_t s3d_decode_workspace_bytes_min(int batch, long n_qry, int n_slices);
  * The objects are created under the same mutex, all or nothing; when they cannot be created the call runs in its one-stream
  * form. */
 int s3d_decode_set_lanes(int n);
+/* 1 (default; env S3D_LAST_FUSED=0 turns it off): the token-0 attention block of the last encoder layer (models.py:83 consumes
+ * nothing else) runs as ONE kernel in the split-precision modes (csrc/decode_last.hip: absorbed q GEMM, 13-row mixing step,
+ * absorbed output GEMM + residual; only the token rows are read and the 512-byte u rows written).  0: the four-launch form of
+ * rounds 2-5 (row copy, row GEMM, mixing kernel, row GEMM).  Same results bit for bit (every accumulator adds the same
+ * products in the same order); the switch exists for the test that says so and for A/B timing.  S3D_PREC_F32 always runs the
+ * four-launch form.  Process-wide (an atomic). */
+int s3d_decode_set_last_fused(int on);
 /* qry (B,Q,3); rot (B,3,3) or NULL; trans (B,4,3) = trans_mat_wo_rot_tp; flip_yz != 0 selects the
  * mode='test' prologue (y,z negated, no rotation; models.py:53-56).  sdf_out (B,Q). */
 int s3d_decode_points_fwd(const void* head_packed, const S3dLatent* latent, const float* qry,

@@ -883,8 +883,26 @@ static int rows_linear(const float* b, size_t w32, size_t w16, int n, int k, con
 // see launch_attn_last_mix.  scratch: gc*16*S3D_LAST_ROW_FLOATS floats.
 // fold_ln: X0 receives the pre-LayerNorm sums u and the caller's final FFN kernel normalises them in its prologue
 // (launch_ffn_layer(..., pre_ln1 = true): the ln_fwd launch and one round trip of the token-0 rows are gone)
+static std::atomic<int> g_last_fused{-1};   // -1: not configured (env S3D_LAST_FUSED, default 1)
+extern "C" int s3d_decode_set_last_fused(int on) {
+    S3D_CHECK_ARG(on == 0 || on == 1, "decode_set_last_fused: %d (0 or 1)", on);
+    g_last_fused.store(on, std::memory_order_relaxed);
+    return 0;
+}
+static bool last_fused() {
+    int v = g_last_fused.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("S3D_LAST_FUSED");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+        g_last_fused.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
 static int attn_last_layer(const float* b, const HeadLayout& H, const LayerPtrs& lp, const float* X, float* X0, long gc,
                            int T, float* scratch, int prec, hipStream_t st, bool fold_ln = false) {
+    if (fold_ln && prec != S3D_PREC_F32 && last_fused())   // one kernel, same bits (decode_last.hip)
+        return launch_attn_last_fused(X, X0, gc, T, b + H.last.wm16, b + H.last.bm, b + H.last.wn16, b + H.last.bn,
+                                      prec == S3D_PREC_F16, st);
     const long rows0 = gc * S3D_GROUP;
     float* x0 = scratch;
     float* u = x0 + rows0 * 128;

@@ -170,6 +170,11 @@ int launch_attn_layer_q_train(const float* xin, float* y, float* u, float* o, lo
 //   qt   [rows0][512]: per head the 128-vector M_h x0 + m_h
 //   xbar [rows0][512]: per head sum_t softmax_t(qt_h . x_t / sqrt(32)) x_t
 int launch_attn_last_mix(const float* X, const float* qt, float* xbar, long groups, int T, hipStream_t stream);
+// decode_last.hip: the whole block (x0 -> qt -> mixing -> u = N xbar + n + x0) in one kernel, split-precision modes only.
+// X [groups][T][16][128] -> U [groups*16][128] (pre-LayerNorm1 sums); wm16 / wn16: the f16 hi|lo fragment images of M / N
+// (HeadLayout::last), bm / bn their bias vectors.  Bit-identical to tok0_copy + row GEMM + launch_attn_last_mix + row GEMM.
+int launch_attn_last_fused(const float* X, float* U, long groups, int T, const float* wm16, const float* bm,
+                           const float* wn16, const float* bn, bool single_pass, hipStream_t stream);
 // the absorbed matrices from in_proj_weight (384,128), in_proj_bias (384), out_proj.weight (128,128), out_proj.bias:
 //   kind 0: out [512][128] = M (row h*128 + c), bias_out [512] = m
 //   kind 1: out [128][512] = N (column h*128 + c), bias_out [128] = n

@@ -1,0 +1,272 @@
+// decode_last.hip — the last encoder layer's attention block for token 0 in ONE kernel (round 6).
+//
+// models.py:83 consumes only token 0 of the last layer, and decode.h describes the absorbed form that makes the layer
+// two dense GEMMs around a 13-row mixing step:   qt = M x0 + m  (128 -> 512),   xbar_h = sum_t softmax_t(qt_h . x_t / sqrt 32) x_t,
+// u = N xbar + n + x0  (512 -> 128).  Until round 5 these were four launches (tok0_copy, a row GEMM, attn_last_mix_kernel,
+// a row GEMM) that wrote and re-read x0, qt (2 KB per query) and xbar (2 KB per query): 1.5 ms per 400 k queries for an
+// operator whose only large operand is the 13 token rows (6.7 KB per query, 2.66 GB per step).  Here a workgroup owns NG
+// groups of 16 queries at a time and nothing but the token rows (in) and the u rows (out, 512 B per query) touches HBM:
+//
+//   phase 1  wave w = head w:  qt[:, 128 w .. +127] of the NG x 16 queries on the split-precision MFMA (A = M fragments
+//            straight from the packed image in L2, B = the x0 tile split in registers), + m, parked in LDS as fp32;
+//   phase 2  round r = group r: wave w mixes queries 4 w .. 4 w + 3 (16 lanes per query, 8 channels per lane, the 13 token
+//            rows in registers — the arithmetic of attn_last_mix_kernel, instruction for instruction); xbar_h is split to
+//            f16 hi | lo and written OVER the query's qt_h (same 512 bytes; the 16 lanes that read qt_h are the ones that
+//            write xbar_h, LDS operations of a wave execute in order) in the B-fragment order of phase 3;
+//   phase 3  wave w = output channels 32 w .. 32 w + 31:  u = N xbar + n + x0 (K = 512: 16 k-steps, A = N fragments from
+//            L2, B = xbar fragments from LDS), stored as the rows the final FFN kernel normalises in its prologue.
+//
+// Every accumulator adds its products in the order of the row-GEMM kernels it replaces (k ascending; hi*lo, lo*hi, hi*hi;
+// then + bias, then + residual) and the mixing step is the same code: the u rows are BIT-IDENTICAL to the four-launch
+// form (tests/test_gpu_parity.py::test_fused_last_layer_is_bit_identical).
+//
+// LDS: one 2 KB + 16 B region per query (the 16-byte pad spreads the phase-3 fragment reads of the 16 queries over the
+// banks); NG = 2: 66 KB per workgroup, two workgroups per CU.  The weight fragments (M, N: 256 KB each as hi | lo) are read
+// from L2 once per NG groups: 512 KB per 32 queries = 6.4 GB per 400 k queries at L2 bandwidth beside the 2.66 GB of rows
+// from HBM.
+#include "decode.h"
+
+typedef _Float16 lhalf8 __attribute__((ext_vector_type(8)));
+
+#define AL_QS (2048 + 16)   // bytes per query region
+
+__device__ __forceinline__ float al_row16_allsum(float v) {   // = row16_allsum of decode.hip
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+    return v;
+}
+
+template <bool SINGLE, int NG>
+__global__ __launch_bounds__(256, 2) void attn_last_fused_kernel(const float* __restrict__ X, float* __restrict__ U,
+                                                                 long groups, int T, const _Float16* __restrict__ wm16,
+                                                                 const float* __restrict__ bm,
+                                                                 const _Float16* __restrict__ wn16,
+                                                                 const float* __restrict__ bn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_q[];   // [NG * 16][AL_QS]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int mq = threadIdx.x >> 4, s16 = threadIdx.x & 15, c0 = s16 * 8;   // phase 2: query of the group, channel octet
+    const float scale = 0.17677669529663687f;                                // 1/sqrt(32)
+    const long n_it = (groups + NG - 1) / NG;
+#pragma unroll 1
+    for (long it = blockIdx.x; it < n_it; it += gridDim.x) {
+        // ---------------- phase 1: qt = M x0 + m for the NG x 16 queries; this wave: head `wave` ----------------
+        {
+            lhalf8 xh[NG][4], xl[NG][4];
+            {
+                f32x4 v0[NG][4], v1[NG][4];
+#pragma unroll
+                for (int ng = 0; ng < NG; ++ng) {
+                    long grp = it * NG + ng;
+                    if (grp >= groups) grp = groups - 1;
+                    const float* row = X + (grp * T * S3D_GROUP + m) * 128 + 8 * g;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        v0[ng][u] = ld4(row + 32 * u);
+                        v1[ng][u] = ld4(row + 32 * u + 4);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float x[8] = {v0[ng][u][0], v0[ng][u][1], v0[ng][u][2], v0[ng][u][3],
+                                            v1[ng][u][0], v1[ng][u][1], v1[ng][u][2], v1[ng][u][3]};
+                        s3d_half8 h, l;
+                        s3d_split8(x, h, l);
+                        xh[ng][u] = __builtin_bit_cast(lhalf8, h);
+                        xl[ng][u] = __builtin_bit_cast(lhalf8, l);
+                    }
+            }
+            S3D_SPLIT_SETTLE();
+            const _Float16* wp = wm16 + (size_t)(8 * wave) * 4 * 1024 + lane * 8;
+            lhalf8 wh[2][4], wl[2][4];   // [buffer][k-step]: the next output tile's fragments are requested under this one's MFMAs
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                wh[0][u] = *reinterpret_cast<const lhalf8*>(wp + u * 1024);
+                if (!SINGLE) wl[0][u] = *reinterpret_cast<const lhalf8*>(wp + u * 1024 + 512);
+            }
+#pragma unroll 2
+            for (int j = 0; j < 8; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < 8) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        wh[(j + 1) & 1][u] = *reinterpret_cast<const lhalf8*>(wp + ((j + 1) * 4 + u) * 1024);
+                        if (!SINGLE) wl[(j + 1) & 1][u] = *reinterpret_cast<const lhalf8*>(wp + ((j + 1) * 4 + u) * 1024 + 512);
+                    }
+                }
+                const int co = (8 * wave + j) * 16 + 4 * g;
+                const f32x4 sh = ld4(bm + co);
+                f32x4 acc[NG];
+#pragma unroll
+                for (int ng = 0; ng < NG; ++ng) acc[ng] = zero4();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!SINGLE) {
+#pragma unroll
+                        for (int ng = 0; ng < NG; ++ng)
+                            acc[ng] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j & 1][u], xl[ng][u], acc[ng], 0, 0, 0);
+#pragma unroll
+                        for (int ng = 0; ng < NG; ++ng)
+                            acc[ng] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j & 1][u], xh[ng][u], acc[ng], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int ng = 0; ng < NG; ++ng)
+                        acc[ng] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j & 1][u], xh[ng][u], acc[ng], 0, 0, 0);
+                }
+#pragma unroll
+                for (int ng = 0; ng < NG; ++ng)
+                    *reinterpret_cast<f32x4*>(s_q + (ng * 16 + m) * AL_QS + co * 4) = acc[ng] + sh;
+            }
+        }
+        __syncthreads();
+        // ---------------- phase 2: the 13-row mixing step, round = group, this wave: queries 4 wave .. + 3 ----------------
+#pragma unroll 1
+        for (int r = 0; r < NG; ++r) {
+            long grp = it * NG + r;
+            if (grp >= groups) grp = groups - 1;
+            const float* xg = X + (grp * T * S3D_GROUP + mq) * 128 + c0;
+            f32x4 xa[S3D_N_TOKENS_MAX], xb[S3D_N_TOKENS_MAX];
+#pragma unroll
+            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+                const int tc = t < T ? t : T - 1;
+                xa[t] = ld4(xg + (long)tc * S3D_GROUP * 128);
+                xb[t] = ld4(xg + (long)tc * S3D_GROUP * 128 + 4);
+            }
+            unsigned char* qreg = s_q + (r * 16 + mq) * AL_QS;
+#pragma unroll 1
+            for (int h = 0; h < 4; ++h) {
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(qreg + (h * 128 + c0) * 4);
+                const f32x4 qb = *reinterpret_cast<const f32x4*>(qreg + (h * 128 + c0 + 4) * 4);
+                float sc[S3D_N_TOKENS_MAX];
+                float mx = -1e30f;
+#pragma unroll
+                for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+                    float d = qa[0] * xa[t][0] + qa[1] * xa[t][1] + qa[2] * xa[t][2] + qa[3] * xa[t][3] +
+                              qb[0] * xb[t][0] + qb[1] * xb[t][1] + qb[2] * xb[t][2] + qb[3] * xb[t][3];
+                    d = al_row16_allsum(d) * scale;
+                    sc[t] = t < T ? d : -1e30f;
+                    mx = fmaxf(mx, sc[t]);
+                }
+                float den = 0.f;
+#pragma unroll
+                for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+                    sc[t] = t < T ? expf(sc[t] - mx) : 0.f;
+                    den += sc[t];
+                }
+                const float inv = 1.f / den;
+                f32x4 oa = zero4(), ob = zero4();
+#pragma unroll
+                for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+                    const float pt = sc[t] * inv;
+                    oa += xa[t] * pt;
+                    ob += xb[t] * pt;
+                }
+                // xbar_h channels c0 .. c0 + 7 = the B fragment of lane (m = mq, g = s16 & 3) of k-step 4 h + (s16 >> 2)
+                const float x[8] = {oa[0], oa[1], oa[2], oa[3], ob[0], ob[1], ob[2], ob[3]};
+                s3d_half8 hh, ll;
+                s3d_split8(x, hh, ll);
+                unsigned char* d = qreg + (4 * h + (s16 >> 2)) * 128 + (s16 & 3) * 16;
+                *reinterpret_cast<s3d_half8*>(d) = hh;
+                if (!SINGLE) *reinterpret_cast<s3d_half8*>(d + 64) = ll;
+            }
+        }
+        __syncthreads();
+        // ---------------- phase 3: u = N xbar + n + x0; this wave: output channels 32 wave .. + 31 ----------------
+        {
+            f32x4 acc[NG][2];
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) acc[ng][0] = acc[ng][1] = zero4();
+            const _Float16* wp = wn16 + (size_t)(2 * wave) * 16 * 1024 + lane * 8;
+            lhalf8 wh[2][2], wl[2][2];   // [buffer][nt]
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                wh[0][nt] = *reinterpret_cast<const lhalf8*>(wp + (size_t)nt * 16 * 1024);
+                if (!SINGLE) wl[0][nt] = *reinterpret_cast<const lhalf8*>(wp + (size_t)nt * 16 * 1024 + 512);
+            }
+            // residual rows and bias of this wave's 32 output channels (the x0 tile again: L1 / L2)
+            f32x4 res[NG][2], sh[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) sh[nt] = ld4(bn + (2 * wave + nt) * 16 + 4 * g);
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) {
+                long grp = it * NG + ng;
+                if (grp >= groups) grp = groups - 1;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    res[ng][nt] = ld4(X + (grp * T * S3D_GROUP + m) * 128 + (2 * wave + nt) * 16 + 4 * g);
+            }
+#pragma unroll 2
+            for (int u = 0; u < 16; ++u) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < 16) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const _Float16* f = wp + ((size_t)nt * 16 + u + 1) * 1024;
+                        wh[(u + 1) & 1][nt] = *reinterpret_cast<const lhalf8*>(f);
+                        if (!SINGLE) wl[(u + 1) & 1][nt] = *reinterpret_cast<const lhalf8*>(f + 512);
+                    }
+                }
+                lhalf8 bh[NG], bl[NG];
+#pragma unroll
+                for (int ng = 0; ng < NG; ++ng) {
+                    const unsigned char* f = s_q + (ng * 16 + m) * AL_QS + u * 128 + g * 16;
+                    bh[ng] = *reinterpret_cast<const lhalf8*>(f);
+                    if (!SINGLE) bl[ng] = *reinterpret_cast<const lhalf8*>(f + 64);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    if (!SINGLE) {
+#pragma unroll
+                        for (int ng = 0; ng < NG; ++ng)
+                            acc[ng][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1][nt], bl[ng], acc[ng][nt], 0, 0, 0);
+#pragma unroll
+                        for (int ng = 0; ng < NG; ++ng)
+                            acc[ng][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u & 1][nt], bh[ng], acc[ng][nt], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int ng = 0; ng < NG; ++ng)
+                        acc[ng][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1][nt], bh[ng], acc[ng][nt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) {
+                const long grp = it * NG + ng;
+                if (grp < groups) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        f32x4 v = acc[ng][nt] + sh[nt];
+                        v += res[ng][nt];
+                        st4(U + (grp * S3D_GROUP + m) * 128 + (2 * wave + nt) * 16 + 4 * g, v);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // phase 1 of the next iteration overwrites the regions phase 3 read
+    }
+}
+
+static std::atomic<unsigned long long> g_al_attr{0};
+int launch_attn_last_fused(const float* X, float* U, long groups, int T, const float* wm16, const float* bm,
+                           const float* wn16, const float* bn, bool single_pass, hipStream_t stream) {
+    if (groups <= 0) return 0;
+    S3D_CHECK_ARG(T >= 1 && T <= S3D_N_TOKENS_MAX, "attn_last_fused: T %d", T);
+    constexpr int NG = 2;
+    const size_t lds = (size_t)NG * 16 * AL_QS;
+    TRY_RET(s3d_set_max_lds(g_al_attr, {(const void*)attn_last_fused_kernel<false, NG>, (const void*)attn_last_fused_kernel<true, NG>}, lds));
+    const long n_it = (groups + NG - 1) / NG;
+    const long cap = 2L * s3d_cu_count();
+    const unsigned grid = (unsigned)(n_it < cap ? n_it : cap);
+    const _Float16* m16 = reinterpret_cast<const _Float16*>(wm16);
+    const _Float16* n16 = reinterpret_cast<const _Float16*>(wn16);
+    if (single_pass)
+        hipLaunchKernelGGL((attn_last_fused_kernel<true, NG>), dim3(grid), dim3(256), lds, stream, X, U, groups, T, m16, bm, n16, bn);
+    else
+        hipLaunchKernelGGL((attn_last_fused_kernel<false, NG>), dim3(grid), dim3(256), lds, stream, X, U, groups, T, m16, bm, n16, bn);
+    S3D_LAUNCH_CHECK();
+    return 0;
+}

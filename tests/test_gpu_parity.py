@@ -315,6 +315,31 @@ def test_decode_is_bit_reproducible_run_to_run(prec):
             assert torch.equal(model.decode_sdf(fd["qry_norot"], code), first)
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_fused_last_layer_is_bit_identical(prec):
+    """Round 6: the token-0 attention block of the last layer is ONE kernel (csrc/decode_last.hip: absorbed q GEMM, 13-row
+    mixing step, absorbed output GEMM + residual) instead of a row copy, two row GEMMs and the mixing kernel.  Every
+    accumulator adds the same products in the same order, so the two forms must agree bit for bit — on odd group counts
+    (the kernel walks two groups at a time), on fewer than 12 slices (T < 13 tokens) and on ragged query counts."""
+    from slice3d_amd import _lib
+    from slice3d_amd.synth import make_feed_dict
+    lib = _lib.load()
+    try:
+        for ns, b, s, q in ((12, 1, 64, 16), (12, 2, 64, 4500), (12, 1, 64, 16 * 37 + 5), (5, 2, 64, 3001), (3, 1, 64, 1),
+                            (12, 2, 128, 150000)):
+            model = get_model(ns, "test", prec)
+            fd = to_gpu(make_feed_dict(b, s, q, ns, seed=91 + ns, with_slices=False))
+            code = model.encode(fd)
+            assert lib.s3d_decode_set_last_fused(0) == 0
+            four = model.decode_sdf(fd["qry_norot"], code).clone()
+            assert lib.s3d_decode_set_last_fused(1) == 0
+            for _ in range(2):
+                assert torch.equal(model.decode_sdf(fd["qry_norot"], code), four), (ns, b, s, q)
+        assert lib.s3d_decode_set_last_fused(2) != 0
+    finally:
+        lib.s3d_decode_set_last_fused(1)
+
+
 def test_two_decode_lanes_and_smaller_passes_give_the_same_bits():
     """The pass of >= 131 072 queries is decoded as two halves whose layer chains run on the caller's stream and on the
     library's side stream (s3d_decode_set_lanes, api.hip): same bits as everything on one stream, and as a decode whose
