@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S3D_VERSION 111          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused */
+#define S3D_VERSION 111          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused, s3d_decode_set_shared_footprint */
 #define S3D_E_ARG (-1)           /* bad argument / unsupported shape */
 #define S3D_E_WORKSPACE (-2)     /* workspace or packed-weight buffer too small */
 
@@ -169,6 +169,12 @@ int s3d_decode_set_lanes(int n);
  * products in the same order); the switch exists for the test that says so and for A/B timing.  S3D_PREC_F32 always runs the
  * four-launch form.  Process-wide (an atomic). */
 int s3d_decode_set_last_fused(int on);
+/* 1 (default; env S3D_SHARED_FOOTPRINT=0 turns it off): the token builder evaluates the three folded pyramid levels of a group of
+ * 16 queries through the group's shared 4 x 4 pixel window on the fp32 MFMA whenever the group's bilinear footprints fit one
+ * (csrc/decode.hip, sample_tokens_kernel) and per lane otherwise.  0: always per lane.  Same results bit for bit (the MFMA is a
+ * k-ordered fmaf chain and the window visits a query's taps in the per-lane order); the switch exists for the test that says so
+ * and for A/B timing.  Applies to the inference decode calls and to s3d_train_step.  Process-wide (an atomic). */
+int s3d_decode_set_shared_footprint(int on);
 /* qry (B,Q,3); rot (B,3,3) or NULL; trans (B,4,3) = trans_mat_wo_rot_tp; flip_yz != 0 selects the
  * mode='test' prologue (y,z negated, no rotation; models.py:53-56).  sdf_out (B,Q). */
 int s3d_decode_points_fwd(const void* head_packed, const S3dLatent* latent, const float* qry,

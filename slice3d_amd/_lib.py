@@ -110,6 +110,7 @@ SYMBOLS = {
     "s3d_decode_workspace_bytes_min": (_sz, [_i, _l, _i]),
     "s3d_decode_set_lanes": (_i, [_i]),
     "s3d_decode_set_last_fused": (_i, [_i]),
+    "s3d_decode_set_shared_footprint": (_i, [_i]),
     "s3d_decode_points_fwd": (_i, [_vp, C.POINTER(S3dLatent), _vp, _vp, _vp, _i, _vp, _i, _l, _i, _i,
                                    _vp, _sz, _vp]),
     "s3d_decode_stages_floats": (_sz, [_i, _l, _i]),

@@ -883,6 +883,21 @@ static int rows_linear(const float* b, size_t w32, size_t w16, int n, int k, con
 // see launch_attn_last_mix.  scratch: gc*16*S3D_LAST_ROW_FLOATS floats.
 // fold_ln: X0 receives the pre-LayerNorm sums u and the caller's final FFN kernel normalises them in its prologue
 // (launch_ffn_layer(..., pre_ln1 = true): the ln_fwd launch and one round trip of the token-0 rows are gone)
+static std::atomic<int> g_shared_footprint{-1};   // -1: not configured (env S3D_SHARED_FOOTPRINT, default 1)
+extern "C" int s3d_decode_set_shared_footprint(int on) {
+    S3D_CHECK_ARG(on == 0 || on == 1, "decode_set_shared_footprint: %d (0 or 1)", on);
+    g_shared_footprint.store(on, std::memory_order_relaxed);
+    return 0;
+}
+int s3d_shared_footprint() {   // (also read by the training entry point)
+    int v = g_shared_footprint.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("S3D_SHARED_FOOTPRINT");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+        g_shared_footprint.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 static std::atomic<int> g_last_fused{-1};   // -1: not configured (env S3D_LAST_FUSED, default 1)
 extern "C" int s3d_decode_set_last_fused(int on) {
     S3D_CHECK_ARG(on == 0 || on == 1, "decode_set_last_fused: %d (0 or 1)", on);
@@ -963,6 +978,7 @@ static int decode_impl(const void* head_packed, const S3dLatent* lat, const floa
         sa.qry = qry; sa.rot = rot; sa.trans = trans; sa.flip_yz = flip_yz;
         sa.n_qry = n_qry; sa.groups_per_batch = gpb; sa.g_begin = g0; sa.g_count = gc;
         sa.nx = nx; sa.box = box; sa.q_offset = q_offset; sa.X = X; sa.perm = perm;
+        sa.lane_footprints = !s3d_shared_footprint();
         {
             ProfScope prof_(S3D_PROF_SAMPLE, st);
             TRY(launch_sample_tokens(sa, st));

@@ -59,9 +59,11 @@ struct SampleArgs {
     float* X;            // out [g_count][T][16][128]
     const int* perm;     // optional: slot -> query index within the batch item (locality sort), (B, Q) ints
     float* raw_out;      // optional (training): sampled level-3/4 features [g_count][T][16][96], token-0 rows zero
+    int lane_footprints; // 1: every folded level in the per-lane form (test / A-B switch; the shared-window form gives the same bits)
 };
 
 int launch_sample_tokens(const SampleArgs& a, hipStream_t stream);
+int s3d_shared_footprint();   // api.hip: the process-wide switch behind s3d_decode_set_shared_footprint (1 = shared windows)
 // X: [groups][T][16][128] in place;  if x0_out != NULL this is the LAST layer: only token 0 is
 // produced, compactly, into x0_out [groups*16][128].
 int launch_attn_layer(float* X, float* x0_out, long groups, int T, const LayerPtrs& w, hipStream_t stream);

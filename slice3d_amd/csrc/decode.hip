@@ -24,6 +24,8 @@ struct Tap4 {          // bilinear footprint of one query in one level (grid_sam
 };
 
 __device__ __forceinline__ Tap4 make_taps(float gx, float gy, int W, int H) {
+#pragma clang fp contract(off)   // the weights must not depend on which products hipcc decides to fuse in a given caller (round 6: two
+                                 // instantiations of the token builder must produce the same bits)
     // ATen grid_sampler_unnormalize (align_corners): ((coord + 1) / 2) * (size - 1)
     const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
     const float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
@@ -91,11 +93,221 @@ __device__ __forceinline__ void layer_norm_row(f32x4 (&y)[8], const float* gamma
 // stamps (round 4, tools/patches/sample_tokens_stamps.patch) showed the fp32 form — 192 dependent-chain v_mfma_f32_16x16x4
 // of 8 passes per (16 queries, slice) task, the matrix pipe's fp32 rate — taking 7 000 of a task's 20 000 cycles; 72 MFMAs
 // of the 32-deep f16 instruction take 1 200.  The fine levels are then read so that a lane owns 8 consecutive channels of
-// each 32-channel block (the k-slots 8g + t of the f16 fragment image, pack_frag f16 form).  The tap rows of the folded
-// levels are requested one round (two taps x 8 loads) AHEAD of their use: the kernel runs one wave per SIMD (its staging
-// arrays need the registers), so nothing else hides a round's L1 / L2 latency.
+// each 32-channel block (the k-slots 8g + t of the f16 fragment image, pack_frag f16 form).
+//
+// Shared footprints (round 6).  Until round 5 every lane gathered the four 512-byte tap rows of its own query in each of the
+// three folded levels: 96 loads of 16 B per lane and task, 96 KB through the CU's L1 per (16 queries, slice) — 36 GB per
+// step, the kernel's bound (one wave per SIMD, 448 registers of staging, the load path 38 % busy).  But the 16 queries of a
+// group are neighbours in the image (s3d_query_sort: Morton order of the projected pixel), so in a folded level (16^2 ..
+// 64^2 pixels at S = 256) their 64 taps fall on a handful of pixels.  When the group's floor cells span at most 3 x 3 cells
+// (taps inside a 4 x 4 pixel window: nearly always in sorted order), the level is evaluated as ONE small GEMM on the fp32
+// MFMA:   out^T [128 ch][16 q] += R^T [128 ch][16 window pixels] * Wt^T [16 pixels][16 q],
+// A = the window's rows, gathered ONCE per group (lane (ch, k) loads pixel 4 s + k, channel 16 j + ch: 32 dword loads, 8 KB
+// per level instead of 32 KB), B = the sparse bilinear weights (four non-zeros per query, computed per lane from its own
+// footprint).  v_mfma_f32_16x16x4_f32 is bitwise a k-ordered fmaf chain and exact zeros in the chain change nothing
+// (tools/unit/t_mfma_f32_chain.hip, run on the GPU), and the window's pixel order (row-major) visits a query's taps in the
+// order NW, NE, SW, SE of the per-lane form — so both forms give the SAME BITS, a group that does not fit (unsorted queries,
+// a jump of the Morton curve) simply takes the per-lane form for that level, and a query's result does not depend on its
+// group mates (tests/test_gpu_parity.py::test_shared_footprint_sampler_is_bit_identical; s3d_decode_set_shared_footprint(0)
+// forces the per-lane form).  With the staging arrays gone the kernel fits 256 registers: two workgroups per CU.
+struct Foot {            // bilinear footprint of one query in one level, factorised (grid_sample, align_corners=True)
+    int x0, y0;          // floor cell; >= 0 because the grid is clamped to [-1, 1]
+    float wx0, wx1, wy0, wy1;  // column / row factors of the tap weights (make_taps: w = wx * wy), 0 for out-of-bounds columns / rows
+                               // (scalars, not arrays: hipcc turns `g == dx ? wx[0] : g == dx + 1 ? wx[1] : 0` into an indexed scratch read)
+};
+__device__ __forceinline__ Foot make_foot(float gx, float gy, int W, int H) {
+#pragma clang fp contract(off)   // (see make_taps)
+    const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    const float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    Foot f;
+    f.x0 = (int)x0f; f.y0 = (int)y0f;
+    const int x1 = f.x0 + 1, y1 = f.y0 + 1;
+    const float xe = x0f + 1.f, ye = y0f + 1.f;
+    f.wx0 = (f.x0 >= 0 && f.x0 < W) ? xe - ix : 0.f;
+    f.wx1 = (x1 >= 0 && x1 < W) ? ix - x0f : 0.f;
+    f.wy0 = (f.y0 >= 0 && f.y0 < H) ? ye - iy : 0.f;
+    f.wy1 = (y1 >= 0 && y1 < H) ? iy - y0f : 0.f;
+    return f;
+}
+// min / max over the 16 lanes of a DPP row (the 16 queries of the group; every row of the wave holds the same 16)
+#define S3D_ROW16_REDUCE(v, OP)                                                                         \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));  /* quad_perm [1,0,3,2] */     \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));  /* quad_perm [2,3,0,1] */     \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false)); /* row_half_mirror */         \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false)); /* row_mirror */
+__device__ __forceinline__ int row16_min(int v) { S3D_ROW16_REDUCE(v, min) return v; }
+__device__ __forceinline__ int row16_max(int v) { S3D_ROW16_REDUCE(v, max) return v; }
+
+// a * w + c per element with ONE rounding, spelled out: the two forms of a task must not depend on hipcc's contraction choices
+__device__ __forceinline__ f32x4 fma4(const f32x4 a, float w, const f32x4 c) {
+    return __builtin_elementwise_fma(a, f32x4{w, w, w, w}, c);
+}
+// One slice-token task: the 16 queries of a group in one slice image -> acc (swapped-form accumulators: lane (m, g) holds
+// channels 16 j + 4 g .. + 3 of query m), starting from the fc_s bias.  WINDOW: the three folded levels through the group's
+// shared 4 x 4 pixel windows on the fp32 MFMA; else the per-lane form (same bits).  Two separate instantiations instead of a
+// per-level choice inside one body: with conditionally issued loads hipcc builds phi webs over the staging arrays and
+// spills 200 - 300 registers.
+template <bool F16, bool WINDOW>
+__device__ __forceinline__ void slice_token_task(const SampleArgs& a, const float* s_ws34, f32x4 (&acc)[8], long img, int S, float gx,
+                                                 float gy, const int (&bx)[3], const int (&by)[3], int tz, float* raw_row, int lane) {
+    // (every fused multiply-add below is an explicit fma4 / MFMA: nothing is left to hipcc's contraction choices)
+    const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = ld4(a.fcs_b + 16 * j + 4 * g + tz);
+    // levels 3,4 (raw 64 + 32 channels): per lane, requested under the folded levels' work.  F16: lane (m, g) owns channels
+    // 8g .. 8g+7 of every 32-channel block (two 16-byte loads); fp32 form: channels 4g .. 4g+3 of every 16-channel block
+    const Tap4 tpf = make_taps(gx, gy, S >> 1, S >> 1), tpq = make_taps(gx, gy, S, S);
+    f32x4 vf[2][4], v4[4][2], braw[6];
+    const char* bf = reinterpret_cast<const char*>(a.fine[0] + img * (long)(S >> 1) * (S >> 1) * 64);
+    const char* bq = reinterpret_cast<const char*>(a.fine[1] + img * (long)S * S * 32);
+    // staged so that at most 64 registers of raw taps are in flight: level 4 first, then level 3 in two tap pairs
+    auto issue_level4 = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                v4[kk][u] = *reinterpret_cast<const f32x4*>(bq + ((unsigned)(tpq.off[kk] * 32 + (F16 ? 8 : 4) * g) * 4u + 4u * (F16 ? 4 * u : 16 * u)));
+    };
+    auto issue_level3 = [&](int kp) {   // taps 2 kp, 2 kp + 1
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                vf[k2][u] = *reinterpret_cast<const f32x4*>(bf + ((unsigned)(tpf.off[2 * kp + k2] * 64 + (F16 ? 8 : 4) * g) * 4u + 4u * (F16 ? 32 * (u >> 1) + 4 * (u & 1) : 16 * u)));
+    };
+    auto blend_level4 = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            braw[4 + u] = fma4(v4[3][u], tpq.w[3], fma4(v4[2][u], tpq.w[2], fma4(v4[1][u], tpq.w[1], v4[0][u] * tpq.w[0])));
+    };
+    auto blend_level3 = [&](int kp) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (kp == 0) braw[u] = fma4(vf[1][u], tpf.w[1], vf[0][u] * tpf.w[0]);
+            else braw[u] = fma4(vf[1][u], tpf.w[3], fma4(vf[0][u], tpf.w[2], braw[u]));
+        }
+    };
+    if (WINDOW) {
+        // the sparse weight matrix first (B operands: query m's weight of window pixel 4 s + g = wx(g - dx) * wy(s - dy)), so that
+        // the footprints are dead before the loads go out
+        float wt[3][4];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const Foot f = make_foot(gx, gy, S >> (4 - l), S >> (4 - l));
+            const int dx = f.x0 - bx[l], dy = f.y0 - by[l];
+            const float wxq = g == dx ? f.wx0 : g == dx + 1 ? f.wx1 : 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wt[l][s] = wxq * (s == dy ? f.wy0 : s == dy + 1 ? f.wy1 : 0.f);
+        }
+        // window rows as MFMA A operands: lane (ch = m, k = g) loads pixel (by + s, bx + g), channel 16 j + ch; two windows in flight
+        float wa[2][4][8];
+        auto issue_window = [&](int l) {
+            const int W = S >> (4 - l);
+            const char* pl = reinterpret_cast<const char*>(a.proj[l] + img * (long)W * W * 128);   // scalar base + 32-bit lane offsets
+            const int cx = min(bx[l] + g, W - 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cy = min(by[l] + s, W - 1);
+                const unsigned off = (unsigned)((cy * W + cx) * 128 + m) * 4u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wa[l & 1][s][j] = *reinterpret_cast<const float*>(pl + (off + 64u * j));
+            }
+        };
+        auto consume_window = [&](int l) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[l & 1][s][j], wt[l][s], acc[j], 0, 0, 0);
+        };
+        issue_window(0);
+        issue_window(1);
+        issue_level4();
+        __builtin_amdgcn_sched_barrier(0);
+        consume_window(0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_window(2);
+        issue_level3(0);
+        __builtin_amdgcn_sched_barrier(0);
+        blend_level4();
+        consume_window(1);
+        __builtin_amdgcn_sched_barrier(0);
+        blend_level3(0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_level3(1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume_window(2);
+        __builtin_amdgcn_sched_barrier(0);
+        blend_level3(1);
+    } else {
+        // per-lane form: the lane's own four tap rows of each level, two taps (16 loads) per round (the taps in the order
+        // NW, NE, SW, SE: the order the window form's pixel list visits them in)
+        const Foot ft[3] = {make_foot(gx, gy, S >> 4, S >> 4), make_foot(gx, gy, S >> 3, S >> 3), make_foot(gx, gy, S >> 2, S >> 2)};
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const int W = S >> (4 - l);
+            const char* base = reinterpret_cast<const char*>(a.proj[l] + img * (long)W * W * 128);
+            const int cx0 = min(max(ft[l].x0, 0), W - 1), cx1 = min(max(ft[l].x0 + 1, 0), W - 1);
+            const int cy0 = min(max(ft[l].y0, 0), W - 1), cy1 = min(max(ft[l].y0 + 1, 0), W - 1);
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const int cy = kp ? cy1 : cy0;
+                const unsigned o0 = (unsigned)((cy * W + cx0) * 128 + 4 * g) * 4u, o1 = (unsigned)((cy * W + cx1) * 128 + 4 * g) * 4u;
+                f32x4 v0[8], v1[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v0[j] = *reinterpret_cast<const f32x4*>(base + (o0 + 64u * j));
+                    v1[j] = *reinterpret_cast<const f32x4*>(base + (o1 + 64u * j));
+                }
+                if (l == 0 && kp == 0) issue_level4();
+                if (l == 1 && kp == 0) { blend_level4(); issue_level3(0); }
+                if (l == 2 && kp == 0) { blend_level3(0); __builtin_amdgcn_sched_barrier(0); issue_level3(1); }
+                __builtin_amdgcn_sched_barrier(0);   // all requests out before the first use
+                const float wyk = kp ? ft[l].wy1 : ft[l].wy0;
+                const float w0 = ft[l].wx0 * wyk, w1 = ft[l].wx1 * wyk;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fma4(v0[j], w0, acc[j]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fma4(v1[j], w1, acc[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        blend_level3(1);
+    }
+    // raw samples of levels 3, 4 = the B operand of the K = 96 product with Ws34
+    if (F16) {
+        const _Float16* sw = reinterpret_cast<const _Float16*>(s_ws34) + tz;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {   // k-slot 8g + t of step kk <-> raw channel 32 kk + 8g + t
+            const float x8[8] = {braw[2 * kk][0], braw[2 * kk][1], braw[2 * kk][2], braw[2 * kk][3],
+                                 braw[2 * kk + 1][0], braw[2 * kk + 1][1], braw[2 * kk + 1][2], braw[2 * kk + 1][3]};
+            s3d_half8 bh, bl;
+            s3d_split8(x8, bh, bl);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const s3d_half8 fh = *reinterpret_cast<const s3d_half8*>(sw + (j * 3 + kk) * 1024 + lane * 8);
+                const s3d_half8 fl = *reinterpret_cast<const s3d_half8*>(sw + (j * 3 + kk) * 1024 + 512 + lane * 8);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bh, acc[j], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] = mfma4(ld4(s_ws34 + ((j * 6 + u) * 64 + lane) * 4 + tz), braw[u], acc[j]);
+    }
+    if (raw_row) {   // rows of 96 raw channels in channel order (braw[u]: see the loads above for the lane's channels)
+        float* ro = raw_row + (F16 ? 8 : 4) * g;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) st4(ro + (F16 ? 32 * (u >> 1) + 4 * (u & 1) : 16 * u), braw[u]);
+    }
+}
+
 template <bool F16>
-__global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) {
+__global__ __launch_bounds__(256, 2) void sample_tokens_kernel(const SampleArgs a) {
     __shared__ __attribute__((aligned(16))) float s_ws34[8 * 6 * 256];  // 48 KiB: fp32 [8][6] fragments or f16 hi|lo [8][3]
     // fc_p (128 x 3) transposed + its bias: [x | y | z | b][128].  Read from global per use it was 128 stride-3 scalar loads
     // per lane and made the point token the longest task of a group (34 000 cycles against 14 000 for a slice token): wave 0,
@@ -111,7 +323,7 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the image bases are SGPR pairs)
     const int m = lane & 15, g = lane >> 4;
     const int T = a.n_slices + 1;
     const int S = a.size;
@@ -122,6 +334,7 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
     const long bb = (nb % 8 == 0) ? (long)(blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : (long)blockIdx.x;
     const long chunk = (a.g_count + nb - 1) / nb;
     const long g_lo = bb * chunk, g_hi = g_lo + chunk < a.g_count ? g_lo + chunk : a.g_count;
+#pragma unroll 1
     for (long gi = g_lo; gi < g_hi; ++gi) {
         const long grp = a.g_begin + gi;
         const int b = (int)(grp / a.groups_per_batch);
@@ -151,110 +364,51 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const SampleArgs a) 
         float gx, gy;
         project(a.trans + b * 12, x, y, z, gx, gy);
 
+        // the group's pixel windows in the three folded levels (the same for every slice of the object): scalars.  The
+        // per-lane footprints themselves are recomputed inside every task (a few dozen VALU): kept live across the token loop
+        // together with everything derived from them they cost ~100 registers, i.e. the second wave per SIMD
+        int bx[3], by[3];
+        bool window = !a.lane_footprints;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const int W = S >> (4 - l);
+            const Foot f = make_foot(gx, gy, W, W);
+            const int mnx = row16_min(f.x0), mny = row16_min(f.y0);
+            const int ex = row16_max(f.x0) - mnx, ey = row16_max(f.y0) - mny;
+            // (every DPP row holds the same 16 queries: the values are wave-uniform; readfirstlane makes them scalars)
+            bx[l] = __builtin_amdgcn_readfirstlane(mnx);
+            by[l] = __builtin_amdgcn_readfirstlane(mny);
+            window = window && __builtin_amdgcn_readfirstlane((int)(ex <= 2 && ey <= 2 && mnx >= 0 && mny >= 0)) != 0;
+        }
+
+#pragma unroll 1
         for (int t = wave; t < T; t += 4) {
             f32x4 acc[8];
+            // an opaque zero added to the index of every loop-invariant operand read of a task (fc_p / Ws34 in LDS, the fc_s bias),
+            // and opaque per-task copies of the projected point: left visible, the optimiser hoists those reads and everything
+            // derived from the footprints out of the loops and keeps > 150 registers of constants live
+            int tz = 0;
+            float tgx = gx, tgy = gy;
+            asm volatile("" : "+v"(tz), "+v"(tgx), "+v"(tgy));
             if (t == 0) {  // fc_p (models.py:79)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int c = 16 * j + 4 * g;
+                    const int c = 16 * j + 4 * g + tz;
                     const f32x4 wx = ld4(s_fcp + c), wy = ld4(s_fcp + 128 + c), wz = ld4(s_fcp + 256 + c), wb = ld4(s_fcp + 384 + c);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[j][i] = wx[i] * x + wy[i] * y + wz[i] * z + wb[i];   // same expression order as before
                 }
             } else {
                 const long img = (long)b * a.n_slices + (t - 1);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = ld4(a.fcs_b + 16 * j + 4 * g);
-                // levels 0..2: projected maps (img, H, W, 128): six rounds (level, tap pair) of 16 loads each, round r + 1 requested
-                // before round r is consumed.  (Loads are issued in whole rounds into staging arrays: left to itself the
-                // scheduler keeps ONE 16-byte load in flight per wave — load, s_waitcnt vmcnt(0), fma, ... — 4x slower.)
-                Tap4 tp3[3];
-                const float* base3[3];
-#pragma unroll
-                for (int l = 0; l < 3; ++l) {
-                    const int W = S >> (4 - l);
-                    tp3[l] = make_taps(gx, gy, W, W);
-                    base3[l] = a.proj[l] + img * (long)W * W * 128 + 4 * g;
-                }
-                f32x4 v[2][2][8];
-                auto issue = [&](int r) {
-                    const int l = r >> 1, kp = r & 1;
-#pragma unroll
-                    for (int k2 = 0; k2 < 2; ++k2) {
-                        const float* p = base3[l] + (long)tp3[l].off[2 * kp + k2] * 128;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[r & 1][k2][j] = ld4(p + 16 * j);
-                    }
-                };
-                // levels 3,4 (raw 64 + 32 channels): requested before the last folded round is consumed
-                const Tap4 tpf = make_taps(gx, gy, S >> 1, S >> 1), tpq = make_taps(gx, gy, S, S);
-                f32x4 vf[4][4], v4[4][2];
-                issue(0);
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    if (r < 5) {
-                        issue(r + 1);
-                    } else {
-                        // F16: lane (m, g) owns channels 8g .. 8g+7 of every 32-channel block (two 16-byte loads); fp32 form:
-                        // channels 4g .. 4g+3 of every 16-channel block
-                        const float* bf = a.fine[0] + img * (long)(S >> 1) * (S >> 1) * 64 + (F16 ? 8 : 4) * g;
-                        const float* bq = a.fine[1] + img * (long)S * S * 32 + (F16 ? 8 : 4) * g;
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                vf[kk][u] = ld4(bf + (long)tpf.off[kk] * 64 + (F16 ? 32 * (u >> 1) + 4 * (u & 1) : 16 * u));
-#pragma unroll
-                            for (int u = 0; u < 2; ++u) v4[kk][u] = ld4(bq + (long)tpq.off[kk] * 32 + (F16 ? 4 * u : 16 * u));
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // the next round's loads are out before this round's first use
-                    const int l = r >> 1, kp = r & 1;
-#pragma unroll
-                    for (int k2 = 0; k2 < 2; ++k2) {
-                        const float w = tp3[l].w[2 * kp + k2];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[j] += v[r & 1][k2][j] * w;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // raw samples of levels 3, 4 -> B operand of the K = 96 product with Ws34
-                f32x4 braw[6];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    braw[u] = vf[0][u] * tpf.w[0] + vf[1][u] * tpf.w[1] + vf[2][u] * tpf.w[2] + vf[3][u] * tpf.w[3];
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    braw[4 + u] = v4[0][u] * tpq.w[0] + v4[1][u] * tpq.w[1] + v4[2][u] * tpq.w[2] + v4[3][u] * tpq.w[3];
-                if (F16) {
-                    const _Float16* sw = reinterpret_cast<const _Float16*>(s_ws34);
-#pragma unroll
-                    for (int kk = 0; kk < 3; ++kk) {   // k-slot 8g + t of step kk <-> raw channel 32 kk + 8g + t
-                        const float x8[8] = {braw[2 * kk][0], braw[2 * kk][1], braw[2 * kk][2], braw[2 * kk][3],
-                                             braw[2 * kk + 1][0], braw[2 * kk + 1][1], braw[2 * kk + 1][2], braw[2 * kk + 1][3]};
-                        s3d_half8 bh, bl;
-                        s3d_split8(x8, bh, bl);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const s3d_half8 fh = *reinterpret_cast<const s3d_half8*>(sw + (j * 3 + kk) * 1024 + lane * 8);
-                            const s3d_half8 fl = *reinterpret_cast<const s3d_half8*>(sw + (j * 3 + kk) * 1024 + 512 + lane * 8);
-                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bl, acc[j], 0, 0, 0);
-                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, bh, acc[j], 0, 0, 0);
-                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bh, acc[j], 0, 0, 0);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 6; ++u)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            acc[j] = mfma4(ld4(s_ws34 + ((j * 6 + u) * 64 + lane) * 4), braw[u], acc[j]);
-                }
-                if (a.raw_out) {   // rows of 96 raw channels in channel order (braw[u]: see the load above for the lane's channels)
-                    float* ro = a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 96 + (F16 ? 8 : 4) * g;
-#pragma unroll
-                    for (int u = 0; u < 6; ++u) st4(ro + (F16 ? 32 * (u >> 1) + 4 * (u & 1) : 16 * u), braw[u]);
-                }
+                float* raw_row = a.raw_out ? a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 96 : nullptr;
+                // (opaque per-task copies of the window origins too: visible, the window loads' lane offsets are formed outside the
+                // token loop as 64-bit values, spilled, and every reload's s_waitcnt vmcnt(0) serialises the loads behind it)
+                int tbx[3] = {bx[0], bx[1], bx[2]}, tby[3] = {by[0], by[1], by[2]};
+                asm volatile("" : "+s"(tbx[0]), "+s"(tbx[1]), "+s"(tbx[2]), "+s"(tby[0]), "+s"(tby[1]), "+s"(tby[2]));
+                if (window)
+                    slice_token_task<F16, true>(a, s_ws34, acc, img, S, tgx, tgy, tbx, tby, tz, raw_row, lane);
+                else
+                    slice_token_task<F16, false>(a, s_ws34, acc, img, S, tgx, tgy, tbx, tby, tz, raw_row, lane);
             }
             // full 128-byte lines per query row (s3d_full_line_pair, common.h): tiles 2J, 2J + 1 of query m are exchanged
             // with lane m ^ 8; one instruction then writes queries 0-7, the next queries 8-15
@@ -279,9 +433,9 @@ static int sampler_cu_count() { return s3d_cu_count(); }   // one workgroup per 
 int launch_sample_tokens(const SampleArgs& a, hipStream_t stream) {
     S3D_CHECK_ARG(a.size % 16 == 0 && a.size >= 16, "sample: size %d", a.size);
     S3D_CHECK_ARG(a.n_slices >= 1 && a.n_slices + 1 <= S3D_N_TOKENS_MAX, "sample: n_slices %d", a.n_slices);
-    // one workgroup per CU (the kernel's registers allow no second one): with 2048 workgroups of 3 - 7 groups each the 48 KiB
-    // weight fill, the cold tap rows and the last, partly filled round cost 22 % (0.80 -> 0.62 ms per 100 k queries)
-    const long cap = sampler_cu_count();
+    // two persistent workgroups per CU (256 registers since round 6; with 2048 workgroups of 3 - 7 groups each the 48 KiB
+    // weight fill, the cold tap rows and the last, partly filled round cost 22 %: 0.80 -> 0.62 ms per 100 k queries, round 4)
+    const long cap = 2L * sampler_cu_count();
     long blocks = a.g_count < cap ? a.g_count : cap;
     if (blocks <= 0) return 0;
     if (blocks >= 8) blocks -= blocks % 8;

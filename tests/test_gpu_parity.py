@@ -340,6 +340,39 @@ def test_fused_last_layer_is_bit_identical(prec):
         lib.s3d_decode_set_last_fused(1)
 
 
+@pytest.mark.parametrize("prec", PRECS)
+def test_shared_footprint_sampler_is_bit_identical(prec):
+    """Round 6: the token builder evaluates the three folded pyramid levels of a group of 16 queries through the group's
+    shared 4 x 4 pixel window on the fp32 MFMA when the group's footprints fit one, per lane otherwise (csrc/decode.hip).
+    The MFMA is a k-ordered fmaf chain, exact zeros in it change nothing and the window visits a query's taps in the
+    per-lane order: both forms must give the same bits — on sorted queries (windows nearly always), on unsorted ones
+    (< 4096 per object: mixed), on the dense grid, on ragged counts and few slices."""
+    from slice3d_amd import _lib
+    from slice3d_amd.synth import make_feed_dict
+    lib = _lib.load()
+    try:
+        for ns, b, s, q in ((12, 1, 64, 16), (12, 2, 64, 3000), (12, 1, 256, 100000), (5, 2, 128, 4097), (3, 1, 64, 1),
+                            (12, 2, 128, 20000)):
+            model = get_model(ns, "test", prec)
+            fd = to_gpu(make_feed_dict(b, s, q, ns, seed=57 + ns, with_slices=False))
+            code = model.encode(fd)
+            assert lib.s3d_decode_set_shared_footprint(0) == 0
+            lanes = model.decode_sdf(fd["qry_norot"], code).clone()
+            assert lib.s3d_decode_set_shared_footprint(1) == 0
+            for _ in range(2):
+                assert torch.equal(model.decode_sdf(fd["qry_norot"], code), lanes), (ns, b, s, q)
+        model = get_model(12, "test", prec)
+        fd = to_gpu(make_feed_dict(1, 64, 16, 12, seed=5, with_slices=False))
+        code = model.encode(fd)
+        assert lib.s3d_decode_set_shared_footprint(0) == 0
+        lanes = model.decode_grid(code, 40).clone()
+        assert lib.s3d_decode_set_shared_footprint(1) == 0
+        assert torch.equal(model.decode_grid(code, 40), lanes)
+        assert lib.s3d_decode_set_shared_footprint(2) != 0
+    finally:
+        lib.s3d_decode_set_shared_footprint(1)
+
+
 def test_two_decode_lanes_and_smaller_passes_give_the_same_bits():
     """The pass of >= 131 072 queries is decoded as two halves whose layer chains run on the caller's stream and on the
     library's side stream (s3d_decode_set_lanes, api.hip): same bits as everything on one stream, and as a decode whose
