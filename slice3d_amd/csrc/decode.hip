@@ -12,6 +12,7 @@
 // the 4-channel groups {16j + 4g .. +3}.  The same registers serve as B operand of the next GEMM, as
 // residual input and as the layout of the LayerNorm reductions (4 lanes per row -> 2 shuffles).
 #include "decode.h"
+#include "attn_last.h"
 
 #define LN_EPS 1e-5f
 
@@ -787,17 +788,9 @@ int launch_ffn_layer_train(const float* Xin, float* Yout, float* Uout, long rows
 // (104 floats per lane) for both passes (scores, then the probability-weighted sum); per head the 16-lane dot
 // products are all-reduced with four DPP steps (quad xor 1, quad xor 2, half mirror, row mirror).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float row16_allsum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
-    return v;
-}
 __global__ __launch_bounds__(256) void attn_last_mix_kernel(const float* __restrict__ X, const float* __restrict__ qt,
                                                             float* __restrict__ xbar, long groups, int T) {
     const int mq = threadIdx.x >> 4, c0 = (threadIdx.x & 15) * 8;   // query of the group, first channel of the lane
-    const float scale = 0.17677669529663687f;                       // 1/sqrt(32)
     for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const float* xg = X + (grp * T * S3D_GROUP + mq) * 128 + c0;
         f32x4 xa[S3D_N_TOKENS_MAX], xb[S3D_N_TOKENS_MAX];
@@ -811,30 +804,8 @@ __global__ __launch_bounds__(256) void attn_last_mix_kernel(const float* __restr
 #pragma unroll 1
         for (int h = 0; h < 4; ++h) {
             const f32x4 qa = ld4(qt + row * 512 + h * 128 + c0), qb = ld4(qt + row * 512 + h * 128 + c0 + 4);
-            float sc[S3D_N_TOKENS_MAX];
-            float mx = -1e30f;
-#pragma unroll
-            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
-                float d = qa[0] * xa[t][0] + qa[1] * xa[t][1] + qa[2] * xa[t][2] + qa[3] * xa[t][3] +
-                          qb[0] * xb[t][0] + qb[1] * xb[t][1] + qb[2] * xb[t][2] + qb[3] * xb[t][3];
-                d = row16_allsum(d) * scale;
-                sc[t] = t < T ? d : -1e30f;
-                mx = fmaxf(mx, sc[t]);
-            }
-            float den = 0.f;
-#pragma unroll
-            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
-                sc[t] = t < T ? expf(sc[t] - mx) : 0.f;
-                den += sc[t];
-            }
-            const float inv = 1.f / den;
-            f32x4 oa = zero4(), ob = zero4();
-#pragma unroll
-            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
-                const float pt = sc[t] * inv;
-                oa += xa[t] * pt;
-                ob += xb[t] * pt;
-            }
+            f32x4 oa, ob;
+            al_mix_head(xa, xb, qa, qb, T, oa, ob);   // attn_last.h: shared with the fused kernel (decode_last.hip)
             st4(xbar + row * 512 + h * 128 + c0, oa);
             st4(xbar + row * 512 + h * 128 + c0 + 4, ob);
         }

@@ -25,18 +25,11 @@
 // from L2 once per NG groups: 512 KB per 32 queries = 6.4 GB per 400 k queries at L2 bandwidth beside the 2.66 GB of rows
 // from HBM.
 #include "decode.h"
+#include "attn_last.h"
 
 typedef _Float16 lhalf8 __attribute__((ext_vector_type(8)));
 
 #define AL_QS (2048 + 16)   // bytes per query region
-
-__device__ __forceinline__ float al_row16_allsum(float v) {   // = row16_allsum of decode.hip
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
-    return v;
-}
 
 template <bool SINGLE, int NG>
 __global__ __launch_bounds__(256, 2) void attn_last_fused_kernel(const float* __restrict__ X, float* __restrict__ U,
@@ -48,7 +41,6 @@ __global__ __launch_bounds__(256, 2) void attn_last_fused_kernel(const float* __
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, g = lane >> 4;
     const int mq = threadIdx.x >> 4, s16 = threadIdx.x & 15, c0 = s16 * 8;   // phase 2: query of the group, channel octet
-    const float scale = 0.17677669529663687f;                                // 1/sqrt(32)
     const long n_it = (groups + NG - 1) / NG;
 #pragma unroll 1
     for (long it = blockIdx.x; it < n_it; it += gridDim.x) {
@@ -142,30 +134,8 @@ __global__ __launch_bounds__(256, 2) void attn_last_fused_kernel(const float* __
             for (int h = 0; h < 4; ++h) {
                 const f32x4 qa = *reinterpret_cast<const f32x4*>(qreg + (h * 128 + c0) * 4);
                 const f32x4 qb = *reinterpret_cast<const f32x4*>(qreg + (h * 128 + c0 + 4) * 4);
-                float sc[S3D_N_TOKENS_MAX];
-                float mx = -1e30f;
-#pragma unroll
-                for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
-                    float d = qa[0] * xa[t][0] + qa[1] * xa[t][1] + qa[2] * xa[t][2] + qa[3] * xa[t][3] +
-                              qb[0] * xb[t][0] + qb[1] * xb[t][1] + qb[2] * xb[t][2] + qb[3] * xb[t][3];
-                    d = al_row16_allsum(d) * scale;
-                    sc[t] = t < T ? d : -1e30f;
-                    mx = fmaxf(mx, sc[t]);
-                }
-                float den = 0.f;
-#pragma unroll
-                for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
-                    sc[t] = t < T ? expf(sc[t] - mx) : 0.f;
-                    den += sc[t];
-                }
-                const float inv = 1.f / den;
-                f32x4 oa = zero4(), ob = zero4();
-#pragma unroll
-                for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
-                    const float pt = sc[t] * inv;
-                    oa += xa[t] * pt;
-                    ob += xb[t] * pt;
-                }
+                f32x4 oa, ob;
+                al_mix_head(xa, xb, qa, qb, T, oa, ob);   // attn_last.h: the arithmetic of attn_last_mix_kernel, instruction for instruction
                 // xbar_h channels c0 .. c0 + 7 = the B fragment of lane (m = mq, g = s16 & 3) of k-step 4 h + (s16 >> 2)
                 const float x[8] = {oa[0], oa[1], oa[2], oa[3], ob[0], ob[1], ob[2], ob[3]};
                 s3d_half8 hh, ll;
