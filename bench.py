@@ -457,6 +457,20 @@ def main():
         # BASELINE configs[3]; N ranks: one slab of the grid's linear index per rank + all_gather of the logits (strong scaling)
         c4 = {"res": args.c4_res, "seconds_device": t_dev, "seconds_incl_d2h": t_host, "query_points_per_s": n_grid / t_dev,
               "query_points_per_s_incl_d2h": n_grid / t_host, "n_gpus": world, "scaling": "strong"}
+        if world > 1:   # the exchange step of the split alone: the all_gather of the slabs' logits (what the N-rank time pays beside 1/N of the decode)
+            from slice3d_amd.parallel import gather_slabs, shard_range
+            lo, hi = shard_range(n_grid, rank, world)
+            slab = torch.zeros(hi - lo, dtype=torch.float32, device="cuda")
+            gather_slabs(slab, n_grid)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                gather_slabs(slab, n_grid)
+            barrier()
+            t = torch.tensor([(time.perf_counter() - t1) / 5 * 1e3], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c4["c4_all_gather_ms"] = float(t.item())
+            del slab
         del grid, host
 
     # ---- reconstruct.py at its default options (mc_res0 64, two upsampling steps): MISE refinement on the
@@ -581,7 +595,7 @@ def main():
         del gtr, gm, gfd
 
     # ---- secondary metric: training samples/s (train.py:41-53 train_step, B = 1 object per GPU) ----
-    train_ms = None
+    train_ms = train_ms_local = None
     if args.train_steps > 0:
         from slice3d_amd.trainer import HipTrainer
         tmodel = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="train")
@@ -602,6 +616,22 @@ def main():
             tdt = float(t.item())
         train_ms = tdt / args.train_steps * 1e3
         del trainer, tmodel
+        if world > 1:   # the same step with the exchange switched off (process_group=False: a lone replica per rank): what the
+                        # bucketed gradient all-reduce leaves exposed beside the backward it overlaps with
+            tmodel = Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="train")
+            load_seeded(tmodel, 0)
+            tmodel.cuda()
+            trainer = HipTrainer(tmodel, dropout=0.1, seed=rank, prec=args.prec, process_group=False)
+            trainer.train_step(tfd)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.train_steps):
+                trainer.train_step(tfd)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t1], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            train_ms_local = float(t.item()) / args.train_steps * 1e3
+            del trainer, tmodel
 
     if rank == 0:
         q_total = args.n_qry * args.batch * world * args.steps
@@ -686,6 +716,9 @@ def main():
         res["gt_train_step"] = gt_train
         res["train_ms_per_step"] = train_ms
         res["train_samples_per_s"] = (world * args.batch / (train_ms * 1e-3)) if train_ms else None
+        if train_ms_local is not None:   # N > 1 only (tools/scaling_table.py reads these)
+            res["train_ms_per_step_no_exchange"] = train_ms_local
+            res["train_allreduce_ms_exposed"] = train_ms - train_ms_local
         exact = ("value", "ms_per_step", "roofline")      # contract numbers stay unrounded (value == queries / time exactly)
         res = {k: (v if k in exact else _r(v)) for k, v in res.items()}
         res["roofline"] = {k: (v if k in ("achieved", "peak", "frac") else _r(v)) for k, v in res["roofline"].items()}
