@@ -218,10 +218,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvLaunc
                 for (int mt = 0; mt < MT; ++mt) b[mt] = ok[mt] ? ld4(bp[mt] + 16 * c) : zero4();
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) w[nt] = ld4(wp + ((size_t)nt * a.KU + c) * 256);
+                // Every 16-deep K chunk is summed on its own (a 16-term fmaf chain from zero) and then added: the accumulation over K is
+                // K / 16 additions of short partial sums instead of ONE fp32 chain of up to 4 608 terms.  Round 6 (profiles/
+                // r06_f32_chains.md): with the single chain the weight gradients of the encoder's convolutions — sums with heavy
+                // cancellation behind train-mode BatchNorm — sat 7e-3 .. 1e-2 from the fp64 oracle in this "exact" mode (the
+                // split-precision mode, whose 32-deep f16 MFMA rounds once per 32 products, and ATen's blocked CPU kernels: 2.5e-3);
+                // with the chunked sum: 2.3e-3.  MT x NT packed adds per 4 MFMAs of 32 cycles: free.
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma4(w[nt], b[mt], acc[mt][nt]);
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += mfma4(w[nt], b[mt], zero4());
             }
         }
         ubase += KS * KS * cu;

@@ -30,6 +30,12 @@
 typedef _Float16 lhalf8 __attribute__((ext_vector_type(8)));
 
 #define AL_QS (2048 + 16)   // bytes per query region
+#ifndef AL_D1
+#define AL_D1 8       // depth (k-steps) of phase 1's weight-fragment ring
+#endif
+#ifndef AL_D3
+#define AL_D3 4       // depth (k-steps, two output tiles each) of phase 3's ring
+#endif
 
 template <bool SINGLE, int NG>
 __global__ __launch_bounds__(256, 2) void attn_last_fused_kernel(const float* __restrict__ X, float* __restrict__ U,
@@ -42,123 +48,139 @@ __global__ __launch_bounds__(256, 2) void attn_last_fused_kernel(const float* __
     const int m = lane & 15, g = lane >> 4;
     const int mq = threadIdx.x >> 4, s16 = threadIdx.x & 15, c0 = s16 * 8;   // phase 2: query of the group, channel octet
     const long n_it = (groups + NG - 1) / NG;
-#pragma unroll 1
-    for (long it = blockIdx.x; it < n_it; it += gridDim.x) {
-        // ---------------- phase 1: qt = M x0 + m for the NG x 16 queries; this wave: head `wave` ----------------
-        {
-            lhalf8 xh[NG][4], xl[NG][4];
-            {
-                f32x4 v0[NG][4], v1[NG][4];
+    // Load schedule.  SQ counters say what bounds this kernel: 37 - 53 % of its wave cycles sit in s_waitcnt, the VALU is 22 % and the
+    // matrix pipe 15 % busy — and halving the mixing step's VALU count, requesting round 0's rows before phase 1, deepening the
+    // weight-fragment rings from 1 to 12 k-steps each left its time at 0.88 ms per 400 k queries (profiles/r06_last_layer.md).  vmcnt
+    // retires in order: a wave that has row loads (HBM, ~2 us under load) in flight and then waits for a weight fragment (L2) requested
+    // after them waits for the rows as well, so inside ONE wave the three load streams — x0 tile, rows, weight fragments — cannot hide
+    // each other; only the CU's other workgroup does (two per CU: the 104 registers of a round's rows and 66 KB of LDS allow no third).
+    // Kept from those experiments because they cost nothing: the x0 tile of iteration i + 1 is requested at the top of phase 3 of
+    // iteration i, and the weight fragments run through register rings of AL_D1 / AL_D3 k-steps.
+    static_assert(NG == 2, "the load schedule below is written for two groups per iteration");
+    f32x4 v0[NG][4], v1[NG][4];   // raw x0 tile of the current iteration (lane (m, g): channels 32 u + 8 g .. + 7 of query m)
+    auto load_x0 = [&](long it_) {
 #pragma unroll
-                for (int ng = 0; ng < NG; ++ng) {
-                    long grp = it * NG + ng;
-                    if (grp >= groups) grp = groups - 1;
-                    const float* row = X + (grp * T * S3D_GROUP + m) * 128 + 8 * g;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        v0[ng][u] = ld4(row + 32 * u);
-                        v1[ng][u] = ld4(row + 32 * u + 4);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float x[8] = {v0[ng][u][0], v0[ng][u][1], v0[ng][u][2], v0[ng][u][3],
-                                            v1[ng][u][0], v1[ng][u][1], v1[ng][u][2], v1[ng][u][3]};
-                        s3d_half8 h, l;
-                        s3d_split8(x, h, l);
-                        xh[ng][u] = __builtin_bit_cast(lhalf8, h);
-                        xl[ng][u] = __builtin_bit_cast(lhalf8, l);
-                    }
-            }
-            S3D_SPLIT_SETTLE();
-            const _Float16* wp = wm16 + (size_t)(8 * wave) * 4 * 1024 + lane * 8;
-            lhalf8 wh[2][4], wl[2][4];   // [buffer][k-step]: the next output tile's fragments are requested under this one's MFMAs
+        for (int ng = 0; ng < NG; ++ng) {
+            long grp = it_ * NG + ng;
+            if (grp >= groups) grp = groups - 1;
+            const float* row = X + (grp * T * S3D_GROUP + m) * 128 + 8 * g;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                wh[0][u] = *reinterpret_cast<const lhalf8*>(wp + u * 1024);
-                if (!SINGLE) wl[0][u] = *reinterpret_cast<const lhalf8*>(wp + u * 1024 + 512);
+                v0[ng][u] = ld4(row + 32 * u);
+                v1[ng][u] = ld4(row + 32 * u + 4);
             }
-#pragma unroll 2
-            for (int j = 0; j < 8; ++j) {
+        }
+    };
+    auto load_rows = [&](long grp, f32x4 (&xa)[S3D_N_TOKENS_MAX], f32x4 (&xb)[S3D_N_TOKENS_MAX]) {
+        if (grp >= groups) grp = groups - 1;
+        const float* xg = X + (grp * T * S3D_GROUP + mq) * 128 + c0;
+#pragma unroll
+        for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
+            const int tc = t < T ? t : T - 1;
+            xa[t] = ld4(xg + (long)tc * S3D_GROUP * 128);
+            xb[t] = ld4(xg + (long)tc * S3D_GROUP * 128 + 4);
+        }
+    };
+    // the 13-row mixing step of one group: this wave's queries 4 wave .. + 3; xbar_h over qt_h in the B-fragment order of phase 3
+    auto mix_round = [&](int r, const f32x4 (&xa)[S3D_N_TOKENS_MAX], const f32x4 (&xb)[S3D_N_TOKENS_MAX]) {
+        unsigned char* qreg = s_q + (r * 16 + mq) * AL_QS;
+#pragma unroll 1
+        for (int h = 0; h < 4; ++h) {
+            const f32x4 qa = *reinterpret_cast<const f32x4*>(qreg + (h * 128 + c0) * 4);
+            const f32x4 qb = *reinterpret_cast<const f32x4*>(qreg + (h * 128 + c0 + 4) * 4);
+            f32x4 oa, ob;
+            al_mix_head(xa, xb, qa, qb, T, oa, ob);   // attn_last.h: the arithmetic of attn_last_mix_kernel, instruction for instruction
+            // xbar_h channels c0 .. c0 + 7 = the B fragment of lane (m = mq, g = s16 & 3) of k-step 4 h + (s16 >> 2)
+            const float x[8] = {oa[0], oa[1], oa[2], oa[3], ob[0], ob[1], ob[2], ob[3]};
+            s3d_half8 hh, ll;
+            s3d_split8(x, hh, ll);
+            unsigned char* d = qreg + (4 * h + (s16 >> 2)) * 128 + (s16 & 3) * 16;
+            *reinterpret_cast<s3d_half8*>(d) = hh;
+            if (!SINGLE) *reinterpret_cast<s3d_half8*>(d + 64) = ll;
+        }
+    };
+    if ((long)blockIdx.x < n_it) load_x0(blockIdx.x);
+#pragma unroll 1
+    for (long it = blockIdx.x; it < n_it; it += gridDim.x) {
+        // the x0 tile (requested an iteration ago) becomes f16 hi | lo B fragments
+        lhalf8 xh[NG][4], xl[NG][4];
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x[8] = {v0[ng][u][0], v0[ng][u][1], v0[ng][u][2], v0[ng][u][3],
+                                    v1[ng][u][0], v1[ng][u][1], v1[ng][u][2], v1[ng][u][3]};
+                s3d_half8 h, l;
+                s3d_split8(x, h, l);
+                xh[ng][u] = __builtin_bit_cast(lhalf8, h);
+                xl[ng][u] = __builtin_bit_cast(lhalf8, l);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- phase 1: qt = M x0 + m for the NG x 16 queries; this wave: head `wave` ----------------
+        {
+            S3D_SPLIT_SETTLE();
+            // scalar base + one 32-bit lane offset (global_load v, v_off, s[base]): with per-step 64-bit lane addresses hipcc forms all 32
+            // of them outside the iteration loop, spills them, and every reload's s_waitcnt vmcnt(0) waits for the prefetched rows
+            const char* wp = reinterpret_cast<const char*>(wm16 + (size_t)(8 * wave) * 4 * 1024);
+            unsigned loff = (unsigned)lane * 16u;
+            asm volatile("" : "+v"(loff));   // (opaque per iteration: the per-step offsets below are not loop invariants to be hoisted and spilled)
+            // Weight fragments through a register ring D1 k-steps deep (32 steps: 8 output tiles x 4 k-steps; hi | lo of a step = 8
+            // registers).  A step is 6 MFMAs (~100 cycles) and a fragment comes from L2 (600+ cycles under load).
+            constexpr int D1 = AL_D1;
+            lhalf8 wh[D1], wl[D1];
+#pragma unroll
+            for (int st = 0; st < D1; ++st) {
+                wh[st] = *reinterpret_cast<const lhalf8*>(wp + (loff + (unsigned)st * 2048u));
+                if (!SINGLE) wl[st] = *reinterpret_cast<const lhalf8*>(wp + (loff + (unsigned)st * 2048u + 1024u));
+            }
+            f32x4 acc[NG];
+#pragma unroll
+            for (int st = 0; st < 32; ++st) {
+                const int j = st >> 2, u = st & 3, sl = st % D1;
                 __builtin_amdgcn_sched_barrier(0);
-                if (j + 1 < 8) {
+                if (u == 0) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        wh[(j + 1) & 1][u] = *reinterpret_cast<const lhalf8*>(wp + ((j + 1) * 4 + u) * 1024);
-                        if (!SINGLE) wl[(j + 1) & 1][u] = *reinterpret_cast<const lhalf8*>(wp + ((j + 1) * 4 + u) * 1024 + 512);
-                    }
+                    for (int ng = 0; ng < NG; ++ng) acc[ng] = zero4();
                 }
-                const int co = (8 * wave + j) * 16 + 4 * g;
-                const f32x4 sh = ld4(bm + co);
-                f32x4 acc[NG];
-#pragma unroll
-                for (int ng = 0; ng < NG; ++ng) acc[ng] = zero4();
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (!SINGLE) {
-#pragma unroll
-                        for (int ng = 0; ng < NG; ++ng)
-                            acc[ng] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j & 1][u], xl[ng][u], acc[ng], 0, 0, 0);
-#pragma unroll
-                        for (int ng = 0; ng < NG; ++ng)
-                            acc[ng] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j & 1][u], xh[ng][u], acc[ng], 0, 0, 0);
-                    }
+                if (!SINGLE) {
 #pragma unroll
                     for (int ng = 0; ng < NG; ++ng)
-                        acc[ng] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j & 1][u], xh[ng][u], acc[ng], 0, 0, 0);
+                        acc[ng] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[sl], xl[ng][u], acc[ng], 0, 0, 0);
+#pragma unroll
+                    for (int ng = 0; ng < NG; ++ng)
+                        acc[ng] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[sl], xh[ng][u], acc[ng], 0, 0, 0);
                 }
 #pragma unroll
                 for (int ng = 0; ng < NG; ++ng)
-                    *reinterpret_cast<f32x4*>(s_q + (ng * 16 + m) * AL_QS + co * 4) = acc[ng] + sh;
+                    acc[ng] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[sl], xh[ng][u], acc[ng], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + D1 < 32) {   // the slot is free: step st + D1
+                    wh[sl] = *reinterpret_cast<const lhalf8*>(wp + (loff + (unsigned)(st + D1) * 2048u));
+                    if (!SINGLE) wl[sl] = *reinterpret_cast<const lhalf8*>(wp + (loff + (unsigned)(st + D1) * 2048u + 1024u));
+                }
+                if (u == 3) {
+                    const int co = (8 * wave + j) * 16 + 4 * g;
+                    const f32x4 sh = ld4(bm + co);
+#pragma unroll
+                    for (int ng = 0; ng < NG; ++ng)
+                        *reinterpret_cast<f32x4*>(s_q + (ng * 16 + m) * AL_QS + co * 4) = acc[ng] + sh;
+                }
             }
         }
         __syncthreads();
-        // ---------------- phase 2: the 13-row mixing step, round = group, this wave: queries 4 wave .. + 3 ----------------
-#pragma unroll 1
-        for (int r = 0; r < NG; ++r) {
-            long grp = it * NG + r;
-            if (grp >= groups) grp = groups - 1;
-            const float* xg = X + (grp * T * S3D_GROUP + mq) * 128 + c0;
-            f32x4 xa[S3D_N_TOKENS_MAX], xb[S3D_N_TOKENS_MAX];
-#pragma unroll
-            for (int t = 0; t < S3D_N_TOKENS_MAX; ++t) {
-                const int tc = t < T ? t : T - 1;
-                xa[t] = ld4(xg + (long)tc * S3D_GROUP * 128);
-                xb[t] = ld4(xg + (long)tc * S3D_GROUP * 128 + 4);
-            }
-            unsigned char* qreg = s_q + (r * 16 + mq) * AL_QS;
-#pragma unroll 1
-            for (int h = 0; h < 4; ++h) {
-                const f32x4 qa = *reinterpret_cast<const f32x4*>(qreg + (h * 128 + c0) * 4);
-                const f32x4 qb = *reinterpret_cast<const f32x4*>(qreg + (h * 128 + c0 + 4) * 4);
-                f32x4 oa, ob;
-                al_mix_head(xa, xb, qa, qb, T, oa, ob);   // attn_last.h: the arithmetic of attn_last_mix_kernel, instruction for instruction
-                // xbar_h channels c0 .. c0 + 7 = the B fragment of lane (m = mq, g = s16 & 3) of k-step 4 h + (s16 >> 2)
-                const float x[8] = {oa[0], oa[1], oa[2], oa[3], ob[0], ob[1], ob[2], ob[3]};
-                s3d_half8 hh, ll;
-                s3d_split8(x, hh, ll);
-                unsigned char* d = qreg + (4 * h + (s16 >> 2)) * 128 + (s16 & 3) * 16;
-                *reinterpret_cast<s3d_half8*>(d) = hh;
-                if (!SINGLE) *reinterpret_cast<s3d_half8*>(d + 64) = ll;
-            }
-        }
+        // ---------------- phase 2: the 13-row mixing step, round = group ----------------
+        f32x4 xa[S3D_N_TOKENS_MAX], xb[S3D_N_TOKENS_MAX];
+        load_rows(it * NG, xa, xb);
+        mix_round(0, xa, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(it * NG + 1, xa, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        mix_round(1, xa, xb);
         __syncthreads();
         // ---------------- phase 3: u = N xbar + n + x0; this wave: output channels 32 wave .. + 31 ----------------
         {
-            f32x4 acc[NG][2];
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng) acc[ng][0] = acc[ng][1] = zero4();
-            const _Float16* wp = wn16 + (size_t)(2 * wave) * 16 * 1024 + lane * 8;
-            lhalf8 wh[2][2], wl[2][2];   // [buffer][nt]
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                wh[0][nt] = *reinterpret_cast<const lhalf8*>(wp + (size_t)nt * 16 * 1024);
-                if (!SINGLE) wl[0][nt] = *reinterpret_cast<const lhalf8*>(wp + (size_t)nt * 16 * 1024 + 512);
-            }
-            // residual rows and bias of this wave's 32 output channels (the x0 tile again: L1 / L2)
+            // residual rows of this iteration's outputs = the x0 tile once more (L1 / L2), BEFORE the next iteration's tile replaces v0 / v1
             f32x4 res[NG][2], sh[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) sh[nt] = ld4(bn + (2 * wave + nt) * 16 + 4 * g);
@@ -170,17 +192,30 @@ __global__ __launch_bounds__(256, 2) void attn_last_fused_kernel(const float* __
                 for (int nt = 0; nt < 2; ++nt)
                     res[ng][nt] = ld4(X + (grp * T * S3D_GROUP + m) * 128 + (2 * wave + nt) * 16 + 4 * g);
             }
-#pragma unroll 2
-            for (int u = 0; u < 16; ++u) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (u + 1 < 16) {
+            // the next iteration's x0 tile: in flight under this phase's MFMAs (unconditional — the last iteration re-reads its own tile: a
+            // conditional load keeps the OLD tile's 64 registers live through all three phases)
+            load_x0(it + gridDim.x < n_it ? it + gridDim.x : it);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[NG][2];
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const _Float16* f = wp + ((size_t)nt * 16 + u + 1) * 1024;
-                        wh[(u + 1) & 1][nt] = *reinterpret_cast<const lhalf8*>(f);
-                        if (!SINGLE) wl[(u + 1) & 1][nt] = *reinterpret_cast<const lhalf8*>(f + 512);
-                    }
+            for (int ng = 0; ng < NG; ++ng) acc[ng][0] = acc[ng][1] = zero4();
+            const char* wp = reinterpret_cast<const char*>(wn16 + (size_t)(2 * wave) * 16 * 1024);   // (scalar base + lane offset: see phase 1)
+            unsigned loff = (unsigned)lane * 16u;
+            asm volatile("" : "+v"(loff));
+            constexpr int D3 = AL_D3;
+            lhalf8 wh[D3][2], wl[D3][2];   // [ring slot][nt]: see phase 1
+#pragma unroll
+            for (int u = 0; u < D3; ++u)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const unsigned fo = loff + (unsigned)(nt * 16 + u) * 2048u;
+                    wh[u][nt] = *reinterpret_cast<const lhalf8*>(wp + fo);
+                    if (!SINGLE) wl[u][nt] = *reinterpret_cast<const lhalf8*>(wp + (fo + 1024u));
                 }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int sl = u % D3;
+                __builtin_amdgcn_sched_barrier(0);
                 lhalf8 bh[NG], bl[NG];
 #pragma unroll
                 for (int ng = 0; ng < NG; ++ng) {
@@ -193,14 +228,23 @@ __global__ __launch_bounds__(256, 2) void attn_last_fused_kernel(const float* __
                     if (!SINGLE) {
 #pragma unroll
                         for (int ng = 0; ng < NG; ++ng)
-                            acc[ng][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1][nt], bl[ng], acc[ng][nt], 0, 0, 0);
+                            acc[ng][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[sl][nt], bl[ng], acc[ng][nt], 0, 0, 0);
 #pragma unroll
                         for (int ng = 0; ng < NG; ++ng)
-                            acc[ng][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u & 1][nt], bh[ng], acc[ng][nt], 0, 0, 0);
+                            acc[ng][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[sl][nt], bh[ng], acc[ng][nt], 0, 0, 0);
                     }
 #pragma unroll
                     for (int ng = 0; ng < NG; ++ng)
-                        acc[ng][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1][nt], bh[ng], acc[ng][nt], 0, 0, 0);
+                        acc[ng][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[sl][nt], bh[ng], acc[ng][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + D3 < 16) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const unsigned fo = loff + (unsigned)(nt * 16 + u + D3) * 2048u;
+                        wh[sl][nt] = *reinterpret_cast<const lhalf8*>(wp + fo);
+                        if (!SINGLE) wl[sl][nt] = *reinterpret_cast<const lhalf8*>(wp + (fo + 1024u));
+                    }
                 }
             }
 #pragma unroll

@@ -35,7 +35,7 @@ import torch  # noqa: E402
 import test_gpu_gt  # noqa: E402
 import test_gpu_parity  # noqa: E402
 import test_gpu_train  # noqa: E402
-from helpers import oracle_golden_path  # noqa: E402
+from helpers import golden_digest, oracle_golden_path  # noqa: E402
 
 CASES = {
     "full256": test_gpu_parity._oc_full256,
@@ -47,12 +47,36 @@ CASES = {
     "train_full_b4_s256": test_gpu_train._full_size_oracle_compact,
 }
 
+def write_digests():
+    """tests/golden/oracle_digests.json: sha256 of the ARRAYS of every committed oracle_*.npz (helpers.golden_digest).
+    tests/test_oracle.py checks the committed files against it and recomputes the host-independent forward case `full256` live."""
+    import glob
+    import json
+    out = {}
+    for p in sorted(glob.glob(os.path.join(HERE, "oracle_*.npz"))):
+        z = np.load(p)
+        out[os.path.basename(p)] = golden_digest({k: z[k] for k in z.files})
+        print("%-44s %s" % (os.path.basename(p), out[os.path.basename(p)]))
+    # the sources the goldens are a function of (ADVICE r5): an edit of the oracle or of the synthetic inputs makes the test ask for
+    # a regeneration instead of letting the files go stale silently
+    import hashlib
+    out["_sources"] = {f: hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest()
+                       for f in ("oracle/ref_cpu.py", "slice3d_amd/synth.py")}
+    json.dump(out, open(os.path.join(HERE, "oracle_digests.json"), "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if sys.argv[1:] == ["--digests"]:
+        write_digests()
+        sys.exit(0)
     for name in (sys.argv[1:] or list(CASES)):
         t0 = time.time()
         z = CASES[name]()
         path = oracle_golden_path(name, os.environ.get("S3D_ORACLE_GOLDEN_DIR"))
         os.makedirs(os.path.dirname(path), exist_ok=True)
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in z.items()})
-        print("%-28s %6.1f s  %7.2f MB  %d arrays" % (name, time.time() - t0, os.path.getsize(path) / 1e6, len(z)), flush=True)
+        print("%-28s %6.1f s  %7.2f MB  %d arrays  sha256(arrays) %s" % (name, time.time() - t0, os.path.getsize(path) / 1e6, len(z),
+                                                                         golden_digest({k: np.asarray(v) for k, v in z.items()})), flush=True)
+    if not os.environ.get("S3D_ORACLE_GOLDEN_DIR"):
+        write_digests()

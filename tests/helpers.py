@@ -125,6 +125,18 @@ def load_oracle_golden(name):
     return {k: z[k] for k in z.files}
 
 
+def golden_digest(z):
+    """sha256 over the arrays of an oracle golden (sorted names, dtype, shape, bytes): the npz container itself carries zip
+    timestamps, the arrays do not."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(z):
+        a = np.ascontiguousarray(z[k])
+        h.update(("%s|%s|%s|" % (k, a.dtype.str, a.shape)).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
 def grad_sample_index(key, n):
     import zlib
     if n <= ORACLE_GRAD_SAMPLE:
@@ -155,7 +167,10 @@ def sampled_grad(z, key, grad):
 
 def fp64_anchored_rows(z, named_grads, skip=()):
     """Rows (name, rel(hip, ref64), rel(ref32, ref64), rel(hip, ref32)) over the sampled entries of every tensor of `z` that
-    has a gradient in `named_grads` (name -> tensor)."""
+    has a gradient in `named_grads` (name -> tensor).  rel(ref32, ref64) is the LARGER of the fp32 oracle passes the golden holds
+    (round 6: 'g32:' = the pass of the GPU box's host CPU, 'g32c:' = the pass of the authoring container; an fp32 evaluation of
+    the network rounds differently on different hosts, the fp64 pass agrees to 1e-13) — the yardstick is then a property of the
+    committed file, not of the machine that wrote or runs it.  rel(hip, ref32) is taken against the closer of the two."""
     rows = []
     for k in z["grad_names"]:
         k = str(k)
@@ -163,16 +178,23 @@ def fp64_anchored_rows(z, named_grads, skip=()):
             continue
         p = sampled_grad(z, k, named_grads[k])
         assert np.isfinite(p).all(), k
-        r64, r32 = z["g64:" + k], z["g32:" + k].astype(np.float64)
+        r64 = z["g64:" + k]
         n64 = np.linalg.norm(r64)
-        rows.append((k, float(np.linalg.norm(p - r64) / n64), float(np.linalg.norm(r32 - r64) / n64),
-                     float(np.linalg.norm(p - r32) / np.linalg.norm(r32))))
+        e_ref, e_hip32 = 0.0, np.inf
+        for tag in ("g32:", "g32c:"):
+            if tag + k in z:
+                r32 = z[tag + k].astype(np.float64)
+                e_ref = max(e_ref, float(np.linalg.norm(r32 - r64) / n64))
+                e_hip32 = min(e_hip32, float(np.linalg.norm(p - r32) / np.linalg.norm(r32)))
+        rows.append((k, float(np.linalg.norm(p - r64) / n64), e_ref, e_hip32))
     return rows
 
 
 def assert_fp64_anchored_gate(rows, gate_free):
     """Per tensor rel(hip, ref64) <= 3 max(rel(ref32, ref64), its median) + 3e-4, medians within a factor 1.5, and the
-    tensors no ReLU gate sits behind within 2e-5 of the fp32 oracle itself.  Returns (median hip, median ref, worst row)."""
+    tensors no ReLU gate sits behind within 2e-5 of the fp32 oracle itself.  Returns (median hip, median ref, worst row).
+    rel(ref32, ref64) comes from fp64_anchored_rows: the larger of the fp32 oracle passes of the hosts the golden holds, so the
+    same file gives the same verdict wherever the test runs (round 6; profiles/r06_f32_chains.md)."""
     assert len(rows) > 100
     med_hip = sorted(r[1] for r in rows)[len(rows) // 2]
     med_ref = sorted(r[2] for r in rows)[len(rows) // 2]

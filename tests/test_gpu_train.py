@@ -373,8 +373,9 @@ def test_train_step_matches_oracle_autograd_128_16k(prec):
         if k in PRE_BN_BIASES:
             assert float(p.grad.abs().max()) < 1e-4
             continue
-        want = z["g32:" + k].astype(np.float64)
-        rel = float(np.linalg.norm(sampled_grad(z, k, p.grad) - want) / np.linalg.norm(want))
+        got_k = sampled_grad(z, k, p.grad)   # against the closer of the fp32 oracle passes the golden holds (GPU box's host, authoring container)
+        rel = min(float(np.linalg.norm(got_k - z[t + k].astype(np.float64)) / np.linalg.norm(z[t + k].astype(np.float64)))
+                  for t in ("g32:", "g32c:") if t + k in z)
         if rel > worst:
             worst, worst_k = rel, k
         assert rel < 2e-2, (k, rel)

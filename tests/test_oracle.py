@@ -148,3 +148,37 @@ def test_train_oracle_matches_reference_golden():
     for key in z.files:
         if key.startswith("bn:") and ".down5_." not in key:
             assert np.abs(ts.new_stats[key[3:]].numpy() - z[key]).max() < 1e-5, key
+
+
+def test_committed_oracle_goldens_are_what_the_digest_file_says_and_what_the_oracle_computes():
+    """Round 6 (the round-5 review's item 4c).  (1) Every committed tests/golden/oracle_*.npz still holds the arrays
+    tests/golden/oracle_digests.json was written for (make_oracle_golden.py --digests): a golden cannot change unnoticed.
+    (2) The host-independent forward case `full256` (BASELINE configs[1]'s inference shape, ~10 s of CPU) is recomputed by the
+    very function the GPU test uses and must reproduce the committed arrays: bit for bit on the authoring container's CPU
+    (asserted through the digest when the digest matches; ATen's fp32 kernels may round differently on another CPU model, where
+    the arrays must still agree to 2e-5, a fifth of the 1e-4 gate they serve)."""
+    import glob
+    from helpers import golden_digest
+    import hashlib
+    want = json.load(open(os.path.join(GOLDEN, "oracle_digests.json")))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f, h in want.pop("_sources").items():   # the goldens are a function of these files: regenerate (make_oracle_golden.py) after editing them
+        assert hashlib.sha256(open(os.path.join(root, f), "rb").read()).hexdigest() == h, \
+            "%s changed since tests/golden/oracle_*.npz were written: rerun tests/golden/make_oracle_golden.py (or --digests after checking that the outputs did not change)" % f
+    files = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "oracle_*.npz")))
+    assert files == sorted(want), (files, sorted(want))
+    for f in files:
+        z = np.load(os.path.join(GOLDEN, f))
+        assert golden_digest({k: z[k] for k in z.files}) == want[f], f
+    import test_gpu_parity
+    os.environ["S3D_LIVE_ORACLE"] = "1"
+    try:
+        live = {k: np.asarray(v) for k, v in test_gpu_parity._oc_full256().items()}
+    finally:
+        del os.environ["S3D_LIVE_ORACLE"]
+    z = np.load(os.path.join(GOLDEN, "oracle_full256.npz"))
+    assert sorted(live) == sorted(z.files)
+    for k in z.files:
+        assert live[k].shape == z[k].shape and np.abs(live[k] - z[k]).max() < 2e-5, k
+    same_bits = golden_digest(live) == want["oracle_full256.npz"]
+    print("oracle_full256 recomputed: %s" % ("bit-identical" if same_bits else "within 2e-5 (another CPU's fp32 rounding)"))
