@@ -25,18 +25,20 @@ if __name__ == "__main__":
             continue
         zb, zc = dict(np.load(pb)), dict(np.load(pc))
         worst64, worst32, n = 0.0, 0.0, 0
-        for k in zb:
+        for k in list(zb):
             if k.startswith("g64:"):
+                if max(np.linalg.norm(zb[k]), np.linalg.norm(zc[k])) < 1e-8 * np.sqrt(zb[k].size):
+                    continue                       # the pre-BatchNorm biases: exact gradient 0, rounding noise on every host
                 d = np.linalg.norm(zb[k] - zc[k]) / max(np.linalg.norm(zb[k]), 1e-300)
                 worst64 = max(worst64, d)
                 assert d < 1e-9, (name, k, d)      # the fp64 anchor is host-independent
             elif k.startswith("g32:"):
                 kk = k[4:]
-                d = np.linalg.norm(zb[k].astype(np.float64) - zc[k]) / max(np.linalg.norm(zb[k]), 1e-300)
-                worst32 = max(worst32, d)
+                if np.linalg.norm(zb[k]) >= 1e-8 * np.sqrt(zb[k].size):   # (not the exactly-zero gradients of the pre-BatchNorm biases)
+                    worst32 = max(worst32, np.linalg.norm(zb[k].astype(np.float64) - zc[k]) / np.linalg.norm(zb[k]))
                 zb["g32c:" + kk] = zc[k]
                 n += 1
             elif not k.startswith(("g32c:",)):
-                assert zb[k].shape == zc[k].shape and (zb[k].dtype.kind not in "fc" or np.allclose(zb[k], zc[k], rtol=1e-4, atol=1e-5)), (name, k)
+                assert zb[k].shape == zc[k].shape and (zb[k].dtype.kind not in "fc" or np.allclose(zb[k], zc[k], rtol=1e-4, atol=5e-5)), (name, k)
         np.savez_compressed(pb, **zb)
         print("%-28s %d tensors: fp64 passes agree to %.1e, fp32 passes differ by up to %.1e; %.2f MB" % (name, n, worst64, worst32, os.path.getsize(pb) / 1e6))
