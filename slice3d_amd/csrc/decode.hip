@@ -201,8 +201,8 @@ __device__ __forceinline__ void slice_token_task(const SampleArgs& a, const floa
 #pragma unroll
             for (int s = 0; s < 4; ++s) wt[l][s] = wxq * (s == dy ? f.wy0 : s == dy + 1 ? f.wy1 : 0.f);
         }
-        // window rows as MFMA A operands: lane (ch = m, k = g) loads pixel (by + s, bx + g), channel 16 j + ch; two windows in flight
-        float wa[2][4][8];
+        // window rows as MFMA A operands: lane (ch = m, k = g) loads pixel (by + s, bx + g), channel 16 j + ch
+        float wa[2][4][8];   // two windows in flight: level l uses buffer l & 1
         auto issue_window = [&](int l) {
             const int W = S >> (4 - l);
             const char* pl = reinterpret_cast<const char*>(a.proj[l] + img * (long)W * W * 128);   // scalar base + 32-bit lane offsets
@@ -221,6 +221,8 @@ __device__ __forceinline__ void slice_token_task(const SampleArgs& a, const floa
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[l & 1][s][j], wt[l][s], acc[j], 0, 0, 0);
         };
+        // (Requesting all three windows and both fine levels up front — one exposed round trip instead of three — measured SLOWER:
+        // 2.11 against 1.70 ms; the 96 + 64 staging registers push the task into spills whose reloads queue behind the loads.)
         issue_window(0);
         issue_window(1);
         issue_level4();
@@ -278,20 +280,29 @@ __device__ __forceinline__ void slice_token_task(const SampleArgs& a, const floa
     // raw samples of levels 3, 4 = the B operand of the K = 96 product with Ws34
     if (F16) {
         const _Float16* sw = reinterpret_cast<const _Float16*>(s_ws34) + tz;
+        s3d_half8 bh[3], bl[3];
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {   // k-slot 8g + t of step kk <-> raw channel 32 kk + 8g + t
             const float x8[8] = {braw[2 * kk][0], braw[2 * kk][1], braw[2 * kk][2], braw[2 * kk][3],
                                  braw[2 * kk + 1][0], braw[2 * kk + 1][1], braw[2 * kk + 1][2], braw[2 * kk + 1][3]};
-            s3d_half8 bh, bl;
-            s3d_split8(x8, bh, bl);
+            s3d_split8(x8, bh[kk], bl[kk]);
+        }
+        // the 24 fragment pairs are read one step ahead of their MFMAs (read in the step they are used, every step waited a full LDS
+        // round trip in front of its three MFMAs: 24 x ~100 cycles per task)
+        s3d_half8 fh[2], fl[2];
+        fh[0] = *reinterpret_cast<const s3d_half8*>(sw + lane * 8);
+        fl[0] = *reinterpret_cast<const s3d_half8*>(sw + 512 + lane * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const s3d_half8 fh = *reinterpret_cast<const s3d_half8*>(sw + (j * 3 + kk) * 1024 + lane * 8);
-                const s3d_half8 fl = *reinterpret_cast<const s3d_half8*>(sw + (j * 3 + kk) * 1024 + 512 + lane * 8);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bl, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, bh, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bh, acc[j], 0, 0, 0);
+        for (int st = 0; st < 24; ++st) {
+            const int kk = st >> 3, j = st & 7;
+            if (st + 1 < 24) {
+                const int kn = (st + 1) >> 3, jn = (st + 1) & 7;
+                fh[(st + 1) & 1] = *reinterpret_cast<const s3d_half8*>(sw + (jn * 3 + kn) * 1024 + lane * 8);
+                fl[(st + 1) & 1] = *reinterpret_cast<const s3d_half8*>(sw + (jn * 3 + kn) * 1024 + 512 + lane * 8);
             }
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[st & 1], bl[kk], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[st & 1], bh[kk], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[st & 1], bh[kk], acc[j], 0, 0, 0);
         }
     } else {
 #pragma unroll
@@ -307,6 +318,14 @@ __device__ __forceinline__ void slice_token_task(const SampleArgs& a, const floa
     }
 }
 
+// Loop order (round 6, second step).  A wave owns the tokens t = wave, wave + 4, ...  Walking group by group and, inside a group,
+// token by token sends every task of a wave to a DIFFERENT slice image: the windows / taps of consecutive groups (neighbours in the
+// image) are re-used a whole group later, after the CU's other tasks have pushed 12 images' worth of rows through L1 and the XCD's
+// L2 (64 workgroups x 12 slices x ~48 KB = 37 MB against 4 MB) — rocprofv3 counted 3.3 M KiB fetched per launch for 0.74 GB of
+// pyramid.  Now a workgroup takes its chunk in blocks of ST_BLK groups: phase A computes the block's query prologue ONCE (rotation /
+// flip, project_coord, the three folded levels' window origins) into LDS, phase B lets every wave walk the block token-major — all
+// groups of one slice image, then the next image — so a task's rows are the rows its predecessor just touched.
+#define ST_BLK 64   // groups per block: 1 024 queries x 20 B + 64 x 32 B of LDS
 template <bool F16>
 __global__ __launch_bounds__(256, 2) void sample_tokens_kernel(const SampleArgs a) {
     __shared__ __attribute__((aligned(16))) float s_ws34[8 * 6 * 256];  // 48 KiB: fp32 [8][6] fragments or f16 hi|lo [8][3]
@@ -314,6 +333,8 @@ __global__ __launch_bounds__(256, 2) void sample_tokens_kernel(const SampleArgs 
     // per lane and made the point token the longest task of a group (34 000 cycles against 14 000 for a slice token): wave 0,
     // which owns it, set the kernel's time
     __shared__ __attribute__((aligned(16))) float s_fcp[4 * 128];
+    __shared__ float s_q[5][ST_BLK * S3D_GROUP];   // x | y | z (rotated / flipped) | gx | gy of the block's queries
+    __shared__ int s_win[ST_BLK][8];               // bx[3] | by[3] | window form? of the block's groups
     {
         const float* wsrc = F16 ? a.ws34_16 : a.ws34;
         for (int i = threadIdx.x; i < 8 * 6 * 64; i += 256) st4(s_ws34 + 4 * i, ld4(wsrc + 4 * i));
@@ -322,7 +343,6 @@ __global__ __launch_bounds__(256, 2) void sample_tokens_kernel(const SampleArgs 
             s_fcp[i] = kx < 3 ? a.fcp_w[c * 3 + kx] : a.fcp_b[c];
         }
     }
-    __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the image bases are SGPR pairs)
     const int m = lane & 15, g = lane >> 4;
@@ -336,83 +356,66 @@ __global__ __launch_bounds__(256, 2) void sample_tokens_kernel(const SampleArgs 
     const long chunk = (a.g_count + nb - 1) / nb;
     const long g_lo = bb * chunk, g_hi = g_lo + chunk < a.g_count ? g_lo + chunk : a.g_count;
 #pragma unroll 1
-    for (long gi = g_lo; gi < g_hi; ++gi) {
-        const long grp = a.g_begin + gi;
-        const int b = (int)(grp / a.groups_per_batch);
-        long q = (grp % a.groups_per_batch) * S3D_GROUP + m;
-        if (q >= a.n_qry) q = a.n_qry - 1;  // padded rows recompute the last query; never stored to sdf
-        if (a.perm) q = a.perm[(long)b * a.n_qry + q];
-        float x, y, z;
-        if (a.qry) {
-            const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
-            x = p[0]; y = p[1]; z = p[2];
-        } else {  // dense grid: x slowest, z fastest (common.py:145-164)
-            const long nn = (long)a.nx * a.nx, ql = q + a.q_offset;
-            const int ixg = (int)(ql / nn), iyg = (int)((ql / a.nx) % a.nx), izg = (int)(ql % a.nx);
-            x = a.box * linspace_at(-0.5f, 0.5f, a.nx, ixg);
-            y = a.box * linspace_at(-0.5f, 0.5f, a.nx, iyg);
-            z = a.box * linspace_at(-0.5f, 0.5f, a.nx, izg);
-        }
-        if (a.flip_yz) {  // mode='test' (models.py:53-56)
-            y = -y; z = -z;
-        } else if (a.rot) {  // qry @ obj_rot_mat (models.py:58-60)
-            const float* R = a.rot + b * 9;
-            const float rx = x * R[0] + y * R[3] + z * R[6];
-            const float ry = x * R[1] + y * R[4] + z * R[7];
-            const float rz = x * R[2] + y * R[5] + z * R[8];
-            x = rx; y = ry; z = rz;
-        }
-        float gx, gy;
-        project(a.trans + b * 12, x, y, z, gx, gy);
-
-        // the group's pixel windows in the three folded levels (the same for every slice of the object): scalars.  The
-        // per-lane footprints themselves are recomputed inside every task (a few dozen VALU): kept live across the token loop
-        // together with everything derived from them they cost ~100 registers, i.e. the second wave per SIMD
-        int bx[3], by[3];
-        bool window = !a.lane_footprints;
-#pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            const int W = S >> (4 - l);
-            const Foot f = make_foot(gx, gy, W, W);
-            const int mnx = row16_min(f.x0), mny = row16_min(f.y0);
-            const int ex = row16_max(f.x0) - mnx, ey = row16_max(f.y0) - mny;
-            // (every DPP row holds the same 16 queries: the values are wave-uniform; readfirstlane makes them scalars)
-            bx[l] = __builtin_amdgcn_readfirstlane(mnx);
-            by[l] = __builtin_amdgcn_readfirstlane(mny);
-            window = window && __builtin_amdgcn_readfirstlane((int)(ex <= 2 && ey <= 2 && mnx >= 0 && mny >= 0)) != 0;
-        }
-
-#pragma unroll 1
-        for (int t = wave; t < T; t += 4) {
-            f32x4 acc[8];
-            // an opaque zero added to the index of every loop-invariant operand read of a task (fc_p / Ws34 in LDS, the fc_s bias),
-            // and opaque per-task copies of the projected point: left visible, the optimiser hoists those reads and everything
-            // derived from the footprints out of the loops and keeps > 150 registers of constants live
-            int tz = 0;
-            float tgx = gx, tgy = gy;
-            asm volatile("" : "+v"(tz), "+v"(tgx), "+v"(tgy));
-            if (t == 0) {  // fc_p (models.py:79)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = 16 * j + 4 * g + tz;
-                    const f32x4 wx = ld4(s_fcp + c), wy = ld4(s_fcp + 128 + c), wz = ld4(s_fcp + 256 + c), wb = ld4(s_fcp + 384 + c);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[j][i] = wx[i] * x + wy[i] * y + wz[i] * z + wb[i];   // same expression order as before
-                }
-            } else {
-                const long img = (long)b * a.n_slices + (t - 1);
-                float* raw_row = a.raw_out ? a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 96 : nullptr;
-                // (opaque per-task copies of the window origins too: visible, the window loads' lane offsets are formed outside the
-                // token loop as 64-bit values, spilled, and every reload's s_waitcnt vmcnt(0) serialises the loads behind it)
-                int tbx[3] = {bx[0], bx[1], bx[2]}, tby[3] = {by[0], by[1], by[2]};
-                asm volatile("" : "+s"(tbx[0]), "+s"(tbx[1]), "+s"(tbx[2]), "+s"(tby[0]), "+s"(tby[1]), "+s"(tby[2]));
-                if (window)
-                    slice_token_task<F16, true>(a, s_ws34, acc, img, S, tgx, tgy, tbx, tby, tz, raw_row, lane);
-                else
-                    slice_token_task<F16, false>(a, s_ws34, acc, img, S, tgx, tgy, tbx, tby, tz, raw_row, lane);
+    for (long g0 = g_lo; g0 < g_hi; g0 += ST_BLK) {
+        const int ng = (int)(g_hi - g0 < ST_BLK ? g_hi - g0 : ST_BLK);
+        __syncthreads();   // the previous block's readers are done (first pass: the weight fill above is published)
+        // ---- phase A.1: one thread per query of the block ----
+        for (int qi = threadIdx.x; qi < ng * S3D_GROUP; qi += 256) {
+            const long grp = a.g_begin + g0 + (qi >> 4);
+            const int b = (int)(grp / a.groups_per_batch);
+            long q = (grp % a.groups_per_batch) * S3D_GROUP + (qi & 15);
+            if (q >= a.n_qry) q = a.n_qry - 1;  // padded rows recompute the last query; never stored to sdf
+            if (a.perm) q = a.perm[(long)b * a.n_qry + q];
+            float x, y, z;
+            if (a.qry) {
+                const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
+                x = p[0]; y = p[1]; z = p[2];
+            } else {  // dense grid: x slowest, z fastest (common.py:145-164)
+                const long nn = (long)a.nx * a.nx, ql = q + a.q_offset;
+                const int ixg = (int)(ql / nn), iyg = (int)((ql / a.nx) % a.nx), izg = (int)(ql % a.nx);
+                x = a.box * linspace_at(-0.5f, 0.5f, a.nx, ixg);
+                y = a.box * linspace_at(-0.5f, 0.5f, a.nx, iyg);
+                z = a.box * linspace_at(-0.5f, 0.5f, a.nx, izg);
             }
-            // full 128-byte lines per query row (s3d_full_line_pair, common.h): tiles 2J, 2J + 1 of query m are exchanged
-            // with lane m ^ 8; one instruction then writes queries 0-7, the next queries 8-15
+            if (a.flip_yz) {  // mode='test' (models.py:53-56)
+                y = -y; z = -z;
+            } else if (a.rot) {  // qry @ obj_rot_mat (models.py:58-60)
+                const float* R = a.rot + b * 9;
+                const float rx = x * R[0] + y * R[3] + z * R[6];
+                const float ry = x * R[1] + y * R[4] + z * R[7];
+                const float rz = x * R[2] + y * R[5] + z * R[8];
+                x = rx; y = ry; z = rz;
+            }
+            float gx, gy;
+            project(a.trans + b * 12, x, y, z, gx, gy);
+            s_q[0][qi] = x; s_q[1][qi] = y; s_q[2][qi] = z; s_q[3][qi] = gx; s_q[4][qi] = gy;
+        }
+        __syncthreads();
+        // ---- phase A.2: the groups' pixel windows in the three folded levels (the same for every slice of the object); 16 lanes per group ----
+        for (int gl = threadIdx.x >> 4; gl < ng; gl += 16) {
+            const float gx = s_q[3][gl * S3D_GROUP + m], gy = s_q[4][gl * S3D_GROUP + m];
+            int ok = !a.lane_footprints;
+            int org[6];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const int W = S >> (4 - l);
+                const Foot f = make_foot(gx, gy, W, W);
+                const int mnx = row16_min(f.x0), mny = row16_min(f.y0);
+                const int ex = row16_max(f.x0) - mnx, ey = row16_max(f.y0) - mny;
+                org[l] = mnx; org[3 + l] = mny;
+                ok = ok && ex <= 2 && ey <= 2 && mnx >= 0 && mny >= 0;
+            }
+            if (m == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) s_win[gl][i] = org[i];
+                s_win[gl][6] = ok;
+            }
+        }
+        __syncthreads();
+        // ---- phase B: token-major walk of the block ----
+        // full 128-byte lines per query row (s3d_full_line_pair, common.h): tiles 2J, 2J + 1 of query m are exchanged
+        // with lane m ^ 8; one instruction then writes queries 0-7, the next queries 8-15
+        auto store_rows = [&](const f32x4 (&acc)[8], long gi, int t) {
             float* o = a.X + ((gi * T + t) * S3D_GROUP + (m & 7)) * 128 + 16 * (m >> 3) + 4 * g;
 #pragma unroll
             for (int J = 0; J < 4; ++J) {
@@ -421,10 +424,54 @@ __global__ __launch_bounds__(256, 2) void sample_tokens_kernel(const SampleArgs 
                 st4(o + 32 * J, va);
                 st4(o + 8 * 128 + 32 * J, vb);
             }
-            if (a.raw_out && t == 0) {
-                float* ro = a.raw_out + ((gi * T) * S3D_GROUP + m) * 96 + 4 * g;
+        };
+#pragma unroll 1
+        for (int t = wave; t < T; t += 4) {
+#pragma unroll 1
+            for (int gl = 0; gl < ng; ++gl) {
+                const long gi = g0 + gl;
+                f32x4 acc[8];
+                // Per task: an opaque zero added to the index of every loop-invariant operand read (fc_p / Ws34 in LDS, the fc_s bias)
+                // and to the LDS index of the prologue values.  Left visible, the optimiser hoists those reads and everything
+                // derived from the footprints out of the loops and keeps > 150 registers of constants live; the window loads' lane
+                // offsets are formed outside the token loop as 64-bit values, spilled, and every reload's s_waitcnt vmcnt(0)
+                // serialises the loads behind it.
+                int tz = 0;
+                asm volatile("" : "+v"(tz));
+                const int qi = gl * S3D_GROUP + m + tz;
+                if (t == 0) {  // fc_p (models.py:79)
+                    const float x = s_q[0][qi], y = s_q[1][qi], z = s_q[2][qi];
 #pragma unroll
-                for (int u = 0; u < 6; ++u) st4(ro + 16 * u, zero4());
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = 16 * j + 4 * g + tz;
+                        const f32x4 wx = ld4(s_fcp + c), wy = ld4(s_fcp + 128 + c), wz = ld4(s_fcp + 256 + c), wb = ld4(s_fcp + 384 + c);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[j][i] = wx[i] * x + wy[i] * y + wz[i] * z + wb[i];   // same expression order as before
+                    }
+                    if (a.raw_out) {
+                        float* ro = a.raw_out + ((gi * T) * S3D_GROUP + m) * 96 + 4 * g;
+#pragma unroll
+                        for (int u = 0; u < 6; ++u) st4(ro + 16 * u, zero4());
+                    }
+                } else {
+                    const float tgx = s_q[3][qi], tgy = s_q[4][qi];
+                    int tbx[3], tby[3];
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) {
+                        tbx[l] = __builtin_amdgcn_readfirstlane(s_win[gl][l]);
+                        tby[l] = __builtin_amdgcn_readfirstlane(s_win[gl][3 + l]);
+                    }
+                    const bool window = __builtin_amdgcn_readfirstlane(s_win[gl][6]) != 0;
+                    asm volatile("" : "+s"(tbx[0]), "+s"(tbx[1]), "+s"(tbx[2]), "+s"(tby[0]), "+s"(tby[1]), "+s"(tby[2]));
+                    const int b = (int)((a.g_begin + gi) / a.groups_per_batch);
+                    const long img = (long)b * a.n_slices + (t - 1);
+                    float* raw_row = a.raw_out ? a.raw_out + ((gi * T + t) * S3D_GROUP + m) * 96 : nullptr;
+                    if (window)
+                        slice_token_task<F16, true>(a, s_ws34, acc, img, S, tgx, tgy, tbx, tby, tz, raw_row, lane);
+                    else
+                        slice_token_task<F16, false>(a, s_ws34, acc, img, S, tgx, tgy, tbx, tby, tz, raw_row, lane);
+                }
+                store_rows(acc, gi, t);
             }
         }
     }

@@ -147,6 +147,11 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert abs(res["value"] - 2 * 4096 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
     c4 = res["c4_dense_grid"]
     assert c4["n_gpus"] == 2 and c4["scaling"] == "strong" and c4["query_points_per_s"] > 0
+    # N > 1 only (round 6): the exchange steps on their own — the slab all_gather of the grid split, the training step with the
+    # gradient all-reduce switched off beside the one with it (tools/scaling_table.py turns the N = 1, 2, 4, 8 lines into DESIGN section 6's table)
+    assert c4["c4_all_gather_ms"] > 0
+    assert res["train_ms_per_step_no_exchange"] > 0
+    assert abs(res["train_allreduce_ms_exposed"] - (res["train_ms_per_step"] - res["train_ms_per_step_no_exchange"])) < 1e-2
     assert res["ldm_denoise_step"]["n_gpus"] == 2 and res["ldm_denoise_step"]["steps_per_s_all_gpus"] > 0
     assert res["train_samples_per_s"] > 0 and "roofline" in res
     lo, hi = res["ms_per_step_rank_min_max"]            # per-rank times: a straggler is visible in the line
