@@ -666,6 +666,11 @@ def main():
         decode_ms = sum(stage_ms[k] for k in ("sample_tokens", "attn_layer", "ffn_layer", "ffn_final"))
         unet_tf = args.batch * UNET_GFLOP_256 * (args.img_size / 256.0) ** 2 / stage_ms["unet_encode"]
         attn_tf = args.n_qry * args.batch * 2 * n_tok * ATTN_FLOP_PER_TOKEN / (stage_ms["attn_layer"] * 1e-3) / 1e12
+        # algorithmic bytes of the token builder per step: the (queries x 13) token rows written once + every pyramid level of the
+        # batch x n_slices slice images read once (folded levels 0-2: 128 channels at S/16, S/8, S/4; raw levels: 64 at S/2, 32 at S)
+        S_ = args.img_size
+        pyr_px_ch = 128 * ((S_ // 16) ** 2 + (S_ // 8) ** 2 + (S_ // 4) ** 2) + 64 * (S_ // 2) ** 2 + 32 * S_ ** 2
+        tok_bytes = 4.0 * (args.batch * args.n_qry * n_tok * 128 + args.batch * args.n_slices * pyr_px_ch)
         # Key order: the driver keeps ~2 KB of the line's tail, so the contract keys and the long objects come first and
         # every secondary result sits at the end, numbers only (what each key means: DESIGN.md section 5, "bench line glossary").
         res = {
@@ -694,6 +699,11 @@ def main():
                  "frac": unet_tf / peak},
                 {"kernel": "attention stage (2 layers + absorbed last layer)", "bound": "mfma",
                  "achieved": attn_tf, "peak": peak, "unit": "TFLOP/s", "frac": attn_tf / peak},
+                # the fused feature-sample + fc_s kernel of the decode path (north_star's "feature-sample kernel" inside the pipeline): token
+                # tensor written once (rows x 512 B) + the five pyramid levels of the B x n_slices images read once, over its stage time
+                {"kernel": "sample_tokens_kernel (project + 5-level sample + fc_p / fc_s -> tokens)", "bound": "hbm",
+                 "achieved": tok_bytes / (stage_ms["sample_tokens"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                 "frac": tok_bytes / (stage_ms["sample_tokens"] * 1e-3) / 1e9 / 8000.0, "kernel_ms": stage_ms["sample_tokens"]},
             ],
             "decode_tflops_fmin": args.n_qry * args.batch * F_MIN_PER_QUERY / (decode_ms * 1e-3) / 1e12,
         }
