@@ -253,11 +253,14 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child pass: inference loop only
     ap.add_argument("--train-steps", type=int, default=10, help="timed training steps for train_samples_per_s (0 = skip)")
     ap.add_argument("--gt-train-steps", type=int, default=5, help="timed Slices3DGTModel training steps (0 = skip)")
+    ap.add_argument("--train-f16-steps", type=int, default=8,
+                    help="timed steps of the training step's single-pass f16 throughput mode (prec='f16'; reported beside "
+                         "train_ms_per_step with its gradient deviation, never instead of it; 0 = skip)")
     ap.add_argument("--infer-only", action="store_true", help="the headline loop alone (A/B scripts): every secondary leg off")
     args = ap.parse_args()
     if args.infer_only:
         for k in ("cpu_sample", "f16_steps", "f32_steps", "noise_steps", "c4_steps", "mesh_steps", "ldm_steps", "train_steps",
-                  "gt_train_steps", "pmc"):
+                  "gt_train_steps", "train_f16_steps", "pmc"):
             setattr(args, k, 0)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -633,6 +636,38 @@ def main():
             train_ms_local = float(t.item()) / args.train_steps * 1e3
             del trainer, tmodel
 
+    # ---- throughput mode of the training step (NOT the reported train_samples_per_s): prec="f16" — the decoder's GEMM kernels run one
+    #      f16 MFMA per product (configs[1] names bf16: this is the reduced-precision leg of the step), everything else as f16x3.
+    #      Rank 0 alone, no exchange; with the gradient deviation of one small step from the split-precision step (same weights,
+    #      batch and dropout masks): median and 95th percentile of the per-tensor relative L2 distance ----
+    train_f16 = None
+    if args.train_f16_steps > 0 and args.train_steps > 0 and rank == 0:
+        from slice3d_amd.trainer import HipTrainer
+
+        def _grads(prec):
+            tm = load_seeded(Slices3DRegModel(img_size=64, n_slices=args.n_slices, mode="train"), 0).cuda()
+            tt = HipTrainer(tm, dropout=0.1, seed=11, prec=prec, process_group=False)
+            tt.forward_backward(make_feed_dict(2, 64, 8192, args.n_slices, seed=17, device="cuda"))
+            return {k: p.grad.detach().clone() for k, p in tm.named_parameters() if p.grad is not None}
+        g3, g1 = _grads("f16x3"), _grads("f16")
+        # (the eight pre-BatchNorm conv biases have an exactly-zero gradient — rounding noise in every mode — and are left out)
+        pre_bn = {"slices_generator.%s.bias" % k for k in ("down1.0", "down2.7", "down3.14", "down3.17", "down4.24", "down4.27", "down5.34", "down5.37")}
+        dev = sorted(float((g1[k] - g).norm() / g.norm()) for k, g in g3.items() if k not in pre_bn and float(g.norm()) > 0)
+        del g3, g1
+        tmodel = load_seeded(Slices3DRegModel(img_size=args.img_size, n_slices=args.n_slices, mode="train"), 0).cuda()
+        trainer = HipTrainer(tmodel, dropout=0.1, seed=0, prec="f16", process_group=False)
+        tfd16 = make_feed_dict(args.batch, args.img_size, args.n_qry, args.n_slices, seed=4321, device="cuda")
+        trainer.train_step(tfd16)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.train_f16_steps):
+            trainer.train_step(tfd16)
+        torch.cuda.synchronize()
+        ms16 = (time.perf_counter() - t1) / args.train_f16_steps * 1e3
+        train_f16 = {"ms_per_step": ms16, "samples_per_s": args.batch / (ms16 * 1e-3), "dtype": "f16 (decoder GEMMs single-pass; rest f16x3)",
+                     "grad_rel_dev_vs_f16x3": {"median": dev[len(dev) // 2], "p95": dev[int(len(dev) * 0.95)], "tensors": len(dev)}}
+        del trainer, tmodel, tfd16
+
     if rank == 0:
         q_total = args.n_qry * args.batch * world * args.steps
         n_tok = args.n_slices + 1
@@ -724,6 +759,7 @@ def main():
         res["ldm_denoise_step"] = ldm
         res["mesh_extraction"] = mesh_leg
         res["gt_train_step"] = gt_train
+        res["train_throughput_mode_f16"] = train_f16
         res["train_ms_per_step"] = train_ms
         res["train_samples_per_s"] = (world * args.batch / (train_ms * 1e-3)) if train_ms else None
         if train_ms_local is not None:   # N > 1 only (tools/scaling_table.py reads these)

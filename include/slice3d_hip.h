@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S3D_VERSION 111          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused, s3d_decode_set_shared_footprint */
+#define S3D_VERSION 112          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused, s3d_decode_set_shared_footprint; 112: S3D_PREC_F16 accepted by s3d_train_* */
 #define S3D_E_ARG (-1)           /* bad argument / unsupported shape */
 #define S3D_E_WORKSPACE (-2)     /* workspace or packed-weight buffer too small */
 
@@ -402,6 +402,12 @@ typedef struct {
     const S3dSyncBn* sync_bn;  /* NULL: per-rank BatchNorm statistics */
 } S3dTrainBatch;
 size_t s3d_train_workspace_bytes(int batch, int size, long n_qry, int n_slices);
+/* prec: S3D_PREC_F32 (exact fp32 MFMAs), S3D_PREC_F16X3 (split precision, fp32-class: the mode every parity test and the
+ * reported train_samples_per_s use) or — since version 112 — S3D_PREC_F16: a THROUGHPUT mode in which the decoder's GEMM kernels
+ * (FFN forward / data pass / both weight-gradient contractions, the fused attention forward and backward, the row-linear layers and
+ * their weight gradients) run ONE f16 MFMA per product; the U-Net, VGG, the samplers, every reduction, the fp32 master weights,
+ * fp32 accumulation and the power-of-two backward scale are those of S3D_PREC_F16X3.  Not fp32-class (gradients deviate by ~1e-2
+ * relative from the split-precision step): bench.py reports it beside the headline as train_throughput_mode_f16. */
 int s3d_train_fwd_bwd(const S3dUNetParams* unet, const S3dHeadParams* head, const S3dVggParams* vgg,
                       const S3dUNetParams* unet_grad, const S3dHeadParams* head_grad,
                       const S3dTrainBatch* batch, int batch_size, int size, long n_qry, int n_slices,

@@ -151,18 +151,18 @@ static inline size_t ffn_mask_dwords(long P) { return (size_t)((P + 31) / 32) * 
 // imgd / imgr (optional, ffn_rec_image_floats(rows) floats each): D^T / R image of DY
 int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
                             const float* timg, float gate_scale, hipStream_t stream, float* imgd = nullptr,
-                            float* imgr = nullptr, const DropCfg* dy_mask = nullptr);
+                            float* imgr = nullptr, const DropCfg* dy_mask = nullptr, bool single = false);   // single: hi * hi products only (S3D_PREC_F16 training throughput mode)
 int launch_pack_ffn_f16x3_bwd(const float* w1, const float* w2, float* out, hipStream_t stream);
 // imgd / imgr (optional): D^T / R image of Xin
 int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
                                  const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
-                                 hipStream_t stream, float* imgd = nullptr, float* imgr = nullptr);
+                                 hipStream_t stream, float* imgd = nullptr, float* imgr = nullptr, bool single = false);
 int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStream_t stream, bool single_pass = false,
                         bool bf16 = false);
 // training forward of the attention block, query-major (decode_attnq.hip): y = LN1(u), u = xin + dropout1(out_proj(MHA(xin)) + b),
 // o = MHA output before out_proj; nothing else is kept (the fused backward of train_attnq.hip recomputes Q / K / V)
 int launch_attn_layer_q_train(const float* xin, float* y, float* u, float* o, long groups, int T, const LayerPtrs& w,
-                              const DropCfg& d0, const DropCfg& d1, hipStream_t stream);
+                              const DropCfg& d0, const DropCfg& d1, hipStream_t stream, bool single = false);
 // Last layer, token 0 only (models.py:83 consumes nothing else), with the projections absorbed.  Per head h, with
 // q = Wq_h x0 + bq_h:   score_h[t] = q . (Wk_h x_t + bk_h) = (M_h x0 + m_h) . x_t + const   (const cancels in the softmax)
 //                       M_h = Wk_h^T Wq_h (128x128),  m_h = Wk_h^T bq_h

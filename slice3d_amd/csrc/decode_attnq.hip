@@ -433,13 +433,16 @@ static int launch_attn_q_any(float* X, long groups, int T, const LayerPtrs& w, h
     const size_t lds = (size_t)(4 * AQ3_SLOT_HALFS) * 2 + 768 * 4;   // 64 KiB ring + the small vectors
     static std::atomic<unsigned long long> attr_done{0};
     TRY_RET(s3d_set_max_lds(attr_done, {(const void*)attn_layer_q_kernel<false, false>, (const void*)attn_layer_q_kernel<true, false>,
-                                        (const void*)attn_layer_q_kernel<false, true>, (const void*)attn_layer_q_kernel<true, false, true>}, lds));
+                                        (const void*)attn_layer_q_kernel<false, true>, (const void*)attn_layer_q_kernel<true, true>,
+                                        (const void*)attn_layer_q_kernel<true, false, true>}, lds));
     const long blocks = 2 * groups < 4096 ? 2 * groups : 4096;
     const _Float16* img = reinterpret_cast<const _Float16*>(bf16 ? w.aqb16 : w.aq16);
     S3D_CHECK_ARG(!bf16 || (single_pass && !ta && w.aqb16), "attn_q: the bf16 mode is a single-pass inference mode with its own image");
     const AttnTrainArgs none = {};
     if (bf16)
         hipLaunchKernelGGL((attn_layer_q_kernel<true, false, true>), dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T, img, w, none);
+    else if (ta && single_pass)   // the training step's single-pass f16 throughput mode (round 6)
+        hipLaunchKernelGGL((attn_layer_q_kernel<true, true>), dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T, img, w, *ta);
     else if (ta)
         hipLaunchKernelGGL((attn_layer_q_kernel<false, true>), dim3((unsigned)blocks), dim3(256), lds, stream, X, groups, T, img, w, *ta);
     else if (single_pass)
@@ -454,10 +457,10 @@ int launch_attn_layer_q(float* X, long groups, int T, const LayerPtrs& w, hipStr
 }
 // training forward of the block (see the kernel): xin -> y = LN1(u), u = xin + dropout1(out_proj(MHA(xin))), o = MHA output
 int launch_attn_layer_q_train(const float* xin, float* y, float* u, float* o, long groups, int T, const LayerPtrs& w,
-                              const DropCfg& d0, const DropCfg& d1, hipStream_t stream) {
+                              const DropCfg& d0, const DropCfg& d1, hipStream_t stream, bool single) {
     S3D_CHECK_ARG(xin && y && u && o, "attn_q train: null buffer");
     AttnTrainArgs ta = {xin, u, o, d0, d1};
-    return launch_attn_q_any(y, groups, T, w, stream, false, &ta);
+    return launch_attn_q_any(y, groups, T, w, stream, single, &ta);
 }
 
 // in_proj (384,128) / out_proj (128,128) -> fragment pairs (hi 512 halfs | lo 512 halfs each) of the query-major kernel

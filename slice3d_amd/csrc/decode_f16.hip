@@ -732,7 +732,7 @@ int launch_ffn_layer_f16x3(float* X, long rows, const LayerPtrs& w, const float*
 // training forward: y = LN2(u), u = x + dropout(FFN(x)); y -> Yout, u -> Uout, activity bits -> Mout
 int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, unsigned* Mout, long rows,
                                  const LayerPtrs& w, const DropCfg& drop_hidden, const DropCfg& drop_out,
-                                 hipStream_t stream, float* imgd, float* imgr) {
+                                 hipStream_t stream, float* imgd, float* imgr, bool single) {
     if (rows <= 0) return 0;
     S3D_CHECK_ARG(w.wf16 != nullptr, "ffn train f16x3: no packed f16 image");
     S3D_CHECK_ARG((imgd == nullptr) == (imgr == nullptr), "ffn train f16x3: both operand images or none");
@@ -740,14 +740,15 @@ int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, uns
     const FfnBwdArgs ba = {};
     const dim3 grid((unsigned)((rows + PIPE_ROWS_PER_WG - 1) / PIPE_ROWS_PER_WG)), block(PIPE_THREADS);
     S3D_CHECK_ARG((drop_hidden.p > 0.f) == (drop_out.p > 0.f), "ffn train f16x3: hidden / output dropout must be on or off together");
-    if (drop_hidden.p > 0.f)
-        hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<2, false>), grid, block, 0, stream, Xin, Yout, rows,
-                           reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr,
-                           ta, ba, 0);
-    else
-        hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<3, false>), grid, block, 0, stream, Xin, Yout, rows,
-                           reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr,
-                           ta, ba, 0);
+#define FFN_TRAIN_LAUNCH(MODE, SGL)                                                                                             \
+    hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<MODE, SGL>), grid, block, 0, stream, Xin, Yout, rows,                       \
+                       reinterpret_cast<const _Float16*>(w.wf16), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr, ta, ba, 0)
+    if (drop_hidden.p > 0.f) {
+        if (single) FFN_TRAIN_LAUNCH(2, true); else FFN_TRAIN_LAUNCH(2, false);
+    } else {
+        if (single) FFN_TRAIN_LAUNCH(3, true); else FFN_TRAIN_LAUNCH(3, false);
+    }
+#undef FFN_TRAIN_LAUNCH
     S3D_LAUNCH_CHECK();
     return 0;
 }
@@ -762,7 +763,7 @@ int launch_ffn_layer_train_f16x3(const float* Xin, float* Yout, float* Uout, uns
 // ---------------------------------------------------------------------------------------------
 int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* M, float* DX, long rows,
                             const float* timg, float gate_scale, hipStream_t stream, float* imgd, float* imgr,
-                            const DropCfg* dy_mask) {
+                            const DropCfg* dy_mask, bool single) {
     if (rows <= 0) return 0;
     S3D_CHECK_ARG((imgd == nullptr) == (imgr == nullptr), "ffn bwd dx: both operand images or none");
     const FfnTrainArgs ta = {};
@@ -770,9 +771,14 @@ int launch_ffn_bwd_dx_f16x3(const float* DY, const float* Dres, const unsigned* 
     if (dy_mask) ba.dq = *dy_mask;
     const LayerPtrs w = {};
     const dim3 grid((unsigned)((rows + PIPE_ROWS_PER_WG - 1) / PIPE_ROWS_PER_WG)), block(PIPE_THREADS);
-    hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<4, false>), grid, block, 0, stream, DY, DX, rows,
-                       reinterpret_cast<const _Float16*>(timg), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr, ta,
-                       ba, 0);
+    if (single)
+        hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<4, true>), grid, block, 0, stream, DY, DX, rows,
+                           reinterpret_cast<const _Float16*>(timg), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr, ta,
+                           ba, 0);
+    else
+        hipLaunchKernelGGL((ffn_layer_f16x3_pipe_kernel<4, false>), grid, block, 0, stream, DY, DX, rows,
+                           reinterpret_cast<const _Float16*>(timg), w, nullptr, nullptr, nullptr, 1.f, 1L, 1L, 0L, nullptr, ta,
+                           ba, 0);
     S3D_LAUNCH_CHECK();
     return 0;
 }

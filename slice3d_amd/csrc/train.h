@@ -29,6 +29,7 @@ struct WgradArgs {
                           // split-precision linear kernel adds them up while it converts dY (no second pass over dY);
                           // the other kernels run launch_colsum with `bias_partial` as its workspace
     float* bias_partial;
+    int single;           // with prec = S3D_PREC_F16X3: only the hi * hi products (S3D_PREC_F16 training throughput mode; linear kernel only)
 };
 int launch_wgrad(const WgradArgs& a, hipStream_t stream);
 
@@ -52,6 +53,7 @@ struct FfnWgradArgs {
     int accumulate;
     float* partial;         // workspace
     size_t partial_floats;
+    int single;             // 1: single-pass f16 (S3D_PREC_F16 throughput mode of the training step): hi * hi products only
 };
 int launch_ffn_wgrad_rec(const FfnWgradArgs& a, hipStream_t stream);
 // W: element (hid, k) at w[hid*sh + k*sk]  ->  image [128 hid tiles][4][64 lanes][8] halfs hi, then lo
@@ -193,6 +195,6 @@ int launch_copy_cols(const float* src, float* dst, int rows, int csrc, int cdst,
 // fused attention-core backward with Q / K / V recomputed on chip (train_attnq.hip): x, dO (rows x 128) -> dQKV (rows x 384)
 struct LayerPtrs;
 int launch_attn_bwd_q(const float* x, const float* d_o, float* dqkv, long groups, int T, const LayerPtrs& w,
-                      const DropCfg& d0, hipStream_t stream);
+                      const DropCfg& d0, hipStream_t stream, bool single = false);
 int launch_emb_grad(const float* dF0, const float* w, float* demds, int B, int ns, int npix, hipStream_t stream);
 #define CS_CHUNKS_MAX 512

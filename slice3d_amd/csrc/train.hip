@@ -260,15 +260,18 @@ __global__ __launch_bounds__(256) void wgrad_lin_f16x3_kernel(const WgradArgs a,
             bh[j] = *reinterpret_cast<const wl_half8*>(&s_t[1][0][o]);
             bl[j] = *reinterpret_cast<const wl_half8*>(&s_t[1][1][o]);
         }
-        // three product kinds, each swept over the 16 independent accumulators
+        // three product kinds, each swept over the 16 independent accumulators (a.single, the S3D_PREC_F16 training throughput
+        // mode: the hi * hi sweep alone — a uniform branch; this kernel is bound by its operand staging, not by its MFMAs)
+        if (!a.single) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -337,7 +340,9 @@ __device__ __forceinline__ void fwr_dma(const _Float16* gblk, _Float16* lbuf, in
     __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
 }
 
-template <int COLSUM>
+// SINGLE (round 6, the training step's single-pass f16 throughput mode, S3D_PREC_F16): only the hi * hi product of every split
+// — the low halves of the images are neither read from LDS nor multiplied; not fp32-class, never the headline mode.
+template <int COLSUM, bool SINGLE>
 __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArgs a, int steps_per_split, int nsplit) {
     __shared__ __attribute__((aligned(16))) _Float16 s_t[2][2][FWR_BLK_HALFS];   // [buffer][D^T | R] hi|lo images, 64 KiB
     __shared__ __attribute__((aligned(16))) unsigned s_m[2][128];                 // [buffer][g'][row] mask dwords of hb
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
             for (int u = 0; u < 4; ++u) {
                 const size_t o = ((size_t)(tile * 4 + u) * 64 + lane) * 8;
                 wh[e][u] = *reinterpret_cast<const wl_half8*>(img + o);
-                wlo[e][u] = *reinterpret_cast<const wl_half8*>(img + (size_t)S3D_FFN * 128 + o);
+                wlo[e][u] = SINGLE ? wh[e][u] : *reinterpret_cast<const wl_half8*>(img + (size_t)S3D_FFN * 128 + o);
             }
             bv[e] = a.bias ? a.bias[tile * 16 + m] : 0.f;
         }
@@ -434,12 +439,25 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
             wl_half8 xh[2][2], xl[2][2];
             {
                 const unsigned xa = x_addr0[0] + boff;
-                FWR_READ(xh[0][0], xa, 0); FWR_READ(xl[0][0], xa, 8192); FWR_READ(xh[0][1], xa, 4096); FWR_READ(xl[0][1], xa, 12288);
+                if (SINGLE) {
+                    FWR_READ(xh[0][0], xa, 0); FWR_READ(xh[0][1], xa, 4096);
+                } else {
+                    FWR_READ(xh[0][0], xa, 0); FWR_READ(xl[0][0], xa, 8192); FWR_READ(xh[0][1], xa, 4096); FWR_READ(xl[0][1], xa, 12288);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int cs = u & 1, ns = cs ^ 1;
-                if (u < 3) {
+                if (SINGLE) {   // (half the reads: the counted waits leave the next step's two / the A fragment's one outstanding)
+                    if (u < 3) {
+                        const unsigned xa = x_addr0[u + 1] + boff;
+                        FWR_READ(xh[ns][0], xa, 0); FWR_READ(xh[ns][1], xa, 4096);
+                        FWR_WAIT2(2, xh[cs][0], xh[cs][1]);
+                    } else {
+                        FWR_READ(ah[0], aa, 0);
+                        FWR_WAIT2(1, xh[cs][0], xh[cs][1]);
+                    }
+                } else if (u < 3) {
                     const unsigned xa = x_addr0[u + 1] + boff;
                     FWR_READ(xh[ns][0], xa, 0); FWR_READ(xl[ns][0], xa, 8192); FWR_READ(xh[ns][1], xa, 4096); FWR_READ(xl[ns][1], xa, 12288);
                     FWR_WAIT4(4, xh[cs][0], xl[cs][0], xh[cs][1], xl[cs][1]);
@@ -447,14 +465,16 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
                     FWR_READ(ah[0], aa, 0); FWR_READ(al[0], aa, 8192);
                     FWR_WAIT4(2, xh[cs][0], xl[cs][0], xh[cs][1], xl[cs][1]);
                 }
+                if (!SINGLE) {
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wlo[e][u], z[rt][e], 0, 0, 0);
+                        for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[cs][rt], wlo[e][u], z[rt][e], 0, 0, 0);
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
+                        for (int e = 0; e < 2; ++e) z[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[cs][rt], wh[e][u], z[rt][e], 0, 0, 0);
+                }
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -485,16 +505,25 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_rec_kernel(const FfnWgradArg
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int cs = i & 1, ns = cs ^ 1;
-            if (i < 7) {
+            if (SINGLE) {
+                if (i < 7) {
+                    FWR_READ(ah[ns], aa, (i + 1) * 1024);
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ah[cs]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[cs]));
+                }
+            } else if (i < 7) {
                 FWR_READ(ah[ns], aa, (i + 1) * 1024); FWR_READ(al[ns], aa, (i + 1) * 1024 + 8192);
                 FWR_WAIT2(2, ah[cs], al[cs]);
             } else {
                 FWR_WAIT2(0, ah[cs], al[cs]);
             }
+            if (!SINGLE) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zl[e], acc[i][e], 0, 0, 0);
+                for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zl[e], acc[i][e], 0, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cs], zh[e], acc[i][e], 0, 0, 0);
+                for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cs], zh[e], acc[i][e], 0, 0, 0);
+            }
 #pragma unroll
             for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cs], zh[e], acc[i][e], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -562,10 +591,15 @@ int launch_ffn_wgrad_rec(const FfnWgradArgs& a, hipStream_t stream) {
     const int spw = (int)((total_steps + splits - 1) / splits);
     splits = (total_steps + spw - 1) / spw;
     dim3 grid((unsigned)((S3D_FFN / 128) * splits));
-    if (a.bias_out)
-        hipLaunchKernelGGL((ffn_wgrad_rec_kernel<1>), grid, dim3(256), 0, stream, a, spw, (int)splits);
+    if (a.single) {
+        if (a.bias_out)
+            hipLaunchKernelGGL((ffn_wgrad_rec_kernel<1, true>), grid, dim3(256), 0, stream, a, spw, (int)splits);
+        else
+            hipLaunchKernelGGL((ffn_wgrad_rec_kernel<0, true>), grid, dim3(256), 0, stream, a, spw, (int)splits);
+    } else if (a.bias_out)
+        hipLaunchKernelGGL((ffn_wgrad_rec_kernel<1, false>), grid, dim3(256), 0, stream, a, spw, (int)splits);
     else
-        hipLaunchKernelGGL((ffn_wgrad_rec_kernel<0>), grid, dim3(256), 0, stream, a, spw, (int)splits);
+        hipLaunchKernelGGL((ffn_wgrad_rec_kernel<0, false>), grid, dim3(256), 0, stream, a, spw, (int)splits);
     S3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(ffn_wgrad_rec_reduce_kernel, dim3(1024), dim3(256), 0, stream, a.partial, (int)splits, a.out,
                        a.transpose_out, a.accumulate);

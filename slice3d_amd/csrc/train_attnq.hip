@@ -53,6 +53,11 @@ __device__ __forceinline__ half4q transpose16(const half4q a, const half4q ident
     asm volatile("s_nop 15" ::: "memory");          \
     __builtin_amdgcn_sched_barrier(0);
 
+// SINGLE: S3D_PREC_F16 training throughput mode (round 6): one f16 MFMA per product of the Q / K / V recomputation (the kernel's
+// projection phases, 90 % of its MFMAs).  The 13 x 13 core backward keeps all three products in every mode: dS = P (dP - sum P dP)
+// cancels to a small difference of similar numbers (the token rows of one query are alike), and with single-pass dP the step's U-Net
+// gradients came out 9x their norm off (profiles/r06_train_f16.md) — with the core exact, 4e-3.
+template <bool SINGLE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdArgs a, long groups, int T, const _Float16* wimg,
                                                              const LayerPtrs w) {
     extern __shared__ __attribute__((aligned(16))) _Float16 s_win[];   // ring 4 x 16 KiB, then the in_proj bias
@@ -173,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdArgs a,
             dma_piece(nph, nbuf, U);                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
-        d[0][j] = mfma3q<false>(fh[B][j], fl[B][j], xh[0][U], xl[0][U], (U) == 0 ? c0[j] : d[0][j]);         \
-        d[1][j] = mfma3q<false>(fh[B][j], fl[B][j], xh[1][U], xl[1][U], (U) == 0 ? c0[j] : d[1][j]);         \
+        d[0][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xh[0][U], xl[0][U], (U) == 0 ? c0[j] : d[0][j]);         \
+        d[1][j] = mfma3q<SINGLE>(fh[B][j], fl[B][j], xh[1][U], xl[1][U], (U) == 0 ? c0[j] : d[1][j]);         \
     }                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);
                 AQB_STEP_READS(0, 0)
@@ -302,16 +307,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdArgs a,
 
 // x (rows x 128), dO (rows x 128) -> dQKV (rows x 384); w.aq16 = the forward's fragment image, w.inb the in_proj bias
 int launch_attn_bwd_q(const float* x, const float* d_o, float* dqkv, long groups, int T, const LayerPtrs& w,
-                      const DropCfg& d0, hipStream_t stream) {
+                      const DropCfg& d0, hipStream_t stream, bool single) {
     if (groups <= 0) return 0;
     S3D_CHECK_ARG(T >= 2 && T <= 16 && w.aq16 != nullptr && x && d_o && dqkv, "attn_bwd_q: T %d", T);
     const size_t lds = (size_t)(4 * AQ3_SLOT_HALFS) * 2 + 384 * 4;
     static std::atomic<unsigned long long> attr_done{0};
-    TRY_RET(s3d_set_max_lds(attr_done, {(const void*)attn_bwd_q_kernel}, lds));
+    TRY_RET(s3d_set_max_lds(attr_done, {(const void*)attn_bwd_q_kernel<false>, (const void*)attn_bwd_q_kernel<true>}, lds));
     const long blocks = 2 * groups < 4096 ? 2 * groups : 4096;
     AttnBwdArgs a = {x, d_o, dqkv, d0};
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a, groups, T,
-                       reinterpret_cast<const _Float16*>(w.aq16), w);
+    if (single)
+        hipLaunchKernelGGL(attn_bwd_q_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, a, groups, T,
+                           reinterpret_cast<const _Float16*>(w.aq16), w);
+    else
+        hipLaunchKernelGGL(attn_bwd_q_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, a, groups, T,
+                           reinterpret_cast<const _Float16*>(w.aq16), w);
     S3D_LAUNCH_CHECK();
     return 0;
 }

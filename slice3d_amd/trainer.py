@@ -43,7 +43,10 @@ class HipTrainer:
         self.lib = _lib.load()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.dropout = dropout
-        self.prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}[prec]   # conv / linear GEMMs; wgrad stays fp32
+        # "f32": exact fp32 MFMAs; "f16x3": split precision, fp32-class (the headline mode); "f16" (round 6): THROUGHPUT mode — the
+        # decoder's GEMM kernels run one f16 MFMA per product, everything else as "f16x3" (fp32 master weights, fp32 accumulation,
+        # the same power-of-two backward scale); not fp32-class, reported beside the headline, never instead of it
+        self.prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16": _lib.PREC_F16}[prec]
         self.group = process_group
         self.overlap_all_reduce = overlap_all_reduce
         self.sync_bn = sync_bn          # BatchNorm statistics over the batches of all ranks (train.py --sync_bn)
@@ -251,7 +254,7 @@ class HipTrainer:
     def auto_grad_scale(self, d_sdf):
         """Power-of-two backward scale for the split-precision path from the incoming gradient itself: puts
         max|d sdf| in [8, 16) (one host sync; the fused step knows 1/n in advance).  0 = let the library choose."""
-        if self.prec != _lib.PREC_F16X3 or d_sdf is None:
+        if self.prec not in (_lib.PREC_F16X3, _lib.PREC_F16) or d_sdf is None:
             return 0.0
         mx = float(d_sdf.abs().max())
         if not (mx > 0.0) or mx != mx or mx == float("inf"):

@@ -793,3 +793,42 @@ def test_full_size_fused_train_step_is_finite_and_repeatable():
             worst = max(worst, diff / float(a.norm()))
             assert diff < 1e-5 * float(a.norm()) + 1e-7 * gmax, (k, diff, float(a.norm()), gmax)
     print("full-size fused step: losses %s; U-Net gradients run to run: worst relative difference %.1e" % (l0.tolist(), worst))
+
+
+def test_single_pass_f16_training_mode_tracks_the_split_precision_step():
+    """Round 6: `HipTrainer(prec="f16")` = S3D_PREC_F16 of s3d_train_fwd_bwd, the THROUGHPUT mode of the training step (the decoder's
+    GEMM kernels run one f16 MFMA per product; the 13 x 13 attention core backward, the U-Net, VGG, samplers, reductions, fp32 master
+    weights and the backward scale are the split-precision path's).  Not fp32-class and never the reported train_samples_per_s —
+    this test pins what it is: from identical weights, batch and dropout masks the forward outputs agree to 2e-2, the losses to
+    1e-2 relative, every parameter gradient (pre-BatchNorm biases aside) to 5e-2 relative L2 with a median below 1e-2, everything
+    finite; and twenty Adam steps of both modes from the same start end with the same loss to 10 %."""
+    from slice3d_amd.models import Slices3DRegModel
+    from slice3d_amd.synth import make_feed_dict
+    from slice3d_amd.trainer import HipTrainer
+    from slice3d_amd.weights import load_seeded
+    fd = make_feed_dict(2, 64, 8192, 12, seed=17, device="cuda")
+    res = {}
+    for prec in ("f16x3", "f16"):
+        m = load_seeded(Slices3DRegModel(img_size=64, n_slices=12, mode="train"), 0).cuda()
+        tr = HipTrainer(m, dropout=0.1, seed=11, prec=prec)
+        losses, sdf, rec = tr.forward_backward(fd, want_outputs=True)
+        res[prec] = (losses.cpu().numpy().copy(), sdf.clone(), rec.clone(),
+                     {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    l3, s3, r3, g3 = res["f16x3"]
+    l1, s1, r1, g1 = res["f16"]
+    assert torch.isfinite(s1).all() and all(torch.isfinite(v).all() for v in g1.values())
+    assert (s1 - s3).abs().max() < 2e-2 and torch.equal(r1, r3)      # the U-Net is the split-precision path in both modes
+    for i in range(3):
+        assert abs(l1[i] - l3[i]) < 1e-2 * abs(l3[i]) + 1e-6, (i, l1, l3)
+    dev = sorted((float((g1[k] - g).norm() / g.norm()), k) for k, g in g3.items() if k not in PRE_BN_BIASES and float(g.norm()) > 0)
+    assert len(dev) > 120 and dev[-1][0] < 5e-2 and dev[len(dev) // 2][0] < 1e-2, (dev[-3:], dev[len(dev) // 2])
+    end = {}
+    for prec in ("f16x3", "f16"):
+        m = load_seeded(Slices3DRegModel(img_size=64, n_slices=12, mode="train"), 0).cuda()
+        tr = HipTrainer(m, dropout=0.1, seed=3, prec=prec)
+        for _ in range(20):
+            lp = tr.train_step(fd)[0]
+        end[prec] = lp
+    assert end["f16"] == end["f16"] and abs(end["f16"] - end["f16x3"]) < 0.1 * abs(end["f16x3"]), end
+    print("single-pass f16 training mode: worst gradient deviation %.2e (%s), median %.2e; loss_pred after 20 steps %.4f vs %.4f"
+          % (dev[-1][0], dev[-1][1], dev[len(dev) // 2][0], end["f16"], end["f16x3"]))
