@@ -64,6 +64,9 @@ _BUILD_FLAGS = [
                                                "batches are staged on the GPU instead of decoding 13 PNGs per sample")),
     ("shards_in_hbm", dict(action=_BOOL, help="[build] keep the packed split resident in GPU memory")),
     ("sync_bn", dict(action=_BOOL, help="[build] data-parallel training: BatchNorm statistics over all ranks")),
+    ("prec", dict(type=str, default="f32", choices=["f32", "f16x3", "f16"],
+                  help="[build] train.py: arithmetic of the step's GEMMs — f32 (exact fp32 MFMAs), f16x3 (split precision, fp32-class, "
+                       "~1.5x faster) or f16 (single-pass throughput mode of the decoder, a further 1.3x, not fp32-class)")),
 ]
 
 

@@ -92,7 +92,7 @@ def train(args):
         for t in list(model.parameters()) + list(model.buffers()):
             torch.distributed.broadcast(t.data, 0)
     trainer = HipTrainer(model, lr=args.lr, dropout=args.dropout, seed=args.seed * 65537 + rank,   # per-rank dropout streams
-                         sync_bn=args.sync_bn)
+                         sync_bn=args.sync_bn, prec=args.prec)
     epoch_latest, n_iter = 0, 0
     if args.resume:
         ckpts = glob.glob(os.path.join(dir_ckpt, "*"))
