@@ -162,12 +162,12 @@ def cpu_baseline(sd, fd, n_slices, n_sample, gpu_sdf, runs=5):
     # (how the figure is formed: DESIGN.md section 5 "bench line glossary")
     return {
         "value": n_qry / (t_unet + per_q * n_qry), "unit": "query-points/s", "cores": best_n, "kind": "port",
-        "host_cores": host, "cpu_model": _cpu_model(),
-        "sample": "oracle/ref_cpu.py: U-Net at %d^2 + %d of %d queries/object; median of %d; best thread count of a probe"
+        "cpu_model": _cpu_model(),
+        "sample": "oracle/ref_cpu.py: U-Net at %d^2 + %d of %d queries/object; median of %d; best of a thread probe"
                   % (fd_cpu["img_input"].shape[-1], n_sample, n_qry, runs),
         "stages": {"unet_s": t_unet, "sample_us_per_query": t_sample / n_sample * 1e6,
                    "decoder_tokens_us_per_query": t_tokens / n_sample * 1e6},
-        "thread_probe_s_per_256_queries": probe,
+        "thread_probe_s": {k: float("%.3g" % v) for k, v in probe.items()},   # seconds per 256 queries at each thread count tried
     }, err
 
 
@@ -543,7 +543,6 @@ def main():
         lc4 = {k: v.repeat(4, 1, 1, 1).contiguous() for k, v in lc.items()}
         lms4, _ = time_ldm(lx4, lt4, lc4)
         ldm["batch4_ms_per_step"] = lms4
-        ldm["batch4_tflops_algorithmic"] = 4 * 0.222 / lms4 * 1e3
         # the precision configs[4] names: single-pass f16 convolutions (prec='f16'), with its deviation from the headline mode
         if args.prec == "f16x3":
             with torch.no_grad():
@@ -554,7 +553,6 @@ def main():
             with torch.no_grad():
                 o16 = um(lx, lt, c_fmaps=lc)
             ldm["f16_ms_per_step"] = lms16
-            ldm["f16_tflops_algorithmic"] = 0.222 / lms16 * 1e3
             ldm["f16_max_abs_diff_vs_headline_mode"] = float((o16 - ref_out).abs().max())
             del o16, ref_out
         del um, lx, lc, lx4, lc4
@@ -571,7 +569,6 @@ def main():
             lms, lms4, lms128 = (float(v) for v in t.tolist())
             ldm["ms_per_step"], ldm["batch4_ms_per_step"] = lms, lms4
             ldm["tflops_algorithmic"] = 0.222 / lms * 1e3
-            ldm["batch4_tflops_algorithmic"] = 4 * 0.222 / lms4 * 1e3
         ldm["latent128_ms_per_step"] = lms128
         ldm["n_gpus"] = world
         ldm["steps_per_s_all_gpus"] = world / (lms * 1e-3)
@@ -664,8 +661,8 @@ def main():
             trainer.train_step(tfd16)
         torch.cuda.synchronize()
         ms16 = (time.perf_counter() - t1) / args.train_f16_steps * 1e3
-        train_f16 = {"ms_per_step": ms16, "samples_per_s": args.batch / (ms16 * 1e-3), "dtype": "f16 (decoder GEMMs single-pass; rest f16x3)",
-                     "grad_rel_dev_vs_f16x3": {"median": dev[len(dev) // 2], "p95": dev[int(len(dev) * 0.95)], "tensors": len(dev)}}
+        train_f16 = {"ms_per_step": ms16, "samples_per_s": args.batch / (ms16 * 1e-3), "dtype": "f16 decoder, f16x3 rest",
+                     "grad_rel_dev_vs_f16x3": {"median": dev[len(dev) // 2], "p95": dev[int(len(dev) * 0.95)]}}
         del trainer, tmodel, tfd16
 
     if rank == 0:
@@ -719,11 +716,10 @@ def main():
                        "objects_per_step": world * args.batch, "parallelism": "objects x%d (no collective)" % world},
             "ms_per_step_rank_min_max": [min(rank_ms), max(rank_ms)],
             "roofline": {"kernel": ("ffn_layer_kernel<false>" if args.prec == "f32" else "ffn_layer_f16x3_pipe_kernel<0>")
-                                   + " (decoder FFN 128->2048->128 + residual + LN2)",
+                                   + " (decoder FFN + residual + LN2)",
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "note": ("algorithmic FLOPs; the pipe executes 3x (f16x3); power-capped, DESIGN.md s5"
-                                  if args.prec != "f32" else "exact fp32 MFMA"),
+                         "note": "f16x3: pipe executes 3x" if args.prec != "f32" else "exact fp32 MFMA",
                          "mfma_pipe_tflops": achieved * (3 if args.prec != "f32" else 1),
                          "traffic_source": traffic_src,
                          "avg_launch_ms": ffn_ms, "launches": counts["ffn_layer"],
@@ -732,11 +728,11 @@ def main():
                 sample_roof,
                 {"kernel": "U-Net conv stack", "bound": "mfma", "achieved": unet_tf, "peak": peak, "unit": "TFLOP/s",
                  "frac": unet_tf / peak},
-                {"kernel": "attention stage (2 layers + absorbed last layer)", "bound": "mfma",
+                {"kernel": "attention stage (2 layers + fused last layer)", "bound": "mfma",
                  "achieved": attn_tf, "peak": peak, "unit": "TFLOP/s", "frac": attn_tf / peak},
                 # the fused feature-sample + fc_s kernel of the decode path (north_star's "feature-sample kernel" inside the pipeline): token
                 # tensor written once (rows x 512 B) + the five pyramid levels of the B x n_slices images read once, over its stage time
-                {"kernel": "sample_tokens_kernel (project + 5-level sample + fc_p / fc_s -> tokens)", "bound": "hbm",
+                {"kernel": "sample_tokens_kernel (fused feature-sample + fc_s)", "bound": "hbm",
                  "achieved": tok_bytes / (stage_ms["sample_tokens"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                  "frac": tok_bytes / (stage_ms["sample_tokens"] * 1e-3) / 1e9 / 8000.0, "kernel_ms": stage_ms["sample_tokens"]},
             ],
