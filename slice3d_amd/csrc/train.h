@@ -173,10 +173,17 @@ struct SampleBwdArgs {
                              // SORTED slot, filled by a pre-pass of launch_sample_bwd — the tiled kernel then loads a slot's
                              // (gx, gy) with one coalesced read instead of walking perm -> qry -> rotate -> project (three
                              // dependent global loads) 2 x n_slices times per query
+    float* partial;          // optional scratch of sample_bwd_partial_floats(size, B, n_slices) floats (with perm, Slices3DRegModel
+                             // levels): the atomic-free form (train_sbd.hip) — every tile writes its footprints to its own slot and
+                             // a second kernel adds the slots into the maps in a fixed order: bit-reproducible gradients
     int gt;                  // Slices3DGTModel levels: dproj[0..2] + dfine[0] are the four folded 128-ch maps
                              // (S/16 ... S/2), dfine[1] the raw 64-ch conv1_2 map, ws34_t the [4][8] image of Wraw^T
 };
 int launch_sample_bwd(const SampleBwdArgs& a, hipStream_t stream);
+// train_sbd.hip: floats of SampleBwdArgs::partial (0: this size runs the atomic kernels); 1 = launched, 0 = not covered, < 0 error
+size_t sample_bwd_partial_floats(int S, long batch, int n_slices);
+bool sample_bwd_dense_covers(const SampleBwdArgs& a);
+int launch_sample_bwd_dense(const SampleBwdArgs& a, hipStream_t stream);
 int launch_tok0_copy(float* full, float* compact, long groups, int T, int dir, int width, hipStream_t stream);
 // perm (optional): row slot -> query index within the batch item (sorted token order)
 int launch_fc_out_fwd(const float* x, const float* w, const float* b, float* sdf, long rows, long gpb, long n_qry,

@@ -732,6 +732,20 @@ static int launch_sample_bwd_t(const SampleBwdArgs& a, hipStream_t stream) {
 
 int launch_sample_bwd(const SampleBwdArgs& a, hipStream_t stream) {
     if (a.groups <= 0) return 0;
+    if (sample_bwd_dense_covers(a)) {
+        if (a.gxy) {
+            const long batch = a.groups / a.groups_per_batch, total = batch * a.n_qry;
+            hipLaunchKernelGGL(sbt_project_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0,
+                               stream, a, (int)batch);
+            S3D_LAUNCH_CHECK();
+        }
+        const int r = launch_sample_bwd_dense(a, stream);
+        if (r < 0) {
+            s3d_set_error("sample_bwd_dense launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return 1;
+        }
+        if (r > 0) return 0;
+    }
     return a.gt ? launch_sample_bwd_t<1>(a, stream) : launch_sample_bwd_t<0>(a, stream);
 }
 

@@ -1,0 +1,454 @@
+// train_sbd.hip — pyramid-sampling backward of Slices3DRegModel WITHOUT float atomics (round 6): the same gradients from the same
+// inputs bit for bit, run after run.  Replaces sample_bwd_tiled_kernel<0> (train2.hip) when the caller hands a partial-sum scratch
+// (SampleBwdArgs::partial); the reference operation is the backward of the five F.grid_sample calls + fc_s of
+// /root/reference/reg_slices/src/models.py:69-81 (bilinear, align_corners=True).
+//
+// One workgroup per (object, slice image, 16 x 16-bin tile of the locality sort), eight waves.  ALL five levels are dense products
+// on the fp32 MFMA with the accumulators stationary in registers:
+//     P_l^T[c][pix] = sum_q dX[q][c] * w_l[q][pix]          (c = 128 token channels, pix = a pixel of the tile's footprint at level l)
+// wave j owns channels 16j .. 16j+15 of every footprint pixel; a k-step is four queries (A[c][q] = the staged dX rows of the chunk,
+// B[q][pix] = the query's bilinear weight on that pixel).  The three folded levels (3 x 3 / 4 x 4 / 6 x 6 pixels at 256^2) are five
+// 16-pixel tiles that every k-step visits.  The two RAW levels (S/2: 64 channels, S: 32 channels; footprints 10 x 10 and 18 x 18)
+// are cut into 4 x 4-pixel blocks — 3 x 3 and 5 x 5 of them — and a k-step visits only the rows x columns of blocks its four
+// queries touch (two wave-uniform bit masks from the staging pass: sorted neighbours share their blocks, ~4 of 34 per step).
+// The raw levels' projection through W_raw^T (fc_s[:, 896:992]) is applied AFTERWARDS, once per footprint pixel instead of once per
+// query: d raw_l[pix][c'] = sum_c P_l[pix][c] W^T[c][c'] — the accumulators go through LDS (a pixel's 128 channels are spread over
+// the eight waves) and come back as rows of the same product the per-query form ran (f16 hi/lo x 3 on the f16 MFMA, or fp32).
+// The round-5 kernel added 384 values per (query, slice) to LDS with ds_add_f32 (~3 cycles per lane: 3/4 of its 8.8 ms).
+//
+// No global atomics either: a workgroup writes its footprints to ITS slot of the partial scratch ([object][slice][tile][G.ptotal]
+// floats) and sbd_reduce_kernel adds, for every pixel of the five gradient maps, the slots of the tiles whose footprint holds it, in
+// ascending tile order.  (A tap outside its tile's footprint cannot occur for the sizes launch_sample_bwd accepts — the tile's bins
+// ARE level-4 pixels and the coarser footprints' borders never fall on integers, sbd_fits — but the staging pass still handles it:
+// such a query's row goes to the maps directly with global atomics, S3D_SBD_SLOW_MOD forces that path for tests.)
+#include "train.h"
+
+#define SBD_THREADS 512
+#define SBD_CHUNK 64          // queries per staged chunk = 16 k-steps
+#define SBD_ROW 144           // floats per staged dX row: the four queries of a k-step sit 16 banks apart
+#define SBD_PROW 132          // floats per staged accumulator row of the projection epilogue
+#define SBD_NB3 3             // 4 x 4-pixel blocks per axis, raw level 3 (footprint <= 12)
+#define SBD_NB4 5             //                               raw level 4 (footprint <= 20)
+#define SBD_NBLK (SBD_NB3 * SBD_NB3 + SBD_NB4 * SBD_NB4)
+#define SBD_NACC (5 + SBD_NBLK)
+#define SBD_XFLOATS (8 * 16 * SBD_PROW)   // staging region: >= SBD_CHUNK * SBD_ROW
+
+struct SbdGeom {
+    int W[5], fw[5], cov[5], poff[5];   // level width, tight footprint width, row width of the slot's footprint image, float offset
+    int ptotal;                         // floats per (object, slice, tile) slot
+    int slow_mod;                       // test hook: sorted slots with qs % slow_mod == 0 take the atomic path
+};
+__host__ __device__ static constexpr int sbd_mt0(int l) { return l == 0 ? 0 : l == 1 ? 1 : 2; }
+__host__ __device__ static constexpr int sbd_nmt(int l) { return l < 2 ? 1 : 3; }
+__host__ __device__ static constexpr int sbd_C(int l) { return l < 3 ? 128 : (l == 3 ? 64 : 32); }
+
+__device__ __forceinline__ unsigned sbd_compact8(unsigned v) {
+    v &= 0x5555u;
+    v = (v | (v >> 1)) & 0x3333u;
+    v = (v | (v >> 2)) & 0x0F0Fu;
+    v = (v | (v >> 4)) & 0x00FFu;
+    return v;
+}
+__device__ __forceinline__ unsigned sbd_spread8(unsigned v) {
+    v = (v | (v << 4)) & 0x0F0Fu;
+    v = (v | (v << 2)) & 0x3333u;
+    v = (v | (v << 1)) & 0x5555u;
+    return v;
+}
+// element (k, c') of W_raw^T in the fp32 fragment image (tile u = c' / 16 of the level's first tile u0; common.h's swapped form)
+__device__ __forceinline__ float sbd_wraw(const float* img, int u0, int k, int c) {
+    const int u = u0 + (c >> 4), mm = c & 15;
+    return img[((u * 8 + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + mm) * 4 + (k & 3)];
+}
+
+// d raw[pix][c'] of one 4 x 4-pixel block: rows = the block's 16 pixels (staged accumulators, SBD_PROW floats apart)
+template <bool F16, int L>
+__device__ __forceinline__ void sbd_project_block(const float* __restrict__ rows, const float* __restrict__ s_wt, float* __restrict__ out,
+                                                  int cov, int bx, int by, int lane) {
+    constexpr int C = sbd_C(L), NT = C / 16, U0 = L == 3 ? 0 : 4;
+    const int m = lane & 15, g = lane >> 4;
+    const float* dp = rows + m * SBD_PROW + (F16 ? 8 : 4) * g;
+    f32x4 dt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dt[j] = ld4(dp + (F16 ? 32 * (j >> 1) + 4 * (j & 1) : 16 * j));
+    f32x4 draw[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) draw[u] = zero4();
+    if (F16) {
+        const _Float16* sw = reinterpret_cast<const _Float16*>(s_wt);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {   // k-slot 8g + t of step kk <-> token channel 32 kk + 8g + t
+            const float x8[8] = {dt[2 * kk][0], dt[2 * kk][1], dt[2 * kk][2], dt[2 * kk][3],
+                                 dt[2 * kk + 1][0], dt[2 * kk + 1][1], dt[2 * kk + 1][2], dt[2 * kk + 1][3]};
+            s3d_half8 bh, bl;
+            s3d_split8(x8, bh, bl);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const s3d_half8 fh = *reinterpret_cast<const s3d_half8*>(sw + ((U0 + u) * 4 + kk) * 1024 + lane * 8);
+                const s3d_half8 fl = *reinterpret_cast<const s3d_half8*>(sw + ((U0 + u) * 4 + kk) * 1024 + 512 + lane * 8);
+                draw[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bl, draw[u], 0, 0, 0);
+                draw[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, bh, draw[u], 0, 0, 0);
+                draw[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, bh, draw[u], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) draw[u] = mfma4(ld4(s_wt + (((U0 + u) * 8 + j) * 64 + lane) * 4), dt[j], draw[u]);
+    }
+    float* o = out + ((long)(4 * by + (m >> 2)) * cov + 4 * bx + (m & 3)) * C + 4 * g;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) st4(o + 16 * u, draw[u]);
+}
+
+// one k-step of a raw level: the blocks in (rows of the mask) x (columns of the mask) take the four queries' weights
+template <int NB, int BASE>
+__device__ __forceinline__ void sbd_raw_step(f32x4 (&acc)[SBD_NACC], float xa, int vmask, const int* __restrict__ e, int m) {
+    const int mask = __builtin_amdgcn_readfirstlane(vmask);
+    if (mask == 0) return;
+    const int4 e0 = *reinterpret_cast<const int4*>(e);
+    const int2 e1 = *reinterpret_cast<const int2*>(e + 4);
+    const int cx = (m & 3) - e0.x, cy = (m >> 2) - e0.y;
+    const float wx0 = __builtin_bit_cast(float, e0.z), wx1 = __builtin_bit_cast(float, e0.w);
+    const float wy0 = __builtin_bit_cast(float, e1.x), wy1 = __builtin_bit_cast(float, e1.y);
+#pragma unroll
+    for (int by = 0; by < NB; ++by) {
+        if (!(mask & (256 << by))) continue;
+        const int dy = cy + 4 * by;
+        const float wy = dy == 0 ? wy0 : (dy == 1 ? wy1 : 0.f);
+#pragma unroll
+        for (int bx = 0; bx < NB; ++bx) {
+            if (!(mask & (1 << bx))) continue;
+            const int dx = cx + 4 * bx;
+            const float wx = dx == 0 ? wx0 : (dx == 1 ? wx1 : 0.f);
+            acc[BASE + by * NB + bx] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wx * wy, acc[BASE + by * NB + bx], 0, 0, 0);
+        }
+    }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const SampleBwdArgs a, const SbdGeom G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_wt = smem;                                          // W_raw^T fragment image [6][8] (fp32) or [6][4] hi|lo pairs
+    float* s_x = s_wt + 6 * 8 * 256;                             // the chunk's dX rows; the epilogue's accumulator rows
+    int* s_tidx = reinterpret_cast<int*>(s_x + SBD_XFLOATS);     // [3][SBD_CHUNK][4] folded levels: footprint pixel of each tap, or -1
+    float* s_tw = reinterpret_cast<float*>(s_tidx + 3 * SBD_CHUNK * 4);   // [3][SBD_CHUNK][4] its weight
+    int* s_raw = reinterpret_cast<int*>(s_tw + 3 * SBD_CHUNK * 4);        // [2][SBD_CHUNK][8] raw levels: x0, y0 in the footprint, wx0 wx1 wy0 wy1
+    int* s_mask = s_raw + 2 * SBD_CHUNK * 8;                     // [2][16] block columns | rows << 8 of every k-step
+    const int tile = blockIdx.x & 255;
+    const int ts = (blockIdx.x >> 8) % a.n_slices;
+    const int b = (blockIdx.x >> 8) / a.n_slices;
+    const int* ends = a.bin_ends + (long)b * 65536;
+    const long qs_lo = tile ? ends[256 * tile - 1] : 0, qs_hi = ends[256 * tile + 255];
+    if (qs_lo >= qs_hi) return;   // sbd_reduce_kernel skips the slot of an empty tile
+    {
+        const float* wsrc = F16 ? a.ws34_t16 : a.ws34_t;
+        for (int i = threadIdx.x; i < 6 * 8 * 64; i += SBD_THREADS) st4(s_wt + 4 * i, ld4(wsrc + 4 * i));
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int T = a.n_slices + 1, t = ts + 1;
+    const int tx = (int)sbd_compact8((unsigned)tile), ty = (int)sbd_compact8((unsigned)tile >> 1);
+    const long img = (long)b * a.n_slices + ts;
+    const float* Tm = a.trans + b * 12;
+    auto project_slot = [&](long qs, float& gx, float& gy) {
+        if (a.gxy) {
+            const s3d_float2 g2 = *reinterpret_cast<const s3d_float2*>(a.gxy + 2 * ((long)b * a.n_qry + qs));
+            gx = g2[0]; gy = g2[1];
+            return;
+        }
+        const long q = a.perm[(long)b * a.n_qry + qs];
+        const float* p = a.qry + ((long)b * a.n_qry + q) * 3;
+        float x = p[0], y = p[1], z = p[2];
+        if (a.flip_yz) {
+            y = -y; z = -z;
+        } else if (a.rot) {
+            const float* R = a.rot + b * 9;
+            const float rx = x * R[0] + y * R[3] + z * R[6];
+            const float ry = x * R[1] + y * R[4] + z * R[7];
+            const float rz = x * R[2] + y * R[5] + z * R[8];
+            x = rx; y = ry; z = rz;
+        }
+        const float X = x * Tm[0] + y * Tm[3] + z * Tm[6] + Tm[9];
+        const float Y = x * Tm[1] + y * Tm[4] + z * Tm[7] + Tm[10];
+        const float Z = x * Tm[2] + y * Tm[5] + z * Tm[8] + Tm[11];
+        gx = fminf(fmaxf(2.f * (X / Z - 0.5f), -1.f), 1.f);
+        gy = fminf(fmaxf(2.f * (Y / Z - 0.5f), -1.f), 1.f);
+    };
+    auto row_of = [&](long qs) { return ((((long)b * a.groups_per_batch + (qs >> 4)) * T + t) * S3D_GROUP + (qs & 15)) * 128; };
+    // the chunk's 64 rows x 128 floats, four 16-byte pieces per thread (slots past the tile's end repeat its last row: their
+    // weights are zero, their values must be finite)
+    auto load_chunk = [&](long c0, f32x4 (&xr)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + SBD_THREADS * i;
+            long qs = c0 + (idx >> 5);
+            qs = qs < qs_hi ? qs : qs_hi - 1;
+            xr[i] = ld4(a.dX + row_of(qs) + 4 * (idx & 31));
+        }
+    };
+
+    f32x4 acc[SBD_NACC];
+#pragma unroll
+    for (int i = 0; i < SBD_NACC; ++i) acc[i] = zero4();
+    f32x4 xr[4];
+    load_chunk(qs_lo, xr);
+    for (long c0 = qs_lo; c0 < qs_hi; c0 += SBD_CHUNK) {
+        __syncthreads();   // the previous chunk has been consumed (first pass: s_wt is complete)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + SBD_THREADS * i;
+            st4(s_x + (idx >> 5) * SBD_ROW + 4 * (idx & 31), xr[i]);
+        }
+        if (c0 + SBD_CHUNK < qs_hi) load_chunk(c0 + SBD_CHUNK, xr);
+        if (threadIdx.x < 5 * SBD_CHUNK) {   // thread = (level, query of the chunk): wave l stages level l
+            const int l = threadIdx.x / SBD_CHUNK, qq = threadIdx.x % SBD_CHUNK;
+            const long qs = c0 + qq;
+            const int W = G.W[l], C = l < 3 ? 128 : (l == 3 ? 64 : 32);
+            const int ox = 16 * tx * (W - 1) / 255, oy = 16 * ty * (W - 1) / 255;
+            int ti[4] = {-1, -1, -1, -1};
+            float tw[4] = {0.f, 0.f, 0.f, 0.f};
+            int lx0 = 0, ly0 = 0, mask = 0;
+            float wxy[4] = {0.f, 0.f, 0.f, 0.f};
+            if (qs < qs_hi) {
+                float gx, gy;
+                project_slot(qs, gx, gy);
+                const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+                const float iy = ((gy + 1.f) / 2.f) * (float)(W - 1);
+                const float x0f = floorf(ix), y0f = floorf(iy);
+                const int x0 = (int)x0f, y0 = (int)y0f;
+                const float xe = x0f + 1.f, ye = y0f + 1.f;
+                float wx[2] = {xe - ix, ix - x0f}, wy[2] = {ye - iy, iy - y0f};
+                if (x0 < 0 || x0 >= W) wx[0] = 0.f;
+                if (x0 + 1 < 0 || x0 + 1 >= W) wx[1] = 0.f;
+                if (y0 < 0 || y0 >= W) wy[0] = 0.f;
+                if (y0 + 1 < 0 || y0 + 1 >= W) wy[1] = 0.f;
+                const int cov = G.cov[l];
+                const int rx = x0 - ox, ry = y0 - oy;
+                bool inside = true;   // every tap that carries weight lies in the tile's footprint
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int lx = rx + (k & 1), ly = ry + (k >> 1);
+                    if (wx[k & 1] * wy[k >> 1] != 0.f && !(lx >= 0 && lx < cov && ly >= 0 && ly < cov)) inside = false;
+                }
+                if (G.slow_mod > 0 && qs % G.slow_mod == 0) inside = false;
+                if (inside) {
+                    if (l < 3) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float w = wx[k & 1] * wy[k >> 1];
+                            if (w != 0.f) {
+                                ti[k] = (ry + (k >> 1)) * cov + rx + (k & 1);
+                                tw[k] = w;
+                            }
+                        }
+                    } else {
+                        // (a weightless tap may sit one pixel outside the footprint: it matches no block pixel)
+                        lx0 = rx; ly0 = ry;
+                        wxy[0] = wx[0]; wxy[1] = wx[1]; wxy[2] = wy[0]; wxy[3] = wy[1];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            if (rx + k >= 0 && rx + k < cov) mask |= 1 << ((rx + k) >> 2);
+                            if (ry + k >= 0 && ry + k < cov) mask |= 256 << ((ry + k) >> 2);
+                        }
+                        if (G.slow_mod < 0) mask = 0x1F1F;
+                    }
+                } else {   // never for the accepted sizes (sbd_fits): this thread adds the query's row to the maps itself
+                    const float* xrow = a.dX + row_of(qs);
+                    float* map = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + img * (long)W * W * C;
+                    for (int c = 0; c < C; ++c) {
+                        float v;
+                        if (l < 3) {
+                            v = xrow[c];
+                        } else {
+                            v = 0.f;
+                            for (int k = 0; k < 128; ++k) v = fmaf(xrow[k], sbd_wraw(a.ws34_t, l == 3 ? 0 : 4, k, c), v);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float w = wx[k & 1] * wy[k >> 1];
+                            if (w != 0.f) unsafeAtomicAdd(map + ((long)(y0 + (k >> 1)) * W + x0 + (k & 1)) * C + c, v * w);
+                        }
+                    }
+                }
+            }
+            if (l < 3) {
+                *reinterpret_cast<int4*>(s_tidx + (l * SBD_CHUNK + qq) * 4) = int4{ti[0], ti[1], ti[2], ti[3]};
+                st4(s_tw + (l * SBD_CHUNK + qq) * 4, f32x4{tw[0], tw[1], tw[2], tw[3]});
+            } else {
+                // integers throughout: a small int travelling as a float is a denormal bit pattern (it arrived as 0)
+                int* e = s_raw + ((l - 3) * SBD_CHUNK + qq) * 8;
+                *reinterpret_cast<int4*>(e) = int4{lx0, ly0, __builtin_bit_cast(int, wxy[0]), __builtin_bit_cast(int, wxy[1])};
+                *reinterpret_cast<int2*>(e + 4) = int2{__builtin_bit_cast(int, wxy[2]), __builtin_bit_cast(int, wxy[3])};
+                mask |= __shfl_xor(mask, 1, 64);
+                mask |= __shfl_xor(mask, 2, 64);
+                if ((qq & 3) == 0) s_mask[(l - 3) * 16 + (qq >> 2)] = mask;
+            }
+        }
+        __syncthreads();
+        const int nst = (int)((qs_hi - c0 + 3) / 4 < 16 ? (qs_hi - c0 + 3) / 4 : 16);
+#pragma unroll 1
+        for (int st = 0; st < nst; ++st) {
+            const int qq = 4 * st + g;
+            const float xa = s_x[qq * SBD_ROW + 16 * wave + m];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const int4 ti = *reinterpret_cast<const int4*>(s_tidx + (l * SBD_CHUNK + qq) * 4);
+                const f32x4 tw = ld4(s_tw + (l * SBD_CHUNK + qq) * 4);
+#pragma unroll
+                for (int k = 0; k < sbd_nmt(l); ++k) {
+                    const int pm = m + 16 * k;
+                    const float wb = (ti.x == pm ? tw[0] : 0.f) + (ti.y == pm ? tw[1] : 0.f) + (ti.z == pm ? tw[2] : 0.f) +
+                                     (ti.w == pm ? tw[3] : 0.f);
+                    acc[sbd_mt0(l) + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wb, acc[sbd_mt0(l) + k], 0, 0, 0);
+                }
+            }
+            sbd_raw_step<SBD_NB3, 5>(acc, xa, s_mask[st], s_raw + qq * 8, m);
+            sbd_raw_step<SBD_NB4, 5 + SBD_NB3 * SBD_NB3>(acc, xa, s_mask[16 + st], s_raw + (SBD_CHUNK + qq) * 8, m);
+        }
+    }
+
+    // ---- the slot: [level][footprint pixel][C_l] ----
+    float* slot = a.partial + ((img * 256 + tile) * (long)G.ptotal);
+    // folded levels straight from the registers: D[row = channel 16 wave + 4g + i][col = pixel 16k + m]
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const int npx = G.fw[l] * G.fw[l];
+#pragma unroll
+        for (int k = 0; k < sbd_nmt(l); ++k) {
+            const int pix = 16 * k + m;
+            if (pix < npx) st4(slot + G.poff[l] + (long)pix * 128 + 16 * wave + 4 * g, acc[sbd_mt0(l) + k]);
+        }
+    }
+    // raw levels: eight blocks per round through LDS (block = 16 pixel rows of 128 channels), one block per wave back out
+#pragma unroll
+    for (int r = 0; r < (SBD_NBLK + 7) / 8; ++r) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (8 * r + k < SBD_NBLK) st4(s_x + (k * 16 + m) * SBD_PROW + 16 * wave + 4 * g, acc[5 + 8 * r + k]);
+        __syncthreads();
+        const int blk = 8 * r + wave;
+        if (blk < SBD_NB3 * SBD_NB3) {
+            sbd_project_block<F16, 3>(s_x + wave * 16 * SBD_PROW, s_wt, slot + G.poff[3], G.cov[3], blk % SBD_NB3, blk / SBD_NB3, lane);
+        } else if (blk < SBD_NBLK) {
+            const int bi = blk - SBD_NB3 * SBD_NB3;
+            sbd_project_block<F16, 4>(s_x + wave * 16 * SBD_PROW, s_wt, slot + G.poff[4], G.cov[4], bi % SBD_NB4, bi / SBD_NB4, lane);
+        }
+    }
+}
+
+// map[l][img][y][x][c] += sum over the tiles whose footprint holds (x, y), ascending (ty, tx), of their slot's value
+__global__ __launch_bounds__(256) void sbd_reduce_kernel(const SampleBwdArgs a, const SbdGeom G, int batch) {
+    const long n_img = (long)batch * a.n_slices;
+    long lvl_end[5];
+    {
+        long s = 0;
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            s += n_img * G.W[l] * G.W[l] * (sbd_C(l) / 4);
+            lvl_end[l] = s;
+        }
+    }
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < lvl_end[4]; idx += (long)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (idx >= lvl_end[l]) ++l;
+        const long r = idx - (l ? lvl_end[l - 1] : 0);
+        const int W = G.W[l], C = sbd_C(l), c4n = C / 4;
+        const int c4 = (int)(r % c4n);
+        const long p = r / c4n;
+        const int x = (int)(p % W), y = (int)((p / W) % W);
+        const long img = p / ((long)W * W);
+        const int b = (int)(img / a.n_slices);
+        const int* ends = a.bin_ends + (long)b * 65536;
+        const int cov = G.cov[l], den = 16 * (W - 1);
+        // ox(t) = 16 t (W-1) / 255 is non-decreasing in t: candidates are the t with ox(t) in (x - cov, x]
+        const int tx_lo = x - cov >= 0 ? (x - cov) * 255 / den : 0, tx_hi = min(15, (x + 1) * 255 / den);
+        const int ty_lo = y - cov >= 0 ? (y - cov) * 255 / den : 0, ty_hi = min(15, (y + 1) * 255 / den);
+        f32x4 s = zero4();
+        bool any = false;
+        for (int ty = ty_lo; ty <= ty_hi; ++ty) {
+            const int ly = y - 16 * ty * (W - 1) / 255;
+            if (ly < 0 || ly >= cov) continue;
+            for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+                const int lx = x - 16 * tx * (W - 1) / 255;
+                if (lx < 0 || lx >= cov) continue;
+                const int tile = (int)(sbd_spread8((unsigned)tx) | (sbd_spread8((unsigned)ty) << 1));
+                const int lo = tile ? ends[256 * tile - 1] : 0, hi = ends[256 * tile + 255];
+                if (lo >= hi) continue;
+                s += ld4(a.partial + (img * 256 + tile) * (long)G.ptotal + G.poff[l] + ((long)ly * cov + lx) * C + 4 * c4);
+                any = true;
+            }
+        }
+        if (any) {
+            float* o = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + p * C + 4 * c4;
+            st4(o, ld4(o) + s);
+        }
+    }
+}
+
+static bool sbd_geom(int S, SbdGeom& G) {
+    int off = 0;
+    bool fits = true;
+    for (int l = 0; l < 5; ++l) {
+        const int W = S >> (4 - l);
+        G.W[l] = W;
+        G.fw[l] = (16 * (W - 1) + 254) / 255 + 2;
+        if (l < 3) {
+            G.cov[l] = G.fw[l];
+            fits = fits && G.fw[l] * G.fw[l] <= 16 * sbd_nmt(l);
+        } else {
+            const int nb = (G.fw[l] + 3) / 4;
+            G.cov[l] = 4 * (l == 3 ? SBD_NB3 : SBD_NB4);
+            fits = fits && nb <= (l == 3 ? SBD_NB3 : SBD_NB4);
+        }
+        // the tile's bins are level-4 pixels of a 256-wide image ((gx + 1) * 127.5, launch_query_sort); a coarser level's footprint
+        // starts at 16 tx (W-1) / 255: when that is never an integer for tx = 1..15 — or the level IS the 256-wide one, whose
+        // coordinate is the bin's own expression — a rounding error of the coordinate (~1e-5 pixels) cannot move a tap across it
+        if (W < 2) fits = false;
+        for (int t = 1; t <= 15 && W != 256; ++t) fits = fits && (16 * t * (W - 1)) % 255 != 0;
+        G.poff[l] = off;
+        off += G.cov[l] * G.cov[l] * sbd_C(l);
+    }
+    G.ptotal = off;
+    G.slow_mod = 0;
+    return fits && S <= 256;
+}
+
+size_t sample_bwd_partial_floats(int S, long batch, int n_slices) {
+    SbdGeom G;
+    if (!sbd_geom(S, G)) return 0;
+    return (size_t)batch * n_slices * 256 * G.ptotal;
+}
+
+bool sample_bwd_dense_covers(const SampleBwdArgs& a) {
+    SbdGeom G;
+    if (a.gt || !a.perm || !a.bin_ends || !a.partial || !sbd_geom(a.size, G)) return false;
+    if (const char* e = getenv("S3D_SBD_OFF")) if (atoi(e)) return false;   // A/B switch of tools/dbg_sbd.py
+    return true;
+}
+
+// 1 = launched, 0 = this size is not covered (the caller falls back to the atomic kernels), < 0: error.  a.gxy, when given, has
+// been filled by the caller (launch_sample_bwd's pre-pass).
+int launch_sample_bwd_dense(const SampleBwdArgs& a, hipStream_t stream) {
+    SbdGeom G;
+    if (!sample_bwd_dense_covers(a) || !sbd_geom(a.size, G)) return 0;
+    if (const char* e = getenv("S3D_SBD_SLOW_MOD")) G.slow_mod = atoi(e);
+    const size_t lds = (size_t)(6 * 8 * 256 + SBD_XFLOATS + 2 * 3 * SBD_CHUNK * 4 + 2 * SBD_CHUNK * 8 + 32) * sizeof(float);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (s3d_set_max_lds(attr_done, {(const void*)sample_bwd_dense_kernel<false>, (const void*)sample_bwd_dense_kernel<true>}, 160 * 1024))
+        return -1;
+    const long batch = a.groups / a.groups_per_batch;
+    if (a.ws34_t16)
+        hipLaunchKernelGGL((sample_bwd_dense_kernel<true>), dim3((unsigned)(batch * a.n_slices * 256)), dim3(SBD_THREADS), lds, stream, a, G);
+    else
+        hipLaunchKernelGGL((sample_bwd_dense_kernel<false>), dim3((unsigned)(batch * a.n_slices * 256)), dim3(SBD_THREADS), lds, stream, a, G);
+    if (hipGetLastError() != hipSuccess) return -1;
+    long quads = 0;
+    for (int l = 0; l < 5; ++l) quads += batch * a.n_slices * G.W[l] * G.W[l] * (sbd_C(l) / 4);
+    const long blocks = (quads + 255) / 256 < 16384 ? (quads + 255) / 256 : 16384;
+    hipLaunchKernelGGL(sbd_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, G, (int)batch);
+    if (hipGetLastError() != hipSuccess) return -1;
+    return 1;
+}
