@@ -25,13 +25,15 @@
 
 #define SBD_THREADS 512
 #define SBD_CHUNK 64          // queries per staged chunk = 16 k-steps
-#define SBD_ROW 144           // floats per staged dX row: the four queries of a k-step sit 16 banks apart
 #define SBD_PROW 132          // floats per staged accumulator row of the projection epilogue
 #define SBD_NB3 3             // 4 x 4-pixel blocks per axis, raw level 3 (footprint <= 12)
 #define SBD_NB4 5             //                               raw level 4 (footprint <= 20)
 #define SBD_NBLK (SBD_NB3 * SBD_NB3 + SBD_NB4 * SBD_NB4)
 #define SBD_NACC (5 + SBD_NBLK)
-#define SBD_XFLOATS (8 * 16 * SBD_PROW)   // staging region: >= SBD_CHUNK * SBD_ROW
+#define SBD_XFLOATS (8 * 16 * SBD_PROW)   // staging region: two chunk buffers of SBD_CHUNK * 128 floats, or the epilogue's eight blocks
+#define SBD_FROW 80           // floats per query of the folded weight table: 16 | 16 | 48 footprint pixels (five 16-pixel tiles)
+#define SBD_RROW 72           // floats per query of the raw weight table: level 3 columns 12 | rows 12, level 4 columns 20 | rows 20
+#define SBD_LDS_FLOATS (6 * 8 * 256 + SBD_XFLOATS + SBD_CHUNK * (SBD_FROW + SBD_RROW) + 32)
 
 struct SbdGeom {
     int W[5], fw[5], cov[5], poff[5];   // level width, tight footprint width, row width of the slot's footprint image, float offset
@@ -102,27 +104,44 @@ __device__ __forceinline__ void sbd_project_block(const float* __restrict__ rows
     for (int u = 0; u < NT; ++u) st4(o + 16 * u, draw[u]);
 }
 
+// operands of one k-step (four queries, query g in lane group g): the staged dX value, the weight on the lane's pixel of the five
+// folded tiles, and for the raw levels the weights on the lane's column / row of every block column / row the step's masks name
+struct SbdOps {
+    float xa, wb[5], wx3[SBD_NB3], wy3[SBD_NB3], wx4[SBD_NB4], wy4[SBD_NB4];
+    int m3, m4;
+};
+__device__ __forceinline__ void sbd_load_ops(SbdOps& o, const float* __restrict__ s_x, const float* __restrict__ s_fw,
+                                             const float* __restrict__ s_rw, int st, int g, int m, int wave, int m3, int m4) {
+    const int qq = 4 * st + g;
+    o.xa = s_x[qq * 128 + 16 * wave + m];   // (the four queries' rows share their banks: one 4-way conflict per step)
+    const float* f = s_fw + qq * SBD_FROW + m;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) o.wb[t] = f[16 * t];
+    const float* r = s_rw + qq * SBD_RROW;
+    o.m3 = m3; o.m4 = m4;
+    // unconditional: a load under a mask bit is followed by its own lgkmcnt(0) (45 waits per step in the first build)
+#pragma unroll
+    for (int b = 0; b < SBD_NB3; ++b) {
+        o.wx3[b] = r[4 * b + (m & 3)];
+        o.wy3[b] = r[12 + 4 * b + (m >> 2)];
+    }
+#pragma unroll
+    for (int b = 0; b < SBD_NB4; ++b) {
+        o.wx4[b] = r[24 + 4 * b + (m & 3)];
+        o.wy4[b] = r[44 + 4 * b + (m >> 2)];
+    }
+}
 // one k-step of a raw level: the blocks in (rows of the mask) x (columns of the mask) take the four queries' weights
 template <int NB, int BASE>
-__device__ __forceinline__ void sbd_raw_step(f32x4 (&acc)[SBD_NACC], float xa, int vmask, const int* __restrict__ e, int m) {
-    const int mask = __builtin_amdgcn_readfirstlane(vmask);
+__device__ __forceinline__ void sbd_raw_step(f32x4 (&acc)[SBD_NACC], float xa, int mask, const float (&wx)[NB], const float (&wy)[NB]) {
     if (mask == 0) return;
-    const int4 e0 = *reinterpret_cast<const int4*>(e);
-    const int2 e1 = *reinterpret_cast<const int2*>(e + 4);
-    const int cx = (m & 3) - e0.x, cy = (m >> 2) - e0.y;
-    const float wx0 = __builtin_bit_cast(float, e0.z), wx1 = __builtin_bit_cast(float, e0.w);
-    const float wy0 = __builtin_bit_cast(float, e1.x), wy1 = __builtin_bit_cast(float, e1.y);
 #pragma unroll
     for (int by = 0; by < NB; ++by) {
         if (!(mask & (256 << by))) continue;
-        const int dy = cy + 4 * by;
-        const float wy = dy == 0 ? wy0 : (dy == 1 ? wy1 : 0.f);
 #pragma unroll
         for (int bx = 0; bx < NB; ++bx) {
             if (!(mask & (1 << bx))) continue;
-            const int dx = cx + 4 * bx;
-            const float wx = dx == 0 ? wx0 : (dx == 1 ? wx1 : 0.f);
-            acc[BASE + by * NB + bx] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wx * wy, acc[BASE + by * NB + bx], 0, 0, 0);
+            acc[BASE + by * NB + bx] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wx[bx] * wy[by], acc[BASE + by * NB + bx], 0, 0, 0);
         }
     }
 }
@@ -132,10 +151,9 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_wt = smem;                                          // W_raw^T fragment image [6][8] (fp32) or [6][4] hi|lo pairs
     float* s_x = s_wt + 6 * 8 * 256;                             // the chunk's dX rows; the epilogue's accumulator rows
-    int* s_tidx = reinterpret_cast<int*>(s_x + SBD_XFLOATS);     // [3][SBD_CHUNK][4] folded levels: footprint pixel of each tap, or -1
-    float* s_tw = reinterpret_cast<float*>(s_tidx + 3 * SBD_CHUNK * 4);   // [3][SBD_CHUNK][4] its weight
-    int* s_raw = reinterpret_cast<int*>(s_tw + 3 * SBD_CHUNK * 4);        // [2][SBD_CHUNK][8] raw levels: x0, y0 in the footprint, wx0 wx1 wy0 wy1
-    int* s_mask = s_raw + 2 * SBD_CHUNK * 8;                     // [2][16] block columns | rows << 8 of every k-step
+    float* s_fw = s_x + SBD_XFLOATS;                             // [SBD_CHUNK][SBD_FROW] folded levels: a query's weight on every footprint pixel
+    float* s_rw = s_fw + SBD_CHUNK * SBD_FROW;                   // [SBD_CHUNK][SBD_RROW] raw levels: its weight on every footprint column | row
+    int* s_mask = reinterpret_cast<int*>(s_rw + SBD_CHUNK * SBD_RROW);    // [2][16] block columns | rows << 8 of every k-step
     const int tile = blockIdx.x & 255;
     const int ts = (blockIdx.x >> 8) % a.n_slices;
     const int b = (blockIdx.x >> 8) / a.n_slices;
@@ -177,40 +195,38 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
         gy = fminf(fmaxf(2.f * (Y / Z - 0.5f), -1.f), 1.f);
     };
     auto row_of = [&](long qs) { return ((((long)b * a.groups_per_batch + (qs >> 4)) * T + t) * S3D_GROUP + (qs & 15)) * 128; };
-    // the chunk's 64 rows x 128 floats, four 16-byte pieces per thread (slots past the tile's end repeat its last row: their
-    // weights are zero, their values must be finite)
-    auto load_chunk = [&](long c0, f32x4 (&xr)[4]) {
+    // the chunk's 64 rows x 128 floats go straight to LDS (global_load_lds, 16 bytes per lane): 32 pieces of two rows, four per wave;
+    // slots past the tile's end repeat its last row (their weights are zero, their values must be finite)
+    auto dma_chunk = [&](long c0, int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = threadIdx.x + SBD_THREADS * i;
-            long qs = c0 + (idx >> 5);
+            const int piece = 4 * wave + i;
+            long qs = c0 + 2 * piece + (lane >> 5);
             qs = qs < qs_hi ? qs : qs_hi - 1;
-            xr[i] = ld4(a.dX + row_of(qs) + 4 * (idx & 31));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.dX + row_of(qs) + 4 * (lane & 31)),
+                                             (__attribute__((address_space(3))) void*)(s_x + buf * (SBD_CHUNK * 128) + piece * 256), 16, 0, 0);
         }
     };
 
     f32x4 acc[SBD_NACC];
 #pragma unroll
     for (int i = 0; i < SBD_NACC; ++i) acc[i] = zero4();
-    f32x4 xr[4];
-    load_chunk(qs_lo, xr);
-    for (long c0 = qs_lo; c0 < qs_hi; c0 += SBD_CHUNK) {
-        __syncthreads();   // the previous chunk has been consumed (first pass: s_wt is complete)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = threadIdx.x + SBD_THREADS * i;
-            st4(s_x + (idx >> 5) * SBD_ROW + 4 * (idx & 31), xr[i]);
-        }
-        if (c0 + SBD_CHUNK < qs_hi) load_chunk(c0 + SBD_CHUNK, xr);
+    dma_chunk(qs_lo, 0);
+    int buf = 0;
+    for (long c0 = qs_lo; c0 < qs_hi; c0 += SBD_CHUNK, buf ^= 1) {
+        __syncthreads();   // the previous chunk's tables have been consumed (first pass: s_wt is complete)
         if (threadIdx.x < 5 * SBD_CHUNK) {   // thread = (level, query of the chunk): wave l stages level l
             const int l = threadIdx.x / SBD_CHUNK, qq = threadIdx.x % SBD_CHUNK;
             const long qs = c0 + qq;
             const int W = G.W[l], C = l < 3 ? 128 : (l == 3 ? 64 : 32);
             const int ox = 16 * tx * (W - 1) / 255, oy = 16 * ty * (W - 1) / 255;
-            int ti[4] = {-1, -1, -1, -1};
-            float tw[4] = {0.f, 0.f, 0.f, 0.f};
-            int lx0 = 0, ly0 = 0, mask = 0;
-            float wxy[4] = {0.f, 0.f, 0.f, 0.f};
+            int mask = 0;
+            // the query's table row, zeroed; its taps are written over it below
+            float* tab = l < 3 ? s_fw + qq * SBD_FROW + (l == 0 ? 0 : l == 1 ? 16 : 32) : s_rw + qq * SBD_RROW + (l == 3 ? 0 : 24);
+            {
+                const int n4 = l < 2 ? 4 : (l == 2 ? 12 : (l == 3 ? 6 : 10));
+                for (int i = 0; i < n4; ++i) st4(tab + 4 * i, zero4());
+            }
             if (qs < qs_hi) {
                 float gx, gy;
                 project_slot(qs, gx, gy);
@@ -238,19 +254,20 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float w = wx[k & 1] * wy[k >> 1];
-                            if (w != 0.f) {
-                                ti[k] = (ry + (k >> 1)) * cov + rx + (k & 1);
-                                tw[k] = w;
-                            }
+                            if (w != 0.f) tab[(ry + (k >> 1)) * cov + rx + (k & 1)] = w;
                         }
                     } else {
-                        // (a weightless tap may sit one pixel outside the footprint: it matches no block pixel)
-                        lx0 = rx; ly0 = ry;
-                        wxy[0] = wx[0]; wxy[1] = wx[1]; wxy[2] = wy[0]; wxy[3] = wy[1];
+                        // (a weightless tap may sit one pixel outside the footprint: it has no table entry)
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
-                            if (rx + k >= 0 && rx + k < cov) mask |= 1 << ((rx + k) >> 2);
-                            if (ry + k >= 0 && ry + k < cov) mask |= 256 << ((ry + k) >> 2);
+                            if (rx + k >= 0 && rx + k < cov) {
+                                tab[rx + k] = wx[k];
+                                mask |= 1 << ((rx + k) >> 2);
+                            }
+                            if (ry + k >= 0 && ry + k < cov) {
+                                tab[cov + ry + k] = wy[k];
+                                mask |= 256 << ((ry + k) >> 2);
+                            }
                         }
                         if (G.slow_mod < 0) mask = 0x1F1F;
                     }
@@ -273,39 +290,37 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
                     }
                 }
             }
-            if (l < 3) {
-                *reinterpret_cast<int4*>(s_tidx + (l * SBD_CHUNK + qq) * 4) = int4{ti[0], ti[1], ti[2], ti[3]};
-                st4(s_tw + (l * SBD_CHUNK + qq) * 4, f32x4{tw[0], tw[1], tw[2], tw[3]});
-            } else {
-                // integers throughout: a small int travelling as a float is a denormal bit pattern (it arrived as 0)
-                int* e = s_raw + ((l - 3) * SBD_CHUNK + qq) * 8;
-                *reinterpret_cast<int4*>(e) = int4{lx0, ly0, __builtin_bit_cast(int, wxy[0]), __builtin_bit_cast(int, wxy[1])};
-                *reinterpret_cast<int2*>(e + 4) = int2{__builtin_bit_cast(int, wxy[2]), __builtin_bit_cast(int, wxy[3])};
+            if (l >= 3) {
                 mask |= __shfl_xor(mask, 1, 64);
                 mask |= __shfl_xor(mask, 2, 64);
                 if ((qq & 3) == 0) s_mask[(l - 3) * 16 + (qq >> 2)] = mask;
             }
         }
-        __syncthreads();
+        dma_publish_barrier();   // the tables and this chunk's rows (every wave's own DMA has landed)
+        if (c0 + SBD_CHUNK < qs_hi) dma_chunk(c0 + SBD_CHUNK, buf ^ 1);   // the other buffer was last read before this chunk's first barrier
+        const float* s_xb = s_x + buf * (SBD_CHUNK * 128);
         const int nst = (int)((qs_hi - c0 + 3) / 4 < 16 ? (qs_hi - c0 + 3) / 4 : 16);
+        const int vm3 = s_mask[lane & 15], vm4 = s_mask[16 + (lane & 15)];   // lane st holds k-step st's masks: no LDS wait per step
+        auto step = [&](const SbdOps& o) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.xa, o.wb[t], acc[t], 0, 0, 0);
+            sbd_raw_step<SBD_NB3, 5>(acc, o.xa, o.m3, o.wx3, o.wy3);
+            sbd_raw_step<SBD_NB4, 5 + SBD_NB3 * SBD_NB3>(acc, o.xa, o.m4, o.wx4, o.wy4);
+        };
+        auto load = [&](SbdOps& o, int st) {
+            st = st < nst ? st : (nst ? nst - 1 : 0);     // (past the end: a valid step again, never computed)
+            sbd_load_ops(o, s_xb, s_fw, s_rw, st, g, m, wave, __builtin_amdgcn_readlane(vm3, st), __builtin_amdgcn_readlane(vm4, st));
+        };
+        SbdOps oa, ob;   // the next step's operands are read while this step's MFMAs run
+        load(oa, 0);
 #pragma unroll 1
-        for (int st = 0; st < nst; ++st) {
-            const int qq = 4 * st + g;
-            const float xa = s_x[qq * SBD_ROW + 16 * wave + m];
-#pragma unroll
-            for (int l = 0; l < 3; ++l) {
-                const int4 ti = *reinterpret_cast<const int4*>(s_tidx + (l * SBD_CHUNK + qq) * 4);
-                const f32x4 tw = ld4(s_tw + (l * SBD_CHUNK + qq) * 4);
-#pragma unroll
-                for (int k = 0; k < sbd_nmt(l); ++k) {
-                    const int pm = m + 16 * k;
-                    const float wb = (ti.x == pm ? tw[0] : 0.f) + (ti.y == pm ? tw[1] : 0.f) + (ti.z == pm ? tw[2] : 0.f) +
-                                     (ti.w == pm ? tw[3] : 0.f);
-                    acc[sbd_mt0(l) + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wb, acc[sbd_mt0(l) + k], 0, 0, 0);
-                }
+        for (int st = 0; st < nst; st += 2) {
+            load(ob, st + 1);
+            step(oa);
+            if (st + 1 < nst) {
+                load(oa, st + 2);
+                step(ob);
             }
-            sbd_raw_step<SBD_NB3, 5>(acc, xa, s_mask[st], s_raw + qq * 8, m);
-            sbd_raw_step<SBD_NB4, 5 + SBD_NB3 * SBD_NB3>(acc, xa, s_mask[16 + st], s_raw + (SBD_CHUNK + qq) * 8, m);
         }
     }
 
@@ -435,7 +450,7 @@ int launch_sample_bwd_dense(const SampleBwdArgs& a, hipStream_t stream) {
     SbdGeom G;
     if (!sample_bwd_dense_covers(a) || !sbd_geom(a.size, G)) return 0;
     if (const char* e = getenv("S3D_SBD_SLOW_MOD")) G.slow_mod = atoi(e);
-    const size_t lds = (size_t)(6 * 8 * 256 + SBD_XFLOATS + 2 * 3 * SBD_CHUNK * 4 + 2 * SBD_CHUNK * 8 + 32) * sizeof(float);
+    const size_t lds = (size_t)SBD_LDS_FLOATS * sizeof(float);
     static std::atomic<unsigned long long> attr_done{0};
     if (s3d_set_max_lds(attr_done, {(const void*)sample_bwd_dense_kernel<false>, (const void*)sample_bwd_dense_kernel<true>}, 160 * 1024))
         return -1;
