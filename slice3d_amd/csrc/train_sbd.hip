@@ -10,7 +10,10 @@
 // B[q][pix] = the query's bilinear weight on that pixel).  The three folded levels (3 x 3 / 4 x 4 / 6 x 6 pixels at 256^2) are five
 // 16-pixel tiles that every k-step visits.  The two RAW levels (S/2: 64 channels, S: 32 channels; footprints 10 x 10 and 18 x 18)
 // are cut into 4 x 4-pixel blocks — 3 x 3 and 5 x 5 of them — and a k-step visits only the rows x columns of blocks its four
-// queries touch (two wave-uniform bit masks from the staging pass: sorted neighbours share their blocks, ~4 of 34 per step).
+// queries touch (two wave-uniform bit masks from the staging pass: sorted neighbours share their blocks, ~6 of 34 per step).
+// Per chunk of 64 queries: the dX rows arrive by LDS-DMA one chunk ahead (two buffers); five waves stage, per (level, query), the
+// query's weight on every footprint pixel (folded) or footprint column | row (raw: a block pixel's weight is column x row) as LDS
+// tables, so that a k-step is LDS reads + MFMAs; the next step's operands are read while this step's MFMAs run.
 // The raw levels' projection through W_raw^T (fc_s[:, 896:992]) is applied AFTERWARDS, once per footprint pixel instead of once per
 // query: d raw_l[pix][c'] = sum_c P_l[pix][c] W^T[c][c'] — the accumulators go through LDS (a pixel's 128 channels are spread over
 // the eight waves) and come back as rows of the same product the per-query form ran (f16 hi/lo x 3 on the f16 MFMA, or fp32).
@@ -19,8 +22,11 @@
 // No global atomics either: a workgroup writes its footprints to ITS slot of the partial scratch ([object][slice][tile][G.ptotal]
 // floats) and sbd_reduce_kernel adds, for every pixel of the five gradient maps, the slots of the tiles whose footprint holds it, in
 // ascending tile order.  (A tap outside its tile's footprint cannot occur for the sizes launch_sample_bwd accepts — the tile's bins
-// ARE level-4 pixels and the coarser footprints' borders never fall on integers, sbd_fits — but the staging pass still handles it:
+// ARE level-4 pixels and the coarser footprints' borders never fall on integers, sbd_geom — but the staging pass still handles it:
 // such a query's row goes to the maps directly with global atomics, S3D_SBD_SLOW_MOD forces that path for tests.)
+// Measured (4 objects x 100 k queries x 12 slices at 256^2): 4.4 ms + 0.8 ms for the reduce pass against 8.85 ms; cycle stamps
+// (-DSBD_STAMPS, tools/r06_sbd_stamps.sh): 71 % of a workgroup's time in the k-steps, whose raw-level part is bound by its scalar
+// bit tests and taken branches (39 conditional MFMA sites), not by the matrix pipe (29 % busy) or LDS.
 #include "train.h"
 
 #define SBD_THREADS 512
@@ -146,6 +152,24 @@ __device__ __forceinline__ void sbd_raw_step(f32x4 (&acc)[SBD_NACC], float xa, i
     }
 }
 
+// -DSBD_STAMPS (tools/r06_sbd_stamps.sh): wave 0 of every workgroup adds the cycles of its phases to eight device counters
+#ifdef SBD_STAMPS
+__device__ unsigned long long sbd_stamps[8];
+#define SBD_STAMP(i)                                                              \
+    do {                                                                          \
+        const long long t__ = wall_clock64();                                    \
+        if (threadIdx.x == 0) atomicAdd(&sbd_stamps[i], (unsigned long long)(t__ - t_last)); \
+        t_last = t__;                                                             \
+    } while (0)
+extern "C" void s3d_debug_sbd_stamps(unsigned long long* out) {
+    unsigned long long z[8] = {0};
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(sbd_stamps), sizeof(z));
+    hipMemcpyToSymbol(HIP_SYMBOL(sbd_stamps), z, sizeof(z));
+}
+#else
+#define SBD_STAMP(i)
+#endif
+
 template <bool F16>
 __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const SampleBwdArgs a, const SbdGeom G) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -211,10 +235,22 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
     f32x4 acc[SBD_NACC];
 #pragma unroll
     for (int i = 0; i < SBD_NACC; ++i) acc[i] = zero4();
+#ifdef SBD_STAMPS
+    long long t_last = wall_clock64();
+#endif
     dma_chunk(qs_lo, 0);
     int buf = 0;
+    // a staging thread's query coordinates are fetched one chunk ahead (their latency sat in front of every chunk's staging)
+    float gx_n = 0.f, gy_n = 0.f;
+    if (threadIdx.x < 5 * SBD_CHUNK && qs_lo + (threadIdx.x % SBD_CHUNK) < qs_hi) project_slot(qs_lo + (threadIdx.x % SBD_CHUNK), gx_n, gy_n);
     for (long c0 = qs_lo; c0 < qs_hi; c0 += SBD_CHUNK, buf ^= 1) {
+        SBD_STAMP(0);      // prologue / k-steps
         __syncthreads();   // the previous chunk's tables have been consumed (first pass: s_wt is complete)
+        SBD_STAMP(1);      // wait at the first barrier
+#ifdef SBD_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SBD_STAMP(5);      // outstanding loads (this chunk's rows, the staging threads' coordinates)
+#endif
         if (threadIdx.x < 5 * SBD_CHUNK) {   // thread = (level, query of the chunk): wave l stages level l
             const int l = threadIdx.x / SBD_CHUNK, qq = threadIdx.x % SBD_CHUNK;
             const long qs = c0 + qq;
@@ -228,8 +264,7 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
                 for (int i = 0; i < n4; ++i) st4(tab + 4 * i, zero4());
             }
             if (qs < qs_hi) {
-                float gx, gy;
-                project_slot(qs, gx, gy);
+                const float gx = gx_n, gy = gy_n;
                 const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
                 const float iy = ((gy + 1.f) / 2.f) * (float)(W - 1);
                 const float x0f = floorf(ix), y0f = floorf(iy);
@@ -296,9 +331,13 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
                 if ((qq & 3) == 0) s_mask[(l - 3) * 16 + (qq >> 2)] = mask;
             }
         }
+        SBD_STAMP(2);      // staging
         dma_publish_barrier();   // the tables and this chunk's rows (every wave's own DMA has landed)
+        SBD_STAMP(3);      // wait at the second barrier
         if (c0 + SBD_CHUNK < qs_hi) dma_chunk(c0 + SBD_CHUNK, buf ^ 1);   // the other buffer was last read before this chunk's first barrier
         const float* s_xb = s_x + buf * (SBD_CHUNK * 128);
+        if (threadIdx.x < 5 * SBD_CHUNK && c0 + SBD_CHUNK + (threadIdx.x % SBD_CHUNK) < qs_hi)
+            project_slot(c0 + SBD_CHUNK + (threadIdx.x % SBD_CHUNK), gx_n, gy_n);
         const int nst = (int)((qs_hi - c0 + 3) / 4 < 16 ? (qs_hi - c0 + 3) / 4 : 16);
         const int vm3 = s_mask[lane & 15], vm4 = s_mask[16 + (lane & 15)];   // lane st holds k-step st's masks: no LDS wait per step
         auto step = [&](const SbdOps& o) {
@@ -324,6 +363,7 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
         }
     }
 
+    SBD_STAMP(0);
     // ---- the slot: [level][footprint pixel][C_l] ----
     float* slot = a.partial + ((img * 256 + tile) * (long)G.ptotal);
     // folded levels straight from the registers: D[row = channel 16 wave + 4g + i][col = pixel 16k + m]
@@ -352,6 +392,7 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
             sbd_project_block<F16, 4>(s_x + wave * 16 * SBD_PROW, s_wt, slot + G.poff[4], G.cov[4], bi % SBD_NB4, bi / SBD_NB4, lane);
         }
     }
+    SBD_STAMP(4);          // epilogue
 }
 
 // map[l][img][y][x][c] += sum over the tiles whose footprint holds (x, y), ascending (ty, tx), of their slot's value
