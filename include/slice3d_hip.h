@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S3D_VERSION 112          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused, s3d_decode_set_shared_footprint; 112: S3D_PREC_F16 accepted by s3d_train_* */
+#define S3D_VERSION 113          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused, s3d_decode_set_shared_footprint; 112: S3D_PREC_F16 accepted by s3d_train_*; 113: atomic-free sampling backward (bit-reproducible s3d_train_* gradients, larger workspace) */
 #define S3D_E_ARG (-1)           /* bad argument / unsupported shape */
 #define S3D_E_WORKSPACE (-2)     /* workspace or packed-weight buffer too small */
 
@@ -402,7 +402,12 @@ typedef struct {
     const S3dSyncBn* sync_bn;  /* NULL: per-rank BatchNorm statistics */
 } S3dTrainBatch;
 size_t s3d_train_workspace_bytes(int batch, int size, long n_qry, int n_slices);
-/* prec: S3D_PREC_F32 (exact fp32 MFMAs), S3D_PREC_F16X3 (split precision, fp32-class: the mode every parity test and the
+/* Reproducibility (version 113): with n_qry >= 4096 (the locality-sorted token order) and size <= 256 the step contains no float
+ * atomics — the pyramid-sampling backward writes per-tile partial sums into the workspace and adds them in a fixed order
+ * (train_sbd.hip) — so the same inputs, seed and weights give bit-identical losses and gradients, call after call.  Smaller query
+ * counts / larger images keep the atomic scatter kernels (gradients equal to fp32 summation-order noise).  The workspace holds
+ * 98 KB of partial sums per (object, slice, 16 x 16-bin image tile): 1.2 GB at 4 objects x 12 slices.
+ * prec: S3D_PREC_F32 (exact fp32 MFMAs), S3D_PREC_F16X3 (split precision, fp32-class: the mode every parity test and the
  * reported train_samples_per_s use) or — since version 112 — S3D_PREC_F16: a THROUGHPUT mode in which the decoder's GEMM kernels
  * (FFN forward / data pass / both weight-gradient contractions, the fused attention forward and backward, the row-linear layers and
  * their weight gradients) run ONE f16 MFMA per product; the U-Net, VGG, the samplers, every reduction, the fp32 master weights,
