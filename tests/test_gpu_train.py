@@ -785,17 +785,19 @@ def test_full_size_fused_train_step_is_finite_and_repeatable():
     print("full-size fused step: losses %s; every gradient bit-identical run to run" % (l0.tolist(),))
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3"])
-def test_atomic_free_sampling_backward_matches_the_atomic_kernels(prec, monkeypatch):
+@pytest.mark.parametrize("prec,size,nq", [("f32", 64, 8192), ("f16x3", 64, 8192), ("f16x3", 128, 6000), ("f32", 96, 4200), ("f16x3", 32, 5000)])
+def test_atomic_free_sampling_backward_matches_the_atomic_kernels(prec, size, nq, monkeypatch):
     """train_sbd.hip against the kernels it replaces (S3D_SBD_OFF=1: sample_bwd_tiled_kernel, LDS + global float atomics) on the same
     step: every gradient within fp32 summation-order noise; and with every fifth sorted slot forced through the new kernel's
-    out-of-footprint path (S3D_SBD_SLOW_MOD=5: that query's row added to the maps directly) the same again."""
+    out-of-footprint path (S3D_SBD_SLOW_MOD=5: that query's row added to the maps directly) the same again.  Sizes 32 ... 128 (96: not a
+    power of two) walk the footprint geometry of sbd_geom / sbd_reduce_kernel; the full size is the repeatability test above."""
     from slice3d_amd.models import Slices3DRegModel
     from slice3d_amd.synth import make_feed_dict
     from slice3d_amd.trainer import HipTrainer
     from slice3d_amd.weights import load_seeded
-    fd = make_feed_dict(2, 64, 8192, 12, seed=5, device="cuda")
-    m = load_seeded(Slices3DRegModel(img_size=64, n_slices=12, mode="train"), 0).cuda()
+    ns = 12 if size <= 64 else 5
+    fd = make_feed_dict(2, size, nq, ns, seed=5, device="cuda")
+    m = load_seeded(Slices3DRegModel(img_size=size, n_slices=ns, mode="train"), 0).cuda()
     tr = HipTrainer(m, prec=prec, dropout=0.0, seed=3)
     stats0 = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
     grads = {}
