@@ -72,7 +72,7 @@ __device__ __forceinline__ float sbd_wraw(const float* img, int u0, int k, int c
 // d raw[pix][c'] of one 4 x 4-pixel block: rows = the block's 16 pixels (staged accumulators, SBD_PROW floats apart)
 template <bool F16, int L>
 __device__ __forceinline__ void sbd_project_block(const float* __restrict__ rows, const float* __restrict__ s_wt, float* __restrict__ out,
-                                                  int cov, int bx, int by, int lane) {
+                                                  int cov, int fw, int bx, int by, int lane) {
     constexpr int C = sbd_C(L), NT = C / 16, U0 = L == 3 ? 0 : 4;
     const int m = lane & 15, g = lane >> 4;
     const float* dp = rows + m * SBD_PROW + (F16 ? 8 : 4) * g;
@@ -105,6 +105,8 @@ __device__ __forceinline__ void sbd_project_block(const float* __restrict__ rows
 #pragma unroll
             for (int j = 0; j < 8; ++j) draw[u] = mfma4(ld4(s_wt + (((U0 + u) * 8 + j) * 64 + lane) * 4), dt[j], draw[u]);
     }
+    // (pixels of the blocks beyond the footprint's fw x fw never receive weight and are never read)
+    if (4 * by + (m >> 2) >= fw || 4 * bx + (m & 3) >= fw) return;
     float* o = out + ((long)(4 * by + (m >> 2)) * cov + 4 * bx + (m & 3)) * C + 4 * g;
 #pragma unroll
     for (int u = 0; u < NT; ++u) st4(o + 16 * u, draw[u]);
@@ -275,13 +277,13 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
                 if (x0 + 1 < 0 || x0 + 1 >= W) wx[1] = 0.f;
                 if (y0 < 0 || y0 >= W) wy[0] = 0.f;
                 if (y0 + 1 < 0 || y0 + 1 >= W) wy[1] = 0.f;
-                const int cov = G.cov[l];
+                const int cov = G.cov[l], fwl = G.fw[l];   // row width of the tables / slot image; the tile's footprint (fwl <= cov)
                 const int rx = x0 - ox, ry = y0 - oy;
                 bool inside = true;   // every tap that carries weight lies in the tile's footprint
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int lx = rx + (k & 1), ly = ry + (k >> 1);
-                    if (wx[k & 1] * wy[k >> 1] != 0.f && !(lx >= 0 && lx < cov && ly >= 0 && ly < cov)) inside = false;
+                    if (wx[k & 1] * wy[k >> 1] != 0.f && !(lx >= 0 && lx < fwl && ly >= 0 && ly < fwl)) inside = false;
                 }
                 if (G.slow_mod > 0 && qs % G.slow_mod == 0) inside = false;
                 if (inside) {
@@ -295,11 +297,11 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
                         // (a weightless tap may sit one pixel outside the footprint: it has no table entry)
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
-                            if (rx + k >= 0 && rx + k < cov) {
+                            if (rx + k >= 0 && rx + k < fwl) {
                                 tab[rx + k] = wx[k];
                                 mask |= 1 << ((rx + k) >> 2);
                             }
-                            if (ry + k >= 0 && ry + k < cov) {
+                            if (ry + k >= 0 && ry + k < fwl) {
                                 tab[cov + ry + k] = wy[k];
                                 mask |= 256 << ((ry + k) >> 2);
                             }
@@ -386,10 +388,10 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
         __syncthreads();
         const int blk = 8 * r + wave;
         if (blk < SBD_NB3 * SBD_NB3) {
-            sbd_project_block<F16, 3>(s_x + wave * 16 * SBD_PROW, s_wt, slot + G.poff[3], G.cov[3], blk % SBD_NB3, blk / SBD_NB3, lane);
+            sbd_project_block<F16, 3>(s_x + wave * 16 * SBD_PROW, s_wt, slot + G.poff[3], G.cov[3], G.fw[3], blk % SBD_NB3, blk / SBD_NB3, lane);
         } else if (blk < SBD_NBLK) {
             const int bi = blk - SBD_NB3 * SBD_NB3;
-            sbd_project_block<F16, 4>(s_x + wave * 16 * SBD_PROW, s_wt, slot + G.poff[4], G.cov[4], bi % SBD_NB4, bi / SBD_NB4, lane);
+            sbd_project_block<F16, 4>(s_x + wave * 16 * SBD_PROW, s_wt, slot + G.poff[4], G.cov[4], G.fw[4], bi % SBD_NB4, bi / SBD_NB4, lane);
         }
     }
     SBD_STAMP(4);          // epilogue
@@ -418,18 +420,18 @@ __global__ __launch_bounds__(256) void sbd_reduce_kernel(const SampleBwdArgs a, 
         const long img = p / ((long)W * W);
         const int b = (int)(img / a.n_slices);
         const int* ends = a.bin_ends + (long)b * 65536;
-        const int cov = G.cov[l], den = 16 * (W - 1);
-        // ox(t) = 16 t (W-1) / 255 is non-decreasing in t: candidates are the t with ox(t) in (x - cov, x]
-        const int tx_lo = x - cov >= 0 ? (x - cov) * 255 / den : 0, tx_hi = min(15, (x + 1) * 255 / den);
-        const int ty_lo = y - cov >= 0 ? (y - cov) * 255 / den : 0, ty_hi = min(15, (y + 1) * 255 / den);
+        const int cov = G.cov[l], fwl = G.fw[l], den = 16 * (W - 1);
+        // ox(t) = 16 t (W-1) / 255 is non-decreasing in t: candidates are the t with ox(t) in (x - fw, x]
+        const int tx_lo = x - fwl >= 0 ? (x - fwl) * 255 / den : 0, tx_hi = min(15, (x + 1) * 255 / den);
+        const int ty_lo = y - fwl >= 0 ? (y - fwl) * 255 / den : 0, ty_hi = min(15, (y + 1) * 255 / den);
         f32x4 s = zero4();
         bool any = false;
         for (int ty = ty_lo; ty <= ty_hi; ++ty) {
             const int ly = y - 16 * ty * (W - 1) / 255;
-            if (ly < 0 || ly >= cov) continue;
+            if (ly < 0 || ly >= fwl) continue;
             for (int tx = tx_lo; tx <= tx_hi; ++tx) {
                 const int lx = x - 16 * tx * (W - 1) / 255;
-                if (lx < 0 || lx >= cov) continue;
+                if (lx < 0 || lx >= fwl) continue;
                 const int tile = (int)(sbd_spread8((unsigned)tx) | (sbd_spread8((unsigned)ty) << 1));
                 const int lo = tile ? ends[256 * tile - 1] : 0, hi = ends[256 * tile + 255];
                 if (lo >= hi) continue;
