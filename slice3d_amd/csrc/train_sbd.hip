@@ -412,18 +412,24 @@ __global__ __launch_bounds__(256) void sbd_reduce_kernel(const SampleBwdArgs a, 
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < lvl_end[4]; idx += (long)gridDim.x * blockDim.x) {
         int l = 0;
         while (idx >= lvl_end[l]) ++l;
-        const long r = idx - (l ? lvl_end[l - 1] : 0);
-        const int W = G.W[l], C = sbd_C(l), c4n = C / 4;
-        const int c4 = (int)(r % c4n);
-        const long p = r / c4n;
-        const int x = (int)(p % W), y = (int)((p / W) % W);
-        const long img = p / ((long)W * W);
+        // 32-bit index arithmetic from here (launch_sample_bwd_dense checks the level sizes): the 64-bit divisions of the first build
+        // were most of this kernel's time
+        const unsigned r = (unsigned)(idx - (l ? lvl_end[l - 1] : 0));
+        const int W = G.W[l], C = sbd_C(l), c4s = l < 3 ? 5 : (l == 3 ? 4 : 3);   // C / 4 = 32, 16, 8 quads per pixel
+        const int c4 = (int)(r & ((1u << c4s) - 1));
+        const unsigned p = r >> c4s;
+        const unsigned row = p / (unsigned)W;
+        const int x = (int)(p - row * (unsigned)W);
+        const unsigned img = row / (unsigned)W;
+        const int y = (int)(row - img * (unsigned)W);
         const int b = (int)(img / a.n_slices);
         const int* ends = a.bin_ends + (long)b * 65536;
         const int cov = G.cov[l], fwl = G.fw[l], den = 16 * (W - 1);
         // ox(t) = 16 t (W-1) / 255 is non-decreasing in t: candidates are the t with ox(t) in (x - fw, x]
         const int tx_lo = x - fwl >= 0 ? (x - fwl) * 255 / den : 0, tx_hi = min(15, (x + 1) * 255 / den);
         const int ty_lo = y - fwl >= 0 ? (y - fwl) * 255 / den : 0, ty_hi = min(15, (y + 1) * 255 / den);
+        float* o = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + (long)p * C + 4 * c4;
+        const f32x4 old = ld4(o);   // requested first: the candidate walk below is two dependent loads deep
         f32x4 s = zero4();
         bool any = false;
         for (int ty = ty_lo; ty <= ty_hi; ++ty) {
@@ -435,14 +441,11 @@ __global__ __launch_bounds__(256) void sbd_reduce_kernel(const SampleBwdArgs a, 
                 const int tile = (int)(sbd_spread8((unsigned)tx) | (sbd_spread8((unsigned)ty) << 1));
                 const int lo = tile ? ends[256 * tile - 1] : 0, hi = ends[256 * tile + 255];
                 if (lo >= hi) continue;
-                s += ld4(a.partial + (img * 256 + tile) * (long)G.ptotal + G.poff[l] + ((long)ly * cov + lx) * C + 4 * c4);
+                s += ld4(a.partial + ((long)img * 256 + tile) * (long)G.ptotal + G.poff[l] + (ly * cov + lx) * C + 4 * c4);
                 any = true;
             }
         }
-        if (any) {
-            float* o = (l < 3 ? a.dproj[l] : a.dfine[l - 3]) + p * C + 4 * c4;
-            st4(o, ld4(o) + s);
-        }
+        if (any) st4(o, old + s);
     }
 }
 
@@ -484,6 +487,8 @@ bool sample_bwd_dense_covers(const SampleBwdArgs& a) {
     SbdGeom G;
     if (a.gt || !a.perm || !a.bin_ends || !a.partial || !sbd_geom(a.size, G)) return false;
     if (const char* e = getenv("S3D_SBD_OFF")) if (atoi(e)) return false;   // A/B switch of tools/dbg_sbd.py
+    const long n_img = a.groups / a.groups_per_batch * a.n_slices;
+    if (n_img * a.size * a.size * 8 >= (1L << 32)) return false;   // sbd_reduce_kernel's 32-bit pixel index (level 4: 8 quads per pixel)
     return true;
 }
 
@@ -504,7 +509,7 @@ int launch_sample_bwd_dense(const SampleBwdArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL((sample_bwd_dense_kernel<false>), dim3((unsigned)(batch * a.n_slices * 256)), dim3(SBD_THREADS), lds, stream, a, G);
     if (hipGetLastError() != hipSuccess) return -1;
     long quads = 0;
-    for (int l = 0; l < 5; ++l) quads += batch * a.n_slices * G.W[l] * G.W[l] * (sbd_C(l) / 4);
+    for (int l = 0; l < 5; ++l) quads += batch * a.n_slices * G.W[l] * G.W[l] * (sbd_C(l) / 4);   // (each level's count < 2^32: checked in sample_bwd_dense_covers)
     const long blocks = (quads + 255) / 256 < 16384 ? (quads + 255) / 256 : 16384;
     hipLaunchKernelGGL(sbd_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, G, (int)batch);
     if (hipGetLastError() != hipSuccess) return -1;
