@@ -279,6 +279,14 @@ __global__ __launch_bounds__(SBD_THREADS) void sample_bwd_dense_kernel(const Sam
                 if (y0 + 1 < 0 || y0 + 1 >= W) wy[1] = 0.f;
                 const int cov = G.cov[l], fwl = G.fw[l];   // row width of the tables / slot image; the tile's footprint (fwl <= cov)
                 const int rx = x0 - ox, ry = y0 - oy;
+                // The sort's bin (floor((gx + 1) * 127.5), possibly one fma) and this level's pixel index (two roundings) are the same
+                // number up to an ulp: a query within 1e-5 pixels of its tile's border can land one pixel outside the footprint with
+                // the weight ~1e-5 on that side.  It is taken AT the border (the side's weight dropped): the generic path below
+                // would cost the workgroup ~1 ms for it.
+                if (rx == -1 && wx[0] < 1e-3f) wx[0] = 0.f;
+                if (rx + 1 == fwl && wx[1] < 1e-3f) wx[1] = 0.f;
+                if (ry == -1 && wy[0] < 1e-3f) wy[0] = 0.f;
+                if (ry + 1 == fwl && wy[1] < 1e-3f) wy[1] = 0.f;
                 bool inside = true;   // every tap that carries weight lies in the tile's footprint
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
