@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S3D_VERSION 113          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused, s3d_decode_set_shared_footprint; 112: S3D_PREC_F16 accepted by s3d_train_*; 113: atomic-free sampling backward (bit-reproducible s3d_train_* gradients, larger workspace) */
+#define S3D_VERSION 114          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused, s3d_decode_set_shared_footprint; 112: S3D_PREC_F16 accepted by s3d_train_*; 113: atomic-free sampling backward (bit-reproducible s3d_train_* gradients, larger workspace); 114: s3d_qkv_attention_ws_* serve head width 48 */
 #define S3D_E_ARG (-1)           /* bad argument / unsupported shape */
 #define S3D_E_WORKSPACE (-2)     /* workspace or packed-weight buffer too small */
 
@@ -342,9 +342,11 @@ int s3d_group_norm2_fwd(const float* x0, int c0, const float* x1, int c1, const 
 /* QKVAttentionLegacy.forward (openaimodel.py:362-377): qkv (N, T, heads*3*ch) -> out (N, T, heads*ch);
  * prec: S3D_PREC_F32 = fp32 MFMA, S3D_PREC_F16X3 = split-precision f16 MFMA (fp32-class accuracy) */
 int s3d_qkv_attention_fwd(const float* qkv, float* out, int N, int T, int heads, int ch, int prec, void* stream);
-/* The same operator for head widths 8 / 16 / 24 / 32 on the f16 MFMA with fp32-class logits (q, k split three ways,
+/* The same operator for head widths 8 / 16 / 24 / 32 / 48 on the f16 MFMA with fp32-class logits (q, k split three ways,
  * p, v two ways; replaces the same reference lines, openaimodel.py:353-381).  ws: s3d_qkv_attention_ws_bytes() bytes of
- * scratch for the pre-split K / V block images (0 = width not served). */
+ * scratch for the pre-split K / V block images (0 = width not served).  Width 48 (version 114): two 32-channel k-steps;
+ * where N * heads * ceil(T / 64) workgroups would not fill the chip (1 024 tokens at batch 1) the keys are split over
+ * 2 - 8 workgroups per query block and a merge launch adds their partial results (the scratch holds those as well). */
 size_t s3d_qkv_attention_ws_bytes(int N, int T, int heads, int ch);
 int s3d_qkv_attention_ws_fwd(const float* qkv, float* out, int N, int T, int heads, int ch, void* ws, size_t ws_bytes,
                              void* stream);

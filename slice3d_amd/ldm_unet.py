@@ -121,6 +121,9 @@ class UNetModel(nn.Module):
         self.out = nn.Sequential(_gn(ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
         self._lib = _lib.load() if backend == "hip" else None
         self._attn_ws = {}   # device -> scratch of the long-sequence attention kernel (pre-split K / V block images)
+        # 48-wide heads at >= 1 024 tokens on the key-split f16-MFMA kernel (ldm_attn.hip la_attention2_kernel); 0 = the
+        # fp32-MFMA kernel of ldm_ops.hip they ran on before round 6 (kept for the A/B)
+        self.wide_head_mfma = os.environ.get("S3D_LDM_WIDE_MFMA", "1") != "0"
         self._packed = {}
         self._packed_key = None
         self._ws = None
@@ -457,7 +460,7 @@ class UNetModel(nn.Module):
         # long sequences of narrow heads: the f16-MFMA kernel with fp32-class logits and pre-split K / V (ldm_attn.hip)
         use_mfma = self._attn_precv() == _lib.PREC_F16X3
         ws_bytes = lib.s3d_qkv_attention_ws_bytes(n, h * w, blk.num_heads, ch) if use_mfma else 0
-        if ws_bytes and h * w >= 1024:
+        if ws_bytes and h * w >= 1024 and (ch <= 32 or self.wide_head_mfma):
             ws = self._attn_ws.get(x.device)
             if ws is None or ws.numel() < ws_bytes:
                 ws = self._attn_ws[x.device] = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)

@@ -274,8 +274,11 @@ def test_ldm_primitives_match_torch():
         assert (out2.cpu() - want2).abs().max() < 2e-5, (ch2, float((out2.cpu() - want2).abs().max()))
     # the f16-MFMA attention with three-way split logits (ldm_attn.hip) holds the SAME 2e-5 bound on random inputs; ragged T
     # (tails of the 64-key blocks and of the 128-query workgroups), all four head widths, batch 2
+    # 48-wide heads (round 6: two k-steps; key split over 4 workgroups at 1 024 / 1 100 tokens, none at 150 / 257, two query
+    # tiles per wave and no split at 2 x 4 200)
     for heads3, ch3, T3, n3 in ((4, 24, 150, 2), (8, 24, 1100, 1), (2, 32, 64, 1), (3, 16, 257, 1), (2, 8, 129, 2),
-                                 (8, 24, 4200, 2)):   # the last one: >= 512 workgroups, two query tiles per wave
+                                 (8, 24, 4200, 2),    # >= 512 workgroups, two query tiles per wave
+                                 (8, 48, 1024, 1), (8, 48, 1100, 1), (2, 48, 150, 2), (3, 48, 257, 1), (8, 48, 4200, 2)):
         qkv3 = torch.randn(n3, heads3 * 3 * ch3, T3, generator=g)
         q3, k3, v3 = qkv3.double().reshape(n3 * heads3, ch3 * 3, T3).split(ch3, dim=1)
         sc3 = 1 / math.sqrt(math.sqrt(ch3))
