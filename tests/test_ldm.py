@@ -294,6 +294,16 @@ def test_ldm_primitives_match_torch():
         err3 = float((out3.cpu().double() - want3).abs().max())
         assert err3 < 2e-5, (heads3, ch3, T3, err3)
     assert lib.s3d_qkv_attention_ws_bytes(1, 64, 8, 96) == 0      # wide heads stay on s3d_qkv_attention_fwd
+    # the timestep-embedding layers (openaimodel.py:718-719 time_embed, the ResBlocks' emb_layers): the streaming form
+    # (K % 4 == 0: four rows per wave, up to four images per pass) and the scalar form, ragged M, more than four images
+    for nl, kl, ml, silu in ((1, 768, 36096 // 8 + 3, 1), (5, 192, 70, 0), (3, 770, 33, 1)):
+        xl = torch.randn(nl, kl, generator=g)
+        lin = torch.nn.Linear(kl, ml)
+        wantl = lin(F.silu(xl) if silu else xl).detach()
+        xg, wg, bg = xl.cuda(), lin.weight.detach().cuda(), lin.bias.detach().cuda()
+        outl = torch.zeros(nl, ml, device="cuda")
+        _lib.check(lib.s3d_small_linear_fwd(xg.data_ptr(), wg.data_ptr(), bg.data_ptr(), outl.data_ptr(), nl, kl, ml, silu, None), "lin")
+        assert (outl.cpu() - wantl).abs().max() < 2e-5, (nl, kl, ml, float((outl.cpu() - wantl).abs().max()))
     up = torch.empty(n, 2 * h, 2 * w, c, device="cuda")
     _lib.check(lib.s3d_resample2x_fwd(xc.data_ptr(), up.data_ptr(), n, h, w, c, 1, None), "up")
     assert torch.equal(up.cpu(), F.interpolate(x, scale_factor=2, mode="nearest").permute(0, 2, 3, 1))
