@@ -296,7 +296,7 @@ def test_ldm_primitives_match_torch():
     assert lib.s3d_qkv_attention_ws_bytes(1, 64, 8, 96) == 0      # wide heads stay on s3d_qkv_attention_fwd
     # the timestep-embedding layers (openaimodel.py:718-719 time_embed, the ResBlocks' emb_layers): the streaming form
     # (K % 4 == 0: four rows per wave, up to four images per pass) and the scalar form, ragged M, more than four images
-    for nl, kl, ml, silu in ((1, 768, 36096 // 8 + 3, 1), (5, 192, 70, 0), (3, 770, 33, 1)):
+    for nl, kl, ml, silu in ((1, 768, 36096 // 8 + 3, 1), (5, 256, 4099, 1), (5, 192, 70, 0), (3, 770, 33, 1)):
         xl = torch.randn(nl, kl, generator=g)
         lin = torch.nn.Linear(kl, ml)
         wantl = lin(F.silu(xl) if silu else xl).detach()
