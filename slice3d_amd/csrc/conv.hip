@@ -1005,6 +1005,181 @@ int launch_conv_splitk_finish(const ConvLaunch& a, int nsplit, hipStream_t strea
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same convolution for maps of a few pixels (round 6): N * H * W <= 64 output pixels in all (dispatched up to 32: the
+// 4 x 4 level of the latent-diffusion U-Net at batch 1 and 2 — 21 of its 70 3x3 convolutions per step; see the launch).  The tiled
+// kernel above gives such a map an 8 x 16 pixel tile per image: 87 % (4 x 4) or 50 % (8 x 8) of its MFMAs multiply padding,
+// two of its four waves own rows that do not exist, and its weights arrive one tap at a time.  Here a pixel tile is 16
+// consecutive output pixels of the flattened (n, y, x) index (PT = 1, 2 or 4 of them), every wave owns ONE 16-channel
+// output tile for all pixel tiles (the accumulators are 4 PT registers), and that leaves room to request all nine taps'
+// weight fragments of a chunk at once (72 registers) and the next chunk's under the current one's products.  The zero-padded
+// input of ALL images ((H + 2) x (W + 2) pixels each) is parked per 32-channel chunk as in the tiled kernel (same swizzle).
+// Split-K only (the launch falls back to the tiled kernel otherwise): partial[split][pixel][CoutPad], same chunk ranges, same
+// order of products per accumulator — bit-identical to the tiled kernel at the same split count.
+// ---------------------------------------------------------------------------------------------
+#define C3S_HP 160           // padded pixels of all images a workgroup parks: 8 x 8 -> 100, four 4 x 4 images -> 144
+#define C3S_HP1 64           // ... of the one-pixel-tile form (a 4 x 4 map: 36)
+// q / d for q < 409, 6 <= d <= 160 as a 16-bit fixed-point multiply (exact in that range)
+__device__ __forceinline__ int c3s_div(int q, int magic) { return (q * magic) >> 16; }
+template <int PT, bool GN>
+__global__ __launch_bounds__(256) void conv3x3_small_f16x3_kernel(const ConvLaunch a, int chunks_per_split) {
+    __shared__ __attribute__((aligned(16))) _Float16 s_in[2][2][C3S_HP * C3_PXS];   // [buf][hi|lo]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int Wp = a.W + 2, HpWp = (a.H + 2) * Wp, HP = a.N * HpWp, HW = a.H * a.W, P = a.N * HW;
+    const int KU32 = a.KU >> 1;
+    const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wpk16);
+    const int jt = blockIdx.x * 4 + wave;
+    const int mg_hpwp = 65536 / HpWp + 1, mg_wp = 65536 / Wp + 1, mg_hw = 65536 / HW + 1, mg_w = 65536 / a.W + 1;   // uniform
+    f32x4 acc[PT];
+    int pix0[PT], pout[PT];   // padded pixel read by tap (0, 0); output pixel index (or -1)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        acc[pt] = zero4();
+        const int p = 16 * pt + m;
+        const int pc = p < P ? p : 0;
+        const int n = c3s_div(pc, mg_hw), r = pc - n * HW, y = c3s_div(r, mg_w), x = r - y * a.W;
+        pix0[pt] = n * HpWp + y * Wp + x;   // tap (dy, dx) reads padded pixel pix0 + dy * Wp + dx
+        pout[pt] = p < P ? p : -1;
+    }
+    constexpr int NPRE = ((PT == 1 ? C3S_HP1 : C3S_HP) * 8 + 255) / 256;   // float4 per thread and chunk: 2 (one pixel tile) or 5
+    f32x4 pre[NPRE];
+    unsigned pre_ok = 0u;
+    int pre_cb = 0;
+    const int Ct = a.src[0].C + (a.nsrc > 1 ? a.src[1].C : 0);
+    auto fetch = [&](const ConvSrc& S, int c, int cbase) {
+        pre_ok = 0u;
+        pre_cb = cbase + 32 * c;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int slot = threadIdx.x + 256 * i;
+            const int pix = slot >> 3, q4 = slot & 7;
+            const int n = c3s_div(pix, mg_hpwp), r = pix - n * HpWp, hy = c3s_div(r, mg_wp), hx = r - hy * Wp;
+            const int y = hy - 1, x = hx - 1;
+            const bool ok = pix < HP && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const int ni = ok ? (S.bmod ? n % S.bmod : n) / S.bdiv : 0;
+            const long off = ((long)(ni * a.H + (ok ? y : 0)) * a.W + (ok ? x : 0)) * S.C + 32 * c + 4 * q4;
+            const f32x4 v = ld4(S.p + off);
+            pre[i] = ok ? v : zero4();
+            if (ok) pre_ok |= 1u << i;
+        }
+    };
+    // GN: the affine table entries of the prefetched slots, straight from L2 (y = x A + B).  Requested BEFORE a chunk's
+    // weights: the vector memory queue returns in order, and park() must not wait behind 18 KB of weight fragments
+    f32x4 gnA[GN ? NPRE : 1], gnB[GN ? NPRE : 1];
+    auto gn_load = [&]() {
+        if (!GN) return;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int slot = threadIdx.x + 256 * i;
+            const int pix = slot >> 3, q4 = slot & 7;
+            const int n = pix < HP ? c3s_div(pix, mg_hpwp) : 0;
+            const float* tb = a.gn.table + (size_t)n * 2 * Ct + pre_cb + 4 * q4;
+            gnA[i] = ld4(tb);
+            gnB[i] = ld4(tb + Ct);
+        }
+    };
+    auto park = [&](int buf) {
+        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int slot = threadIdx.x + 256 * i;
+            const int pix = slot >> 3, q4 = slot & 7;
+            if (pix < HP) {
+                if (GN) {
+                    const f32x4 A = gnA[i], B = gnB[i];
+                    f32x4 t = pre[i] * A + B;
+                    if (a.gn.silu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            t[e] = t[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t[e]));
+                    }
+                    pre[i] = (pre_ok >> i) & 1u ? t : zero4();
+                }
+                half4_t hi, lo;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const _Float16 h = (_Float16)pre[i][t];
+                    hi[t] = h;
+                    lo[t] = (_Float16)(pre[i][t] - (float)h);
+                }
+                const int po = pix * C3_PXS + C3_SWZ(pix, q4 >> 1) + 4 * (q4 & 1);
+                *reinterpret_cast<half4_t*>(&s_in[buf][0][po]) = hi;
+                *reinterpret_cast<half4_t*>(&s_in[buf][1][po]) = lo;
+            }
+        }
+    };
+    const int cu0 = a.src[0].C >> 5, cu1 = a.nsrc > 1 ? a.src[1].C >> 5 : 0;
+    const int ch_lo = blockIdx.y * chunks_per_split;
+    const int nchunk = min(cu0 + cu1, ch_lo + chunks_per_split);
+    constexpr bool DBW = PT == 1;   // the next chunk's weights under this chunk's products (144 registers); PT >= 2: after them
+    chalf8 wh[9], wl[9], nwh[DBW ? 9 : 1], nwl[DBW ? 9 : 1];
+    auto request = [&](int ch, chalf8 (&h)[9], chalf8 (&l)[9]) {
+        const int s = ch < cu0 ? 0 : 1, c = s ? ch - cu0 : ch, cu = s ? cu1 : cu0;
+        const _Float16* f0 = wimg + ((size_t)jt * KU32 + (s ? 9 * cu0 : 0) + c) * 1024 + lane * 8;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            h[tap] = *reinterpret_cast<const chalf8*>(f0 + (size_t)tap * cu * 1024);
+            l[tap] = *reinterpret_cast<const chalf8*>(f0 + (size_t)tap * cu * 1024 + 512);
+        }
+    };
+    fetch(a.src[ch_lo < cu0 ? 0 : 1], ch_lo < cu0 ? ch_lo : ch_lo - cu0, ch_lo < cu0 ? 0 : a.src[0].C);
+    gn_load();
+    request(ch_lo, wh, wl);   // behind the input loads in the (in-order) queue: park() waits for those only
+    park(ch_lo & 1);
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = ch_lo; ch < nchunk; ++ch) {
+        if (ch + 1 < nchunk) {
+            const int s1 = ch + 1 < cu0 ? 0 : 1;
+            fetch(a.src[s1], s1 ? ch + 1 - cu0 : ch + 1, s1 ? a.src[0].C : 0);
+            if constexpr (DBW) request(ch + 1, nwh, nwl);
+        }
+        const _Float16* sh = s_in[ch & 1][0];
+        const _Float16* sl = s_in[ch & 1][1];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * Wp + tap % 3;
+            chalf8 bh[PT], bl[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int pix = pix0[pt] + toff;
+                const int po = pix * C3_PXS + C3_SWZ(pix, g);
+                bh[pt] = *reinterpret_cast<const chalf8*>(sh + po);
+                bl[pt] = *reinterpret_cast<const chalf8*>(sl + po);
+            }
+            if (!a.single_pass) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[tap], bl[pt], acc[pt], 0, 0, 0);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[tap], bh[pt], acc[pt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[tap], bh[pt], acc[pt], 0, 0, 0);
+        }
+        if (ch + 1 < nchunk) {
+            if constexpr (DBW) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    wh[tap] = nwh[tap];
+                    wl[tap] = nwl[tap];
+                }
+                gn_load();
+            } else {
+                gn_load();
+                request(ch + 1, wh, wl);
+            }
+            park((ch + 1) & 1);
+        }
+        __syncthreads();
+    }
+    float* part = a.splitk_ws + (size_t)blockIdx.y * ((size_t)P * a.CoutPad);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+        if (pout[pt] >= 0) st4(part + (size_t)pout[pt] * a.CoutPad + jt * 16 + 4 * g, acc[pt]);
+}
+
 static bool conv3x3_lds_eligible(const ConvLaunch& a) {
     if (a.ks != 3 || a.stride > 1 || (a.Hin && a.Hin != a.H) || (a.Win && a.Win != a.W)) return false;
     if (!a.wpk16 || a.KU % 2 || a.CoutPad % 32) return false;
@@ -1025,7 +1200,17 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     // split-K when the pixel x channel tiling cannot fill the chip (deep encoder layers at batch 1)
     int splits = 1;
     const size_t out_floats = (size_t)a.N * a.H * a.W * a.CoutPad;
-    if (a.splitk_ws && a.out_mode == S3D_OUT_NHWC && nblk < 512) {
+    // maps of a few pixels (all images together at most 64 pixels, 160 with their zero borders): conv3x3_small_f16x3_kernel
+    static const bool small_on = !(getenv("S3D_CONV_SMALL") && atoi(getenv("S3D_CONV_SMALL")) == 0);
+    const long P_all = (long)a.N * a.H * a.W;
+    // (P_all <= 32: at the 8 x 8 maps — four pixel tiles — this kernel measured 16.7-17.5 us per call against the tiled kernel's
+    //  16.1, in the compact form, in a conflict-free form over the zero-bordered index space and with the table loads ahead of
+    //  the weights; at the 4 x 4 maps 11.2 against 16.0: profiles/r06_ldm_small_maps.md.  S3D_CONV_SMALL=64 forces it there.)
+    static const long small_pmax = getenv("S3D_CONV_SMALL") && atoi(getenv("S3D_CONV_SMALL")) > 1 ? atoi(getenv("S3D_CONV_SMALL")) : 32;
+    const bool small = small_on && a.splitk_ws && a.out_mode == S3D_OUT_NHWC && co_wg == 64 && P_all <= (small_pmax < 64 ? small_pmax : 64) &&
+                       (long)a.N * (a.H + 2) * (a.W + 2) <= C3S_HP;
+    const long nblk_k = small ? a.CoutPad / 64 : nblk;   // workgroups per split
+    if (a.splitk_ws && a.out_mode == S3D_OUT_NHWC && nblk_k < 512) {
         // The chip holds 512 of these workgroups at a time (two per CU).  A launch runs in ceil(workgroups / 512) rounds of
         // (chunks per split + a fixed fetch / epilogue share) each: 640 workgroups of 3 chunks are two rounds, the second
         // a quarter full, where 480 of 4 chunks are one.  Pick the split count with the least rounds x length (doubling
@@ -1034,7 +1219,7 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
         for (int sp = 1; sp <= nchunk && (size_t)sp * out_floats <= a.splitk_floats; ++sp) {
             const int c = (nchunk + sp - 1) / sp, se = (nchunk + c - 1) / c;
             if (se != sp) continue;   // (the same chunking as a smaller count)
-            const long rounds = (nblk * se + 511) / 512;
+            const long rounds = (nblk_k * se + 511) / 512;
             const long cost = rounds * (2 * c + 3) + (se > 1 ? 1 + se / 8 : 0);   // half-chunk units; the finish pass reads `se` partials
             if (best < 0 || cost < best) {
                 best = cost;
@@ -1044,6 +1229,24 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     }
     const int cps = (nchunk + splits - 1) / splits;
     splits = (nchunk + cps - 1) / cps;
+    if (small && splits > 1) {
+        dim3 sgrid((unsigned)(a.CoutPad / 64), (unsigned)splits);
+        const int pt = (int)((P_all + 15) / 16);
+        const long hp_all = (long)a.N * (a.H + 2) * (a.W + 2);
+#define C3S_LAUNCH(PT_)                                                                                                  \
+    if (a.gn.table) hipLaunchKernelGGL((conv3x3_small_f16x3_kernel<PT_, true>), sgrid, dim3(256), 0, stream, a, cps);      \
+    else hipLaunchKernelGGL((conv3x3_small_f16x3_kernel<PT_, false>), sgrid, dim3(256), 0, stream, a, cps)
+        if (pt == 1 && hp_all <= C3S_HP1) { C3S_LAUNCH(1); }
+        else if (pt <= 2) { C3S_LAUNCH(2); }
+        else { C3S_LAUNCH(4); }
+#undef C3S_LAUNCH
+        S3D_LAUNCH_CHECK();
+        if (a.splits_out) {
+            *a.splits_out = splits;
+            return 0;
+        }
+        return launch_conv_splitk_finish(a, splits, stream);
+    }
     dim3 grid((unsigned)nblk, (unsigned)splits);
     constexpr int one_buf_max = 2;   // chunks per workgroup up to which the single-buffer variant runs
     const bool one = cps <= one_buf_max;   // 32-channel-output layers only: measured -13 % there, +5 % on the 64-wide tile

@@ -92,6 +92,27 @@ def test_ldm_fused_group_norm_convolution_equals_the_two_operator_form(name, cfg
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 4])
+def test_small_map_convolution_kernel_is_bit_identical_to_the_tiled_kernel(batch, tmp_path):
+    """conv3x3_small_f16x3_kernel (conv.hip; the 4 x 4 / 8 x 8 maps) keeps the tiled kernel's chunk ranges per split and
+    its order of products per accumulator: at batch 1 (same split counts) the step's output must not change by a bit; at
+    batch 4 the 4 x 4 maps get their own split counts (all images in one workgroup), so the outputs agree to rounding."""
+    import subprocess, sys
+    outs = []
+    for sw in ("0", "1"):
+        f = str(tmp_path / ("y%s.pt" % sw))
+        env = dict(os.environ, S3D_CONV_SMALL=sw)
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                                                         "ldm_out.py"), f, str(batch)], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    if batch == 1:
+        assert torch.equal(outs[0], outs[1])
+    else:
+        assert (outs[0] - outs[1]).abs().max() < 2e-5 * outs[0].abs().max()
+
+
+@pytest.mark.gpu
 def test_ldm_single_pass_f16_mode_runs_and_reports_its_error():
     """prec='f16' (S3D_PREC_F16 through s3d_conv_fwd: one f16 MFMA per product in every convolution with 32-aligned channel
     counts; the attention operators keep the split form) — the precision BASELINE configs[4] names ("bf16").  Not fp32-class:
