@@ -780,6 +780,24 @@ static int launch_lin_stream(const ConvLaunch& a, hipStream_t stream) {
 // one buffer (22.5 KiB, seven workgroups per CU) for layers whose K is one or two chunks — there a workgroup's life is a
 // fetch, a split and 108-216 MFMAs per wave, nothing overlaps inside it, and what hides the fetch latency is the number
 // of OTHER workgroups on the CU (the 32- and 64-channel layers at full resolution: 0.51 / 0.34 ms -> see DESIGN.md).
+// -DC3_STAMPS (tools/r06_conv_stamps.sh; not the shipped library): wave 0 of every workgroup adds the 100 MHz ticks of its
+// phases to device counters keyed by the launch's grid (gridDim.x 96 / 48 / 12 / other)
+#ifdef C3_STAMPS
+__device__ unsigned long long c3_stamps[4][8];
+#define C3_STAMP(i)                                                                                              \
+    do {                                                                                                         \
+        const long long t__ = wall_clock64();                                                                    \
+        if (threadIdx.x == 0) atomicAdd(&c3_stamps[c3_cls][i], (unsigned long long)(t__ - c3_last));              \
+        c3_last = t__;                                                                                           \
+    } while (0)
+extern "C" void s3d_debug_c3_stamps(unsigned long long* out) {
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(c3_stamps), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c3_stamps), z, sizeof(z));
+}
+#else
+#define C3_STAMP(i)
+#endif
 template <int MT, int WP, int WC, int NBUF, bool GN = false>
 __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch a, int tiles_x, int tiles_y,
                                                                 int chunks_per_split) {
@@ -788,6 +806,11 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
     __shared__ __attribute__((aligned(16))) _Float16 s_in[NBUF][2][C3_HALO * C3_PXS];   // [buf][hi|lo]
     // GN: per-channel affine table of this image's GroupNorm (+ FiLM), A | B
     __shared__ __attribute__((aligned(16))) float s_gn[GN ? 2 * S3D_GN_CMAX : 4];
+#ifdef C3_STAMPS
+    long long c3_last = wall_clock64();
+    const int c3_cls = gridDim.x == 96 ? 0 : gridDim.x == 48 ? 1 : gridDim.x == 12 ? 2 : 3;
+    if (threadIdx.x == 0) atomicAdd(&c3_stamps[c3_cls][7], 1ull);
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int wp = wave % WP, wc = wave / WP;
@@ -879,8 +902,11 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
         }
         __syncthreads();
     }
+    C3_STAMP(0);   // first fetch issued, table in LDS
     park(ch_lo & (NBUF - 1));
+    C3_STAMP(1);   // first halo arrived and parked
     __syncthreads();
+    C3_STAMP(2);   // barrier
 #pragma unroll 1
     for (int ch = ch_lo; ch < nchunk; ++ch) {
         const int s = ch < cu0 ? 0 : 1, c = s ? ch - cu0 : ch, cu = s ? cu1 : cu0;
@@ -942,9 +968,12 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
                 }
             }
         }
+        C3_STAMP(3);   // nine taps
         if (NBUF == 1) __syncthreads();   // everyone is done reading the single buffer before it is refilled
         if (ch + 1 < nchunk) park((ch + 1) & (NBUF - 1));
+        C3_STAMP(4);   // next halo parked
         __syncthreads();
+        C3_STAMP(5);   // barrier
     }
     int pn[MT], py[MT], px[MT];
     bool pv[MT];
@@ -964,6 +993,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_f16x3_kernel(const ConvLaunch
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) st4(o + (jt0 + nt) * 16, acc[mt][nt]);
             }
+        C3_STAMP(6);   // partial stores issued
         return;
     }
     conv_epilogue<MT, NT>(a, acc, pn, py, px, pv, jt0, g);
