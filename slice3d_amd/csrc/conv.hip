@@ -1052,12 +1052,16 @@ int launch_conv_splitk_finish(const ConvLaunch& a, int nsplit, hipStream_t strea
 #define C3S_HP1 64           // ... of the one-pixel-tile form (a 4 x 4 map: 36)
 // q / d for q < 409, 6 <= d <= 160 as a 16-bit fixed-point multiply (exact in that range)
 __device__ __forceinline__ int c3s_div(int q, int magic) { return (q * magic) >> 16; }
-template <int PT, bool GN>
+// TAPS = 1: the 1x1 convolutions of the same levels (qkv / proj_out of the attention blocks, the ResBlocks' skip convolutions):
+// no zero border, one weight fragment pair per chunk — what it buys them is the split-K (the implicit-GEMM kernel they ran on
+// has none: 768 -> 2 304 at a 4 x 4 map was 24 workgroups pulling 7 MB of weights, 21 us).
+template <int PT, bool GN, int TAPS = 9>
 __global__ __launch_bounds__(256) void conv3x3_small_f16x3_kernel(const ConvLaunch a, int chunks_per_split) {
+    constexpr int BORD = TAPS == 9 ? 1 : 0;
     __shared__ __attribute__((aligned(16))) _Float16 s_in[2][2][C3S_HP * C3_PXS];   // [buf][hi|lo]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
-    const int Wp = a.W + 2, HpWp = (a.H + 2) * Wp, HP = a.N * HpWp, HW = a.H * a.W, P = a.N * HW;
+    const int Wp = a.W + 2 * BORD, HpWp = (a.H + 2 * BORD) * Wp, HP = a.N * HpWp, HW = a.H * a.W, P = a.N * HW;
     const int KU32 = a.KU >> 1;
     const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wpk16);
     const int jt = blockIdx.x * 4 + wave;
@@ -1086,7 +1090,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_f16x3_kernel(const ConvLaun
             const int slot = threadIdx.x + 256 * i;
             const int pix = slot >> 3, q4 = slot & 7;
             const int n = c3s_div(pix, mg_hpwp), r = pix - n * HpWp, hy = c3s_div(r, mg_wp), hx = r - hy * Wp;
-            const int y = hy - 1, x = hx - 1;
+            const int y = hy - BORD, x = hx - BORD;
             const bool ok = pix < HP && y >= 0 && y < a.H && x >= 0 && x < a.W;
             const int ni = ok ? (S.bmod ? n % S.bmod : n) / S.bdiv : 0;
             const long off = ((long)(ni * a.H + (ok ? y : 0)) * a.W + (ok ? x : 0)) * S.C + 32 * c + 4 * q4;
@@ -1144,12 +1148,12 @@ __global__ __launch_bounds__(256) void conv3x3_small_f16x3_kernel(const ConvLaun
     const int ch_lo = blockIdx.y * chunks_per_split;
     const int nchunk = min(cu0 + cu1, ch_lo + chunks_per_split);
     constexpr bool DBW = PT == 1;   // the next chunk's weights under this chunk's products (144 registers); PT >= 2: after them
-    chalf8 wh[9], wl[9], nwh[DBW ? 9 : 1], nwl[DBW ? 9 : 1];
-    auto request = [&](int ch, chalf8 (&h)[9], chalf8 (&l)[9]) {
+    chalf8 wh[TAPS], wl[TAPS], nwh[DBW ? TAPS : 1], nwl[DBW ? TAPS : 1];
+    auto request = [&](int ch, chalf8 (&h)[TAPS], chalf8 (&l)[TAPS]) {
         const int s = ch < cu0 ? 0 : 1, c = s ? ch - cu0 : ch, cu = s ? cu1 : cu0;
-        const _Float16* f0 = wimg + ((size_t)jt * KU32 + (s ? 9 * cu0 : 0) + c) * 1024 + lane * 8;
+        const _Float16* f0 = wimg + ((size_t)jt * KU32 + (s ? TAPS * cu0 : 0) + c) * 1024 + lane * 8;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < TAPS; ++tap) {
             h[tap] = *reinterpret_cast<const chalf8*>(f0 + (size_t)tap * cu * 1024);
             l[tap] = *reinterpret_cast<const chalf8*>(f0 + (size_t)tap * cu * 1024 + 512);
         }
@@ -1169,8 +1173,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_f16x3_kernel(const ConvLaun
         const _Float16* sh = s_in[ch & 1][0];
         const _Float16* sl = s_in[ch & 1][1];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = (tap / 3) * Wp + tap % 3;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = TAPS == 9 ? (tap / 3) * Wp + tap % 3 : 0;
             chalf8 bh[PT], bl[PT];
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
@@ -1191,7 +1195,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_f16x3_kernel(const ConvLaun
         if (ch + 1 < nchunk) {
             if constexpr (DBW) {
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
+                for (int tap = 0; tap < TAPS; ++tap) {
                     wh[tap] = nwh[tap];
                     wl[tap] = nwl[tap];
                 }
@@ -1219,6 +1223,59 @@ static bool conv3x3_lds_eligible(const ConvLaunch& a) {
         if (a.src[s].C % 32 || a.src[s].sbcast) return false;
     return true;
 }
+// Split count of a split-K launch of `nblk_k` workgroups per split over `nchunk` 32-channel chunks: the chip holds 512 of these
+// workgroups at a time (two per CU); a launch runs in ceil(workgroups / 512) rounds of (chunks per split + a fixed fetch /
+// epilogue share) each; the finish pass reads `se` partials.  Pick the count with the least rounds x length.
+static int conv_choose_splits(long nblk_k, int nchunk, size_t out_floats, size_t splitk_floats) {
+    int splits = 1;
+    long best = -1;
+    for (int sp = 1; sp <= nchunk && (size_t)sp * out_floats <= splitk_floats; ++sp) {
+        const int c = (nchunk + sp - 1) / sp, se = (nchunk + c - 1) / c;
+        if (se != sp) continue;   // (the same chunking as a smaller count)
+        const long rounds = (nblk_k * se + 511) / 512;
+        const long cost = rounds * (2 * c + 3) + (se > 1 ? 1 + se / 8 : 0);   // half-chunk units
+        if (best < 0 || cost < best) {
+            best = cost;
+            splits = se;
+        }
+    }
+    return splits;
+}
+static const bool g_conv_small_on = !(getenv("S3D_CONV_SMALL") && atoi(getenv("S3D_CONV_SMALL")) == 0);
+static const long g_conv_small_pmax = getenv("S3D_CONV_SMALL") && atoi(getenv("S3D_CONV_SMALL")) > 1 ? atoi(getenv("S3D_CONV_SMALL")) : 32;
+
+// 1x1 convolutions of maps of a few pixels on conv3x3_small_f16x3_kernel<PT, false, 1> (split-K); false: not served
+static bool conv1x1_small_eligible(const ConvLaunch& a) {
+    if (!g_conv_small_on || a.ks != 1 || a.stride > 1 || a.Hin || a.Win || !a.wpk16 || a.KU % 2 || a.CoutPad % 64) return false;
+    if (!a.splitk_ws || a.out_mode != S3D_OUT_NHWC || a.gn.table) return false;
+    const long P = (long)a.N * a.H * a.W;
+    if (P > (g_conv_small_pmax < 64 ? g_conv_small_pmax : 64) || P > C3S_HP) return false;
+    for (int s = 0; s < a.nsrc; ++s)
+        if (a.src[s].C % 32 || a.src[s].sbcast) return false;
+    return true;
+}
+static int launch_conv1x1_small(const ConvLaunch& a, hipStream_t stream, bool& served) {
+    int nchunk = 0;
+    for (int s = 0; s < a.nsrc; ++s) nchunk += a.src[s].C >> 5;
+    const long P = (long)a.N * a.H * a.W;
+    int splits = conv_choose_splits(a.CoutPad / 64, nchunk, (size_t)P * a.CoutPad, a.splitk_floats);
+    const int cps = (nchunk + splits - 1) / splits;
+    splits = (nchunk + cps - 1) / cps;
+    served = splits > 1;
+    if (!served) return 0;
+    dim3 grid((unsigned)(a.CoutPad / 64), (unsigned)splits);
+    const int pt = (int)((P + 15) / 16);
+    if (pt == 1 && P <= C3S_HP1) hipLaunchKernelGGL((conv3x3_small_f16x3_kernel<1, false, 1>), grid, dim3(256), 0, stream, a, cps);
+    else if (pt <= 2) hipLaunchKernelGGL((conv3x3_small_f16x3_kernel<2, false, 1>), grid, dim3(256), 0, stream, a, cps);
+    else hipLaunchKernelGGL((conv3x3_small_f16x3_kernel<4, false, 1>), grid, dim3(256), 0, stream, a, cps);
+    S3D_LAUNCH_CHECK();
+    if (a.splits_out) {
+        *a.splits_out = splits;
+        return 0;
+    }
+    return launch_conv_splitk_finish(a, splits, stream);
+}
+
 static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
     const long tiles = (long)tiles_x * tiles_y * a.N;
@@ -1231,32 +1288,17 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     int splits = 1;
     const size_t out_floats = (size_t)a.N * a.H * a.W * a.CoutPad;
     // maps of a few pixels (all images together at most 64 pixels, 160 with their zero borders): conv3x3_small_f16x3_kernel
-    static const bool small_on = !(getenv("S3D_CONV_SMALL") && atoi(getenv("S3D_CONV_SMALL")) == 0);
     const long P_all = (long)a.N * a.H * a.W;
     // (P_all <= 32: at the 8 x 8 maps — four pixel tiles — this kernel measured 16.7-17.5 us per call against the tiled kernel's
     //  16.1, in the compact form, in a conflict-free form over the zero-bordered index space and with the table loads ahead of
     //  the weights; at the 4 x 4 maps 11.2 against 16.0: profiles/r06_ldm_small_maps.md.  S3D_CONV_SMALL=64 forces it there.)
-    static const long small_pmax = getenv("S3D_CONV_SMALL") && atoi(getenv("S3D_CONV_SMALL")) > 1 ? atoi(getenv("S3D_CONV_SMALL")) : 32;
-    const bool small = small_on && a.splitk_ws && a.out_mode == S3D_OUT_NHWC && co_wg == 64 && P_all <= (small_pmax < 64 ? small_pmax : 64) &&
+    const bool small = g_conv_small_on && a.splitk_ws && a.out_mode == S3D_OUT_NHWC && co_wg == 64 &&
+                       P_all <= (g_conv_small_pmax < 64 ? g_conv_small_pmax : 64) &&
                        (long)a.N * (a.H + 2) * (a.W + 2) <= C3S_HP;
     const long nblk_k = small ? a.CoutPad / 64 : nblk;   // workgroups per split
-    if (a.splitk_ws && a.out_mode == S3D_OUT_NHWC && nblk_k < 512) {
-        // The chip holds 512 of these workgroups at a time (two per CU).  A launch runs in ceil(workgroups / 512) rounds of
-        // (chunks per split + a fixed fetch / epilogue share) each: 640 workgroups of 3 chunks are two rounds, the second
-        // a quarter full, where 480 of 4 chunks are one.  Pick the split count with the least rounds x length (doubling
-        // until 512 workgroups was the rule before: it landed on 640 for every 64 x 64 x 320 layer of the LDM U-Net).
-        long best = -1;
-        for (int sp = 1; sp <= nchunk && (size_t)sp * out_floats <= a.splitk_floats; ++sp) {
-            const int c = (nchunk + sp - 1) / sp, se = (nchunk + c - 1) / c;
-            if (se != sp) continue;   // (the same chunking as a smaller count)
-            const long rounds = (nblk_k * se + 511) / 512;
-            const long cost = rounds * (2 * c + 3) + (se > 1 ? 1 + se / 8 : 0);   // half-chunk units; the finish pass reads `se` partials
-            if (best < 0 || cost < best) {
-                best = cost;
-                splits = se;
-            }
-        }
-    }
+    if (a.splitk_ws && a.out_mode == S3D_OUT_NHWC && nblk_k < 512) splits = conv_choose_splits(nblk_k, nchunk, out_floats, a.splitk_floats);
+    // (doubling until 512 workgroups was the rule before round 4: it landed on 640 — two rounds, the second a quarter full — for
+    //  every 64 x 64 x 320 layer of the LDM U-Net)
     const int cps = (nchunk + splits - 1) / splits;
     splits = (nchunk + cps - 1) / cps;
     if (small && splits > 1) {
@@ -1346,6 +1388,11 @@ int launch_conv(const ConvLaunch& a_in, hipStream_t stream) {
                   "conv: ConvTranspose output takes no dropout / gate / residual / accumulate");
     if (conv3x3_lds_eligible(a)) return launch_conv3x3_lds(a, stream);
     S3D_CHECK_ARG(!a.gn.table, "conv: a fused GroupNorm needs the LDS-staged 3x3 kernel (ks 3, stride 1, channel counts multiples of 32)");
+    if (conv1x1_small_eligible(a)) {
+        bool served = false;
+        const int rc = launch_conv1x1_small(a, stream, served);
+        if (rc || served) return rc;
+    }
     if (lin_stream_eligible(a)) return launch_lin_stream(a, stream);
     if (lin_rows_eligible(a)) return launch_lin_rows(a, stream);
     const long P = (long)a.N * a.H * a.W;
