@@ -1245,11 +1245,14 @@ static const bool g_conv_small_on = !(getenv("S3D_CONV_SMALL") && atoi(getenv("S
 static const long g_conv_small_pmax = getenv("S3D_CONV_SMALL") && atoi(getenv("S3D_CONV_SMALL")) > 1 ? atoi(getenv("S3D_CONV_SMALL")) : 32;
 
 // 1x1 convolutions of maps of a few pixels on conv3x3_small_f16x3_kernel<PT, false, 1> (split-K); false: not served
+static const bool g_conv_small1_on = !(getenv("S3D_CONV_SMALL_1X1") && atoi(getenv("S3D_CONV_SMALL_1X1")) == 0);
+// (up to 64 pixels — four pixel tiles: step 4.00-4.08 -> 3.96 ms with 32, 3.88 with 64; S3D_CONV_SMALL_1X1=0 / 32 for the A/B)
+static const long g_conv_small1_pmax = getenv("S3D_CONV_SMALL_1X1") && atoi(getenv("S3D_CONV_SMALL_1X1")) > 1 ? atoi(getenv("S3D_CONV_SMALL_1X1")) : 64;
 static bool conv1x1_small_eligible(const ConvLaunch& a) {
-    if (!g_conv_small_on || a.ks != 1 || a.stride > 1 || a.Hin || a.Win || !a.wpk16 || a.KU % 2 || a.CoutPad % 64) return false;
+    if (!g_conv_small1_on || a.ks != 1 || a.stride > 1 || a.Hin || a.Win || !a.wpk16 || a.KU % 2 || a.CoutPad % 64) return false;
     if (!a.splitk_ws || a.out_mode != S3D_OUT_NHWC || a.gn.table) return false;
     const long P = (long)a.N * a.H * a.W;
-    if (P > (g_conv_small_pmax < 64 ? g_conv_small_pmax : 64) || P > C3S_HP) return false;
+    if (P > (g_conv_small1_pmax < 64 ? g_conv_small1_pmax : 64) || P > C3S_HP) return false;
     for (int s = 0; s < a.nsrc; ++s)
         if (a.src[s].C % 32 || a.src[s].sbcast) return false;
     return true;

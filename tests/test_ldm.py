@@ -364,3 +364,37 @@ def test_row_linear_path_matches_torch(k, n, rows):
         assert err < 2e-5, (prec, err)
         outs.append(out)
     assert float((outs[0] - outs[1]).abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w,cin0,cin1,cout,ks", [(1, 4, 4, 768, 0, 768, 3), (1, 4, 4, 384, 384, 768, 3), (2, 4, 4, 256, 0, 128, 3),
+                                                      (1, 4, 4, 768, 0, 2304, 1), (1, 8, 8, 384, 384, 768, 1), (4, 4, 4, 256, 0, 192, 1),
+                                                      (3, 3, 5, 64, 0, 64, 3), (2, 3, 5, 64, 32, 64, 3), (1, 2, 7, 96, 32, 128, 1)])
+def test_small_map_convolutions_match_torch(n, h, w, cin0, cin1, cout, ks):
+    """conv3x3_small_f16x3_kernel (conv.hip): the split-K kernel of maps of a few pixels — 3x3 (zero border, all images of the
+    batch in one workgroup, odd map shapes) and 1x1, one and two sources, bias and residual — against a float64 convolution."""
+    import torch.nn.functional as F
+    from slice3d_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n * 1000 + h * 100 + cin0 + cout + ks)
+    cin = cin0 + cin1
+    wt = torch.randn(cout, cin, ks, ks, generator=g) * (1.0 / (cin * ks * ks) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    x = torch.randn(n, cin, h, w, generator=g)
+    res = torch.randn(n, cout, h, w, generator=g)
+    want = F.conv2d(x.double(), wt.double(), b.double(), padding=ks // 2) + res.double()
+    xc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    x0 = xc[..., :cin0].contiguous()
+    x1 = xc[..., cin0:].contiguous() if cin1 else None
+    rc = res.permute(0, 2, 3, 1).contiguous().cuda()
+    wg, bg = wt.cuda(), b.cuda()
+    nb = lib.s3d_conv_packed_bytes(cout, cin0, cin1, ks)
+    buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.s3d_conv_pack(wg.data_ptr(), bg.data_ptr(), cout, cin0, cin1, ks, buf.data_ptr(), nb, None), "pack")
+    ws = torch.empty(1 << 22, dtype=torch.float32, device="cuda")
+    out = torch.full((n, h, w, cout), float("nan"), device="cuda")
+    _lib.check(lib.s3d_conv_fwd(buf.data_ptr(), x0.data_ptr(), x1.data_ptr() if x1 is not None else None, rc.data_ptr(), out.data_ptr(),
+                                n, h, w, cout, cin0, cin1, ks, _lib.PREC_F16X3, ws.data_ptr(), ws.numel() * 4, None), "conv")
+    torch.cuda.synchronize()
+    err = float((out.cpu().double().permute(0, 3, 1, 2) - want).abs().max())
+    assert err < 2e-5, err
