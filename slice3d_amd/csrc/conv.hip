@@ -1296,7 +1296,7 @@ static int launch_conv3x3_lds(const ConvLaunch& a, hipStream_t stream) {
     //  16.1, in the compact form, in a conflict-free form over the zero-bordered index space and with the table loads ahead of
     //  the weights; at the 4 x 4 maps 11.2 against 16.0: profiles/r06_ldm_small_maps.md.  S3D_CONV_SMALL=64 forces it there.)
     const bool small = g_conv_small_on && a.splitk_ws && a.out_mode == S3D_OUT_NHWC && co_wg == 64 &&
-                       P_all <= (g_conv_small_pmax < 64 ? g_conv_small_pmax : 64) &&
+                       (P_all <= (g_conv_small_pmax < 64 ? g_conv_small_pmax : 64) || ((long)a.H * a.W <= 16 && P_all <= 64)) &&   // (four 4 x 4 images: 7.08 -> 7.01 ms per batch-4 step)
                        (long)a.N * (a.H + 2) * (a.W + 2) <= C3S_HP;
     const long nblk_k = small ? a.CoutPad / 64 : nblk;   // workgroups per split
     if (a.splitk_ws && a.out_mode == S3D_OUT_NHWC && nblk_k < 512) splits = conv_choose_splits(nblk_k, nchunk, out_floats, a.splitk_floats);

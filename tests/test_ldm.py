@@ -366,7 +366,7 @@ def test_row_linear_path_matches_torch(k, n, rows):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,h,w,cin0,cin1,cout,ks", [(1, 4, 4, 768, 0, 768, 3), (1, 4, 4, 384, 384, 768, 3), (2, 4, 4, 256, 0, 128, 3),
-                                                      (1, 4, 4, 768, 0, 2304, 1), (1, 8, 8, 384, 384, 768, 1), (4, 4, 4, 256, 0, 192, 1),
+                                                      (4, 4, 4, 256, 0, 128, 3), (1, 4, 4, 768, 0, 2304, 1), (1, 8, 8, 384, 384, 768, 1), (4, 4, 4, 256, 0, 192, 1),
                                                       (3, 3, 5, 64, 0, 64, 3), (2, 3, 5, 64, 32, 64, 3), (1, 2, 7, 96, 32, 128, 1),
                                                       (1, 16, 16, 384, 0, 384, 1), (1, 9, 9, 64, 32, 128, 1)])   # 1x1 beyond 64 pixels: the implicit-GEMM kernel
 def test_small_map_convolutions_match_torch(n, h, w, cin0, cin1, cout, ks):
