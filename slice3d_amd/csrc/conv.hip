@@ -1050,7 +1050,8 @@ int launch_conv_splitk_finish(const ConvLaunch& a, int nsplit, hipStream_t strea
 // ---------------------------------------------------------------------------------------------
 #define C3S_HP 160           // padded pixels of all images a workgroup parks: 8 x 8 -> 100, four 4 x 4 images -> 144
 #define C3S_HP1 64           // ... of the one-pixel-tile form (a 4 x 4 map: 36)
-// q / d for q < 409, 6 <= d <= 160 as a 16-bit fixed-point multiply (exact in that range)
+// q / d for q < 409, 1 <= d <= 160 as a 16-bit fixed-point multiply with magic = 65536 / d + 1: magic d = 65536 + e, 1 <= e <= d, and
+// the quotient is exact while q e < 65536 (the dispatch keeps every divisor here at or below 160 and every dividend below 256)
 __device__ __forceinline__ int c3s_div(int q, int magic) { return (q * magic) >> 16; }
 // TAPS = 1: the 1x1 convolutions of the same levels (qkv / proj_out of the attention blocks, the ResBlocks' skip convolutions):
 // no zero border, one weight fragment pair per chunk — what it buys them is the split-K (the implicit-GEMM kernel they ran on
