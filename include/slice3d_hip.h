@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S3D_VERSION 114          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused, s3d_decode_set_shared_footprint; 112: S3D_PREC_F16 accepted by s3d_train_*; 113: atomic-free sampling backward (bit-reproducible s3d_train_* gradients, larger workspace); 114: s3d_qkv_attention_ws_* serve head width 48 */
+#define S3D_VERSION 115          /* 0.1.1: s3d_conv_fwd prec semantics, s3d_conv_gn_supported; 111: s3d_decode_set_last_fused, s3d_decode_set_shared_footprint; 112: S3D_PREC_F16 accepted by s3d_train_*; 113: atomic-free sampling backward (bit-reproducible s3d_train_* gradients, larger workspace); 114: s3d_qkv_attention_ws_* serve head width 48; 115: s3d_add_nchw_fwd */
 #define S3D_E_ARG (-1)           /* bad argument / unsupported shape */
 #define S3D_E_WORKSPACE (-2)     /* workspace or packed-weight buffer too small */
 
@@ -360,6 +360,8 @@ int s3d_timestep_embedding_fwd(const float* t, float* out, int N, int dim, float
 /* out = a + b (c_fmaps injection, openaimodel.py:735-746) */
 int s3d_add_fwd(const float* a, const float* b, float* out, long n, void* stream);
 int s3d_nchw_to_nhwc_pad(const float* in, float* out, int n, int c, int h, int w, int cpad, void* stream);
+/* out (N,H,W,C) = a (N,H,W,C) + b (N,C,H,W): the same injection with the feature map taken as the reference hands it over (version 115) */
+int s3d_add_nchw_fwd(const float* a, const float* b, float* out, int n, int c, int h, int w, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training step — replaces train_step (reg_slices/train.py:41-53): train-mode forward (batch-statistic

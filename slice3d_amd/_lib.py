@@ -149,6 +149,7 @@ SYMBOLS = {
     "s3d_timestep_embedding_fwd": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "s3d_add_fwd": (_i, [_vp, _vp, _vp, _l, _vp]),
     "s3d_nchw_to_nhwc_pad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "s3d_add_nchw_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "s3d_vgg_packed_bytes": (_sz, []),
     "s3d_vgg_pack": (_i, [C.POINTER(S3dVggParams), _vp, _sz, _vp]),
     "s3d_vgg_workspace_bytes": (_sz, [_i, _i]),

@@ -123,6 +123,7 @@ int launch_bn_relu_pool(const float* in, const float* scale, const float* shift,
                         int w, int c, hipStream_t stream);
 int launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int cpad, hipStream_t stream);
 int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, hipStream_t stream);
+int launch_add_nchw(const float* a, const float* b, float* out, int n, int c, int h, int w, hipStream_t stream);   // out NHWC = a NHWC + b NCHW
 
 // VGG-loss helpers (conv.hip)
 int launch_vgg_prep(const float* pred, const float* target, const float* mean, const float* stdv, float* out,

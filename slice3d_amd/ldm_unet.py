@@ -392,6 +392,17 @@ class UNetModel(nn.Module):
         _lib.check(lib.s3d_add_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), self._stream()), "s3d_add_fwd")
         return out
 
+    def _add_nchw(self, a, b):
+        """h + c_fmap (openaimodel.py:735-746) with the feature map read in the reference's NCHW layout: one launch."""
+        self._finish_pending()
+        b = b.to(device=self._dev(), dtype=torch.float32).contiguous()
+        n, c, h, w = b.shape
+        if tuple(a.shape) != (n, h, w, c):
+            return self._add(a, self._to_nhwc(b))
+        out = torch.empty_like(a)
+        _lib.check(self._lib.s3d_add_nchw_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, c, h, w, self._stream()), "s3d_add_nchw_fwd")
+        return out
+
     def _to_nhwc(self, x, cpad=None):
         lib = self._lib
         x = x.to(device=self._dev(), dtype=torch.float32).contiguous()
@@ -512,7 +523,7 @@ class UNetModel(nn.Module):
         for m_id, module in enumerate(self.input_blocks):
             h = self._run(module, h, emb)
             if c_fmaps is not None and m_id in inject:
-                h = self._add(h, self._to_nhwc(c_fmaps[inject[m_id]]))
+                h = self._add_nchw(h, c_fmaps[inject[m_id]])
             hs.append(h)
         h = self._run(self.middle_block, h, emb)
         for module in self.output_blocks:

@@ -326,6 +326,12 @@ def test_ldm_primitives_match_torch():
     up = torch.empty(n, 2 * h, 2 * w, c, device="cuda")
     _lib.check(lib.s3d_resample2x_fwd(xc.data_ptr(), up.data_ptr(), n, h, w, c, 1, None), "up")
     assert torch.equal(up.cpu(), F.interpolate(x, scale_factor=2, mode="nearest").permute(0, 2, 3, 1))
+    # c_fmaps injection with the feature map in the reference's NCHW layout (openaimodel.py:735-746): one launch
+    fm = torch.randn(n, c, h, w, generator=g)
+    inj = torch.empty_like(xc)
+    fmc = fm.cuda()
+    _lib.check(lib.s3d_add_nchw_fwd(xc.data_ptr(), fmc.data_ptr(), inj.data_ptr(), n, c, h, w, None), "add_nchw")
+    assert torch.equal(inj.cpu(), (x + fm).permute(0, 2, 3, 1).contiguous())
     dn = torch.empty(n, h // 2, w // 2, c, device="cuda")
     _lib.check(lib.s3d_resample2x_fwd(xc.data_ptr(), dn.data_ptr(), n, h, w, c, 0, None), "down")
     assert (dn.cpu() - F.avg_pool2d(x, 2).permute(0, 2, 3, 1)).abs().max() < 1e-6
